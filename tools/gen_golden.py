@@ -1,0 +1,390 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python modules on CPU.
+
+Runs ONLY in the build container (needs /root/reference, which never travels to the GPU box).
+Nothing from the reference is copied: we import its modules, feed seeded inputs/weights and
+store the numbers it produces.  Missing third-party deps of the reference are stubbed
+(SURVEY Appendix B):
+  thop, fvcore.nn, skimage, cv2      -> import-only stubs
+  torchvision.models.vgg16/inception_v3 -> torch.nn restatements of the published layer tables
+  roi_align.roi_align.RoIAlign       -> wrapper over oracle.roi_align (third-party code absent
+                                        from the tree => that row stays "parity unpinned")
+While generating, every golden tensor is also cross-checked against oracle/din_oracle.py;
+the script aborts if the oracle disagrees with the reference.
+
+usage: python tools/gen_golden.py [--ref /root/reference] [--out tests/golden]
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import din_oracle as O  # noqa: E402
+
+
+# ------------------------------------------------------------------ stubs for missing deps
+class _BasicConv2d(nn.Module):
+    def __init__(self, cin, cout, **kw):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, bias=False, **kw)
+        self.bn = nn.BatchNorm2d(cout, eps=0.001)
+
+    def forward(self, x):
+        return F.relu(self.bn(self.conv(x)), inplace=True)
+
+
+class _IncA(nn.Module):
+    def __init__(self, cin, pf):
+        super().__init__()
+        self.branch1x1 = _BasicConv2d(cin, 64, kernel_size=1)
+        self.branch5x5_1 = _BasicConv2d(cin, 48, kernel_size=1)
+        self.branch5x5_2 = _BasicConv2d(48, 64, kernel_size=5, padding=2)
+        self.branch3x3dbl_1 = _BasicConv2d(cin, 64, kernel_size=1)
+        self.branch3x3dbl_2 = _BasicConv2d(64, 96, kernel_size=3, padding=1)
+        self.branch3x3dbl_3 = _BasicConv2d(96, 96, kernel_size=3, padding=1)
+        self.branch_pool = _BasicConv2d(cin, pf, kernel_size=1)
+
+    def forward(self, x):
+        a = self.branch1x1(x)
+        b = self.branch5x5_2(self.branch5x5_1(x))
+        c = self.branch3x3dbl_3(self.branch3x3dbl_2(self.branch3x3dbl_1(x)))
+        d = self.branch_pool(F.avg_pool2d(x, kernel_size=3, stride=1, padding=1))
+        return torch.cat([a, b, c, d], 1)
+
+
+class _IncB(nn.Module):
+    def __init__(self, cin):
+        super().__init__()
+        self.branch3x3 = _BasicConv2d(cin, 384, kernel_size=3, stride=2)
+        self.branch3x3dbl_1 = _BasicConv2d(cin, 64, kernel_size=1)
+        self.branch3x3dbl_2 = _BasicConv2d(64, 96, kernel_size=3, padding=1)
+        self.branch3x3dbl_3 = _BasicConv2d(96, 96, kernel_size=3, stride=2)
+
+    def forward(self, x):
+        a = self.branch3x3(x)
+        b = self.branch3x3dbl_3(self.branch3x3dbl_2(self.branch3x3dbl_1(x)))
+        c = F.max_pool2d(x, kernel_size=3, stride=2)
+        return torch.cat([a, b, c], 1)
+
+
+class _IncC(nn.Module):
+    def __init__(self, cin, c7):
+        super().__init__()
+        self.branch1x1 = _BasicConv2d(cin, 192, kernel_size=1)
+        self.branch7x7_1 = _BasicConv2d(cin, c7, kernel_size=1)
+        self.branch7x7_2 = _BasicConv2d(c7, c7, kernel_size=(1, 7), padding=(0, 3))
+        self.branch7x7_3 = _BasicConv2d(c7, 192, kernel_size=(7, 1), padding=(3, 0))
+        self.branch7x7dbl_1 = _BasicConv2d(cin, c7, kernel_size=1)
+        self.branch7x7dbl_2 = _BasicConv2d(c7, c7, kernel_size=(7, 1), padding=(3, 0))
+        self.branch7x7dbl_3 = _BasicConv2d(c7, c7, kernel_size=(1, 7), padding=(0, 3))
+        self.branch7x7dbl_4 = _BasicConv2d(c7, c7, kernel_size=(7, 1), padding=(3, 0))
+        self.branch7x7dbl_5 = _BasicConv2d(c7, 192, kernel_size=(1, 7), padding=(0, 3))
+        self.branch_pool = _BasicConv2d(cin, 192, kernel_size=1)
+
+    def forward(self, x):
+        a = self.branch1x1(x)
+        b = self.branch7x7_3(self.branch7x7_2(self.branch7x7_1(x)))
+        c = self.branch7x7dbl_5(self.branch7x7dbl_4(self.branch7x7dbl_3(self.branch7x7dbl_2(self.branch7x7dbl_1(x)))))
+        d = self.branch_pool(F.avg_pool2d(x, kernel_size=3, stride=1, padding=1))
+        return torch.cat([a, b, c, d], 1)
+
+
+class _Inception3(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.Conv2d_1a_3x3 = _BasicConv2d(3, 32, kernel_size=3, stride=2)
+        self.Conv2d_2a_3x3 = _BasicConv2d(32, 32, kernel_size=3)
+        self.Conv2d_2b_3x3 = _BasicConv2d(32, 64, kernel_size=3, padding=1)
+        self.Conv2d_3b_1x1 = _BasicConv2d(64, 80, kernel_size=1)
+        self.Conv2d_4a_3x3 = _BasicConv2d(80, 192, kernel_size=3)
+        self.Mixed_5b = _IncA(192, 32)
+        self.Mixed_5c = _IncA(256, 64)
+        self.Mixed_5d = _IncA(288, 64)
+        self.Mixed_6a = _IncB(288)
+        self.Mixed_6b = _IncC(768, 128)
+        self.Mixed_6c = _IncC(768, 160)
+        self.Mixed_6d = _IncC(768, 160)
+        self.Mixed_6e = _IncC(768, 192)
+
+
+class _VGG(nn.Module):
+    def __init__(self):
+        super().__init__()
+        layers, cin = [], 3
+        for v in O.VGG16_TABLE:
+            if v == "M":
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        self.features = nn.Sequential(*layers)
+
+
+class _RoIAlignStub(nn.Module):
+    def __init__(self, crop_h, crop_w, extrapolation_value=0, transform_fpcoor=True):
+        super().__init__()
+        assert crop_h == crop_w
+        self.k = crop_h
+
+    def forward(self, fm, boxes, box_ind):
+        return O.roi_align(fm, boxes, box_ind, self.k)
+
+
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    ident = lambda *a, **k: None  # noqa: E731
+    mod("thop", profile=ident, clever_format=ident)
+    mod("fvcore")
+    mod("fvcore.nn", activation_count=ident, flop_count=ident, parameter_count=ident,
+        parameter_count_table=ident)
+    tv = mod("torchvision")
+    tvm = mod("torchvision.models", vgg16=lambda pretrained=False: _VGG(),
+              inception_v3=lambda pretrained=False: _Inception3(),
+              vgg19=ident, resnet18=ident, resnet50=ident, alexnet=ident)
+    tvt = mod("torchvision.transforms")
+    tv.models, tv.transforms = tvm, tvt
+    ra = mod("roi_align")
+    ram = mod("roi_align.roi_align", RoIAlign=_RoIAlignStub)
+    ra.roi_align = ram
+    sk = mod("skimage")
+    sk.io = mod("skimage.io")
+    sk.transform = mod("skimage.transform")
+    mod("cv2")
+
+
+# ------------------------------------------------------------------ helpers
+def seeded(shape, seed, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g, dtype=torch.float64) * scale).to(dtype)
+
+
+def close(a, b, tol, what):
+    a, b = a.double(), b.double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item() + 1e-30
+    assert err <= tol * ref, f"ORACLE != REFERENCE for {what}: max abs err {err:.3e} (scale {ref:.3e})"
+    return err / ref
+
+
+def din_case(name, refmod, b, t, n, c, kernels, ratios, beta, num_dim, dtype, out_dir,
+             x_seed, w_seed, store_full=True, din_std=0.05, offset_boost=1.0):
+    """Run the reference Multi_Dynamic_Inference / bare DPI fwd+bwd; compare oracle; save."""
+    DPI, MDI = refmod.Dynamic_Person_Inference, refmod.Multi_Dynamic_Inference
+    torch.manual_seed(0)
+    m = MDI(in_dim=c, person_mat_shape=(10, 12), stride=1, kernel_size=kernels, dynamic_sampling=True,
+            sampling_ratio=ratios, group=1, scale_factor=True, beta_factor=beta,
+            parallel_inference=False, num_DIM=num_dim, cfg=None).to(dtype)
+    shapes = {}
+    for i in range(num_dim):
+        shapes.update(O.din_param_shapes(f"DIMlist.{i}.", c, tuple(kernels[i]), ratios, True, beta))
+    p = O.synth_params(shapes, seed=w_seed, din_std=din_std, dtype=dtype)
+    for k in p:
+        if "p_conv" in k:
+            p[k] = p[k] * offset_boost          # push some samples past the clamp range
+        if k.endswith("beta"):
+            p[k] = 1.0 + 0.25 * seeded(p[k].shape, w_seed + 7, 1.0, dtype)
+    missing, unexpected = m.load_state_dict(p, strict=False)
+    assert not unexpected and not [k for k in missing if "zero_padding" not in k], (missing, unexpected)
+    x = seeded((b, t, n, c), x_seed, 1.0, dtype).requires_grad_(True)
+    cot = seeded((b, t, n, c), x_seed + 1, 1.0, dtype)
+    out, mad = m(x)
+    (out * cot).sum().backward()
+    ref_gx = x.grad.detach().clone()
+    ref_gp = {k: v.grad.detach().clone() for k, v in m.named_parameters()}
+
+    # oracle on the same numbers
+    po = {("DPI." + k): v.clone().requires_grad_(True) for k, v in p.items()}
+    xo = x.detach().clone().requires_grad_(True)
+    oo, omad = O.din_multi_inference(xo, po, "DPI.", kernels, ratios, True, beta)
+    (oo * cot).sum().backward()
+    tol = 1e-5 if dtype == torch.float32 else 1e-11
+    errs = dict(out=close(oo, out, tol, name + ".out"), mad=close(omad, mad, tol, name + ".mad"),
+                gx=close(xo.grad, ref_gx, 10 * tol, name + ".gx"))
+    for k, v in ref_gp.items():
+        errs["g_" + k] = close(po["DPI." + k].grad, v, 10 * tol, name + ".g_" + k)
+
+    # integer corner decisions of the LAST module/ratio, re-evaluated from the reference's own
+    # conv (same expressions as dynamic_infer_module.py:191,208-223)
+    last = m.DIMlist[num_dim - 1]
+    r = ratios[-1]
+    kh, kw = kernels[num_dim - 1]
+    k2 = kh * kw
+    with torch.no_grad():
+        off = last.p_conv[str(r)](x.detach().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        pos = last._get_pos(off, r)
+        lt = pos.floor()
+        pt, pl = (kh - 1) // 2 * r, (kw - 1) // 2 * r
+        ly = lt[..., :k2].clamp(0, t + 2 * pt - 1).long()
+        lx = lt[..., k2:].clamp(0, n + 2 * pl - 1).long()
+        ry = (lt[..., :k2] + 1).clamp(0, t + 2 * pt - 1).long()
+        rx = (lt[..., k2:] + 1).clamp(0, n + 2 * pl - 1).long()
+        scale = torch.softmax(last.scale_conv[str(r)](x.detach().permute(0, 3, 1, 2)).permute(0, 2, 3, 1), -1)
+    frac_clamped = float(((lt[..., :k2] < 0) | (lt[..., :k2] + 1 > t + 2 * pt - 1)).double().mean())
+
+    rec = dict(meta=np.array([b, t, n, c, num_dim, int(beta)], dtype=np.int64),
+               kernels=np.array(kernels, dtype=np.int64), ratios=np.array(ratios, dtype=np.int64),
+               x_seed=np.int64(x_seed), w_seed=np.int64(w_seed), din_std=np.float64(din_std),
+               offset_boost=np.float64(offset_boost),
+               dtype=np.array(str(dtype).replace("torch.", "")),
+               out=out.detach().numpy(), gx=ref_gx.numpy(),
+               ly=ly.numpy().astype(np.int32), lx=lx.numpy().astype(np.int32),
+               ry=ry.numpy().astype(np.int32), rx=rx.numpy().astype(np.int32),
+               offset=off.numpy(), scale=scale.numpy())
+    if store_full:
+        rec["x"] = x.detach().numpy()
+        rec["cot"] = cot.numpy()
+        rec["mad"] = mad.detach().numpy()
+        for k, v in p.items():
+            rec["p." + k] = v.numpy()
+    else:
+        rec["mad_checksum"] = np.float64(mad.detach().double().sum().item())
+    for k, v in ref_gp.items():
+        if store_full or v.numel() <= 65536:
+            rec["g." + k] = v.numpy()
+        else:
+            rec["gsum." + k] = np.float64(v.double().sum().item())
+            rec["gabs." + k] = np.float64(v.double().abs().sum().item())
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
+    print(f"[din] {name}: oracle-vs-reference rel err max {max(errs.values()):.2e}; "
+          f"clamped-row fraction {frac_clamped:.3f}")
+
+
+def prep_case(refutils, out_dir):
+    x = torch.arange(0, 256, dtype=torch.float32)
+    y = refutils.prep_images(x)
+    assert torch.equal(O.prep_images(x), y), "prep_images oracle mismatch (must be bit-exact)"
+    np.savez_compressed(os.path.join(out_dir, "prep_images.npz"), x=x.numpy(), y=y.numpy())
+    print("[prep] 256 uint8 levels: oracle bit-exact with reference")
+
+
+def model_case(name, refim, refcfg, out_dir, *, backbone, H, W, OH, OW, D, B, T, N, NFB, kernels, ratios,
+               num_dim=1, beta=False, lite=None, seed=0, dtype=torch.float32, hier=False):
+    """Whole Dynamic_volleyball forward (+ backward of CE loss) from the reference."""
+    cfg = refcfg.Config("volleyball")
+    cfg.log_path = None
+    cfg.backbone = backbone
+    cfg.image_size, cfg.out_size, cfg.emb_features = (H, W), (OH, OW), D
+    cfg.num_boxes, cfg.num_frames, cfg.batch_size = N, T, B
+    cfg.num_features_boxes = cfg.num_features_gcn = NFB
+    cfg.ST_kernel_size, cfg.sampling_ratio, cfg.num_DIM = kernels, ratios, num_dim
+    cfg.dynamic_sampling, cfg.scale_factor, cfg.beta_factor = True, True, beta
+    cfg.lite_dim, cfg.hierarchical_inference = lite, hier
+    cfg.train_backbone = True
+    cfg.train_dropout_prob = 0.3
+    torch.manual_seed(0)
+    model = refim.Dynamic_volleyball(cfg).to(dtype)
+    model.eval()                                   # dropout off, BN running stats
+    if backbone == "inv3":
+        # reference has no 'inv3' head branch (infer_model.py:203-216; SURVEY section 0 bug 1):
+        # oracle recipe = run the vgg16 branch (residual -> LN -> ReLU -> dropout)
+        model.cfg.backbone = "vgg16"
+    ocfg = O.OracleCfg(backbone=backbone, image_size=(H, W), out_size=(OH, OW), emb_features=D,
+                       num_boxes=N, num_frames=T, num_features_boxes=NFB, ST_kernel_size=kernels,
+                       sampling_ratio=ratios, num_DIM=num_dim, beta_factor=beta, lite_dim=lite,
+                       hierarchical_inference=hier)
+    shapes = O.model_param_shapes(ocfg)
+    p = O.synth_params(shapes, seed=seed + 3, din_std=0.02, dtype=dtype)
+    missing, unexpected = model.load_state_dict(p, strict=False)
+    bad = [k for k in missing if "num_batches_tracked" not in k]
+    assert not unexpected and not bad, (bad, unexpected)
+    images, boxes, labels = O.synth_inputs(B, T, N, H, W, OH, OW, 8, seed=seed)
+    images = images.to(dtype)
+    boxes = boxes.to(dtype)
+    ret = model((images, boxes))
+    loss = F.cross_entropy(ret["activities"], labels)
+    loss.backward()
+    ref_grads = {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}
+
+    po = {k: v.clone().requires_grad_("running_" not in k) for k, v in p.items()}
+    oret, inter = O.dynamic_volleyball_forward(ocfg, po, images, boxes, return_intermediates=True)
+    oloss = F.cross_entropy(oret["activities"], labels)
+    oloss.backward()
+    tol = 2e-4 if dtype == torch.float32 else 1e-10
+    e = close(oret["activities"], ret["activities"], tol, name + ".logits")
+    eg = 0.0
+    for k, v in ref_grads.items():
+        if po[k].grad is None:
+            raise AssertionError("oracle produced no grad for " + k)
+        eg = max(eg, close(po[k].grad, v, 50 * tol, name + ".grad." + k))
+    rec = dict(meta=np.array([B, T, N, H, W, OH, OW, D, NFB, num_dim, int(beta), lite or 0, int(hier)], dtype=np.int64),
+               backbone=np.array(backbone), kernels=np.array(kernels, dtype=np.int64),
+               ratios=np.array(ratios, dtype=np.int64), seed=np.int64(seed),
+               dtype=np.array(str(dtype).replace("torch.", "")),
+               logits=ret["activities"].detach().numpy(), loss=np.float64(loss.item()),
+               labels=labels.numpy())
+    for k, v in ref_grads.items():
+        rec["gsum." + k] = np.float64(v.double().sum().item())
+        rec["gabs." + k] = np.float64(v.double().abs().sum().item())
+    for k in ("fc_activities.weight", "fc_activities.bias", "nl_emb_1.weight"):
+        rec["g." + k] = ref_grads[k].numpy()
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
+    print(f"[model] {name}: logits rel err {e:.2e}, worst grad rel err {eg:.2e}, loss {loss.item():.6f}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--skip-big", action="store_true")
+    a = ap.parse_args()
+    sys.dont_write_bytecode = True
+    install_stubs()
+    sys.path.insert(0, a.ref)
+    os.makedirs(a.out, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    import importlib
+    refutils = importlib.import_module("utils")
+    refdin = importlib.import_module("infer_module.dynamic_infer_module")
+    refim = importlib.import_module("infer_model")
+    refcfg = importlib.import_module("config")
+
+    prep_case(refutils, a.out)
+    f32, f64 = torch.float32, torch.float64
+    # small, fully stored DIN cases (C=32) -- every structural variant that runs as shipped
+    din_case("din_k33_c32_f64", refdin, 2, 3, 12, 32, [(3, 3)], [1], False, 1, f64, a.out, 11, 21, offset_boost=8.0)
+    din_case("din_k33_c32", refdin, 2, 3, 12, 32, [(3, 3)], [1], False, 1, f32, a.out, 11, 21, offset_boost=8.0)
+    din_case("din_k13_c32", refdin, 2, 3, 12, 32, [(1, 3)], [1], False, 1, f32, a.out, 12, 22, offset_boost=8.0)
+    din_case("din_k31_c32", refdin, 2, 3, 12, 32, [(3, 1)], [1], False, 1, f32, a.out, 13, 23, offset_boost=8.0)
+    din_case("din_k33_r13_beta_c32", refdin, 2, 4, 12, 32, [(3, 3)], [1, 3], True, 1, f32, a.out, 14, 24, offset_boost=8.0)
+    din_case("din_2dim_k13_k31_c32", refdin, 2, 10, 12, 32, [(1, 3), (3, 1)], [1], False, 2, f32, a.out, 15, 25, offset_boost=8.0)
+    din_case("din_k33_zero_init_c32", refdin, 1, 3, 5, 32, [(3, 3)], [1], False, 1, f32, a.out, 16, 26, din_std=0.0)
+    din_case("din_k33_lite128", refdin, 2, 3, 12, 128, [(3, 3)], [1], False, 1, f32, a.out, 17, 27, offset_boost=4.0)
+    din_case("din_k33_n1_c32", refdin, 1, 3, 1, 32, [(3, 3)], [1], False, 1, f32, a.out, 18, 28, offset_boost=8.0)
+    din_case("din_k55_c32", refdin, 1, 5, 7, 32, [(5, 5)], [1], False, 1, f32, a.out, 19, 29, offset_boost=8.0)
+    if not a.skip_big:
+        # config-1 shape and the authors' smoke shape (inputs/weights from seeds, outputs stored)
+        din_case("din_k33_c1024_cfg1", refdin, 2, 3, 12, 1024, [(3, 3)], [1], False, 1, f32, a.out, 31, 41,
+                 store_full=False, din_std=0.02, offset_boost=1.0)
+        din_case("din_k33_c1024_smoke_t10", refdin, 1, 10, 12, 1024, [(3, 3)], [1], False, 1, f32, a.out, 32, 42,
+                 store_full=False, din_std=0.02, offset_boost=1.0)
+
+    # whole-network fixtures at reduced image sizes (reference wiring: trunk + head)
+    model_case("model_vgg16_96x160_nfb64", refim, refcfg, a.out, backbone="vgg16", H=96, W=160, OH=3, OW=5, D=512,
+               B=2, T=3, N=12, NFB=64, kernels=[(3, 3)], ratios=[1], seed=100)
+    model_case("model_vgg16_96x160_lite", refim, refcfg, a.out, backbone="vgg16", H=96, W=160, OH=3, OW=5, D=512,
+               B=2, T=3, N=12, NFB=64, kernels=[(3, 3)], ratios=[1], lite=32, seed=101)
+    model_case("model_vgg16_96x160_2dim", refim, refcfg, a.out, backbone="vgg16", H=96, W=160, OH=3, OW=5, D=512,
+               B=1, T=4, N=6, NFB=64, kernels=[(1, 3), (3, 1)], ratios=[1], num_dim=2, seed=102)
+    if not a.skip_big:
+        model_case("model_vgg16_192x320_nfb1024", refim, refcfg, a.out, backbone="vgg16", H=192, W=320, OH=6, OW=10,
+                   D=512, B=2, T=3, N=12, NFB=1024, kernels=[(3, 3)], ratios=[1], seed=103)
+        # Inception-v3: 299x299-ish small frame; OHxOW follows the layer arithmetic
+        model_case("model_inv3_139x203_nfb64", refim, refcfg, a.out, backbone="inv3", H=139, W=203, OH=15, OW=23,
+                   D=1056, B=1, T=3, N=6, NFB=64, kernels=[(3, 3)], ratios=[1], seed=104)
+    print("golden vectors written to", a.out)
+
+
+if __name__ == "__main__":
+    main()
