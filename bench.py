@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- clips/sec (fwd+bwd+Adam) of the DIN stage-2 hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched under torch.distributed.run, one
+rank per GPU over RCCL.  W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + torch.cuda.synchronize()
+on both sides, MAX over ranks, rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json): default = configs[1] "Volleyball stage-2 DIN, Inception-v3, T=3 ST_kernel=(3,3) N=12, bf16"
+with the global batch of configs[2] (32 clips) sharded over the ranks (strong scaling: total work fixed).
+`--workload vgg16_fp32|vgg16_bf16|inv3_fp32` select the other single-GPU configurations.
+A step = forward + cross-entropy + backward + gradient all-reduce (N>1) + fused Adam over one batch of synthetic,
+HBM-resident uint8 clips (inputs are on the device before the timed region starts).
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (implicit-GEMM gather conv, fwd+dgrad launches of the 128-filter tile variant): algorithmic
+                FLOPs per launch / live HIP-event launch time, against the dense MFMA peak of the compute dtype
+  cpu_baseline  the CPU oracle (oracle/din_oracle.py, torch-CPU fp32 "port") timed on this box's host cores on a bounded
+                sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+WORKLOADS = {
+    # name: (backbone, dtype, (OH, OW), D)
+    "inv3_bf16": ("inv3", "bf16", (87, 157), 1056),
+    "inv3_fp32": ("inv3", "fp32", (87, 157), 1056),
+    "vgg16_bf16": ("vgg16", "bf16", (22, 40), 512),
+    "vgg16_fp32": ("vgg16", "fp32", (22, 40), 512),
+}
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def make_cfg(workload, T=3, N=12, H=720, W=1280, lite=None):
+    from din_amd.config import Config
+    backbone, dt, out_size, D = WORKLOADS[workload]
+    cfg = Config("volleyball")
+    cfg.backbone, cfg.backbone_dtype, cfg.out_size, cfg.emb_features = backbone, dt, out_size, D
+    cfg.image_size, cfg.num_frames, cfg.num_boxes = (H, W), T, N
+    cfg.ST_kernel_size, cfg.sampling_ratio, cfg.num_DIM = [(3, 3)], [1], 1
+    cfg.dynamic_sampling, cfg.scale_factor, cfg.beta_factor = True, True, False
+    cfg.lite_dim, cfg.hierarchical_inference, cfg.train_backbone = lite, False, True
+    cfg.train_dropout_prob, cfg.set_bn_eval = 0.3, True
+    return cfg
+
+
+def synth_weights(model, seed=3):
+    """seeded synthetic weights: He-normal convs/linears are the module defaults; DIN predictors N(0, 0.02) so the
+    dynamic-walk path is exercised (the reference zero-inits them); BN running stats non-trivial."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if "p_conv" in name or "scale_conv" in name:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+        for name, b in model.named_buffers():
+            if name.endswith("running_var"):
+                b.copy_(0.5 + torch.rand(b.shape, generator=g))
+            elif name.endswith("running_mean"):
+                b.copy_(0.1 * torch.randn(b.shape, generator=g))
+
+
+def cpu_baseline(workload, T, N, H, W, budget_s=25.0):
+    """Oracle fwd+bwd on host cores for a bounded sample (B=1 clip per step)."""
+    from oracle import din_oracle as O
+    backbone, _dt, (OH, OW), D = WORKLOADS[workload]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ocfg = O.OracleCfg(backbone=backbone, image_size=(H, W), out_size=(OH, OW), emb_features=D, num_boxes=N, num_frames=T)
+    p = O.synth_params(O.model_param_shapes(ocfg), seed=3, din_std=0.02)
+    p = {k: v.requires_grad_("running_" not in k) for k, v in p.items()}
+    B = 1
+    images, boxes, labels = O.synth_inputs(B, T, N, H, W, OH, OW, 8, seed=0)
+    images = images.float()
+
+    def step():
+        for v in p.values():
+            v.grad = None
+        out = O.dynamic_volleyball_forward(ocfg, p, images, boxes)
+        F.cross_entropy(out["activities"], labels).backward()
+
+    t0 = time.time()
+    step()                                   # warm-up (also sizes the budget)
+    warm = time.time() - t0
+    n = max(1, min(5, int(budget_s / max(warm, 1e-3)) - 1))
+    t0 = time.time()
+    for _ in range(n):
+        step()
+    dt = (time.time() - t0) / n
+    return {"value": B / dt, "unit": "clips/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} timed fwd+bwd step(s) of B={B} clip (T={T}, {H}x{W}, {backbone}, fp32 torch-CPU oracle) after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="inv3_bf16", choices=sorted(WORKLOADS))
+    ap.add_argument("--global-batch", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-adam", action="store_true")
+    a = ap.parse_args()
+
+    from din_amd import nhwc, parallel
+    from din_amd.infer_model import Dynamic_volleyball
+    from din_amd.optim import FusedAdam
+
+    rank, local, world = parallel.init_from_env()
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    T, N, H, W = a.frames, 12, 720, 1280
+    backbone, dtype, (OH, OW), D = WORKLOADS[a.workload]
+    cfg = make_cfg(a.workload, T, N, H, W)
+    torch.manual_seed(0)
+    model = Dynamic_volleyball(cfg)
+    synth_weights(model)
+    model = model.to(dev).train()
+    parallel.broadcast_parameters(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = FusedAdam(params, lr=1e-4, weight_decay=0.0)
+    buckets = parallel.GradBuckets(params) if world > 1 else None
+
+    mine = parallel.shard_range(a.global_batch, rank, world)
+    B = len(mine)
+    from oracle.din_oracle import synth_inputs          # input generator only (numpy RNG recipe of SURVEY 8d), not a checker use
+    g = torch.Generator().manual_seed(1000 + rank)
+    images = torch.randint(0, 256, (B, T, 3, H, W), dtype=torch.uint8, generator=g).to(dev)     # uint8, HBM-resident
+    _, boxes, labels = synth_inputs(a.global_batch, T, N, 8, 8, OH, OW, 8, seed=0)
+    boxes, labels = boxes[mine.start:mine.stop].to(dev), labels[mine.start:mine.stop].to(dev)
+
+    def step():
+        opt.zero_grad()
+        ret = model((images, boxes))
+        loss = F.cross_entropy(ret["activities"], labels)
+        loss.backward()
+        if buckets is not None:
+            buckets.allreduce()
+        if not a.no_adam:
+            opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    nhwc.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof, nhwc.PROFILE = nhwc.PROFILE, None
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    # ---- roofline of the dominant kernel from the live HIP events -------------------------------------------
+    agg = {}
+    for kind, variant, flops, dt_, e0, e1 in prof:
+        rec = agg.setdefault(variant, [0.0, 0.0, 0])
+        rec[0] += flops
+        rec[1] += e0.elapsed_time(e1) * 1e-3
+        rec[2] += 1
+    dom = "gather_bn128"
+    fl, sec, cnt = agg.get(dom, [0.0, 1e-9, 1])
+    achieved = fl / sec / 1e12
+    peak = PEAK_TFLOPS[dtype]
+    roofline = {"bound": "mfma", "kernel": f"conv_gather_kernel<{'bf16' if dtype == 'bf16' else 'float'},128>",
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "traffic": None, "launches": cnt, "avg_launch_ms": round(sec / max(cnt, 1) * 1e3, 4),
+                "flops_per_launch_avg": fl / max(cnt, 1),
+                "other_kernels": {k: {"TFLOP/s": round(v[0] / max(v[1], 1e-9) / 1e12, 2), "launches": v[2],
+                                      "time_s": round(v[1], 4)} for k, v in agg.items() if k != dom}}
+    conv_time = sum(v[1] for v in agg.values())
+
+    if rank == 0:
+        clips = a.global_batch * a.steps if world > 1 else B * a.steps
+        out = {
+            "metric": "clips/sec (fwd+bwd), Volleyball DIN stage-2, BxTx12 actors",
+            "value": round(clips / elapsed, 3), "unit": "clips/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"Volleyball stage-2 DIN, {backbone}, T={T}, ST_kernel=(3,3), N=12, 720x1280, {dtype}",
+                       "global_batch": a.global_batch, "clips_per_gpu": B, "frames": T, "parallelism": f"dp{world}",
+                       "includes": "fwd + cross-entropy + bwd" + (" + RCCL grad all-reduce" if world > 1 else "")
+                                   + ("" if a.no_adam else " + fused Adam"),
+                       "bn_mode": "running statistics (set_bn_eval)" if backbone == "inv3" else "n/a"},
+            "roofline": roofline,
+            "conv_time_frac": round(conv_time / elapsed, 4),
+            "final_loss": round(float(loss.item()), 5),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.workload, T, N, H, W)
+            out["vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,129 @@
+"""ctypes binding of libdin_hip.so (C ABI declared in include/din_hip.h).
+
+The product path has NO fallback: if the shared library is missing or was built for another
+target this module raises, and every op raises on non-GPU tensors.  The library travels in-tree
+(built by `__graft_entry__.build()` / `make -C .../csrc`), never from site-packages.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import subprocess
+from typing import Dict, List
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdin_hip.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "din_hip.h")
+
+DIN_F32, DIN_BF16 = 0, 1
+CONV_BIAS, CONV_RELU, CONV_ACCUM, CONV_MASK = 1, 2, 4, 8
+
+
+class DinError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nb", "h", "w", "cin", "oh", "ow", "cout", "kh", "kw", "sh", "sw", "ph", "pw", "dh", "dw",
+        "ldi", "cioff", "ldo", "cooff", "dtype")]
+
+
+class PoolDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nb", "h", "w", "c", "oh", "ow", "k", "stride", "pad", "ldi", "cioff", "ldo", "cooff", "dtype")]
+
+
+_P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+_CD, _PD = C.POINTER(ConvDesc), C.POINTER(PoolDesc)
+
+# name -> (restype, argtypes); mirrors include/din_hip.h one to one
+SIGNATURES: Dict[str, tuple] = {
+    "din_abi_version": (_I, []),
+    "din_last_error_string": (C.c_char_p, []),
+    "din_build_arch": (C.c_char_p, []),
+    "din_prep_images_f32": (_I, [_P, _P, _L, _P]),
+    "din_prep_images_nhwc": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "din_conv_packed_elems": (_L, [_CD, _I]),
+    "din_conv_pack_weights": (_I, [_CD, _P, _P, _P, _I, _P]),
+    "din_conv_workspace_bytes": (_L, [_CD, _I]),
+    "din_conv_fwd": (_I, [_CD, _P, _P, _P, _P, _I, _P, _L, _P]),
+    "din_conv_dgrad": (_I, [_CD, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P]),
+    "din_conv_wgrad": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P]),
+    "din_bn_fold": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
+    "din_bn_fold_bwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
+    "din_maxpool_fwd": (_I, [_PD, _P, _P, _P]),
+    "din_maxpool_bwd": (_I, [_PD, _P, _P, _P, _I, _I, _P]),
+    "din_avgpool_fwd": (_I, [_PD, _P, _P, _P]),
+    "din_avgpool_bwd": (_I, [_PD, _P, _P, _P, _I, _P]),
+    "din_bilinear_fwd": (_I, [_PD, _P, _P, _P]),
+    "din_bilinear_bwd": (_I, [_PD, _P, _P, _P, _I, _P]),
+    "din_roi_align_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P]),
+    "din_roi_align_bwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
+    "din_grad_cast_mask": (_I, [_P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _I, _P]),
+    "din_boxes_frame_index": (_I, [_P, _I, _I, _P]),
+    "din_layernorm_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _L, _L, _I, _F, _U64, _P]),
+    "din_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _F, _U64, _P]),
+    "din_walk_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "din_walk_bwd": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "din_head_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "din_head_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "din_axpby": (_I, [_P, _P, _P, _F, _F, _L, _P]),
+    "din_scale_by_param": (_I, [_P, _P, _I, _P, _I, _L, _P]),
+    "din_dot_accum": (_I, [_P, _P, _P, _I, _L, _P]),
+    "din_cast": (_I, [_P, _I, _P, _I, _L, _P]),
+    "din_nhwc_to_nchw_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "din_nchw_f32_to_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
+    "din_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
+}
+
+_lib = None
+
+
+def header_symbols() -> List[str]:
+    """Every function name include/din_hip.h declares (used by the CPU symbol test)."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(din_[a-z0-9_]+)\s*\(", text)))
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into the in-tree libdin_hip.so (hipcc cross-compiles w/o a GPU)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j", str(os.cpu_count() or 4)]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise DinError("building libdin_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def load():
+    """Load the library (once).  Raises DinError loudly -- there is no CPU/eager fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DinError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       f"(or `make -C {CSRC_DIR}`); the DIN hot path has no fallback implementation")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise DinError(f"libdin_hip.so does not export {name}; stale build?") from e
+        fn.restype, fn.argtypes = res, args
+    if lib.din_abi_version() != 1:
+        raise DinError(f"libdin_hip.so ABI version {lib.din_abi_version()} != 1")
+    if lib.din_build_arch() != b"gfx950":
+        raise DinError("libdin_hip.so was not built for gfx950")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().din_last_error_string().decode("utf-8", "replace")
+        raise DinError(f"{what or 'libdin_hip'} failed (code {rc}): {msg}")

@@ -1,0 +1,245 @@
+"""MyVGG16 / MyInception_v3 -- drop-in for the reference's backbone/backbone.py:10-99 on MI355X.
+
+Same class names, constructor arguments, `forward(x) -> list of NCHW feature maps` contract and state_dict keys
+(`features.<i>.{weight,bias}` / torchvision Inception naming), but the conv stacks execute as one NHWC graph of
+hand-written gfx950 kernels (din_amd.nhwc).  `forward_nhwc(images)` is the fast path used by Dynamic_volleyball:
+raw 0..255 images in (uint8 welcome), prep_images fused into the loader, pixel-major buffers out, no layout copies.
+
+Weights: there is no network here, so `pretrained=True` only records the request; real torchvision / stage-1
+weights drop in through load_state_dict (key names are identical).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from ..nhwc import Graph, GraphBuilder, NHWCGraphFunction, View
+from ..ops import NHWCToNCHWFunction
+
+VGG16_TABLE = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M")
+
+
+def _dt(compute_dtype: str) -> int:
+    if compute_dtype in ("fp32", "float32", "f32"):
+        return L.DIN_F32
+    if compute_dtype in ("bf16", "bfloat16"):
+        return L.DIN_BF16
+    raise ValueError(f"compute_dtype must be 'fp32' or 'bf16', got {compute_dtype!r}")
+
+
+def _cpad_image(dt: int) -> int:
+    return 4 if dt == L.DIN_F32 else 8
+
+
+class _GraphBackbone(nn.Module):
+    """Common machinery: lazily builds (and caches) the NHWC graph for an input size and runs it."""
+
+    def __init__(self, compute_dtype: str = "fp32"):
+        super().__init__()
+        self.compute_dtype = compute_dtype
+        self._graphs: Dict[Tuple[int, int, int], Graph] = {}
+
+    # subclasses: build_graph(h, w, dt) -> Graph ; named params must match graph.param_names() with prefix removed
+    def build_graph(self, h: int, w: int, dt: int) -> Graph:
+        raise NotImplementedError
+
+    def graph_for(self, h: int, w: int) -> Tuple[Graph, int]:
+        dt = _dt(self.compute_dtype)
+        key = (h, w, dt)
+        if key not in self._graphs:
+            self._graphs[key] = self.build_graph(h, w, dt)
+        return self._graphs[key], dt
+
+    def _ordered_params(self, graph: Graph) -> List[torch.Tensor]:
+        table = dict(self.named_parameters())
+        table.update(dict(self.named_buffers()))
+        return [table[n] for n in graph.param_names()]
+
+    def forward_nhwc(self, images: torch.Tensor, prenormalised: bool = False):
+        """images [NB,3,H,W] (uint8 or float, 0..255 unless prenormalised).  Returns (list of NHWC buffers, graph)."""
+        graph, dt = self.graph_for(images.shape[2], images.shape[3])
+        outs = NHWCGraphFunction.apply(graph, dt, images, prenormalised, *self._ordered_params(graph))
+        if not isinstance(outs, tuple):
+            outs = (outs,)
+        return list(outs), graph
+
+    def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
+        """API parity with the reference: x is already normalised (prep_images), returns NCHW fp32 maps."""
+        bufs, graph = self.forward_nhwc(x, prenormalised=True)
+        outs = []
+        for buf, (tid, coff, c) in zip(bufs, self.output_views(graph)):
+            outs.append(NHWCToNCHWFunction.apply(buf, coff, c, graph.tensors[tid].relu_masked))
+        return outs
+
+    def output_views(self, graph: Graph):
+        return [(t, 0, graph.tensors[t].c) for t in graph.output_tids]
+
+
+class MyVGG16(_GraphBackbone):
+    """reference backbone/backbone.py:88-99 (torchvision vgg16().features, table 'D')."""
+
+    def __init__(self, pretrained: bool = False, compute_dtype: str = "fp32"):
+        super().__init__(compute_dtype)
+        self.pretrained_requested = pretrained
+        layers, cin = [], 3
+        for v in VGG16_TABLE:
+            if v == "M":
+                layers.append(nn.Identity())             # placeholder keeps torchvision's Sequential indices
+            else:
+                conv = nn.Conv2d(cin, v, kernel_size=3, padding=1)
+                nn.init.normal_(conv.weight, 0.0, math.sqrt(2.0 / (cin * 9)))
+                nn.init.zeros_(conv.bias)
+                layers += [conv, nn.Identity()]
+                cin = v
+        self.features = nn.Sequential(*layers)
+
+    def build_graph(self, h, w, dt) -> Graph:
+        gb = GraphBuilder(h, w, _cpad_image(dt))
+        v = gb.full(gb.g.input_tid)
+        idx = 0
+        for item in VGG16_TABLE:
+            if item == "M":
+                v = gb.pool("maxpool", v, 2, 2, 0)
+                idx += 1
+            else:
+                v = gb.conv(f"features.{idx}", v, item, (3, 3), (1, 1), (1, 1), relu=True, bias=True)
+                idx += 2
+        gb.g.output_tids = [v.tid]
+        return gb.g
+
+
+class _BasicConv2d(nn.Module):
+    """parameter holder with torchvision's names: .conv.weight, .bn.{weight,bias,running_mean,running_var}"""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, kernel_size=k, bias=False)
+        self.bn = nn.BatchNorm2d(cout, eps=0.001)
+        nn.init.normal_(self.conv.weight, 0.0, math.sqrt(2.0 / (cin * k[0] * k[1])))
+
+
+def _inception_specs():
+    """(module path, cin, cout, k, s, p) for every BasicConv2d up to Mixed_6e (torchvision Inception3)."""
+    def a(pre, cin, pf):
+        return [(pre + "branch1x1", cin, 64, (1, 1), (1, 1), (0, 0)), (pre + "branch5x5_1", cin, 48, (1, 1), (1, 1), (0, 0)),
+                (pre + "branch5x5_2", 48, 64, (5, 5), (1, 1), (2, 2)), (pre + "branch3x3dbl_1", cin, 64, (1, 1), (1, 1), (0, 0)),
+                (pre + "branch3x3dbl_2", 64, 96, (3, 3), (1, 1), (1, 1)), (pre + "branch3x3dbl_3", 96, 96, (3, 3), (1, 1), (1, 1)),
+                (pre + "branch_pool", cin, pf, (1, 1), (1, 1), (0, 0))]
+
+    def b(pre, cin):
+        return [(pre + "branch3x3", cin, 384, (3, 3), (2, 2), (0, 0)), (pre + "branch3x3dbl_1", cin, 64, (1, 1), (1, 1), (0, 0)),
+                (pre + "branch3x3dbl_2", 64, 96, (3, 3), (1, 1), (1, 1)), (pre + "branch3x3dbl_3", 96, 96, (3, 3), (2, 2), (0, 0))]
+
+    def c(pre, cin, c7):
+        return [(pre + "branch1x1", cin, 192, (1, 1), (1, 1), (0, 0)), (pre + "branch7x7_1", cin, c7, (1, 1), (1, 1), (0, 0)),
+                (pre + "branch7x7_2", c7, c7, (1, 7), (1, 1), (0, 3)), (pre + "branch7x7_3", c7, 192, (7, 1), (1, 1), (3, 0)),
+                (pre + "branch7x7dbl_1", cin, c7, (1, 1), (1, 1), (0, 0)), (pre + "branch7x7dbl_2", c7, c7, (7, 1), (1, 1), (3, 0)),
+                (pre + "branch7x7dbl_3", c7, c7, (1, 7), (1, 1), (0, 3)), (pre + "branch7x7dbl_4", c7, c7, (7, 1), (1, 1), (3, 0)),
+                (pre + "branch7x7dbl_5", c7, 192, (1, 7), (1, 1), (0, 3)), (pre + "branch_pool", cin, 192, (1, 1), (1, 1), (0, 0))]
+
+    s = [("Conv2d_1a_3x3", 3, 32, (3, 3), (2, 2), (0, 0)), ("Conv2d_2a_3x3", 32, 32, (3, 3), (1, 1), (0, 0)),
+         ("Conv2d_2b_3x3", 32, 64, (3, 3), (1, 1), (1, 1)), ("Conv2d_3b_1x1", 64, 80, (1, 1), (1, 1), (0, 0)),
+         ("Conv2d_4a_3x3", 80, 192, (3, 3), (1, 1), (0, 0))]
+    s += a("Mixed_5b.", 192, 32) + a("Mixed_5c.", 256, 64) + a("Mixed_5d.", 288, 64) + b("Mixed_6a.", 288)
+    s += c("Mixed_6b.", 768, 128) + c("Mixed_6c.", 768, 160) + c("Mixed_6d.", 768, 160) + c("Mixed_6e.", 768, 192)
+    return s
+
+
+class MyInception_v3(_GraphBackbone):
+    """reference backbone/backbone.py:10-85: Inception-v3 truncated after Mixed_6e, outputs [Mixed_5d, Mixed_6e].
+
+    BatchNorm runs with running statistics (the reference's `set_bn_eval` mode, train_net_dynamic.py:17-20), folded into
+    the packed filters; gamma/beta still receive gradients.  Batch-statistics BN is not implemented."""
+
+    def __init__(self, transform_input: bool = False, pretrained: bool = False, compute_dtype: str = "fp32"):
+        super().__init__(compute_dtype)
+        if transform_input:
+            raise NotImplementedError("transform_input=True is never used by the DIN path (infer_model.py:32)")
+        self.transform_input = transform_input
+        self.pretrained_requested = pretrained
+        self._specs = _inception_specs()
+        for path, cin, cout, k, _s, _p in self._specs:
+            mod = self
+            parts = path.split(".")
+            for part in parts[:-1]:
+                if not hasattr(mod, part):
+                    setattr(mod, part, nn.Module())
+                mod = getattr(mod, part)
+            setattr(mod, parts[-1], _BasicConv2d(cin, cout, k))
+        self.fuse_output_size = None      # set by the model: (OH, OW) -> append the fused [5d | resize(6e)] tensor
+
+    def build_graph(self, h, w, dt) -> Graph:
+        gb = GraphBuilder(h, w, _cpad_image(dt))
+        spec = {s[0]: s for s in self._specs}
+
+        def bc(name, src: View, dst=None) -> View:
+            _, _cin, cout, k, s, p = spec[name]
+            return gb.conv(name, src, cout, k, s, p, relu=True, bn=True, dst=dst)
+
+        v = gb.full(gb.g.input_tid)
+        v = bc("Conv2d_1a_3x3", v)
+        v = bc("Conv2d_2a_3x3", v)
+        v = bc("Conv2d_2b_3x3", v)
+        v = gb.pool("maxpool", v, 3, 2, 0)
+        v = bc("Conv2d_3b_1x1", v)
+        v = bc("Conv2d_4a_3x3", v)
+        v = gb.pool("maxpool", v, 3, 2, 0)
+        ts = gb.g.tensors[v.tid]
+        h5, w5 = ts.h, ts.w
+        fused_tid = None
+        for blk, pf in (("Mixed_5b.", 32), ("Mixed_5c.", 64), ("Mixed_5d.", 64)):
+            ctot = 64 + 64 + 96 + pf
+            if blk == "Mixed_5d." :
+                # Mixed_5d writes straight into the fused multi-scale tensor [5d (288) | resize(6e) (768)]
+                fused_tid = gb.tensor(h5, w5, ctot + 768)
+                out_tid, base = fused_tid, 0
+            else:
+                out_tid, base = gb.tensor(h5, w5, ctot), 0
+            bc(blk + "branch1x1", v, View(out_tid, base, 64))
+            t = bc(blk + "branch5x5_1", v)
+            bc(blk + "branch5x5_2", t, View(out_tid, base + 64, 64))
+            t = bc(blk + "branch3x3dbl_1", v)
+            t = bc(blk + "branch3x3dbl_2", t)
+            bc(blk + "branch3x3dbl_3", t, View(out_tid, base + 128, 96))
+            t = gb.pool("avgpool", v, 3, 1, 1)
+            bc(blk + "branch_pool", t, View(out_tid, base + 224, pf))
+            v = View(out_tid, base, ctot)
+        v5d = v
+        # Mixed_6a (InceptionB)
+        h6, w6 = (h5 - 3) // 2 + 1, (w5 - 3) // 2 + 1
+        out_tid = gb.tensor(h6, w6, 768)
+        bc("Mixed_6a.branch3x3", v, View(out_tid, 0, 384))
+        t = bc("Mixed_6a.branch3x3dbl_1", v)
+        t = bc("Mixed_6a.branch3x3dbl_2", t)
+        bc("Mixed_6a.branch3x3dbl_3", t, View(out_tid, 384, 96))
+        gb.pool("maxpool", v, 3, 2, 0, View(out_tid, 480, 288))
+        gb.g.tensors[out_tid].relu_masked = True     # pool branch of ReLU outputs: masking by (y>0) is exact
+        v = View(out_tid, 0, 768)
+        for blk in ("Mixed_6b.", "Mixed_6c.", "Mixed_6d.", "Mixed_6e."):
+            out_tid = gb.tensor(h6, w6, 768)
+            bc(blk + "branch1x1", v, View(out_tid, 0, 192))
+            t = bc(blk + "branch7x7_1", v)
+            t = bc(blk + "branch7x7_2", t)
+            bc(blk + "branch7x7_3", t, View(out_tid, 192, 192))
+            t = bc(blk + "branch7x7dbl_1", v)
+            t = bc(blk + "branch7x7dbl_2", t)
+            t = bc(blk + "branch7x7dbl_3", t)
+            t = bc(blk + "branch7x7dbl_4", t)
+            bc(blk + "branch7x7dbl_5", t, View(out_tid, 384, 192))
+            t = gb.pool("avgpool", v, 3, 1, 1)
+            bc(blk + "branch_pool", t, View(out_tid, 576, 192))
+            v = View(out_tid, 0, 768)
+        # multiscale fuse (infer_model.py:165-172): resize Mixed_6e to the Mixed_5d grid into channels [288, 1056)
+        gb.bilinear(v, View(fused_tid, 288, 768))
+        gb.g.tensors[fused_tid].relu_masked = True   # bilinear of non-negative maps: zero output <=> all taps zero
+        gb.g.output_tids = [fused_tid, v.tid]
+        self._v5d = v5d
+        return gb.g
+
+    def output_views(self, graph: Graph):
+        fused, t6e = graph.output_tids
+        return [(fused, 0, 288), (t6e, 0, 768)]

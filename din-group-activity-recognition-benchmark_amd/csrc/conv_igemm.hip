@@ -1,0 +1,871 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): fwd / dgrad share one gather kernel, wgrad has its own.
+//
+//   D[co][pix] = sum_k  Wpk[co][k] * im2col(X)[pix][k]          k = (r, s, ci)   (NHWC, ci contiguous)
+//
+// One template covers both storage types because the byte geometry is identical: every operand moves in
+// 16-byte "chunks" along the reduction axis (4 fp32 or 8 bf16).  A lane feeds the MFMA one chunk:
+//   bf16 : v_mfma_f32_16x16x32_bf16  -- the chunk is the lane's 8 k-values          (1 MFMA / chunk set)
+//   fp32 : v_mfma_f32_16x16x4_f32    -- element j of the chunk feeds the j-th of 4 MFMAs (exact fp32)
+// (the k order inside a k-step is permuted identically for both operands, which a sum does not care about).
+//
+// Tile: 128 pixels x BN (128|64) filters per 256-thread workgroup (4 waves as 2x2), k-step = 8 chunks
+// (128 B per row), LDS double-buffered with an XOR swizzle (chunk ^ ((row>>1)&7)) that makes both the
+// 8-lane ds_write_b128 groups and the 16-lane ds_read_b128 groups conflict-free.  The MFMA's i index is the
+// FILTER and j the PIXEL so that a lane ends up holding 4 consecutive output channels of one pixel
+// (16-/8-byte NHWC stores).  Epilogue fuses bias, ReLU, the ReLU-backward mask, accumulation and the
+// channel-offset write that makes torch.cat free.
+//
+// Replaces the arithmetic of torch.nn.Conv2d / nn.Linear reached from the reference at
+// backbone/backbone.py:44-99, infer_model.py:184,190,226 and infer_module/dynamic_infer_module.py:149,191,195.
+#include "din_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BM = 128;      // pixels per workgroup tile
+constexpr int KC = 8;        // 16-byte chunks per k-step (=> 128 B per tile row)
+constexpr int NTHREADS = 256;
+
+struct ConvK {
+    const void* in; const void* w; void* out; const float* bias; const void* mask; float* partial;
+    int NB, H, W, Cin, ldi, cioff;
+    int OH, OW, Cout, ldo, cooff;
+    int kh, kw;
+    int ay, by, cy, divy;       // ty = oy*ay + by + r*cy ; needs ty % divy == 0 ; iy = ty / divy
+    int ax, bx, cx, divx;
+    int cpt, Q, nk, M, wld;     // chunks per tap, total chunks, k-steps, pixels, packed row length (chunks)
+    int flags, ldm, moff;
+    int splitk, ks_per_split, n_co_tiles;
+};
+
+__device__ __forceinline__ int lds_slot(int row, int chunk) { return row * KC + (chunk ^ ((row >> 1) & 7)); }
+
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+    __device__ static void run(const u32x4& a, const u32x4& b, f32x4& c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16_t> {
+    __device__ static void run(const u32x4& a, const u32x4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// fwd / dgrad gather kernel
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BN>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(ConvK p) {
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int TI = BN / 32;          // filter 16-tiles per wave
+    constexpr int TJ = BM / 32;          // pixel 16-tiles per wave (=4)
+    constexpr int PA = BM / 32;          // loader passes over the pixel tile
+    constexpr int PB = BN / 32;          // loader passes over the filter tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* smem = reinterpret_cast<u32x4*>(smem_raw);
+    // layout: [buf][ A: BM*KC | B: BN*KC ] in 16-byte units
+    constexpr int BUF = (BM + BN) * KC;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;          // wave position: pixels x filters
+    const int bid = blockIdx.x;
+    const int co_tile = bid % p.n_co_tiles;
+    const int px_tile = bid / p.n_co_tiles;
+    const int split = blockIdx.y;
+    const int ks_begin = split * p.ks_per_split;
+    int ks_end = ks_begin + p.ks_per_split;
+    if (ks_end > p.nk) ks_end = p.nk;
+
+    // ---- loader coordinates -------------------------------------------------------------------
+    const int cq = tid & 7, r0 = tid >> 3;
+    int tyb[PA], txb[PA], nbase[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        int m = px_tile * BM + r0 + 32 * i;
+        if (m < p.M) {
+            int n = m / (p.OH * p.OW);
+            int rem = m - n * (p.OH * p.OW);
+            int oy = rem / p.OW, ox = rem - oy * p.OW;
+            tyb[i] = oy * p.ay + p.by;
+            txb[i] = ox * p.ax + p.bx;
+            nbase[i] = n * p.H * p.W;
+        } else {
+            tyb[i] = -(1 << 28); txb[i] = 0; nbase[i] = 0;     // always out of range -> zeros
+        }
+    }
+    const T* __restrict__ inp = reinterpret_cast<const T*>(p.in);
+    const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(p.w);
+
+    u32x4 ga[PA], gb[PB];
+    auto load_global = [&](int ks) {
+        const int q = ks * KC + cq;
+        const bool qok = q < p.Q;
+        int tap = qok ? q / p.cpt : 0;
+        int cc = q - tap * p.cpt;
+        int r = tap / p.kw, s = tap - r * p.kw;
+        const int dyk = r * p.cy, dxk = s * p.cx;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            int ty = tyb[i] + dyk, tx = txb[i] + dxk;
+            bool ok = qok && ty >= 0 && tx >= 0;
+            int iy = ty, ix = tx;
+            if (p.divy > 1) { iy = ty / p.divy; ok = ok && (iy * p.divy == ty); }
+            if (p.divx > 1) { ix = tx / p.divx; ok = ok && (ix * p.divx == tx); }
+            ok = ok && iy < p.H && ix < p.W;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) {
+                int64_t off = (int64_t)(nbase[i] + iy * p.W + ix) * p.ldi + p.cioff + cc * EPC;
+                v = *reinterpret_cast<const u32x4*>(inp + off);
+            }
+            ga[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            int row = co_tile * BN + r0 + 32 * i;
+            gb[i] = wp[(int64_t)row * p.wld + ks * KC + cq];
+        }
+    };
+    auto store_lds = [&](int buf) {
+        u32x4* A = smem + buf * BUF;
+        u32x4* B = A + BM * KC;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) A[lds_slot(r0 + 32 * i, cq)] = ga[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) B[lds_slot(r0 + 32 * i, cq)] = gb[i];
+    };
+
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    if (ks_begin < ks_end) {
+        load_global(ks_begin);
+        store_lds(0);
+        __syncthreads();
+        for (int ks = ks_begin; ks < ks_end; ++ks) {
+            const int cur = (ks - ks_begin) & 1;
+            const bool more = ks + 1 < ks_end;
+            if (more) load_global(ks + 1);
+            const u32x4* A = smem + cur * BUF;
+            const u32x4* B = A + BM * KC;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x4 wf[TI], xf[TJ];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) wf[i] = B[lds_slot(wn * (BN / 2) + i * 16 + frow, kk * 4 + fchunk)];
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) xf[j] = A[lds_slot(wm * (BM / 2) + j * 16 + frow, kk * 4 + fchunk)];
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
+            }
+            if (more) store_lds(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------
+    // lane holds D[co = co0 + i*16 + (lane>>4)*4 + e][pix = pix0 + j*16 + (lane&15)], e = 0..3
+    const int co_base = co_tile * BN + wn * (BN / 2) + (lane >> 4) * 4;
+    const int px_base = px_tile * BM + wm * (BM / 2) + (lane & 15);
+    if (p.splitk > 1) {
+        // raw fp32 partial sums: partial[split][pix][cout_pad]   (cout_pad = n_co_tiles*BN)
+        const int cpad = p.n_co_tiles * BN;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            int m = px_base + j * 16;
+            if (m >= p.M) continue;
+            float* dst = p.partial + ((int64_t)split * p.M + m) * cpad;
+#pragma unroll
+            for (int i = 0; i < TI; ++i) *reinterpret_cast<f32x4*>(dst + co_base + i * 16) = acc[i][j];
+        }
+        return;
+    }
+    T* __restrict__ outp = reinterpret_cast<T*>(p.out);
+    const T* __restrict__ maskp = reinterpret_cast<const T*>(p.mask);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        int m = px_base + j * 16;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            int co = co_base + i * 16;
+            if (co >= p.Cout) continue;
+            f32x4 v = acc[i][j];
+            int64_t o = (int64_t)m * p.ldo + p.cooff + co;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (co + e >= p.Cout) break;
+                float x = v[e];
+                if (p.flags & DIN_CONV_BIAS) x += p.bias[co + e];
+                if (p.flags & DIN_CONV_RELU) x = fmaxf(x, 0.f);
+                if (p.flags & DIN_CONV_MASK) {
+                    float y = Elem<T>::ld(maskp + (int64_t)m * p.ldm + p.moff + co + e);
+                    x = y > 0.f ? x : 0.f;
+                }
+                if (p.flags & DIN_CONV_ACCUM) x += Elem<T>::ld(outp + o + e);
+                v[e] = x;
+            }
+            if (co + 3 < p.Cout && ((o & 3) == 0)) {
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<f32x4*>(outp + o) = v;
+                } else {
+                    u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(outp + o) = pk;
+                }
+            } else {
+                for (int e = 0; e < 4 && co + e < p.Cout; ++e) Elem<T>::st(outp + o + e, v[e]);
+            }
+        }
+    }
+}
+
+// split-K finish: out = epilogue(sum_s partial[s])
+template <typename T>
+__global__ void conv_splitk_finish_kernel(ConvK p, int cpad) {
+    int64_t total = (int64_t)p.M * p.Cout;
+    T* __restrict__ outp = reinterpret_cast<T*>(p.out);
+    const T* __restrict__ maskp = reinterpret_cast<const T*>(p.mask);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int m = (int)(i / p.Cout), co = (int)(i - (int64_t)m * p.Cout);
+        float x = 0.f;
+        for (int s = 0; s < p.splitk; ++s) x += p.partial[((int64_t)s * p.M + m) * cpad + co];
+        if (p.flags & DIN_CONV_BIAS) x += p.bias[co];
+        if (p.flags & DIN_CONV_RELU) x = fmaxf(x, 0.f);
+        if (p.flags & DIN_CONV_MASK) {
+            float y = Elem<T>::ld(maskp + (int64_t)m * p.ldm + p.moff + co);
+            x = y > 0.f ? x : 0.f;
+        }
+        int64_t o = (int64_t)m * p.ldo + p.cooff + co;
+        if (p.flags & DIN_CONV_ACCUM) x += Elem<T>::ld(outp + o);
+        Elem<T>::st(outp + o, x);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing:  w[cout][cin][kh][kw] fp32 (* scale[cout]) -> T[rows_pad][nk*KC*EPC]
+//   transposed = 0: row = co, k = (r,s,ci)      (fwd)
+//   transposed = 1: row = ci, k = (r,s,co)      (dgrad)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void conv_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ out,
+                                 int cout, int cin, int kh, int kw, int rows, int rows_pad, int inner, int inner_pad,
+                                 int kelems, int transposed) {
+    // inner = reduction channels per tap (cin or cout), inner_pad = padded to EPC; kelems = padded row length
+    int64_t total = (int64_t)rows_pad * kelems;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int row = (int)(i / kelems), k = (int)(i - (int64_t)row * kelems);
+        int tap = k / inner_pad, c = k - tap * inner_pad;
+        float v = 0.f;
+        if (row < rows && tap < kh * kw && c < inner) {
+            int r = tap / kw, s = tap - r * kw;
+            int co = transposed ? c : row, ci = transposed ? row : c;
+            v = w[(((int64_t)co * cin + ci) * kh + r) * kw + s];
+            if (scale) v *= scale[co];
+        }
+        Elem<T>::st(out + i, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad:  dW[co][(r,s,ci)] = sum_pix G[pix][co] * im2col(X)[pix][(r,s,ci)]
+// 128 (co) x 128 (k columns) tile per workgroup, reduction over a slice of the pixels; partials to a
+// workspace [slice][cout_pad][kcols_pad] fp32, reduced (and un-permuted to [cout][cin][kh][kw]) afterwards.
+// ------------------------------------------------------------------------------------------------
+struct WgradK {
+    const void* in; const void* g; float* partial;
+    int NB, H, W, Cin, ldi, cioff;
+    int OH, OW, Cout, ldo, cooff;
+    int kh, kw, sh, sw, ph, pw, dh, dw;
+    int cin_pad, kcols, kcols_pad, cout_pad;   // kcols = kh*kw*cin_pad
+    int M, n_co_tiles, n_k_tiles, slices, m_per_slice;
+};
+
+constexpr int WG_TILE = 128;
+
+// fp32: 16 pixels per k-step, operands read with ds_read_b32 (lane k-index = pixel row)
+__global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_f32_kernel(WgradK p) {
+    constexpr int PK = 16;
+    constexpr int RS = WG_TILE + 16;     // padded row (floats): 4 k-rows hit 4 disjoint bank ranges
+    __shared__ float Gs[2][PK][RS];
+    __shared__ float Xs[2][PK][RS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    int bid = blockIdx.x;
+    const int k_tile = bid % p.n_k_tiles;
+    const int co_tile = bid / p.n_k_tiles;
+    const int slice = blockIdx.y;
+    const int m_begin = slice * p.m_per_slice;
+    int m_end = m_begin + p.m_per_slice;
+    if (m_end > p.M) m_end = p.M;
+
+    // loader: 16 rows x 32 chunks (of 4 floats) per operand -> 2 chunks per thread per operand
+    const int cc = tid & 31, rr = tid >> 5;         // chunk column 0..31, row 0..7 (+8)
+    // fixed k column of this thread's X chunk
+    const int kcol = k_tile * WG_TILE + cc * 4;
+    const bool kok = kcol < p.kcols;
+    const int tap = kok ? kcol / p.cin_pad : 0;
+    const int ci = kcol - tap * p.cin_pad;
+    const int r = tap / p.kw, s = tap - r * p.kw;
+    const bool ci_ok = kok && ci < p.Cin;           // Cin % 4 == 0 is enforced by the host unless cin_pad>Cin (conv1)
+    const int gco = co_tile * WG_TILE + cc * 4;
+    const float* __restrict__ inp = reinterpret_cast<const float*>(p.in);
+    const float* __restrict__ gp = reinterpret_cast<const float*>(p.g);
+
+    // pixel coordinates of the two rows this thread loads, advanced incrementally (no divisions in the loop)
+    int pn[2], py[2], px[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int m = m_begin + rr + 8 * i;
+        int n = m / (p.OH * p.OW);
+        int rem = m - n * (p.OH * p.OW);
+        pn[i] = n; py[i] = rem / p.OW; px[i] = rem - py[i] * p.OW;
+    }
+    f32x4 xa[2], ga[2];
+    auto load_global = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int m = m0 + rr + 8 * i;
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f}, gv = {0.f, 0.f, 0.f, 0.f};
+            if (m < m_end) {
+                int iy = py[i] * p.sh - p.ph + r * p.dh, ix = px[i] * p.sw - p.pw + s * p.dw;
+                if (ci_ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                    const float* src = inp + (int64_t)((pn[i] * p.H + iy) * p.W + ix) * p.ldi + p.cioff + ci;
+                    if (ci + 3 < p.Cin) xv = *reinterpret_cast<const f32x4*>(src);
+                    else for (int e = 0; e < 4 && ci + e < p.Cin; ++e) xv[e] = src[e];
+                }
+                if (gco < p.Cout) {
+                    const float* src = gp + (int64_t)m * p.ldo + p.cooff + gco;
+                    if (gco + 3 < p.Cout) gv = *reinterpret_cast<const f32x4*>(src);
+                    else for (int e = 0; e < 4 && gco + e < p.Cout; ++e) gv[e] = src[e];
+                }
+            }
+            xa[i] = xv; ga[i] = gv;
+            // advance this row by PK pixels
+            px[i] += PK;
+            while (px[i] >= p.OW) { px[i] -= p.OW; if (++py[i] == p.OH) { py[i] = 0; ++pn[i]; } }
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4*>(&Xs[buf][rr + 8 * i][cc * 4]) = xa[i];
+            *reinterpret_cast<f32x4*>(&Gs[buf][rr + 8 * i][cc * 4]) = ga[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fcol = lane & 15, frow = lane >> 4;
+    if (m_begin < m_end) {
+        load_global(m_begin);
+        store_lds(0);
+        __syncthreads();
+        int it = 0;
+        for (int m0 = m_begin; m0 < m_end; m0 += PK, ++it) {
+            const int cur = it & 1;
+            const bool more = m0 + PK < m_end;
+            if (more) load_global(m0 + PK);
+#pragma unroll
+            for (int kk = 0; kk < PK / 4; ++kk) {
+                float gf[4], xf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gf[i] = Gs[cur][kk * 4 + frow][wm * 64 + i * 16 + fcol];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xf[j] = Xs[cur][kk * 4 + frow][wn * 64 + j * 16 + fcol];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[i], xf[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) store_lds(cur ^ 1);
+            __syncthreads();
+        }
+    }
+    // D[i = co][j = kcol]: lane holds co = ..+(lane>>4)*4+e, kcol = ..+(lane&15)
+    float* dst = p.partial + (int64_t)slice * p.cout_pad * p.kcols_pad;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int co = co_tile * WG_TILE + wm * 64 + i * 16 + (lane >> 4) * 4;
+            int kc = k_tile * WG_TILE + wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(int64_t)(co + e) * p.kcols_pad + kc] = acc[i][j][e];
+        }
+}
+
+// bf16: 32 pixels per k-step; operands are stored [pixel][channel] in LDS (as they sit in HBM) and read with the
+// gfx950 transpose read ds_read_b64_tr_b16, which hands lane i of a 16-lane group column i of a 4x16 block.
+// k (pixel) order inside the k-step: lane group g, element e -> pixel 4g+e (e<4) or 16+4g+(e-4): the two
+// 32-lane halves of each ds_read_b64 then cover 8 consecutive rows = one full 256-byte bank row (RS pad 32 B).
+__device__ __forceinline__ u32x2 lds_tr_read(uint32_t byte_addr) {
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(byte_addr) : "memory");
+    return r;
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) {
+    constexpr int PK = 32;
+    constexpr int RSB = WG_TILE * 2 + 32;          // row stride in bytes (288)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // layout: [buf][ G: PK*RSB | X: PK*RSB ]
+    constexpr int OPB = PK * RSB;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    int bid = blockIdx.x;
+    const int k_tile = bid % p.n_k_tiles;
+    const int co_tile = bid / p.n_k_tiles;
+    const int slice = blockIdx.y;
+    const int m_begin = slice * p.m_per_slice;
+    int m_end = m_begin + p.m_per_slice;
+    if (m_end > p.M) m_end = p.M;
+
+    // loader: 32 rows x 16 chunks (8 bf16) per operand -> 2 chunks per thread per operand
+    const int cc = tid & 15, rr = tid >> 4;         // chunk column 0..15, row 0..15 (+16)
+    const int kcol = k_tile * WG_TILE + cc * 8;
+    const bool kok = kcol < p.kcols;
+    const int tap = kok ? kcol / p.cin_pad : 0;
+    const int ci = kcol - tap * p.cin_pad;
+    const int r = tap / p.kw, s = tap - r * p.kw;
+    const bool ci_ok = kok && ci < p.Cin;
+    const int gco = co_tile * WG_TILE + cc * 8;
+    const bf16_t* __restrict__ inp = reinterpret_cast<const bf16_t*>(p.in);
+    const bf16_t* __restrict__ gp = reinterpret_cast<const bf16_t*>(p.g);
+
+    int pn[2], py[2], px[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int m = m_begin + rr + 16 * i;
+        int n = m / (p.OH * p.OW);
+        int rem = m - n * (p.OH * p.OW);
+        pn[i] = n; py[i] = rem / p.OW; px[i] = rem - py[i] * p.OW;
+    }
+    u32x4 xa[2], ga[2];
+    auto load_global = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int m = m0 + rr + 16 * i;
+            u32x4 xv = {0u, 0u, 0u, 0u}, gv = {0u, 0u, 0u, 0u};
+            if (m < m_end) {
+                int iy = py[i] * p.sh - p.ph + r * p.dh, ix = px[i] * p.sw - p.pw + s * p.dw;
+                if (ci_ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                    const bf16_t* src = inp + (int64_t)((pn[i] * p.H + iy) * p.W + ix) * p.ldi + p.cioff + ci;
+                    if (ci + 7 < p.Cin) xv = *reinterpret_cast<const u32x4*>(src);
+                    else {
+                        bf16_t tmp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        for (int e = 0; e < 8 && ci + e < p.Cin; ++e) tmp[e] = src[e];
+                        xv = *reinterpret_cast<u32x4*>(tmp);
+                    }
+                }
+                if (gco < p.Cout) {
+                    const bf16_t* src = gp + (int64_t)m * p.ldo + p.cooff + gco;
+                    if (gco + 7 < p.Cout) gv = *reinterpret_cast<const u32x4*>(src);
+                    else {
+                        bf16_t tmp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        for (int e = 0; e < 8 && gco + e < p.Cout; ++e) tmp[e] = src[e];
+                        gv = *reinterpret_cast<u32x4*>(tmp);
+                    }
+                }
+            }
+            xa[i] = xv; ga[i] = gv;
+            px[i] += PK;
+            while (px[i] >= p.OW) { px[i] -= p.OW; if (++py[i] == p.OH) { py[i] = 0; ++pn[i]; } }
+        }
+    };
+    auto store_lds = [&](int buf) {
+        unsigned char* G = smem_raw + buf * 2 * OPB;
+        unsigned char* X = G + OPB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<u32x4*>(G + (rr + 16 * i) * RSB + cc * 16) = ga[i];
+            *reinterpret_cast<u32x4*>(X + (rr + 16 * i) * RSB + cc * 16) = xa[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transpose-read addressing: lane i of a 16-lane group supplies the 8-byte piece (row i>>2, cols 4*(i&3)..+3)
+    const int li = lane & 15, lg = lane >> 4;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw;
+    const uint32_t piece = (uint32_t)((4 * lg + (li >> 2)) * RSB + (li & 3) * 8);
+    if (m_begin < m_end) {
+        load_global(m_begin);
+        store_lds(0);
+        __syncthreads();
+        int it = 0;
+        for (int m0 = m_begin; m0 < m_end; m0 += PK, ++it) {
+            const int cur = it & 1;
+            const bool more = m0 + PK < m_end;
+            if (more) load_global(m0 + PK);
+            const uint32_t Gb = lds_base + cur * 2 * OPB + piece;
+            const uint32_t Xb = Gb + OPB;
+            u32x4 gf[4], xf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t a = Gb + (wm * 64 + i * 16) * 2;
+                u32x2 lo = lds_tr_read(a), hi = lds_tr_read(a + 16 * RSB);
+                gf[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t a = Xb + (wn * 64 + j * 16) * 2;
+                u32x2 lo = lds_tr_read(a), hi = lds_tr_read(a + 16 * RSB);
+                xf[j] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gf[i]),
+                                                                        __builtin_bit_cast(bf16x8, xf[j]), acc[i][j], 0, 0, 0);
+            if (more) store_lds(cur ^ 1);
+            __syncthreads();
+        }
+    }
+    float* dst = p.partial + (int64_t)slice * p.cout_pad * p.kcols_pad;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int co = co_tile * WG_TILE + wm * 64 + i * 16 + (lane >> 4) * 4;
+            int kc = k_tile * WG_TILE + wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(int64_t)(co + e) * p.kcols_pad + kc] = acc[i][j][e];
+        }
+}
+
+// reduce the slices, un-permute to the reference layout [cout][cin][kh][kw], apply scale, optional <w, dw_raw>
+__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                         const float* __restrict__ scale, const float* __restrict__ w,
+                                         float* __restrict__ wdot, int cout, int cin, int kh, int kw, int cin_pad,
+                                         int cout_pad, int kcols_pad, int slices, int accumulate) {
+    // one workgroup per output filter co; partials are read in their own (coalesced) column order
+    const int co = blockIdx.x;
+    const int taps = kh * kw;
+    const int per = cin * taps;
+    float dot = 0.f;
+    for (int kc = threadIdx.x; kc < taps * cin_pad; kc += blockDim.x) {
+        int t = kc / cin_pad, ci = kc - t * cin_pad;            // t = r*kw + s
+        if (ci >= cin) continue;
+        float v = 0.f;
+        for (int s = 0; s < slices; ++s) v += partial[((int64_t)s * cout_pad + co) * kcols_pad + kc];
+        int64_t o = (int64_t)co * per + (int64_t)ci * taps + t;
+        if (wdot) dot += v * w[o];
+        if (scale) v *= scale[co];
+        dw[o] = accumulate ? dw[o] + v : v;
+    }
+    if (wdot) {
+        __shared__ float red[4];
+        dot = wave_sum(dot);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+        __syncthreads();
+        if (threadIdx.x == 0) wdot[co] = red[0] + red[1] + red[2] + red[3];
+    }
+}
+
+// column sums of G [M][cout] (pixel stride ld, offset coff) -> dbias[cout] (atomic accumulate; caller zeroes)
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ g, float* __restrict__ out, int64_t M, int cout, int ld, int coff,
+                              int64_t rows_per_block) {
+    // block handles rows [b*rpb, (b+1)*rpb); thread t handles columns t, t+256, ...
+    int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    for (int c = threadIdx.x; c < cout; c += blockDim.x) {
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) s += Elem<T>::ld(g + r * ld + coff + c);
+        atomicAdd(out + c, s);
+    }
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                               float* scale, float* shift, int c) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < c) {
+        float s = gamma[i] / sqrtf(var[i] + eps);
+        scale[i] = s;
+        shift[i] = beta[i] - mean[i] * s;
+    }
+}
+__global__ void bn_fold_bwd_kernel(const float* wdot, const float* dshift, const float* mean, const float* var, float eps,
+                                   float* dgamma, float* dbeta, int c) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < c) {
+        float rstd = 1.f / sqrtf(var[i] + eps);
+        dgamma[i] = (wdot[i] - dshift[i] * mean[i]) * rstd;
+        dbeta[i] = dshift[i];
+    }
+}
+
+// ---- host-side planning ----------------------------------------------------------------------------
+inline int epc_of(int dtype) { return dtype == DIN_F32 ? 4 : 8; }
+inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+struct GatherPlan { int bn, n_co_tiles, n_px_tiles, cpt, Q, nk, splitk, ks_per_split, cout_pad; int64_t ws_bytes; };
+
+// geometry of a gather launch whose reduction runs over `cred` channels x taps and produces `cprod` channels
+GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype) {
+    GatherPlan g;
+    int epc = epc_of(dtype);
+    g.cpt = pad_to(cred, epc) / epc;
+    g.Q = taps * g.cpt;
+    g.nk = (g.Q + KC - 1) / KC;
+    g.bn = cprod <= 64 ? 64 : 128;
+    g.cout_pad = pad_to(cprod, 128);
+    g.n_co_tiles = (cprod + g.bn - 1) / g.bn;
+    g.n_px_tiles = (M + BM - 1) / BM;
+    // split-K only when the launch cannot fill the chip and the reduction is long
+    int tiles = g.n_co_tiles * g.n_px_tiles;
+    g.splitk = 1;
+    if (tiles < 192 && g.nk >= 8) {
+        int want = (512 + tiles - 1) / tiles;
+        int maxs = g.nk / 2;
+        g.splitk = want < maxs ? want : maxs;
+        if (g.splitk < 1) g.splitk = 1;
+        if (g.splitk > 64) g.splitk = 64;
+    }
+    g.ks_per_split = (g.nk + g.splitk - 1) / g.splitk;
+    g.splitk = (g.nk + g.ks_per_split - 1) / g.ks_per_split;
+    g.ws_bytes = g.splitk > 1 ? (int64_t)g.splitk * M * (g.n_co_tiles * g.bn) * 4 : 0;
+    return g;
+}
+
+struct WgradPlan { int cin_pad, kcols, kcols_pad, cout_pad, n_co_tiles, n_k_tiles, slices, m_per_slice; int64_t ws_bytes; };
+WgradPlan plan_wgrad(const din_conv_desc* d) {
+    WgradPlan w;
+    int epc = epc_of(d->dtype);
+    int pk = d->dtype == DIN_F32 ? 16 : 32;
+    w.cin_pad = pad_to(d->cin, epc);
+    w.kcols = d->kh * d->kw * w.cin_pad;
+    w.kcols_pad = pad_to(w.kcols, WG_TILE);
+    w.cout_pad = pad_to(d->cout, WG_TILE);
+    w.n_co_tiles = w.cout_pad / WG_TILE;
+    w.n_k_tiles = w.kcols_pad / WG_TILE;
+    int M = d->nb * d->oh * d->ow;
+    int tiles = w.n_co_tiles * w.n_k_tiles;
+    int want = (1024 + tiles - 1) / tiles;             // ~4 workgroups per CU
+    int64_t max_by_ws = ((int64_t)1 << 30) / ((int64_t)w.cout_pad * w.kcols_pad * 4);   // keep workspace <= 1 GiB
+    if (max_by_ws < 1) max_by_ws = 1;
+    if (want > max_by_ws) want = (int)max_by_ws;
+    int mps = (M + want - 1) / want;
+    mps = pad_to(mps < pk ? pk : mps, pk);
+    w.m_per_slice = mps;
+    w.slices = (M + mps - 1) / mps;
+    w.ws_bytes = (int64_t)w.slices * w.cout_pad * w.kcols_pad * 4;
+    return w;
+}
+
+int check_desc(const din_conv_desc* d) {
+    DIN_REQUIRE(d != nullptr, "conv: null descriptor");
+    DIN_REQUIRE(d->dtype == DIN_F32 || d->dtype == DIN_BF16, "conv: bad dtype %d", d->dtype);
+    int epc = epc_of(d->dtype);
+    DIN_REQUIRE(d->nb > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, "conv: empty tensor");
+    DIN_REQUIRE(d->ldi % epc == 0 && d->cioff % epc == 0, "conv: input pixel stride/offset must be multiples of %d", epc);
+    DIN_REQUIRE(d->ldo % 4 == 0 && d->cooff % 4 == 0, "conv: output pixel stride/offset must be multiples of 4");
+    // operands are read in whole 16-byte chunks: a channel count that is not a chunk multiple must be followed by
+    // finite (zero) padding inside the pixel stride -- the packed filters hold zeros there
+    DIN_REQUIRE(d->ldi >= d->cioff + pad_to(d->cin, epc), "conv: ldi %d too small for cin %d (+pad)", d->ldi, d->cin);
+    DIN_REQUIRE(d->ldo >= d->cooff + d->cout, "conv: ldo too small");
+    int eoh = (d->h + 2 * d->ph - d->dh * (d->kh - 1) - 1) / d->sh + 1;
+    int eow = (d->w + 2 * d->pw - d->dw * (d->kw - 1) - 1) / d->sw + 1;
+    DIN_REQUIRE(eoh == d->oh && eow == d->ow, "conv: output size %dx%d inconsistent (expected %dx%d)", d->oh, d->ow, eoh, eow);
+    DIN_REQUIRE((int64_t)d->nb * d->h * d->w < (1ll << 31) && (int64_t)d->nb * d->oh * d->ow < (1ll << 31), "conv: too many pixels");
+    return DIN_OK;
+}
+
+template <typename T, int BN>
+void launch_gather(const ConvK& k, int n_px_tiles, hipStream_t st) {
+    size_t lds = 2 * (BM + BN) * KC * 16;
+    hipLaunchKernelGGL((conv_gather_kernel<T, BN>), dim3(n_px_tiles * k.n_co_tiles, k.splitk), dim3(NTHREADS), lds, st, k);
+}
+
+int run_gather(ConvK& k, const GatherPlan& g, int dtype, void* workspace, int64_t ws_bytes, hipStream_t st, const char* what) {
+    k.cpt = g.cpt; k.Q = g.Q; k.nk = g.nk; k.wld = g.nk * KC;
+    k.splitk = g.splitk; k.ks_per_split = g.ks_per_split; k.n_co_tiles = g.n_co_tiles;
+    if (g.splitk > 1) {
+        if (ws_bytes < g.ws_bytes || workspace == nullptr)
+            DIN_FAIL(DIN_E_WORKSPACE, "%s: workspace %lld < %lld bytes", what, (long long)ws_bytes, (long long)g.ws_bytes);
+        k.partial = reinterpret_cast<float*>(workspace);
+    }
+    if (dtype == DIN_F32) {
+        if (g.bn == 128) launch_gather<float, 128>(k, g.n_px_tiles, st); else launch_gather<float, 64>(k, g.n_px_tiles, st);
+    } else {
+        if (g.bn == 128) launch_gather<bf16_t, 128>(k, g.n_px_tiles, st); else launch_gather<bf16_t, 64>(k, g.n_px_tiles, st);
+    }
+    DIN_CHECK_LAUNCH(what);
+    if (g.splitk > 1) {
+        int64_t total = (int64_t)k.M * k.Cout;
+        int cpad = g.n_co_tiles * g.bn;
+        if (dtype == DIN_F32) hipLaunchKernelGGL(conv_splitk_finish_kernel<float>, dim3(grid_1d(total, 256)), dim3(256), 0, st, k, cpad);
+        else hipLaunchKernelGGL(conv_splitk_finish_kernel<bf16_t>, dim3(grid_1d(total, 256)), dim3(256), 0, st, k, cpad);
+        DIN_CHECK_LAUNCH(what);
+    }
+    return DIN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t din_conv_packed_elems(const din_conv_desc* d, int transposed) {
+    if (!d) return 0;
+    int epc = epc_of(d->dtype);
+    int cred = transposed ? d->cout : d->cin, cprod = transposed ? d->cin : d->cout;
+    int cpt = pad_to(cred, epc) / epc;
+    int nk = (d->kh * d->kw * cpt + KC - 1) / KC;
+    return (int64_t)pad_to(cprod, 128) * nk * KC * epc;
+}
+
+int din_conv_pack_weights(const din_conv_desc* d, const float* w, const float* scale, void* wpk, int transposed, void* stream) {
+    DIN_REQUIRE(d && w && wpk, "conv_pack: null pointer");
+    int epc = epc_of(d->dtype);
+    int cred = transposed ? d->cout : d->cin, cprod = transposed ? d->cin : d->cout;
+    int inner_pad = pad_to(cred, epc);
+    int cpt = inner_pad / epc;
+    int nk = (d->kh * d->kw * cpt + KC - 1) / KC;
+    int kelems = nk * KC * epc;
+    int rows_pad = pad_to(cprod, 128);
+    int64_t total = (int64_t)rows_pad * kelems;
+    hipStream_t st = as_stream(stream);
+    if (d->dtype == DIN_F32)
+        hipLaunchKernelGGL(conv_pack_kernel<float>, dim3(grid_1d(total, 256)), dim3(256), 0, st, w, scale, (float*)wpk,
+                           d->cout, d->cin, d->kh, d->kw, cprod, rows_pad, cred, inner_pad, kelems, transposed);
+    else
+        hipLaunchKernelGGL(conv_pack_kernel<bf16_t>, dim3(grid_1d(total, 256)), dim3(256), 0, st, w, scale, (bf16_t*)wpk,
+                           d->cout, d->cin, d->kh, d->kw, cprod, rows_pad, cred, inner_pad, kelems, transposed);
+    DIN_CHECK_LAUNCH("conv_pack");
+    return DIN_OK;
+}
+
+int64_t din_conv_workspace_bytes(const din_conv_desc* d, int which) {
+    if (!d) return 0;
+    if (which == 0) return plan_gather(d->nb * d->oh * d->ow, d->cin, d->cout, d->kh * d->kw, d->dtype).ws_bytes;
+    if (which == 1) return plan_gather(d->nb * d->h * d->w, d->cout, d->cin, d->kh * d->kw, d->dtype).ws_bytes;
+    return plan_wgrad(d).ws_bytes;
+}
+
+int din_conv_fwd(const din_conv_desc* d, const void* in, const void* wpk, const float* bias, void* out, int flags,
+                 void* workspace, int64_t workspace_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    DIN_REQUIRE(in && wpk && out, "conv_fwd: null pointer");
+    DIN_REQUIRE(!(flags & DIN_CONV_BIAS) || bias, "conv_fwd: BIAS flag without bias");
+    DIN_REQUIRE(!(flags & (DIN_CONV_ACCUM | DIN_CONV_MASK)), "conv_fwd: ACCUM/MASK are dgrad-only flags");
+    ConvK k{};
+    k.in = in; k.w = wpk; k.out = out; k.bias = bias; k.mask = nullptr; k.partial = nullptr;
+    k.NB = d->nb; k.H = d->h; k.W = d->w; k.Cin = d->cin; k.ldi = d->ldi; k.cioff = d->cioff;
+    k.OH = d->oh; k.OW = d->ow; k.Cout = d->cout; k.ldo = d->ldo; k.cooff = d->cooff;
+    k.kh = d->kh; k.kw = d->kw;
+    k.ay = d->sh; k.by = -d->ph; k.cy = d->dh; k.divy = 1;
+    k.ax = d->sw; k.bx = -d->pw; k.cx = d->dw; k.divx = 1;
+    k.M = d->nb * d->oh * d->ow; k.flags = flags; k.ldm = 0; k.moff = 0;
+    GatherPlan g = plan_gather(k.M, d->cin, d->cout, d->kh * d->kw, d->dtype);
+    return run_gather(k, g, d->dtype, workspace, workspace_bytes, as_stream(stream), "conv_fwd");
+}
+
+int din_conv_dgrad(const din_conv_desc* d, const void* dout, const void* wpk_t, void* din_, const void* mask, int ldm,
+                   int moff, int flags, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    DIN_REQUIRE(dout && wpk_t && din_, "conv_dgrad: null pointer");
+    DIN_REQUIRE(!(flags & (DIN_CONV_BIAS | DIN_CONV_RELU)), "conv_dgrad: BIAS/RELU are fwd-only flags");
+    DIN_REQUIRE(!(flags & DIN_CONV_MASK) || mask, "conv_dgrad: MASK flag without mask");
+    int epc = epc_of(d->dtype);
+    DIN_REQUIRE(d->ldo % epc == 0 && d->cooff % epc == 0 && d->ldo >= d->cooff + pad_to(d->cout, epc),
+                "conv_dgrad: dout stride/offset must be multiples of %d and cover cout (+zero pad)", epc);
+    DIN_REQUIRE(d->ldi % 4 == 0 && d->cioff % 4 == 0, "conv_dgrad: din stride/offset must be multiples of 4");
+    // the "input" of the gather is dout (geometry oh x ow x cout), the "output" is din (h x w x cin)
+    ConvK k{};
+    k.in = dout; k.w = wpk_t; k.out = din_; k.bias = nullptr; k.mask = mask; k.partial = nullptr;
+    k.NB = d->nb; k.H = d->oh; k.W = d->ow; k.Cin = d->cout; k.ldi = d->ldo; k.cioff = d->cooff;
+    k.OH = d->h; k.OW = d->w; k.Cout = d->cin; k.ldo = d->ldi; k.cooff = d->cioff;
+    k.kh = d->kh; k.kw = d->kw;
+    // y_in = oy*sh - ph + r*dh  =>  oy = (y_in + ph - r*dh) / sh
+    k.ay = 1; k.by = d->ph; k.cy = -d->dh; k.divy = d->sh;
+    k.ax = 1; k.bx = d->pw; k.cx = -d->dw; k.divx = d->sw;
+    k.M = d->nb * d->h * d->w; k.flags = flags; k.ldm = ldm; k.moff = moff;
+    GatherPlan g = plan_gather(k.M, d->cout, d->cin, d->kh * d->kw, d->dtype);
+    return run_gather(k, g, d->dtype, workspace, workspace_bytes, as_stream(stream), "conv_dgrad");
+}
+
+int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, float* dw, float* dbias, const float* scale,
+                   const float* w, float* wdot, int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    DIN_REQUIRE(in && dout && dw, "conv_wgrad: null pointer");
+    DIN_REQUIRE(!wdot || w, "conv_wgrad: wdot needs w");
+    hipStream_t st = as_stream(stream);
+    WgradPlan wp = plan_wgrad(d);
+    if (workspace_bytes < wp.ws_bytes || !workspace)
+        DIN_FAIL(DIN_E_WORKSPACE, "conv_wgrad: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)wp.ws_bytes);
+    WgradK k{};
+    k.in = in; k.g = dout; k.partial = reinterpret_cast<float*>(workspace);
+    k.NB = d->nb; k.H = d->h; k.W = d->w; k.Cin = d->cin; k.ldi = d->ldi; k.cioff = d->cioff;
+    k.OH = d->oh; k.OW = d->ow; k.Cout = d->cout; k.ldo = d->ldo; k.cooff = d->cooff;
+    k.kh = d->kh; k.kw = d->kw; k.sh = d->sh; k.sw = d->sw; k.ph = d->ph; k.pw = d->pw; k.dh = d->dh; k.dw = d->dw;
+    k.cin_pad = wp.cin_pad; k.kcols = wp.kcols; k.kcols_pad = wp.kcols_pad; k.cout_pad = wp.cout_pad;
+    k.M = d->nb * d->oh * d->ow; k.n_co_tiles = wp.n_co_tiles; k.n_k_tiles = wp.n_k_tiles;
+    k.slices = wp.slices; k.m_per_slice = wp.m_per_slice;
+    dim3 grid(wp.n_co_tiles * wp.n_k_tiles, wp.slices);
+    if (d->dtype == DIN_F32) {
+        hipLaunchKernelGGL(conv_wgrad_f32_kernel, grid, dim3(NTHREADS), 0, st, k);
+    } else {
+        int epc = 8;
+        DIN_REQUIRE(d->ldo % epc == 0 && d->cooff % epc == 0, "conv_wgrad: bf16 dout stride/offset must be multiples of 8");
+        size_t lds = 2 * 2 * 32 * (WG_TILE * 2 + 32);
+        hipLaunchKernelGGL(conv_wgrad_bf16_kernel, grid, dim3(NTHREADS), lds, st, k);
+    }
+    DIN_CHECK_LAUNCH("conv_wgrad");
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(d->cout), dim3(256), 0, st, k.partial, dw, scale, w, wdot,
+                       d->cout, d->cin, d->kh, d->kw, wp.cin_pad, wp.cout_pad, wp.kcols_pad, wp.slices, accumulate);
+    DIN_CHECK_LAUNCH("conv_wgrad_reduce");
+    if (dbias) {
+        int64_t M = k.M;
+        hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st);
+        int64_t rpb = 512;
+        int blocks = (int)ceil_div64(M, rpb);
+        if (d->dtype == DIN_F32)
+            hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dout, dbias, M, d->cout, d->ldo, d->cooff, rpb);
+        else
+            hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dout, dbias, M, d->cout, d->ldo, d->cooff, rpb);
+        DIN_CHECK_LAUNCH("conv_colsum");
+    }
+    return DIN_OK;
+}
+
+int din_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,
+                float* shift, int c, void* stream) {
+    DIN_REQUIRE(gamma && beta && mean && var && scale && shift && c > 0, "bn_fold: bad argument");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), gamma, beta, mean, var, eps, scale, shift, c);
+    DIN_CHECK_LAUNCH("bn_fold");
+    return DIN_OK;
+}
+int din_bn_fold_bwd(const float* wdot, const float* dshift, const float* mean, const float* var, float eps, float* dgamma,
+                    float* dbeta, int c, void* stream) {
+    DIN_REQUIRE(wdot && dshift && mean && var && dgamma && dbeta && c > 0, "bn_fold_bwd: bad argument");
+    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), wdot, dshift, mean, var, eps, dgamma, dbeta, c);
+    DIN_CHECK_LAUNCH("bn_fold_bwd");
+    return DIN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,251 @@
+// Rows D2-D4: fused Dynamic Relation + Dynamic Walk (infer_module/dynamic_infer_module.py:184-282, 344-404).
+//
+// One workgroup owns (clip b, 64-channel chunk).  The zero-padded (T+2pt) x (N+2pl) x 64 actor-feature tile of the
+// clip is staged ONCE into LDS with coalesced 256-byte rows; every wave then walks actor positions with lane ==
+// channel, so the k2 x 4 bilinear corner fetches are conflict-free LDS reads instead of the reference's four
+// materialised [B,T,N,k2,C] torch.gather tensors.  The relation softmax over k2 and the floor/clamp/coefficients
+// are computed from the fused p_conv/scale_conv prediction `pred` (produced by the MFMA conv kernel).
+// No MFMA here: the gather is sparse per actor.
+//
+// Bit-exactness: floor/clamp corner indices are integer decisions and reproduce the reference's fp32 expression
+// order (pos = (pos_0 + pos_k) + offset; lt = floor(pos); clamp) exactly; compile with -ffp-contract=off.
+#include "din_common.h"
+
+namespace {
+
+constexpr int CH = 64;            // channels per workgroup (one lane each)
+constexpr int WALK_THREADS = 256;
+constexpr int MAXK2 = 49;         // up to 7x7 ST kernels
+
+struct WalkK {
+    const float* x; const float* pred; float* z; float* a; int32_t* idx; float* mad;
+    const float* gz; float* dx; float* scratch;          // backward only
+    int cp, b, t, n, c, kh, kw, ratio, scale_factor;
+    int pt, pl, hp, wp, k2, ky0, kx0;
+};
+
+struct Corner { int ly, ry, lx, rx; float py, px, py0, px0; };
+
+__device__ __forceinline__ Corner corners(const WalkK& p, int tt, int nn, int k, float oy, float ox) {
+    const int r = k / p.kw, s = k - r * p.kw;
+    const float base_y = (float)(p.pt + tt + p.ky0 + r * p.ratio);     // pos_0 + pos_k : exact small integers
+    const float base_x = (float)(p.pl + nn + p.kx0 + s * p.ratio);
+    Corner c;
+    c.py0 = __fadd_rn(base_y, oy);
+    c.px0 = __fadd_rn(base_x, ox);
+    const float fy = floorf(c.py0), fx = floorf(c.px0);
+    const float hy = (float)(p.hp - 1), hx = (float)(p.wp - 1);
+    c.ly = (int)fminf(fmaxf(fy, 0.f), hy);
+    c.ry = (int)fminf(fmaxf(fy + 1.f, 0.f), hy);
+    c.lx = (int)fminf(fmaxf(fx, 0.f), hx);
+    c.rx = (int)fminf(fmaxf(fx + 1.f, 0.f), hx);
+    c.py = fminf(fmaxf(c.py0, 0.f), hy);
+    c.px = fminf(fmaxf(c.px0, 0.f), hx);
+    return c;
+}
+__device__ __forceinline__ float coef(float p, int c) { return __fsub_rn(1.f, fabsf(__fsub_rn(p, (float)c))); }
+
+// stage the zero-padded tile of clip b / channel chunk c0 into LDS: tile[(y*wp + x)*CH + lane]
+__device__ __forceinline__ void stage_tile(const WalkK& p, const float* __restrict__ src, int b, int c0, float* tile) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool cok = c0 + lane < p.c;
+    for (int cell = w; cell < p.hp * p.wp; cell += WALK_THREADS / 64) {
+        int y = cell / p.wp, xx = cell - y * p.wp;
+        int tt = y - p.pt, nn = xx - p.pl;
+        float v = 0.f;
+        if (cok && tt >= 0 && tt < p.t && nn >= 0 && nn < p.n)
+            v = src[((int64_t)(b * p.t + tt) * p.n + nn) * p.c + c0 + lane];
+        tile[cell * CH + lane] = v;
+    }
+}
+
+// softmax over k2 of the relation logits of every position of clip b -> LDS a_s[pos*k2 + k]
+__device__ __forceinline__ void stage_relation(const WalkK& p, int b, float* a_s) {
+    for (int pos = threadIdx.x; pos < p.t * p.n; pos += WALK_THREADS) {
+        const float* pr = p.pred + ((int64_t)b * p.t * p.n + pos) * p.cp;
+        if (p.scale_factor) {
+            float mx = -INFINITY;
+            for (int k = 0; k < p.k2; ++k) mx = fmaxf(mx, pr[2 * p.k2 + k]);
+            float sum = 0.f;
+            for (int k = 0; k < p.k2; ++k) { float e = expf(pr[2 * p.k2 + k] - mx); a_s[pos * p.k2 + k] = e; sum += e; }
+            for (int k = 0; k < p.k2; ++k) a_s[pos * p.k2 + k] = a_s[pos * p.k2 + k] / sum;
+        } else {
+            for (int k = 0; k < p.k2; ++k) a_s[pos * p.k2 + k] = 1.f / (float)p.k2;
+        }
+    }
+}
+
+__global__ __launch_bounds__(WALK_THREADS) void din_walk_fwd_kernel(WalkK p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tile = smem;                                   // hp*wp*CH
+    float* a_s = tile + p.hp * p.wp * CH;                 // t*n*k2
+    const int nchunks = (p.c + CH - 1) / CH;
+    const int b = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks, c0 = chunk * CH;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    stage_tile(p, p.x, b, c0, tile);
+    stage_relation(p, b, a_s);
+    __syncthreads();
+    if (chunk == 0) {
+        // saved relation weights and the (bit-exact) integer corners
+        for (int i = threadIdx.x; i < p.t * p.n * p.k2; i += WALK_THREADS) {
+            int pos = i / p.k2, k = i - pos * p.k2;
+            int tt = pos / p.n, nn = pos - tt * p.n;
+            const float* pr = p.pred + ((int64_t)b * p.t * p.n + pos) * p.cp;
+            Corner c = corners(p, tt, nn, k, pr[k], pr[p.k2 + k]);
+            int64_t o = ((int64_t)b * p.t * p.n + pos) * p.k2 + k;
+            p.a[o] = a_s[i];
+            if (p.idx) { p.idx[o * 4 + 0] = c.ly; p.idx[o * 4 + 1] = c.ry; p.idx[o * 4 + 2] = c.lx; p.idx[o * 4 + 3] = c.rx; }
+        }
+    }
+    const bool cok = c0 + lane < p.c;
+    for (int pos = w; pos < p.t * p.n; pos += WALK_THREADS / 64) {
+        int tt = pos / p.n, nn = pos - tt * p.n;
+        const float* pr = p.pred + ((int64_t)b * p.t * p.n + pos) * p.cp;
+        float zacc = 0.f;
+        for (int k = 0; k < p.k2; ++k) {
+            Corner c = corners(p, tt, nn, k, pr[k], pr[p.k2 + k]);
+            float wy_l = coef(c.py, c.ly), wy_r = coef(c.py, c.ry), wx_l = coef(c.px, c.lx), wx_r = coef(c.px, c.rx);
+            float v_lt = tile[(c.ly * p.wp + c.lx) * CH + lane], v_rb = tile[(c.ry * p.wp + c.rx) * CH + lane];
+            float v_lb = tile[(c.ry * p.wp + c.lx) * CH + lane], v_rt = tile[(c.ly * p.wp + c.rx) * CH + lane];
+            // same association as the reference: lt*coe_lt + rb*coe_rb + lb*coe_lb + rt*coe_rt  (:255-258)
+            float sk = v_lt * (wy_l * wx_l) + v_rb * (wy_r * wx_r);
+            sk = sk + v_lb * (wy_r * wx_l);
+            sk = sk + v_rt * (wy_l * wx_r);
+            if (p.mad && cok) p.mad[(((int64_t)b * p.t * p.n + pos) * p.k2 + k) * p.c + c0 + lane] = sk;
+            zacc += sk * a_s[pos * p.k2 + k];
+        }
+        if (cok) p.z[((int64_t)b * p.t * p.n + pos) * p.c + c0 + lane] = zacc;
+    }
+}
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(WALK_THREADS) void din_walk_bwd_kernel(WalkK p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int cells = p.hp * p.wp;
+    float* tile = smem;                       // P
+    float* dtile = tile + cells * CH;         // dP
+    const int nchunks = (p.c + CH - 1) / CH;
+    const int b = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks, c0 = chunk * CH;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    stage_tile(p, p.x, b, c0, tile);
+    for (int i = threadIdx.x; i < cells * CH; i += WALK_THREADS) dtile[i] = 0.f;
+    __syncthreads();
+    const bool cok = c0 + lane < p.c;
+    float* d_off = p.scratch;                                     // [b,t,n,2k2]
+    float* d_a = p.scratch + (int64_t)p.b * p.t * p.n * 2 * p.k2;  // [b,t,n,k2]
+    for (int pos = w; pos < p.t * p.n; pos += WALK_THREADS / 64) {
+        int tt = pos / p.n, nn = pos - tt * p.n;
+        const int64_t gpos = (int64_t)b * p.t * p.n + pos;
+        const float* pr = p.pred + gpos * p.cp;
+        const float g = cok ? p.gz[gpos * p.c + c0 + lane] : 0.f;
+        for (int k = 0; k < p.k2; ++k) {
+            Corner c = corners(p, tt, nn, k, pr[k], pr[p.k2 + k]);
+            const float ak = p.a[gpos * p.k2 + k];
+            float wy_l = coef(c.py, c.ly), wy_r = coef(c.py, c.ry), wx_l = coef(c.px, c.lx), wx_r = coef(c.px, c.rx);
+            const int i_lt = (c.ly * p.wp + c.lx) * CH + lane, i_rb = (c.ry * p.wp + c.rx) * CH + lane;
+            const int i_lb = (c.ry * p.wp + c.lx) * CH + lane, i_rt = (c.ly * p.wp + c.rx) * CH + lane;
+            float v_lt = tile[i_lt], v_rb = tile[i_rb], v_lb = tile[i_lb], v_rt = tile[i_rt];
+            float sk = v_lt * (wy_l * wx_l) + v_rb * (wy_r * wx_r) + v_lb * (wy_r * wx_l) + v_rt * (wy_l * wx_r);
+            // feature gradient: scatter-add a_k * w_corner * gz into the padded tile (LDS atomics; waves may collide)
+            const float ag = ak * g;
+            atomicAdd(&dtile[i_lt], ag * (wy_l * wx_l));
+            atomicAdd(&dtile[i_rb], ag * (wy_r * wx_r));
+            atomicAdd(&dtile[i_lb], ag * (wy_r * wx_l));
+            atomicAdd(&dtile[i_rt], ag * (wy_l * wx_r));
+            // per-corner <gz, P_corner> and <gz, S_k> over this channel chunk
+            float d_s = wave_sum(g * sk);
+            float d_lt = wave_sum(g * v_lt), d_rb = wave_sum(g * v_rb), d_lb = wave_sum(g * v_lb), d_rt = wave_sum(g * v_rt);
+            if (lane == 0) {
+                // d/d py of (1-|py-cy|) = -sign(py-cy); clamp passes gradient on the closed interval (Q8, Q9)
+                const float my = (c.py0 >= 0.f && c.py0 <= (float)(p.hp - 1)) ? 1.f : 0.f;
+                const float mx = (c.px0 >= 0.f && c.px0 <= (float)(p.wp - 1)) ? 1.f : 0.f;
+                const float sy_l = -sgn(c.py - (float)c.ly), sy_r = -sgn(c.py - (float)c.ry);
+                const float sx_l = -sgn(c.px - (float)c.lx), sx_r = -sgn(c.px - (float)c.rx);
+                float doy = d_lt * sy_l * wx_l + d_rb * sy_r * wx_r + d_lb * sy_r * wx_l + d_rt * sy_l * wx_r;
+                float dox = d_lt * wy_l * sx_l + d_rb * wy_r * sx_r + d_lb * wy_r * sx_l + d_rt * wy_l * sx_r;
+                atomicAdd(d_off + gpos * 2 * p.k2 + k, my * ak * doy);
+                atomicAdd(d_off + gpos * 2 * p.k2 + p.k2 + k, mx * ak * dox);
+                if (p.scale_factor) atomicAdd(d_a + gpos * p.k2 + k, d_s);
+            }
+        }
+    }
+    __syncthreads();
+    // un-pad: dx[b,t,n,c] = dP[pt+t][pl+n][c]
+    for (int pos = w; pos < p.t * p.n; pos += WALK_THREADS / 64) {
+        int tt = pos / p.n, nn = pos - tt * p.n;
+        if (cok) p.dx[((int64_t)b * p.t * p.n + pos) * p.c + c0 + lane] = dtile[((p.pt + tt) * p.wp + p.pl + nn) * CH + lane];
+    }
+}
+
+// dpred[.., 0:2k2] = d offset ; dpred[.., 2k2:3k2] = a_k (dA_k - sum_j a_j dA_j)
+__global__ void din_walk_bwd_finish_kernel(const float* __restrict__ scratch, const float* __restrict__ a, float* __restrict__ dpred,
+                                           int64_t positions, int k2, int cp, int scale_factor) {
+    int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= positions) return;
+    const float* d_off = scratch + pos * 2 * k2;
+    const float* d_a = scratch + positions * 2 * k2 + pos * k2;
+    float* o = dpred + pos * cp;
+    for (int k = 0; k < 2 * k2; ++k) o[k] = d_off[k];
+    if (scale_factor) {
+        float dot = 0.f;
+        for (int k = 0; k < k2; ++k) dot += a[pos * k2 + k] * d_a[k];
+        for (int k = 0; k < k2; ++k) o[2 * k2 + k] = a[pos * k2 + k] * (d_a[k] - dot);
+    }
+}
+
+int fill(WalkK& p, int cp, int b, int t, int n, int c, int kh, int kw, int ratio, int scale_factor) {
+    DIN_REQUIRE(b > 0 && t > 0 && n > 0 && c > 0 && kh > 0 && kw > 0 && ratio > 0, "din_walk: bad shape");
+    DIN_REQUIRE(kh * kw <= MAXK2, "din_walk: ST kernel larger than %d taps unsupported", MAXK2);
+    DIN_REQUIRE(cp >= (scale_factor ? 3 : 2) * kh * kw, "din_walk: pred pixel stride too small");
+    p.cp = cp; p.b = b; p.t = t; p.n = n; p.c = c; p.kh = kh; p.kw = kw; p.ratio = ratio; p.scale_factor = scale_factor;
+    p.pt = (kh - 1) / 2 * ratio; p.pl = (kw - 1) / 2 * ratio;
+    p.hp = t + 2 * p.pt; p.wp = n + 2 * p.pl; p.k2 = kh * kw;
+    // lattice start = floor(-((k-1)*ratio) / 2)   (dynamic_infer_module.py:388-389)
+    auto fl2 = [](int v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); };
+    p.ky0 = fl2(-((kh - 1) * ratio)); p.kx0 = fl2(-((kw - 1) * ratio));
+    return DIN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int din_walk_fwd(const float* x, const float* pred, int cp, int b, int t, int n, int c, int kh, int kw, int ratio,
+                 int scale_factor, float* z, float* a, int32_t* idx, float* mad, void* stream) {
+    DIN_REQUIRE(x && pred && z && a, "din_walk_fwd: null pointer");
+    WalkK p{};
+    if (int e = fill(p, cp, b, t, n, c, kh, kw, ratio, scale_factor)) return e;
+    p.x = x; p.pred = pred; p.z = z; p.a = a; p.idx = idx; p.mad = mad;
+    size_t lds = ((size_t)p.hp * p.wp * CH + (size_t)t * n * p.k2) * sizeof(float);
+    DIN_REQUIRE(lds <= 160 * 1024, "din_walk_fwd: T x N grid too large for one LDS tile (%zu bytes)", lds);
+    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(din_walk_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int nchunks = (c + CH - 1) / CH;
+    hipLaunchKernelGGL(din_walk_fwd_kernel, dim3(b * nchunks), dim3(WALK_THREADS), lds, as_stream(stream), p);
+    DIN_CHECK_LAUNCH("din_walk_fwd");
+    return DIN_OK;
+}
+
+int din_walk_bwd(const float* x, const float* pred, int cp, const float* a, const float* gz, int b, int t, int n, int c,
+                 int kh, int kw, int ratio, int scale_factor, float* dx, float* dpred, float* scratch, void* stream) {
+    DIN_REQUIRE(x && pred && a && gz && dx && dpred && scratch, "din_walk_bwd: null pointer");
+    WalkK p{};
+    if (int e = fill(p, cp, b, t, n, c, kh, kw, ratio, scale_factor)) return e;
+    p.x = x; p.pred = pred; p.a = const_cast<float*>(a); p.gz = gz; p.dx = dx; p.scratch = scratch;
+    hipStream_t st = as_stream(stream);
+    int64_t positions = (int64_t)b * t * n;
+    hipError_t me = hipMemsetAsync(scratch, 0, sizeof(float) * positions * 3 * p.k2, st);
+    if (me != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "din_walk_bwd: memset: %s", hipGetErrorString(me));
+    size_t lds = (size_t)2 * p.hp * p.wp * CH * sizeof(float);
+    DIN_REQUIRE(lds <= 160 * 1024, "din_walk_bwd: T x N grid too large for the LDS tiles (%zu bytes)", lds);
+    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(din_walk_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int nchunks = (c + CH - 1) / CH;
+    hipLaunchKernelGGL(din_walk_bwd_kernel, dim3(b * nchunks), dim3(WALK_THREADS), lds, st, p);
+    DIN_CHECK_LAUNCH("din_walk_bwd");
+    hipLaunchKernelGGL(din_walk_bwd_finish_kernel, dim3((unsigned)ceil_div64(positions, 128)), dim3(128), 0, st, scratch, a, dpred,
+                       positions, p.k2, cp, scale_factor);
+    DIN_CHECK_LAUNCH("din_walk_bwd_finish");
+    return DIN_OK;
+}
+
+}  // extern "C"

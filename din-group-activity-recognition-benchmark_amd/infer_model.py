@@ -1,0 +1,198 @@
+"""Dynamic_volleyball / Dynamic_collective -- drop-in for the reference's infer_model.py:15-234 and :1135-1319.
+
+Same constructor (`Model(cfg)`), same `forward((images, boxes[, bboxes_num])) -> {'activities': [B, A]}`, same
+`loadmodel(path)` and state_dict keys (backbone.*, fc_emb_1, nl_emb_1, point_conv, point_ln, DPI.*, dpi_nl,
+fc_activities), so stage-1 / stage-2 checkpoints of the reference load unchanged.  Every arithmetic step runs in
+hand-written gfx950 kernels behind the C ABI; see DESIGN.md for the kernel map.
+
+Deliberate differences from the reference (all documented in DESIGN.md):
+  * `cfg.backbone == 'inv3'` works (the reference has no head branch for it, infer_model.py:203-216 -> crash);
+    it uses the vgg16 residual -> LN -> ReLU -> dropout order.
+  * no torch.cuda.empty_cache() per step (infer_model.py:200 is a perf bug), images may be uint8.
+  * new optional cfg field `backbone_dtype` ('fp32' parity mode | 'bf16' throughput mode), default 'fp32'.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .backbone.backbone import MyInception_v3, MyVGG16
+from .infer_module.dynamic_infer_module import (Dynamic_Person_Inference, Hierarchical_Dynamic_Inference,
+                                                Multi_Dynamic_Inference)
+from .roi_align.roi_align import RoIAlign
+from .utils import print_log
+
+
+def _as_kernel_list(k):
+    if isinstance(k, (list,)) and len(k) and isinstance(k[0], (tuple, list)):
+        return [tuple(x) for x in k]
+    if isinstance(k, int):
+        return [(k, k)]
+    return [tuple(k)]
+
+
+class _DynamicBase(nn.Module):
+    def _build_trunk(self, cfg):
+        D, K, NFB = cfg.emb_features, cfg.crop_size[0], cfg.num_features_boxes
+        dt = getattr(cfg, "backbone_dtype", "fp32")
+        if cfg.backbone == "inv3":
+            self.backbone = MyInception_v3(transform_input=False, pretrained=True, compute_dtype=dt)
+        elif cfg.backbone == "vgg16":
+            self.backbone = MyVGG16(pretrained=True, compute_dtype=dt)
+        else:
+            raise NotImplementedError(f"backbone {cfg.backbone!r}: the MI355X hot path covers 'vgg16' and 'inv3' "
+                                      f"(BASELINE.json configs); vgg19/res18/alex are out of scope")
+        if not cfg.train_backbone:
+            for p in self.backbone.parameters():
+                p.requires_grad = False
+        self.roi_align = RoIAlign(*cfg.crop_size)
+        self.fc_emb_1 = nn.Linear(K * K * D, NFB)
+        self.nl_emb_1 = nn.LayerNorm([NFB])
+
+    def _init_linears(self):
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.kaiming_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def loadmodel(self, filepath):
+        state = torch.load(filepath, map_location="cpu")
+        self.backbone.load_state_dict(state["backbone_state_dict"])
+        self.fc_emb_1.load_state_dict(state["fc_emb_state_dict"])
+        print("Load model states from: ", filepath)
+
+    # ---- shared front: images -> per-box embeddings [B,T,N,NFB] ------------------------------------------
+    def _embed(self, images_in, boxes_in, N):
+        cfg = self.cfg
+        B, T = images_in.shape[0], images_in.shape[1]
+        H, W = cfg.image_size
+        OH, OW = cfg.out_size
+        D, K = cfg.emb_features, cfg.crop_size[0]
+        images_flat = images_in.reshape(B * T, 3, H, W)
+        boxes_flat = boxes_in.reshape(B * T * N, 4)
+        boxes_idx = ops.boxes_frame_index(B * T, N, boxes_in.device)                  # infer_model.py:155-157
+        bufs, graph = self.backbone.forward_nhwc(images_flat)                        # prep fused (:161-162)
+        fm = bufs[0]                                                                 # multiscale-fused map (:165-172)
+        assert tuple(fm.shape[1:3]) == (OH, OW), f"backbone output {tuple(fm.shape[1:3])} != cfg.out_size {(OH, OW)}"
+        assert fm.shape[3] >= D
+        tid = graph.output_tids[0]
+        crops = self.roi_align(fm, boxes_flat, boxes_idx, nhwc=True, channels=D,
+                               relu_masked=graph.tensors[tid].relu_masked)          # [BTN, D, K, K]  (:178-180)
+        feats = crops.reshape(B, T, N, D * K * K)
+        x = ops.linear(feats, self.fc_emb_1.weight, self.fc_emb_1.bias)              # :184
+        x = ops.layer_norm(x, self.nl_emb_1.weight, self.nl_emb_1.bias, relu=True)   # :185-186
+        return x
+
+    def _dropout_seed(self):
+        self._step = getattr(self, "_step", 0) + 1
+        base = int(getattr(self.cfg, "train_random_seed", 0))
+        return (base * 1000003 + self._step * 7919) & 0x7FFFFFFFFFFFFFFF
+
+
+class Dynamic_volleyball(_DynamicBase):
+    """main module of DIN for the volleyball dataset (reference infer_model.py:15-234)"""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        T, N = cfg.num_frames, cfg.num_boxes
+        NFB = cfg.num_features_boxes
+        self._build_trunk(cfg)
+        in_dim = cfg.lite_dim if cfg.lite_dim else NFB
+        print_log(getattr(cfg, "log_path", None), ("Activate" if cfg.lite_dim else "Deactivate") + " lite model inference.")
+        kernels = _as_kernel_list(cfg.ST_kernel_size)
+        if not cfg.hierarchical_inference:
+            self.DPI = Multi_Dynamic_Inference(in_dim=in_dim, person_mat_shape=(10, 12), stride=cfg.stride,
+                                               kernel_size=kernels, dynamic_sampling=cfg.dynamic_sampling,
+                                               sampling_ratio=cfg.sampling_ratio, group=cfg.group,
+                                               scale_factor=cfg.scale_factor, beta_factor=cfg.beta_factor,
+                                               parallel_inference=cfg.parallel_inference, num_DIM=cfg.num_DIM, cfg=cfg)
+        else:
+            self.DPI = Hierarchical_Dynamic_Inference(in_dim=in_dim, person_mat_shape=(T, N), stride=cfg.stride,
+                                                      kernel_size=kernels, dynamic_sampling=cfg.dynamic_sampling,
+                                                      sampling_ratio=cfg.sampling_ratio, group=cfg.group,
+                                                      scale_factor=cfg.scale_factor, beta_factor=cfg.beta_factor,
+                                                      parallel_inference=cfg.parallel_inference, cfg=cfg)
+        print_log(getattr(cfg, "log_path", None), "Hierarchical Inference : " + str(cfg.hierarchical_inference))
+        self.dpi_nl = nn.LayerNorm([T, N, in_dim])
+        self.dropout_global = nn.Dropout(p=cfg.train_dropout_prob)      # holder of p; the mask is fused in the LN kernel
+        if cfg.lite_dim:
+            self.point_conv = nn.Conv2d(NFB, in_dim, kernel_size=1, stride=1)
+            self.point_ln = nn.LayerNorm([T, N, in_dim])
+            self.fc_activities = nn.Linear(in_dim, cfg.num_activities)
+        else:
+            self.fc_activities = nn.Linear(cfg.num_features_gcn, cfg.num_activities)
+        self._init_linears()
+
+    def forward(self, batch_data):
+        images_in, boxes_in = batch_data
+        cfg = self.cfg
+        B, T, N = images_in.shape[0], images_in.shape[1], cfg.num_boxes
+        x = self._embed(images_in, boxes_in, N)                                       # [B,T,N,NFB]
+        if cfg.lite_dim:                                                              # :188-193
+            x = ops.GridConvFunction.apply(x, self.point_conv.weight, self.point_conv.bias, 1)
+            x = ops.layer_norm(x, self.point_ln.weight, self.point_ln.bias, relu=True)
+        graph, _mad = self.DPI(x)                                                     # :199
+        p = cfg.train_dropout_prob if self.training else 0.0
+        head_mode = "res18" if cfg.backbone == "res18" else "vgg16"
+        if head_mode == "vgg16":                                                      # :210-216 (also used for inv3)
+            s = ops.layer_norm(graph, self.dpi_nl.weight, self.dpi_nl.bias, res=x, relu=True, drop_p=p,
+                               seed=self._dropout_seed())
+        else:                                                                         # :203-209
+            raise NotImplementedError
+        scores = ops.HeadFunction.apply(s, self.fc_activities.weight, self.fc_activities.bias, None)   # :224-232
+        return {"activities": scores}
+
+
+class Dynamic_collective(_DynamicBase):
+    """DIN for the Collective Activity dataset (reference infer_model.py:1135-1319), variable actors per clip.
+
+    The reference crashes here (tuple/tensor mismatch, SURVEY section 0 bug 3); this implements the intended dataflow:
+    per clip b with N_b = bboxes_num[b,0] valid boxes: DIN on [1,T,N_b,C] -> +x -> LayerNorm([T,C]) per actor -> ReLU ->
+    dropout -> max over actors -> fc -> mean over T."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        T, N = cfg.num_frames, cfg.num_boxes
+        NFB = cfg.num_features_boxes
+        self._build_trunk(cfg)
+        in_dim = cfg.lite_dim if cfg.lite_dim else NFB
+        k = _as_kernel_list(cfg.ST_kernel_size)[0]
+        self.DPI = Dynamic_Person_Inference(in_dim=in_dim, person_mat_shape=(10, 12), stride=cfg.stride, kernel_size=k,
+                                            dynamic_sampling=cfg.dynamic_sampling, sampling_ratio=cfg.sampling_ratio,
+                                            group=cfg.group, scale_factor=cfg.scale_factor, beta_factor=cfg.beta_factor,
+                                            parallel_inference=cfg.parallel_inference, cfg=cfg)
+        self.dpi_nl = nn.LayerNorm([T, in_dim])
+        self.dropout_global = nn.Dropout(p=cfg.train_dropout_prob)
+        if cfg.lite_dim:
+            self.point_conv = nn.Conv2d(NFB, in_dim, kernel_size=1, stride=1)
+            self.point_ln = nn.LayerNorm([T, N, in_dim])
+            self.fc_activities = nn.Linear(in_dim, cfg.num_activities)
+        else:
+            self.fc_activities = nn.Linear(cfg.num_features_gcn, cfg.num_activities)
+        self._init_linears()
+
+    def forward(self, batch_data):
+        images_in, boxes_in, bboxes_num_in = batch_data
+        cfg = self.cfg
+        B, T, MAX_N = images_in.shape[0], images_in.shape[1], cfg.num_boxes
+        x = self._embed(images_in, boxes_in, MAX_N)                                   # [B,T,MAX_N,NFB]
+        if cfg.lite_dim:
+            x = ops.GridConvFunction.apply(x, self.point_conv.weight, self.point_conv.bias, 1)
+            x = ops.layer_norm(x, self.point_ln.weight, self.point_ln.bias, relu=True)
+        counts = bboxes_num_in.reshape(B, T)[:, 0].to("cpu").tolist()                 # one host read per batch (reference: per clip)
+        p = cfg.train_dropout_prob if self.training else 0.0
+        outs = []
+        for b in range(B):
+            nb = int(counts[b])
+            xb = x[b:b + 1, :, :nb].contiguous()                                      # [1,T,nb,C]
+            g, _ = self.DPI(xb)
+            # LayerNorm([T,C]) per actor: rows = actors -> permute to [nb,T,C]
+            sb = ops.AxpbyFunction.apply(g, xb, 1.0, 1.0)[0].permute(1, 0, 2).contiguous()
+            sb = ops.layer_norm(sb, self.dpi_nl.weight, self.dpi_nl.bias, relu=True, drop_p=p, seed=self._dropout_seed())
+            sb = sb.permute(1, 0, 2).contiguous().unsqueeze(0)                        # [1,T,nb,C]
+            outs.append(ops.HeadFunction.apply(sb, self.fc_activities.weight, self.fc_activities.bias, None))
+        return {"activities": torch.cat(outs, 0)}

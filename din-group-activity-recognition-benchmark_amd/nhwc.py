@@ -1,0 +1,424 @@
+"""NHWC execution graph for the backbone conv stacks (rows V, I, M of SURVEY section 8).
+
+A backbone is described once as a static list of ops over *views* (tensor id, channel offset, channels) of
+pixel-major NHWC buffers, then run forward and backward through libdin_hip.so by ONE torch.autograd.Function.
+That gives the MI355X design its properties:
+  * torch.cat(dim=1) (Inception blocks, infer_model.py:172) costs nothing: producers write channel ranges;
+  * ReLU backward is fused into whatever kernel produces a gradient (conv dgrad epilogue / pool backward);
+  * BatchNorm(eval) is folded into the packed filters (scale) and the conv bias (shift);
+  * images stay uint8 until the fused prep loader (no fp32 image copies, SURVEY 7 hard part 7).
+Nothing here falls back to ATen: every arithmetic op is a C-ABI call and raises if the library is absent.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def torch_dtype(dt: int):
+    return torch.float32 if dt == L.DIN_F32 else torch.bfloat16
+
+
+def din_dtype(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return L.DIN_F32
+    if t.dtype == torch.bfloat16:
+        return L.DIN_BF16
+    raise L.DinError(f"unsupported storage dtype {t.dtype}")
+
+
+def require_gpu(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise L.DinError("din_amd ops run only on MI355X device tensors (no CPU fallback); got a CPU tensor")
+        if not t.is_contiguous():
+            raise L.DinError("din_amd ops need contiguous tensors")
+
+
+# ------------------------------------------------------------------------------------------------
+# optional per-launch timing (bench.py roofline): when PROFILE is a list, every conv launch appends
+# (kind, flops, start_event, end_event) recorded on the stream the kernel is launched on.
+# ------------------------------------------------------------------------------------------------
+PROFILE = None
+
+
+def _conv_flops(d) -> float:
+    return 2.0 * d.nb * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
+
+
+class _timed:
+    def __init__(self, kind, d):
+        self.kind, self.d = kind, d
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e1.record(torch.cuda.current_stream())
+            d = self.d
+            cprod = d.cin if self.kind == "dgrad" else d.cout          # channels the launch produces (tile variant)
+            variant = "wgrad" if self.kind == "wgrad" else ("gather_bn64" if cprod <= 64 else "gather_bn128")
+            PROFILE.append((self.kind, variant, _conv_flops(d), int(d.dtype), self.e0, self.e1))
+        return False
+
+
+# ------------------------------------------------------------------------------------------------
+# shared split-K / wgrad workspace (per device; ops on one stream are serialised, so one buffer is safe)
+# ------------------------------------------------------------------------------------------------
+_WS: Dict[int, torch.Tensor] = {}
+
+
+def workspace(nbytes: int, device) -> Tuple[Optional[torch.Tensor], int]:
+    if nbytes <= 0:
+        return None, 0
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws, ws.numel()
+
+
+# ------------------------------------------------------------------------------------------------
+# graph description
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class TensorSpec:
+    h: int
+    w: int
+    c: int                  # pixel stride (total channels incl. padding)
+    relu_masked: bool = False   # some producer applies ReLU -> gradients into it are masked by (value > 0)
+
+
+@dataclass
+class View:
+    tid: int
+    coff: int
+    c: int
+
+
+@dataclass
+class Op:
+    kind: str               # conv | maxpool | avgpool | bilinear
+    src: View
+    dst: View
+    name: str = ""
+    k: Tuple[int, int] = (1, 1)
+    s: Tuple[int, int] = (1, 1)
+    p: Tuple[int, int] = (0, 0)
+    relu: bool = False
+    bias: bool = False      # conv has its own bias parameter (VGG)
+    bn: bool = False        # conv followed by BatchNorm (Inception BasicConv2d)
+
+
+@dataclass
+class Graph:
+    tensors: List[TensorSpec] = field(default_factory=list)
+    ops: List[Op] = field(default_factory=list)
+    input_tid: int = 0
+    output_tids: List[int] = field(default_factory=list)
+    cin_image: int = 3
+
+    def add_tensor(self, h, w, c) -> int:
+        self.tensors.append(TensorSpec(h, w, c))
+        return len(self.tensors) - 1
+
+    def param_names(self) -> List[str]:
+        """Parameter (and BN buffer) names in the order the autograd Function receives them."""
+        names = []
+        for op in self.ops:
+            if op.kind != "conv":
+                continue
+            if op.bn:
+                names += [op.name + ".conv.weight", op.name + ".bn.weight", op.name + ".bn.bias",
+                          op.name + ".bn.running_mean", op.name + ".bn.running_var"]
+            else:
+                names.append(op.name + ".weight")
+                if op.bias:
+                    names.append(op.name + ".bias")
+        return names
+
+
+def conv_out(h, k, s, p, d=1):
+    return (h + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+class GraphBuilder:
+    """Tiny helper used by backbone/backbone.py to lay out the layer tables."""
+
+    def __init__(self, h: int, w: int, cpad_image: int):
+        self.g = Graph()
+        self.g.input_tid = self.g.add_tensor(h, w, cpad_image)
+
+    def tensor(self, h, w, c) -> int:
+        return self.g.add_tensor(h, w, c)
+
+    def full(self, tid) -> View:
+        return View(tid, 0, self.g.tensors[tid].c)
+
+    def conv(self, name, src: View, cout, k, s=(1, 1), p=(0, 0), relu=True, bias=False, bn=False,
+             dst: Optional[View] = None) -> View:
+        ts = self.g.tensors[src.tid]
+        oh, ow = conv_out(ts.h, k[0], s[0], p[0]), conv_out(ts.w, k[1], s[1], p[1])
+        if dst is None:
+            dst = self.full(self.tensor(oh, ow, cout))
+        td = self.g.tensors[dst.tid]
+        assert (td.h, td.w) == (oh, ow) and dst.c == cout, (name, td, oh, ow)
+        td.relu_masked = td.relu_masked or relu
+        self.g.ops.append(Op("conv", src, dst, name, tuple(k), tuple(s), tuple(p), relu, bias, bn))
+        return dst
+
+    def pool(self, kind, src: View, k, s, p, dst: Optional[View] = None) -> View:
+        ts = self.g.tensors[src.tid]
+        oh, ow = conv_out(ts.h, k, s, p), conv_out(ts.w, k, s, p)
+        if dst is None:
+            dst = self.full(self.tensor(oh, ow, src.c))
+        td = self.g.tensors[dst.tid]
+        assert (td.h, td.w) == (oh, ow) and dst.c == src.c
+        self.g.ops.append(Op(kind, src, dst, kind, (k, k), (s, s), (p, p)))
+        return dst
+
+    def bilinear(self, src: View, dst: View) -> View:
+        assert dst.c == src.c
+        self.g.ops.append(Op("bilinear", src, dst, "bilinear"))
+        return dst
+
+
+# ------------------------------------------------------------------------------------------------
+# executor
+# ------------------------------------------------------------------------------------------------
+def _conv_desc(g: Graph, op: Op, nb: int, dt: int, cin: Optional[int] = None) -> L.ConvDesc:
+    ts, td = g.tensors[op.src.tid], g.tensors[op.dst.tid]
+    d = L.ConvDesc()
+    d.nb, d.h, d.w, d.cin = nb, ts.h, ts.w, cin if cin is not None else op.src.c
+    d.oh, d.ow, d.cout = td.h, td.w, op.dst.c
+    d.kh, d.kw = op.k
+    d.sh, d.sw = op.s
+    d.ph, d.pw = op.p
+    d.dh = d.dw = 1
+    d.ldi, d.cioff, d.ldo, d.cooff = ts.c, op.src.coff, td.c, op.dst.coff
+    d.dtype = dt
+    return d
+
+
+def _pool_desc(g: Graph, op: Op, nb: int, dt: int) -> L.PoolDesc:
+    ts, td = g.tensors[op.src.tid], g.tensors[op.dst.tid]
+    d = L.PoolDesc()
+    d.nb, d.h, d.w, d.c, d.oh, d.ow = nb, ts.h, ts.w, op.src.c, td.h, td.w
+    d.k, d.stride, d.pad = op.k[0], op.s[0], op.p[0]
+    d.ldi, d.cioff, d.ldo, d.cooff = ts.c, op.src.coff, td.c, op.dst.coff
+    d.dtype = dt
+    return d
+
+
+BN_EPS = 1e-3      # torchvision BasicConv2d
+
+
+def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tensor], dt: int):
+    """Run the graph.  image_buf: NHWC [nb,h,w,cpad] of dtype dt.  Returns (bufs, aux) for backward."""
+    lib = L.load()
+    nb = image_buf.shape[0]
+    dev = image_buf.device
+    tdt = torch_dtype(dt)
+    bufs: List[Optional[torch.Tensor]] = [None] * len(g.tensors)
+    bufs[g.input_tid] = image_buf
+    it = iter(params)
+    aux = []
+    st = _stream()
+    for op in g.ops:
+        td = g.tensors[op.dst.tid]
+        if bufs[op.dst.tid] is None:
+            bufs[op.dst.tid] = torch.empty((nb, td.h, td.w, td.c), dtype=tdt, device=dev)
+        src, dst = bufs[op.src.tid], bufs[op.dst.tid]
+        if op.kind == "conv":
+            cin = g.cin_image if op.src.tid == g.input_tid else op.src.c
+            d = _conv_desc(g, op, nb, dt, cin)
+            w = next(it)
+            scale = shift = None
+            if op.bn:
+                gamma, beta, mean, var = next(it), next(it), next(it), next(it)
+                scale = torch.empty_like(gamma)
+                shift = torch.empty_like(gamma)
+                L.check(lib.din_bn_fold(_ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), BN_EPS, _ptr(scale), _ptr(shift),
+                                        gamma.numel(), st), "bn_fold")
+                bias = shift
+            else:
+                bias = next(it) if op.bias else None
+            wpk = torch.empty(lib.din_conv_packed_elems(C.byref(d), 0), dtype=tdt, device=dev)
+            L.check(lib.din_conv_pack_weights(C.byref(d), _ptr(w), _ptr(scale), _ptr(wpk), 0, st), "conv_pack")
+            ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 0), dev)
+            flags = (L.CONV_BIAS if bias is not None else 0) | (L.CONV_RELU if op.relu else 0)
+            with _timed("fwd", d):
+                L.check(lib.din_conv_fwd(C.byref(d), _ptr(src), _ptr(wpk), _ptr(bias), _ptr(dst), flags, _ptr(ws), wsb, st),
+                        "conv_fwd " + op.name)
+            aux.append((scale,))
+        elif op.kind in ("maxpool", "avgpool", "bilinear"):
+            d = _pool_desc(g, op, nb, dt)
+            fn = {"maxpool": lib.din_maxpool_fwd, "avgpool": lib.din_avgpool_fwd, "bilinear": lib.din_bilinear_fwd}[op.kind]
+            L.check(fn(C.byref(d), _ptr(src), _ptr(dst), st), op.kind + "_fwd")
+            aux.append(())
+        else:
+            raise L.DinError("unknown op " + op.kind)
+    return bufs, aux
+
+
+def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
+                   out_grads: Dict[int, torch.Tensor], need_param_grad: Sequence[bool]):
+    """Reverse pass.  out_grads: tid -> gradient buffer (same geometry/dtype as the tensor, already ReLU-masked where
+    the tensor is relu_masked).  Returns the list of parameter gradients aligned with `params` (None for buffers)."""
+    lib = L.load()
+    nb = bufs[g.input_tid].shape[0]
+    dev = bufs[g.input_tid].device
+    tdt = torch_dtype(dt)
+    st = _stream()
+    gbufs: Dict[int, torch.Tensor] = dict(out_grads)
+
+    def grad_target(view: View) -> Tuple[torch.Tensor, bool]:
+        """gradient buffer of view.tid and whether to accumulate into it"""
+        ts = g.tensors[view.tid]
+        if view.tid in gbufs:
+            return gbufs[view.tid], True
+        full = view.coff == 0 and view.c == ts.c
+        buf = (torch.empty if full else torch.zeros)((nb, ts.h, ts.w, ts.c), dtype=tdt, device=dev)
+        gbufs[view.tid] = buf
+        return buf, (not full)
+
+    # index params per conv op
+    offsets, pos = [], 0
+    for op in g.ops:
+        if op.kind == "conv":
+            offsets.append(pos)
+            pos += 5 if op.bn else (2 if op.bias else 1)
+        else:
+            offsets.append(-1)
+    grads: List[Optional[torch.Tensor]] = [None] * len(params)
+
+    for oi in range(len(g.ops) - 1, -1, -1):
+        op = g.ops[oi]
+        if op.dst.tid not in gbufs:
+            continue                                  # nothing flows back through this op
+        gout = gbufs[op.dst.tid]
+        src_needs_grad = op.src.tid != g.input_tid
+        ts = g.tensors[op.src.tid]
+        if op.kind == "conv":
+            cin = g.cin_image if op.src.tid == g.input_tid else op.src.c
+            d = _conv_desc(g, op, nb, dt, cin)
+            po = offsets[oi]
+            w = params[po]
+            (scale,) = aux[oi]
+            # ---- wgrad (+ bias / BN parameter gradients)
+            dw = torch.empty_like(w)
+            if op.bn:
+                gamma, beta, mean, var = params[po + 1:po + 5]
+                dshift = torch.empty_like(gamma)
+                wdot = torch.empty_like(gamma)
+                ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 2), dev)
+                with _timed("wgrad", d):
+                    L.check(lib.din_conv_wgrad(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dw), _ptr(dshift), _ptr(scale),
+                                               _ptr(w), _ptr(wdot), 0, _ptr(ws), wsb, st), "conv_wgrad " + op.name)
+                dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+                L.check(lib.din_bn_fold_bwd(_ptr(wdot), _ptr(dshift), _ptr(mean), _ptr(var), BN_EPS, _ptr(dgamma), _ptr(dbeta),
+                                            gamma.numel(), st), "bn_fold_bwd")
+                grads[po], grads[po + 1], grads[po + 2] = dw, dgamma, dbeta
+            else:
+                db = torch.empty_like(params[po + 1]) if op.bias else None
+                ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 2), dev)
+                with _timed("wgrad", d):
+                    L.check(lib.din_conv_wgrad(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dw), _ptr(db), None, None, None, 0,
+                                               _ptr(ws), wsb, st), "conv_wgrad " + op.name)
+                grads[po] = dw
+                if op.bias:
+                    grads[po + 1] = db
+            # ---- dgrad
+            if src_needs_grad:
+                gsrc, acc = grad_target(op.src)
+                wpt = torch.empty(lib.din_conv_packed_elems(C.byref(d), 1), dtype=tdt, device=dev)
+                L.check(lib.din_conv_pack_weights(C.byref(d), _ptr(w), _ptr(scale), _ptr(wpt), 1, st), "conv_pack_t")
+                flags = (L.CONV_ACCUM if acc else 0) | (L.CONV_MASK if ts.relu_masked else 0)
+                ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 1), dev)
+                with _timed("dgrad", d):
+                    L.check(lib.din_conv_dgrad(C.byref(d), _ptr(gout), _ptr(wpt), _ptr(gsrc),
+                                               _ptr(bufs[op.src.tid]) if ts.relu_masked else None, ts.c, op.src.coff, flags,
+                                               _ptr(ws), wsb, st), "conv_dgrad " + op.name)
+        elif src_needs_grad:
+            d = _pool_desc(g, op, nb, dt)
+            gsrc, acc = grad_target(op.src)
+            mask = _ptr(bufs[op.src.tid]) if ts.relu_masked else None
+            if op.kind == "maxpool":
+                L.check(lib.din_maxpool_bwd(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(gsrc), int(ts.relu_masked),
+                                            int(acc), st), "maxpool_bwd")
+            elif op.kind == "avgpool":
+                L.check(lib.din_avgpool_bwd(C.byref(d), _ptr(gout), _ptr(gsrc), mask, int(acc), st), "avgpool_bwd")
+            else:
+                L.check(lib.din_bilinear_bwd(C.byref(d), _ptr(gout), _ptr(gsrc), mask, int(acc), st), "bilinear_bwd")
+        # the gradient of dst is dead once all its producers ran; producers of one tensor are contiguous in program
+        # order for our graphs only per view, so free conservatively when no earlier op writes this tensor
+        if not any(o.dst.tid == op.dst.tid for o in g.ops[:oi]):
+            gbufs.pop(op.dst.tid, None)
+    return grads
+
+
+class NHWCGraphFunction(torch.autograd.Function):
+    """images (uint8|fp32 NCHW, 0..255) -> output NHWC buffers.  One autograd node for the whole conv stack."""
+
+    @staticmethod
+    def forward(ctx, graph: Graph, dt: int, images: torch.Tensor, prenormalised: bool, *params):
+        lib = L.load()
+        require_gpu(images, *params)
+        nb, _, h, w = images.shape
+        ti = graph.tensors[graph.input_tid]
+        assert (h, w) == (ti.h, ti.w), f"image {h}x{w} does not match the graph ({ti.h}x{ti.w})"
+        img = torch.empty((nb, h, w, ti.c), dtype=torch_dtype(dt), device=images.device)
+        st = _stream()
+        if prenormalised:
+            if ti.c > 3:
+                img.zero_()
+            L.check(lib.din_nchw_f32_to_nhwc(_ptr(images.float().contiguous()), nb, h, w, 3, _ptr(img), dt, ti.c, 0, st),
+                    "nchw_to_nhwc")
+        else:
+            if images.dtype == torch.uint8:
+                L.check(lib.din_prep_images_nhwc(_ptr(images), 1, _ptr(img), dt, nb, h, w, ti.c, st), "prep_nhwc")
+            else:
+                L.check(lib.din_prep_images_nhwc(_ptr(images.float().contiguous()), 0, _ptr(img), dt, nb, h, w, ti.c, st),
+                        "prep_nhwc")
+        with torch.no_grad():
+            bufs, aux = graph_forward(graph, img, params, dt)
+        ctx.graph, ctx.dt, ctx.bufs, ctx.aux = graph, dt, bufs, aux
+        ctx.params = params
+        ctx.need = [p.requires_grad for p in params]
+        outs = tuple(bufs[t] for t in graph.output_tids)
+        ctx.mark_non_differentiable()
+        return outs if len(outs) > 1 else outs[0]
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        graph = ctx.graph
+        og = {}
+        for tid, go in zip(graph.output_tids, gouts):
+            if go is not None:
+                og[tid] = go.contiguous()
+        with torch.no_grad():
+            grads = graph_backward(graph, ctx.bufs, ctx.aux, ctx.params, ctx.dt, og, ctx.need)
+        ctx.bufs = ctx.aux = None
+        grads = [gr if need else None for gr, need in zip(grads, ctx.need)]
+        return (None, None, None, None, *grads)

@@ -1,0 +1,222 @@
+/* din_hip.h -- C ABI of libdin_hip.so: the MI355X (gfx950) kernels behind the DIN stage-2 hot path.
+ *
+ * The reference (JacobYuan7/DIN-Group-Activity-Recognition-Benchmark) is pure Python; its only native
+ * boundary is the third-party `roi_align` torch extension.  This header therefore DEFINES the native
+ * boundary a maintainer would bind (ctypes stub shown in INTEGRATION.md); each entry cites the reference
+ * interface (file:line, relative to the reference root) whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - plain C types only; every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm allocates);
+ *    the library never allocates, never frees, never synchronises, never throws.
+ *  - every function returns 0 on success or a negative DIN_E_* code; din_last_error_string() gives the
+ *    thread-local message.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *  - activations are NHWC ("pixel-major"): element (n,y,x,c) of a tensor with pixel stride `ld` and
+ *    channel offset `coff` lives at ((n*H+y)*W+x)*ld + coff + c.  ld/coff let several producers write
+ *    disjoint channel ranges of one buffer (torch.cat(dim=1) at infer_model.py:172 and in the Inception
+ *    blocks costs nothing).
+ *  - dtype: DIN_F32 (parity mode, fp32 storage + fp32 MFMA accumulate) or DIN_BF16 (throughput mode:
+ *    bf16 storage, fp32 MFMA accumulate).  Everything after RoIAlign is always fp32.
+ *  - stateless and re-entrant: safe from autograd worker threads, concurrently on different streams.
+ */
+#ifndef DIN_HIP_H
+#define DIN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIN_ABI_VERSION 1
+
+enum { DIN_F32 = 0, DIN_BF16 = 1 };
+
+enum {
+    DIN_OK = 0,
+    DIN_E_ARG = -1,      /* bad argument (shape, alignment, null pointer)            */
+    DIN_E_LAUNCH = -2,   /* hipLaunch / hipGetLastError failure                       */
+    DIN_E_WORKSPACE = -3,/* caller-provided workspace too small                       */
+    DIN_E_UNSUPPORTED = -4
+};
+
+int din_abi_version(void);
+const char* din_last_error_string(void);
+/* name of the device code object's target ("gfx950"); lets the host fail loudly on a wrong build */
+const char* din_build_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row P  prep_images  (utils.py:8-19): y = ((x/255) - 0.5) * 2, same three fp32 roundings.
+ * ---------------------------------------------------------------------------------------------- */
+/* NCHW fp32 -> NCHW fp32, API-parity form of utils.prep_images */
+int din_prep_images_f32(const float* in, float* out, int64_t n, void* stream);
+/* fused loader for the backbone: NCHW (uint8 or fp32, values 0..255) -> normalised NHWC with the channel
+ * dimension zero-padded to `cpad` (4 for DIN_F32, 8 for DIN_BF16) so conv1 reads 16-byte pixels.      */
+int din_prep_images_nhwc(const void* in, int in_is_u8, void* out, int out_dtype,
+                         int nb, int h, int w, int cpad, void* stream);
+/* backward of the loader is never needed (images carry no gradient: train_net_dynamic.py:175). */
+
+/* ------------------------------------------------------------------------------------------------
+ * Rows V, I, E, L, D1  dense contractions: implicit-GEMM convolution on MFMA.
+ * Replaces torch.nn.Conv2d / nn.Linear arithmetic reached from backbone/backbone.py:44-99,
+ * infer_model.py:184 (fc_emb_1), :190 (point_conv), :226 (fc_activities),
+ * dynamic_infer_module.py:149 (hidden_weight), :191 (p_conv), :195 (scale_conv).
+ * A Linear layer is the 1x1 case with NB=1, H=1, W=rows.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct din_conv_desc {
+    int32_t nb, h, w, cin;          /* input  tensor [nb,h,w,cin], pixel stride ldi, channel offset cioff   */
+    int32_t oh, ow, cout;           /* output tensor [nb,oh,ow,cout], pixel stride ldo, channel offset cooff */
+    int32_t kh, kw, sh, sw, ph, pw, dh, dw;
+    int32_t ldi, cioff, ldo, cooff;
+    int32_t dtype;                  /* DIN_F32 / DIN_BF16 : storage type of in, out and packed weights       */
+} din_conv_desc;
+
+enum {
+    DIN_CONV_BIAS = 1,   /* out += bias[cout]  (fp32 vector)                                    */
+    DIN_CONV_RELU = 2,   /* out = max(out, 0)                                                    */
+    DIN_CONV_ACCUM = 4,  /* dgrad only: out += result (several consumers of one tensor)          */
+    DIN_CONV_MASK = 8    /* dgrad only: result *= (mask > 0)  -- fused ReLU backward, mask has the
+                            layout of the dgrad output (pixel stride ldm, channel offset moff)    */
+};
+
+/* number of elements (of desc->dtype) of the packed filter bank for fwd (transposed=0) / dgrad (=1) */
+int64_t din_conv_packed_elems(const din_conv_desc* d, int transposed);
+/* w: reference layout [cout][cin][kh][kw] fp32.  scale (nullable, [cout] fp32) is folded into the filters
+ * (BatchNorm-eval: backbone.py BasicConv2d).  transposed=0 -> [cout_pad][(r,s,ci)], =1 -> [cin_pad][(r,s,co)] */
+int din_conv_pack_weights(const din_conv_desc* d, const float* w, const float* scale, void* wpk,
+                          int transposed, void* stream);
+/* workspace bytes needed by fwd / dgrad / wgrad for this descriptor (split-K partial sums) */
+int64_t din_conv_workspace_bytes(const din_conv_desc* d, int which /*0 fwd,1 dgrad,2 wgrad*/);
+
+int din_conv_fwd(const din_conv_desc* d, const void* in, const void* wpk, const float* bias, void* out,
+                 int flags, void* workspace, int64_t workspace_bytes, void* stream);
+/* dout has the OUTPUT geometry of d (pixel stride ldo/cooff); din gets the INPUT geometry (ldi/cioff).   */
+int din_conv_dgrad(const din_conv_desc* d, const void* dout, const void* wpk_t, void* din,
+                   const void* mask, int ldm, int moff, int flags,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+/* dw: [cout][cin][kh][kw] fp32, overwritten (or += when accumulate!=0), multiplied by scale[cout] when scale
+ * is given.  dbias (nullable) [cout] fp32 = column sums of dout.  wdot (nullable) [cout] fp32 =
+ * <w[co,:], dw_raw[co,:]> (needs w) -- the BatchNorm-eval scale gradient.                                */
+int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, float* dw, float* dbias,
+                   const float* scale, const float* w, float* wdot, int accumulate,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+
+/* BatchNorm(eval) folding helpers (torchvision BasicConv2d, eps=1e-3; train_net_dynamic.py:17-20 set_bn_eval)
+ * scale = gamma*rsqrt(var+eps); shift = beta - mean*scale                                                */
+int din_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                float* scale, float* shift, int c, void* stream);
+/* dgamma = (wdot - dshift*mean)*rsqrt(var+eps); dbeta = dshift                                            */
+int din_bn_fold_bwd(const float* wdot, const float* dshift, const float* mean, const float* var, float eps,
+                    float* dgamma, float* dbeta, int c, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pools / resize (backbone.py:51,57 max_pool2d; torchvision InceptionA/C avg_pool2d(3,1,1), InceptionB
+ * max_pool2d(3,2); vgg.features MaxPool2d(2,2); infer_model.py:169 F.interpolate bilinear align_corners)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct din_pool_desc {
+    int32_t nb, h, w, c, oh, ow;
+    int32_t k, stride, pad;
+    int32_t ldi, cioff, ldo, cooff;
+    int32_t dtype;
+} din_pool_desc;
+int din_maxpool_fwd(const din_pool_desc* d, const void* in, void* out, void* stream);
+/* din = scatter of dout to the first maximal element of each window; relu_mask!=0 additionally multiplies by
+ * (in > 0) -- the fused backward of the ReLU that produced `in`.  accumulate!=0: din += ...             */
+int din_maxpool_bwd(const din_pool_desc* d, const void* in, const void* dout, void* din_, int relu_mask,
+                    int accumulate, void* stream);
+int din_avgpool_fwd(const din_pool_desc* d, const void* in, void* out, void* stream);   /* count_include_pad */
+int din_avgpool_bwd(const din_pool_desc* d, const void* dout, void* din_, const void* mask, int accumulate,
+                    void* stream);
+int din_bilinear_fwd(const din_pool_desc* d, const void* in, void* out, void* stream); /* align_corners=True */
+int din_bilinear_bwd(const din_pool_desc* d, const void* dout, void* din_, const void* mask, int accumulate,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row R  RoIAlign(K,K) = TF crop_and_resize, transform_fpcoor=True (third-party longcw/RoIAlign.pytorch;
+ * call site infer_model.py:178-180).  fm: NHWC [nb,hf,wf,c] (dtype fm_dtype, pixel stride ldf);
+ * boxes [m,4]=(x1,y1,x2,y2) feature px fp32; box_ind [m] int32; out fp32 [m][c][k][k] (the reference's
+ * flatten order d,ky,kx: infer_model.py:181).  idx_out (nullable) int32 [m][k][6] =
+ * (top,bottom,left,right,oob_y,oob_x) per sample row/col for bit-exact index tests.
+ * ---------------------------------------------------------------------------------------------- */
+int din_roi_align_fwd(const void* fm, int fm_dtype, int nb, int hf, int wf, int c, int ldf,
+                      const float* boxes, const int32_t* box_ind, int m, int k,
+                      float* out, int32_t* idx_out, void* stream);
+/* dfm fp32 [nb,hf,wf,c] must be zeroed by the caller; 4-corner atomic scatter; no gradient to boxes */
+int din_roi_align_bwd(const float* dout, int nb, int hf, int wf, int c,
+                      const float* boxes, const int32_t* box_ind, int m, int k,
+                      float* dfm, void* stream);
+/* fp32 gradient map -> backbone dtype, fused with the ReLU mask of the feature map that was cropped */
+int din_grad_cast_mask(const float* g, const void* y, void* out, int dtype, int64_t pixels, int c,
+                       int ldy, int yoff, int ldo, int ooff, int use_mask, void* stream);
+/* builds box_ind[i*n+j] = i (infer_model.py:155-157) */
+int din_boxes_frame_index(int32_t* out, int bt, int n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm (+residual, +ReLU, +dropout): nl_emb_1 (infer_model.py:185), point_ln (:192), dpi_nl (:214),
+ * hier_LN (dynamic_infer_module.py:493).  x, res: [rows][len]; gamma/beta [len]; eps 1e-5.
+ * y = dropout(relu?(LN(x + res?)*gamma + beta)).  stats: [rows][2] = (mean, rstd) saved for backward.
+ * dropout: keep-mask from a counter-based hash of (seed, element index), scale 1/(1-p); p=0 disables.
+ * ---------------------------------------------------------------------------------------------- */
+int din_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps,
+                      float* y, float* stats, int64_t rows, int64_t len, int relu, float drop_p,
+                      uint64_t seed, void* stream);
+/* dx [rows][len] (also the gradient of res); dgamma/dbeta [len] are ACCUMULATED atomically (caller zeroes) */
+int din_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma,
+                      const float* y, const float* stats, float* dx, float* dgamma, float* dbeta,
+                      int64_t rows, int64_t len, int relu, float drop_p, uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rows D2-D4  Dynamic Relation + Dynamic Walk (dynamic_infer_module.py:184-282, 344-404), one module,
+ * one sampling ratio.  x fp32 [b,t,n,c].  pred fp32 [b,t,n,cp] is the output of the fused
+ * p_conv/scale_conv contraction (din_conv_fwd with cout = 3*k2: channels [0,k2) y-offsets, [k2,2k2)
+ * x-offsets, [2k2,3k2) relation logits; cp = its pixel stride).  scale_factor=0 -> mean over k2, no logits.
+ *   z   [b,t,n,c]      = sum_k a_k * S_k                   (:278 / :280)
+ *   a   [b,t,n,k2]     = softmax_k(logits)  (saved)        (:196)
+ *   idx [b,t,n,k2,4]   int32 (ly,ry,lx,rx) clamped corners (:208-223)  -- bit-exact row
+ *   mad (nullable) [b,t,n,k2,c] = S (ft_infer_MAD, :259); not materialised when NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int din_walk_fwd(const float* x, const float* pred, int cp, int b, int t, int n, int c,
+                 int kh, int kw, int ratio, int scale_factor,
+                 float* z, float* a, int32_t* idx, float* mad, void* stream);
+/* gz [b,t,n,c] -> dx_walk [b,t,n,c] (overwritten), dpred [b,t,n,cp] (first 3*k2 channels written):
+ * d offset through the |.| coefficients with detached floor (Q4), inclusive clamp pass-through (Q9),
+ * sign(0)=0 (Q8); d logits through the softmax.  scratch: fp32 [b,t,n,3*k2] zeroed by the call.     */
+int din_walk_bwd(const float* x, const float* pred, int cp, const float* a, const float* gz,
+                 int b, int t, int n, int c, int kh, int kw, int ratio, int scale_factor,
+                 float* dx, float* dpred, float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row H  head (infer_model.py:224-232): max over actors -> fc_activities -> mean over frames.
+ * s fp32 [b,t,n,c]; w [a,c]; bias [a]; argmax int32 [b,t,c] saved for backward.
+ * scores: caller allocates b*a + b*t*a floats: [0, b*a) = clip scores [b,a], the tail = per-frame scores [b,t,a].
+ * n_per_clip (nullable, int32 [b]) = number of valid actors of each clip (Collective: variable N).
+ * ---------------------------------------------------------------------------------------------- */
+int din_head_fwd(const float* s, const float* w, const float* bias, const int32_t* n_per_clip,
+                 int b, int t, int n, int c, int a, float* scores, int32_t* argmax, void* stream);
+/* ds overwritten; dw, dbias ACCUMULATED atomically (caller zeroes) */
+int din_head_bwd(const float* dscores, const float* s, const float* w, const int32_t* argmax,
+                 int b, int t, int n, int c, int a, float* ds, float* dw, float* dbias, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small helpers used by the host mirror
+ * ---------------------------------------------------------------------------------------------- */
+/* out = alpha*x + beta*y (fp32, elementwise) -- ratio mean / beta-weighted sum (:144-147), residual sums */
+int din_axpby(const float* x, const float* y, float* out, float alpha, float beta, int64_t n, void* stream);
+/* out (+)= x * scalar[idx] with a DEVICE scalar (learnable beta, :42-44,145); out[idx] += <x,y> for its gradient */
+int din_scale_by_param(const float* x, const float* scalar, int idx, float* out, int accumulate, int64_t n, void* stream);
+int din_dot_accum(const float* x, const float* y, float* out, int idx, int64_t n, void* stream);
+/* dst[i] = (dtype)src[i] conversions between fp32 and bf16 */
+int din_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* NHWC(dtype, ld/coff) -> NCHW fp32 and back: API-parity views for MyVGG16/MyInception_v3 outputs */
+int din_nhwc_to_nchw_f32(const void* in, int dtype, int nb, int h, int w, int c, int ld, int coff,
+                         float* out, void* stream);
+int din_nchw_f32_to_nhwc(const float* in, int nb, int h, int w, int c, void* out, int dtype, int ld,
+                         int coff, void* stream);
+/* fused Adam step over a flat fp32 parameter/gradient buffer (train_net_dynamic.py:104,224) */
+int din_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIN_HIP_H */

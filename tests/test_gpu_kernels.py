@@ -1,0 +1,335 @@
+"""GPU (-m gpu): per-kernel parity of the HIP path, called through the C ABI (ctypes), against CPU fp32 references.
+Integer/index outputs are compared bit-exactly; fp32 within the tolerance written next to each check."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import din_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from din_amd import _lib, nhwc, ops
+    return _lib.load(), _lib, nhwc, ops
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def to_nhwc(x, dtype, ld=None, coff=0):
+    """CPU NCHW fp32 -> device NHWC buffer (test plumbing)."""
+    n, c, h, w = x.shape
+    ld = ld or c
+    buf = torch.zeros(n, h, w, ld, dtype=dtype)
+    buf[..., coff:coff + c] = x.permute(0, 2, 3, 1).to(dtype)
+    return buf.cuda()
+
+
+def from_nhwc(buf, c, coff=0):
+    return buf[..., coff:coff + c].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # name, nb, cin, h, w, cout, k, s, p, d
+    ("3x3_s1_p1", 2, 16, 13, 17, 24, (3, 3), (1, 1), (1, 1), 1),
+    ("conv1_cin3", 2, 3, 20, 24, 64, (3, 3), (1, 1), (1, 1), 1),
+    ("1x1", 1, 64, 9, 11, 80, (1, 1), (1, 1), (0, 0), 1),
+    ("3x3_s2_p0", 2, 32, 15, 19, 48, (3, 3), (2, 2), (0, 0), 1),
+    ("5x5_p2", 1, 48, 10, 12, 64, (5, 5), (1, 1), (2, 2), 1),
+    ("1x7", 1, 32, 9, 14, 32, (1, 7), (1, 1), (0, 3), 1),
+    ("7x1", 1, 32, 14, 9, 192, (7, 1), (1, 1), (3, 0), 1),
+    ("dil3_grid", 2, 32, 10, 12, 27, (3, 3), (1, 1), (3, 3), 3),
+    ("big_tile", 1, 128, 40, 48, 256, (3, 3), (1, 1), (1, 1), 1),
+    ("linear_splitk", 1, 1600, 1, 72, 128, (1, 1), (1, 1), (0, 0), 1),
+]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(env, case, dtype):
+    lib, L, nhwc, ops = env
+    name, nb, cin, h, w, cout, k, s, p, dil = case
+    dt = L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
+    tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    epc = 4 if dtype == "fp32" else 8
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    x = torch.randn(nb, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, *k, generator=g) * (2.0 / (cin * k[0] * k[1])) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    if dtype == "bf16":                       # compare like with like: reference sees the bf16-rounded operands
+        x, wt = x.bfloat16().float(), wt.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    y_ref = F.relu(F.conv2d(xr, wr, br, stride=s, padding=p, dilation=dil))
+    oh, ow = y_ref.shape[2:]
+    cot = torch.randn(y_ref.shape, generator=g)
+    if dtype == "bf16":
+        cot = cot.bfloat16().float()
+    gz_ref = cot * (y_ref > 0).float()                      # dZ: gradient at the pre-activation
+    y_ref.backward(cot)
+
+    ldi = (cin + epc - 1) // epc * epc
+    ldo = (cout + 7) // 8 * 8 + 16                          # extra room: exercise pixel stride != channels
+    coff = 8
+    d = L.ConvDesc()
+    d.nb, d.h, d.w, d.cin, d.oh, d.ow, d.cout = nb, h, w, cin, oh, ow, cout
+    d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.dh, d.dw = k[0], k[1], s[0], s[1], p[0], p[1], dil, dil
+    d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = ldi, 0, ldo, coff, dt
+    st = None
+    xin = to_nhwc(x, tdt, ldi)
+    wdev, bdev = wt.cuda(), bias.cuda()
+    wpk = torch.empty(lib.din_conv_packed_elems(C.byref(d), 0), dtype=tdt, device="cuda")
+    L.check(lib.din_conv_pack_weights(C.byref(d), wdev.data_ptr(), None, wpk.data_ptr(), 0, st))
+    out = torch.full((nb, oh, ow, ldo), 7.0, dtype=tdt, device="cuda")
+    wsb = lib.din_conv_workspace_bytes(C.byref(d), 0)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device="cuda")
+    L.check(lib.din_conv_fwd(C.byref(d), xin.data_ptr(), wpk.data_ptr(), bdev.data_ptr(), out.data_ptr(),
+                             L.CONV_BIAS | L.CONV_RELU, ws.data_ptr(), wsb, st))
+    torch.cuda.synchronize()
+    tol = 2e-5 if dtype == "fp32" else 1.5e-2               # bf16: output rounding 2^-8 + fp32-accumulated products
+    assert rel(from_nhwc(out, cout, coff), y_ref) <= tol
+    assert float(out[..., :coff].float().min()) == 7.0 and float(out[..., coff + cout:].float().min()) == 7.0, "wrote outside its channel range"
+
+    # ---- wgrad + bias grad
+    gz = to_nhwc(gz_ref, tdt, ldo, coff)
+    dw = torch.empty_like(wdev)
+    db = torch.empty(cout, device="cuda")
+    wsb = lib.din_conv_workspace_bytes(C.byref(d), 2)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device="cuda")
+    L.check(lib.din_conv_wgrad(C.byref(d), xin.data_ptr(), gz.data_ptr(), dw.data_ptr(), db.data_ptr(), None, None, None, 0,
+                               ws.data_ptr(), wsb, st))
+    torch.cuda.synchronize()
+    tolg = 5e-5 if dtype == "fp32" else 2e-2
+    assert rel(dw, wr.grad) <= tolg
+    assert rel(db, br.grad) <= tolg
+
+    # ---- dgrad (+ fused ReLU mask of the producer of x, + accumulate)
+    if cin % epc == 0:
+        wpt = torch.empty(lib.din_conv_packed_elems(C.byref(d), 1), dtype=tdt, device="cuda")
+        L.check(lib.din_conv_pack_weights(C.byref(d), wdev.data_ptr(), None, wpt.data_ptr(), 1, st))
+        dx = torch.zeros((nb, h, w, ldi), dtype=tdt, device="cuda")
+        wsb = lib.din_conv_workspace_bytes(C.byref(d), 1)
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device="cuda")
+        L.check(lib.din_conv_dgrad(C.byref(d), gz.data_ptr(), wpt.data_ptr(), dx.data_ptr(), None, 0, 0, 0, ws.data_ptr(), wsb, st))
+        torch.cuda.synchronize()
+        assert rel(from_nhwc(dx, cin), xr.grad) <= tolg
+        L.check(lib.din_conv_dgrad(C.byref(d), gz.data_ptr(), wpt.data_ptr(), dx.data_ptr(), xin.data_ptr(), ldi, 0,
+                                   L.CONV_MASK | L.CONV_ACCUM, ws.data_ptr(), wsb, st))
+        torch.cuda.synchronize()
+        want = xr.grad + xr.grad * (x > 0).float()
+        assert rel(from_nhwc(dx, cin), want) <= 2 * tolg
+
+
+def test_bn_fold_and_wdot(env):
+    lib, L, nhwc, ops = env
+    c = 24
+    g = torch.Generator().manual_seed(3)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    mean, var = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    x = torch.randn(2, 16, 9, 9, generator=g)
+    wt = torch.randn(c, 16, 3, 3, generator=g) * 0.1
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = F.relu(F.batch_norm(F.conv2d(xr, wr, None, padding=1), mean, var, gr, br, False, 0.0, 1e-3))
+    cot = torch.randn(y.shape, generator=g)
+    y.backward(cot)
+    ga = cot * (y > 0).float()
+    dev = lambda t: t.cuda().contiguous()
+    gd_, bd_, md_, vd_ = dev(gamma), dev(beta), dev(mean), dev(var)        # keep alive: raw pointers below
+    scale, shift = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    L.check(lib.din_bn_fold(gd_.data_ptr(), bd_.data_ptr(), md_.data_ptr(), vd_.data_ptr(), 1e-3,
+                            scale.data_ptr(), shift.data_ptr(), c, None))
+    d = L.ConvDesc()
+    d.nb, d.h, d.w, d.cin, d.oh, d.ow, d.cout = 2, 9, 9, 16, 9, 9, c
+    d.kh = d.kw = 3
+    d.sh = d.sw = d.ph = d.pw = d.dh = d.dw = 1
+    d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = 16, 0, c, 0, L.DIN_F32
+    xin, wdev = to_nhwc(x, torch.float32), dev(wt)
+    wpk = torch.empty(lib.din_conv_packed_elems(C.byref(d), 0), device="cuda")
+    L.check(lib.din_conv_pack_weights(C.byref(d), wdev.data_ptr(), scale.data_ptr(), wpk.data_ptr(), 0, None))
+    out = torch.empty(2, 9, 9, c, device="cuda")
+    L.check(lib.din_conv_fwd(C.byref(d), xin.data_ptr(), wpk.data_ptr(), shift.data_ptr(), out.data_ptr(), L.CONV_BIAS | L.CONV_RELU, None, 0, None))
+    assert rel(from_nhwc(out, c), y) <= 2e-5
+    gdev = to_nhwc(ga, torch.float32)
+    dw, dshift, wdot = torch.empty_like(wdev), torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    wsb = lib.din_conv_workspace_bytes(C.byref(d), 2)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    L.check(lib.din_conv_wgrad(C.byref(d), xin.data_ptr(), gdev.data_ptr(), dw.data_ptr(), dshift.data_ptr(), scale.data_ptr(),
+                               wdev.data_ptr(), wdot.data_ptr(), 0, ws.data_ptr(), wsb, None))
+    dgamma, dbeta = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    L.check(lib.din_bn_fold_bwd(wdot.data_ptr(), dshift.data_ptr(), md_.data_ptr(), vd_.data_ptr(), 1e-3,
+                                dgamma.data_ptr(), dbeta.data_ptr(), c, None))
+    torch.cuda.synchronize()
+    assert rel(dw, wr.grad) <= 5e-5 and rel(dgamma, gr.grad) <= 5e-5 and rel(dbeta, br.grad) <= 5e-5
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("kind,k,s,p", [("maxpool", 2, 2, 0), ("maxpool", 3, 2, 0), ("avgpool", 3, 1, 1)])
+def test_pools(env, kind, k, s, p, dtype):
+    lib, L, nhwc, ops = env
+    tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    g = torch.Generator().manual_seed(k * 10 + s)
+    x = F.relu(torch.randn(2, 16, 13, 15, generator=g))            # post-ReLU input with ties at zero
+    if dtype == "bf16":
+        x = x.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    y = F.max_pool2d(xr, k, s, p) if kind == "maxpool" else F.avg_pool2d(xr, k, s, p)
+    cot = torch.randn(y.shape, generator=g)
+    if dtype == "bf16":
+        cot = cot.bfloat16().float()
+    y.backward(cot)
+    d = L.PoolDesc()
+    d.nb, d.h, d.w, d.c, d.oh, d.ow = 2, 13, 15, 16, y.shape[2], y.shape[3]
+    d.k, d.stride, d.pad, d.ldi, d.cioff, d.ldo, d.cooff = k, s, p, 24, 4, 16, 0
+    d.dtype = L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
+    xin = to_nhwc(x, tdt, 24, 4)
+    out = torch.empty(2, y.shape[2], y.shape[3], 16, dtype=tdt, device="cuda")
+    fwd = lib.din_maxpool_fwd if kind == "maxpool" else lib.din_avgpool_fwd
+    L.check(fwd(C.byref(d), xin.data_ptr(), out.data_ptr(), None))
+    tol = 1e-6 if dtype == "fp32" else 8e-3
+    assert rel(from_nhwc(out, 16), y) <= tol
+    gout = to_nhwc(cot, tdt)
+    dx = torch.zeros_like(xin)
+    if kind == "maxpool":
+        L.check(lib.din_maxpool_bwd(C.byref(d), xin.data_ptr(), gout.data_ptr(), dx.data_ptr(), 1, 0, None))
+    else:
+        L.check(lib.din_avgpool_bwd(C.byref(d), gout.data_ptr(), dx.data_ptr(), xin.data_ptr(), 0, None))
+    torch.cuda.synchronize()
+    want = xr.grad * (x > 0).float()
+    assert rel(from_nhwc(dx, 16, 4), want) <= (1e-6 if dtype == "fp32" else 1.5e-2)
+
+
+def test_bilinear_align_corners(env):
+    lib, L, nhwc, ops = env
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 8, 7, 11, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y = F.interpolate(xr, size=(15, 23), mode="bilinear", align_corners=True)
+    assert rel(O.bilinear_resize_align_corners(x, 15, 23), y) <= 1e-6        # oracle restatement vs ATen
+    cot = torch.randn(y.shape, generator=g)
+    y.backward(cot)
+    d = L.PoolDesc()
+    d.nb, d.h, d.w, d.c, d.oh, d.ow = 2, 7, 11, 8, 15, 23
+    d.k, d.stride, d.pad, d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = 1, 1, 0, 8, 0, 16, 8, L.DIN_F32
+    xin = to_nhwc(x, torch.float32)
+    out = torch.zeros(2, 15, 23, 16, device="cuda")
+    L.check(lib.din_bilinear_fwd(C.byref(d), xin.data_ptr(), out.data_ptr(), None))
+    assert rel(from_nhwc(out, 8, 8), y) <= 2e-6
+    gout = to_nhwc(cot, torch.float32, 16, 8)
+    dx = torch.empty_like(xin)
+    L.check(lib.din_bilinear_bwd(C.byref(d), gout.data_ptr(), dx.data_ptr(), None, 0, None))
+    torch.cuda.synchronize()
+    assert rel(from_nhwc(dx, 8), xr.grad) <= 5e-6
+
+
+def test_prep_images_bit_exact(env):
+    lib, L, nhwc, ops = env
+    x = torch.arange(0, 256, dtype=torch.float32)
+    y = ops.prep_images_f32(x.cuda()).cpu()
+    assert torch.equal(y, O.prep_images(x))
+    img = torch.randint(0, 256, (2, 3, 5, 7), dtype=torch.uint8)
+    out = torch.empty(2, 5, 7, 4, device="cuda")
+    L.check(lib.din_prep_images_nhwc(img.cuda().data_ptr(), 1, out.data_ptr(), L.DIN_F32, 2, 5, 7, 4, None))
+    torch.cuda.synchronize()
+    assert torch.equal(out[..., :3].cpu(), O.prep_images(img.float()).permute(0, 2, 3, 1))
+    assert float(out[..., 3].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("k", [5, 1, 3])
+def test_roi_align_index_bit_exact_and_values(env, k):
+    lib, L, nhwc, ops = env
+    g = torch.Generator().manual_seed(5)
+    nb, c, hf, wf, n = 3, 96, 22, 40, 12
+    fm = torch.randn(nb, c, hf, wf, generator=g)
+    _, boxes, _ = O.synth_inputs(1, nb, n, 8, 8, hf, wf, seed=7)
+    boxes = boxes.reshape(nb * n, 4).clone()
+    boxes[5] = 0.0                                     # Collective padding box -> out of range -> zeros
+    boxes[6] = torch.tensor([-3.0, 2.0, 50.0, 30.0])   # partially outside
+    boxes[7] = torch.tensor([4.0, 4.0, 9.0, 9.0])      # integer-aligned samples (floor == ceil)
+    ind = O.boxes_frame_index(nb, n)
+    fmr = fm.clone().requires_grad_(True)
+    ref, ridx = O.roi_align(fmr, boxes, ind, k, return_index=True)
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot)
+    fmd = to_nhwc(fm, torch.float32).requires_grad_(True)
+    out, idx = ops.RoIAlignFunction.apply(fmd, boxes.cuda(), ind.cuda(), k, c, False, True)
+    idx = idx.cpu()
+    # integer decisions: bit-exact
+    assert torch.equal(idx[:, :, 0, 0], ridx["top"]) and torch.equal(idx[:, :, 0, 1], ridx["bot"])
+    assert torch.equal(idx[:, 0, :, 2], ridx["left"]) and torch.equal(idx[:, 0, :, 3], ridx["right"])
+    assert torch.equal(idx[:, :, 0, 4].bool(), ridx["oob_y"]) and torch.equal(idx[:, 0, :, 5].bool(), ridx["oob_x"])
+    assert torch.equal(out.detach().cpu(), ref.detach()), "RoIAlign values must be bit-exact in fp32 (same op order)"
+    out.backward(cot.cuda())
+    assert rel(fmd.grad.cpu().permute(0, 3, 1, 2), fmr.grad) <= 1e-5
+    assert torch.equal(ops.boxes_frame_index(nb, n, "cuda").cpu(), ind)
+
+
+def test_layernorm_variants(env):
+    lib, L, nhwc, ops = env
+    g = torch.Generator().manual_seed(11)
+    for shape, norm in [((72, 1024), (1024,)), ((2, 3, 12, 128), (3, 12, 128)), ((5, 10, 64), (10, 64))]:
+        x = torch.randn(shape, generator=g)
+        r = torch.randn(shape, generator=g)
+        gamma, beta = torch.rand(norm, generator=g) + 0.5, torch.randn(norm, generator=g)
+        for use_res in (False, True):
+            xr, rr = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+            gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+            y = F.relu(F.layer_norm(xr + rr if use_res else xr, norm, gr, br, 1e-5))
+            cot = torch.randn(shape, generator=g)
+            y.backward(cot)
+            xd, rd = x.cuda().requires_grad_(True), r.cuda().requires_grad_(True)
+            gd, bd = gamma.cuda().requires_grad_(True), beta.cuda().requires_grad_(True)
+            yd = ops.layer_norm(xd, gd, bd, res=rd if use_res else None, relu=True)
+            yd.backward(cot.cuda())
+            assert rel(yd, y) <= 1e-5
+            assert rel(xd.grad, xr.grad) <= 1e-4 and rel(gd.grad, gr.grad) <= 1e-4 and rel(bd.grad, br.grad) <= 1e-4
+            if use_res:
+                assert rel(rd.grad, rr.grad) <= 1e-4
+    # dropout: same mask forward/backward, keep-rate ~ 1-p, survivors scaled by 1/(1-p)
+    x = torch.randn(4, 4096, generator=g).cuda().requires_grad_(True)
+    ga, be = torch.ones(4096, device="cuda"), torch.zeros(4096, device="cuda")
+    y0 = ops.layer_norm(x, ga, be, relu=False, drop_p=0.0)
+    y1 = ops.layer_norm(x, ga, be, relu=False, drop_p=0.3, seed=1234)
+    keep = (y1 != 0)
+    assert abs(keep.float().mean().item() - 0.7) < 0.02
+    assert rel(y1[keep], y0[keep] / 0.7) <= 1e-5
+    y1b = ops.layer_norm(x, ga, be, relu=False, drop_p=0.3, seed=1234)
+    assert torch.equal(y1, y1b)
+
+
+def test_head_and_adam(env):
+    lib, L, nhwc, ops = env
+    g = torch.Generator().manual_seed(13)
+    b, t, n, c, a = 2, 3, 12, 256, 8
+    s = torch.randn(b, t, n, c, generator=g)
+    w, bias = torch.randn(a, c, generator=g) * 0.1, torch.randn(a, generator=g)
+    sr, wr, br = s.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    pooled = sr.max(dim=2).values
+    ref = F.linear(pooled.reshape(b * t, c), wr, br).reshape(b, t, a).mean(1)
+    cot = torch.randn(b, a, generator=g)
+    ref.backward(cot)
+    sd, wd, bd = s.cuda().requires_grad_(True), w.cuda().requires_grad_(True), bias.cuda().requires_grad_(True)
+    out = ops.HeadFunction.apply(sd, wd, bd, None)
+    out.backward(cot.cuda())
+    assert rel(out, ref) <= 1e-5 and rel(sd.grad, sr.grad) <= 1e-5 and rel(wd.grad, wr.grad) <= 1e-5 and rel(bd.grad, br.grad) <= 1e-5
+    # Adam vs torch.optim.Adam
+    p = torch.randn(1000, generator=g)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-2, weight_decay=0.01)
+    pd, m, v = p.cuda(), torch.zeros(1000, device="cuda"), torch.zeros(1000, device="cuda")
+    for step in range(1, 4):
+        gr = torch.randn(1000, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        ops.adam_step(pd, gr.cuda(), m, v, 1e-2, 0.9, 0.999, 1e-8, 0.01, step)
+    assert rel(pd, pr) <= 1e-5

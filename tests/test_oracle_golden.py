@@ -1,0 +1,158 @@
+"""CPU: the oracle (oracle/din_oracle.py) reproduces the golden vectors captured from the imported reference
+(tools/gen_golden.py).  This is what pins the oracle; the GPU parity tests then compare the HIP path to the oracle."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import din_oracle as O
+
+TORCH_DT = {"float32": torch.float32, "float64": torch.float64}
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def seeded(shape, seed, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g, dtype=torch.float64) * scale).to(dtype)
+
+
+def load_din_case(path):
+    z = np.load(path)
+    b, t, n, c, num_dim, beta = [int(v) for v in z["meta"]]
+    kernels = [tuple(int(x) for x in k) for k in z["kernels"]]
+    ratios = [int(r) for r in z["ratios"]]
+    dt = TORCH_DT[str(z["dtype"])]
+    if "x" in z.files:
+        x = torch.from_numpy(z["x"])
+        cot = torch.from_numpy(z["cot"])
+        p = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}
+    else:   # big cases: regenerate inputs / weights from the recorded seeds (same recipe as tools/gen_golden.py)
+        x_seed, w_seed = int(z["x_seed"]), int(z["w_seed"])
+        x = seeded((b, t, n, c), x_seed, 1.0, dt)
+        cot = seeded((b, t, n, c), x_seed + 1, 1.0, dt)
+        shapes = {}
+        for i in range(num_dim):
+            shapes.update(O.din_param_shapes(f"DIMlist.{i}.", c, kernels[i], ratios, True, bool(beta)))
+        p = O.synth_params(shapes, seed=w_seed, din_std=float(z["din_std"]), dtype=dt)
+        for k in p:
+            if "p_conv" in k:
+                p[k] = p[k] * float(z["offset_boost"])
+    return z, dict(b=b, t=t, n=n, c=c, num_dim=num_dim, beta=bool(beta), kernels=kernels, ratios=ratios, dt=dt), x, cot, p
+
+
+DIN_CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "din_*.npz")))
+
+
+def test_golden_present():
+    assert len(DIN_CASES) >= 10
+
+
+def test_prep_images_bit_exact(golden_dir):
+    z = np.load(os.path.join(golden_dir, "prep_images.npz"))
+    y = O.prep_images(torch.from_numpy(z["x"]))
+    assert np.array_equal(y.numpy(), z["y"])
+
+
+@pytest.mark.parametrize("path", DIN_CASES, ids=[os.path.basename(p)[:-4] for p in DIN_CASES])
+def test_din_oracle_matches_reference(path):
+    z, m, x, cot, p = load_din_case(path)
+    po = {("DPI." + k): v.clone().requires_grad_(True) for k, v in p.items()}
+    xo = x.clone().requires_grad_(True)
+    out, mad = O.din_multi_inference(xo, po, "DPI.", m["kernels"], m["ratios"], True, m["beta"])
+    (out * cot).sum().backward()
+    tol = 1e-5 if m["dt"] == torch.float32 else 1e-11
+    assert _rel(out.detach(), z["out"]) <= tol
+    assert _rel(xo.grad, z["gx"]) <= 10 * tol
+    if "mad" in z.files:
+        assert _rel(mad.detach(), z["mad"]) <= tol
+    for k in z.files:
+        if k.startswith("g."):
+            assert _rel(po["DPI." + k[2:]].grad, z[k]) <= 10 * tol, k
+        if k.startswith("gsum."):
+            g = po["DPI." + k[5:]].grad.double()
+            assert abs(g.sum().item() - float(z[k])) <= 1e-3 * float(z["gabs." + k[5:]]) + 1e-6, k
+    # integer corner decisions of the last module / ratio: bit-exact
+    kh, kw = m["kernels"][-1]
+    r = m["ratios"][-1]
+    pre = f"DPI.DIMlist.{m['num_dim'] - 1}."
+    _, _, aux = O.din_ratio_forward(x, p[pre[4:] + f"p_conv.{r}.weight"], p[pre[4:] + f"p_conv.{r}.bias"],
+                                    p[pre[4:] + f"scale_conv.{r}.weight"], p[pre[4:] + f"scale_conv.{r}.bias"], (kh, kw), r,
+                                    want_aux=True)
+    for name in ("ly", "ry", "lx", "rx"):
+        assert np.array_equal(aux[name].long().numpy().astype(np.int32), z[name]), name
+
+
+MODEL_CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "model_*.npz")))
+
+
+def load_model_case(path):
+    z = np.load(path)
+    B, T, N, H, W, OH, OW, D, NFB, num_dim, beta, lite, hier = [int(v) for v in z["meta"]]
+    kernels = [tuple(int(x) for x in k) for k in z["kernels"]]
+    cfg = O.OracleCfg(backbone=str(z["backbone"]), image_size=(H, W), out_size=(OH, OW), emb_features=D, num_boxes=N,
+                      num_frames=T, num_features_boxes=NFB, ST_kernel_size=kernels, sampling_ratio=[int(r) for r in z["ratios"]],
+                      num_DIM=num_dim, beta_factor=bool(beta), lite_dim=lite or None, hierarchical_inference=bool(hier))
+    seed = int(z["seed"])
+    p = O.synth_params(O.model_param_shapes(cfg), seed=seed + 3, din_std=0.02)
+    images, boxes, labels = O.synth_inputs(B, T, N, H, W, OH, OW, 8, seed=seed)
+    return z, cfg, p, images, boxes, labels
+
+
+@pytest.mark.parametrize("path", MODEL_CASES, ids=[os.path.basename(p)[:-4] for p in MODEL_CASES])
+def test_model_oracle_matches_reference(path):
+    z, cfg, p, images, boxes, labels = load_model_case(path)
+    assert np.array_equal(labels.numpy(), z["labels"])
+    po = {k: v.clone().requires_grad_("running_" not in k) for k, v in p.items()}
+    out = O.dynamic_volleyball_forward(cfg, po, images.float(), boxes)
+    loss = F.cross_entropy(out["activities"], labels)
+    loss.backward()
+    assert _rel(out["activities"].detach(), z["logits"]) <= 2e-4
+    assert abs(loss.item() - float(z["loss"])) <= 2e-4 * max(1.0, abs(float(z["loss"])))
+    for k in ("fc_activities.weight", "fc_activities.bias", "nl_emb_1.weight"):
+        assert _rel(po[k].grad, z["g." + k]) <= 1e-2, k
+
+
+def test_roi_align_known_answers():
+    """RoIAlign oracle (third-party algorithm, parity unpinned by the reference): hand-checked identities."""
+    fm = torch.arange(2 * 3 * 6 * 8, dtype=torch.float32).reshape(2, 3, 6, 8)
+    # a box whose K sample points land exactly on integer cells: x1=1,x2=6,K=5 -> spacing 1, first sample at 1+0.5-0.5=1
+    boxes = torch.tensor([[1.0, 0.0, 6.0, 5.0], [0.0, 0.0, 0.0, 0.0]])
+    ind = torch.tensor([1, 0], dtype=torch.int32)
+    out, idx = O.roi_align(fm, boxes, ind, 5, return_index=True)
+    assert torch.equal(out[0], fm[1][:, 0:5, 1:6])
+    # zero box: samples at -0.5 -> out of range -> extrapolation value 0 (collective.py:201-203 padding boxes)
+    assert torch.count_nonzero(out[1]) == 0 and bool(idx["oob_y"][1].all())
+    # K == 1 special case: centre sample
+    out1 = O.roi_align(fm, torch.tensor([[2.0, 2.0, 4.0, 4.0]]), torch.tensor([0], dtype=torch.int32), 1)
+    assert torch.allclose(out1[0, :, 0, 0], fm[0][:, 2:4, 2:4].mean((1, 2)))
+
+
+def test_din_zero_init_is_neighbourhood_mean():
+    """Q5: zero-initialised p_conv/scale_conv => DIN = mean of the zero-padded 3x3 neighbourhood, then projection."""
+    b, t, n, c = 1, 3, 5, 8
+    x = seeded((b, t, n, c), 5)
+    shapes = O.din_param_shapes("m.", c, (3, 3), [1], True, False)
+    p = O.synth_params(shapes, seed=1, din_std=0.0)
+    p["m.hidden_weight.weight"] = torch.eye(c)
+    out, mad = O.din_person_inference(x, p, "m.", (3, 3), [1], True, False)
+    ref = F.avg_pool2d(x.permute(0, 3, 1, 2), 3, 1, 1, count_include_pad=True).permute(0, 2, 3, 1)
+    assert torch.allclose(out, ref, atol=1e-6)
+
+
+def test_din_clamp_double_count_quirk():
+    """Q3: with a size-1 kernel axis (no padding) the last row is counted twice at zero offset."""
+    x = torch.ones(1, 4, 6, 2)
+    shapes = O.din_param_shapes("m.", 2, (1, 3), [1], True, False)
+    p = O.synth_params(shapes, seed=1, din_std=0.0)
+    z, _ = O.din_ratio_forward(x, p["m.p_conv.1.weight"], p["m.p_conv.1.bias"], p["m.scale_conv.1.weight"],
+                               p["m.scale_conv.1.bias"], (1, 3), 1)
+    # interior columns: mean of three ones = 1; last time row doubled -> 2; edge columns lose one neighbour
+    assert torch.allclose(z[0, 3, 2], torch.full((2,), 2.0))
+    assert torch.allclose(z[0, 1, 2], torch.full((2,), 1.0))
