@@ -40,6 +40,7 @@ struct ConvK {
     int cpt, Q, nk, M, wld;     // chunks per tap, total chunks, k-steps, pixels, packed row length (chunks)
     int flags, ldm, moff;
     int splitk, ks_per_split, n_co_tiles;
+    long long in_bytes, w_bytes;    // extents for the buffer resources
 };
 
 __device__ __forceinline__ int lds_slot(int row, int chunk) { return row * KC + (chunk ^ ((row >> 1) & 7)); }
@@ -59,125 +60,11 @@ template <> struct Mma<bf16_t> {
 };
 
 // ------------------------------------------------------------------------------------------------
-// fwd / dgrad gather kernel
+// fwd / dgrad gather kernels
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BN>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(ConvK p) {
-    constexpr int EPC = Elem<T>::EPC;
-    constexpr int TI = BN / 32;          // filter 16-tiles per wave
-    constexpr int TJ = BM / 32;          // pixel 16-tiles per wave (=4)
-    constexpr int PA = BM / 32;          // loader passes over the pixel tile
-    constexpr int PB = BN / 32;          // loader passes over the filter tile
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u32x4* smem = reinterpret_cast<u32x4*>(smem_raw);
-    // layout: [buf][ A: BM*KC | B: BN*KC ] in 16-byte units
-    constexpr int BUF = (BM + BN) * KC;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;          // wave position: pixels x filters
-    const int bid = blockIdx.x;
-    const int co_tile = bid % p.n_co_tiles;
-    const int px_tile = bid / p.n_co_tiles;
-    const int split = blockIdx.y;
-    const int ks_begin = split * p.ks_per_split;
-    int ks_end = ks_begin + p.ks_per_split;
-    if (ks_end > p.nk) ks_end = p.nk;
-
-    // ---- loader coordinates -------------------------------------------------------------------
-    const int cq = tid & 7, r0 = tid >> 3;
-    int tyb[PA], txb[PA], nbase[PA];
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        int m = px_tile * BM + r0 + 32 * i;
-        if (m < p.M) {
-            int n = m / (p.OH * p.OW);
-            int rem = m - n * (p.OH * p.OW);
-            int oy = rem / p.OW, ox = rem - oy * p.OW;
-            tyb[i] = oy * p.ay + p.by;
-            txb[i] = ox * p.ax + p.bx;
-            nbase[i] = n * p.H * p.W;
-        } else {
-            tyb[i] = -(1 << 28); txb[i] = 0; nbase[i] = 0;     // always out of range -> zeros
-        }
-    }
-    const T* __restrict__ inp = reinterpret_cast<const T*>(p.in);
-    const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(p.w);
-
-    u32x4 ga[PA], gb[PB];
-    auto load_global = [&](int ks) {
-        const int q = ks * KC + cq;
-        const bool qok = q < p.Q;
-        int tap = qok ? q / p.cpt : 0;
-        int cc = q - tap * p.cpt;
-        int r = tap / p.kw, s = tap - r * p.kw;
-        const int dyk = r * p.cy, dxk = s * p.cx;
-#pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            int ty = tyb[i] + dyk, tx = txb[i] + dxk;
-            bool ok = qok && ty >= 0 && tx >= 0;
-            int iy = ty, ix = tx;
-            if (p.divy > 1) { iy = ty / p.divy; ok = ok && (iy * p.divy == ty); }
-            if (p.divx > 1) { ix = tx / p.divx; ok = ok && (ix * p.divx == tx); }
-            ok = ok && iy < p.H && ix < p.W;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) {
-                int64_t off = (int64_t)(nbase[i] + iy * p.W + ix) * p.ldi + p.cioff + cc * EPC;
-                v = *reinterpret_cast<const u32x4*>(inp + off);
-            }
-            ga[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            int row = co_tile * BN + r0 + 32 * i;
-            gb[i] = wp[(int64_t)row * p.wld + ks * KC + cq];
-        }
-    };
-    auto store_lds = [&](int buf) {
-        u32x4* A = smem + buf * BUF;
-        u32x4* B = A + BM * KC;
-#pragma unroll
-        for (int i = 0; i < PA; ++i) A[lds_slot(r0 + 32 * i, cq)] = ga[i];
-#pragma unroll
-        for (int i = 0; i < PB; ++i) B[lds_slot(r0 + 32 * i, cq)] = gb[i];
-    };
-
-    f32x4 acc[TI][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int frow = lane & 15, fchunk = lane >> 4;
-    if (ks_begin < ks_end) {
-        load_global(ks_begin);
-        store_lds(0);
-        __syncthreads();
-        for (int ks = ks_begin; ks < ks_end; ++ks) {
-            const int cur = (ks - ks_begin) & 1;
-            const bool more = ks + 1 < ks_end;
-            if (more) load_global(ks + 1);
-            const u32x4* A = smem + cur * BUF;
-            const u32x4* B = A + BM * KC;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                u32x4 wf[TI], xf[TJ];
-#pragma unroll
-                for (int i = 0; i < TI; ++i) wf[i] = B[lds_slot(wn * (BN / 2) + i * 16 + frow, kk * 4 + fchunk)];
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) xf[j] = A[lds_slot(wm * (BM / 2) + j * 16 + frow, kk * 4 + fchunk)];
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
-            }
-            if (more) store_lds(cur ^ 1);
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue ---------------------------------------------------------------------------------
-    // lane holds D[co = co0 + i*16 + (lane>>4)*4 + e][pix = pix0 + j*16 + (lane&15)], e = 0..3
+// direct (un-staged) epilogue shared by both kernels: lane holds D[co0 + i*16 + (lane>>4)*4 + e][pix0 + j*16 + (lane&15)]
+template <typename T, int TI, int TJ, int BN>
+__device__ __forceinline__ void epilogue_direct(const ConvK& p, f32x4 (&acc)[TI][TJ], int co_tile, int px_tile, int wm, int wn, int lane, int split) {
     const int co_base = co_tile * BN + wn * (BN / 2) + (lane >> 4) * 4;
     const int px_base = px_tile * BM + wm * (BM / 2) + (lane & 15);
     if (p.splitk > 1) {
@@ -227,6 +114,332 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(ConvK p) {
                 }
             } else {
                 for (int e = 0; e < 4 && co + e < p.Cout; ++e) Elem<T>::st(outp + o + e, v[e]);
+            }
+        }
+    }
+}
+
+// Generic addressing (strided dgrad / > 64 taps): plain loads with per-k-step coordinate arithmetic.
+template <typename T, int BN>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_gather_generic_kernel(ConvK p) {
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int TI = BN / 32, TJ = BM / 32, PA = BM / 32, PB = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* smem = reinterpret_cast<u32x4*>(smem_raw);
+    constexpr int BUF = (BM + BN) * KC;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int co_tile = blockIdx.x % p.n_co_tiles, px_tile = blockIdx.x / p.n_co_tiles;
+    const int split = blockIdx.y;
+    const int ks_begin = split * p.ks_per_split;
+    int ks_end = ks_begin + p.ks_per_split;
+    if (ks_end > p.nk) ks_end = p.nk;
+    const int cq = tid & 7, r0 = tid >> 3;
+    int tyb[PA], txb[PA], nbase[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        int m = px_tile * BM + r0 + 32 * i;
+        tyb[i] = -(1 << 28); txb[i] = 0; nbase[i] = 0;
+        if (m < p.M) {
+            int n = m / (p.OH * p.OW);
+            int rem = m - n * (p.OH * p.OW);
+            int oy = rem / p.OW, ox = rem - oy * p.OW;
+            tyb[i] = oy * p.ay + p.by; txb[i] = ox * p.ax + p.bx; nbase[i] = n * p.H * p.W;
+        }
+    }
+    const T* __restrict__ inp = reinterpret_cast<const T*>(p.in);
+    const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(p.w);
+    u32x4 ga[PA], gb[PB];
+    auto load_global = [&](int ks) {
+        const int q = ks * KC + cq;
+        const bool qok = q < p.Q;
+        int tap = qok ? q / p.cpt : 0;
+        int cc = q - tap * p.cpt;
+        int r = tap / p.kw, s = tap - r * p.kw;
+        const int dyk = r * p.cy, dxk = s * p.cx;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            int ty = tyb[i] + dyk, tx = txb[i] + dxk;
+            bool ok = qok && ty >= 0 && tx >= 0;
+            int iy = ty, ix = tx;
+            if (p.divy > 1) { iy = ty / p.divy; ok = ok && (iy * p.divy == ty); }
+            if (p.divx > 1) { ix = tx / p.divx; ok = ok && (ix * p.divx == tx); }
+            ok = ok && iy < p.H && ix < p.W;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) v = *reinterpret_cast<const u32x4*>(inp + (int64_t)(nbase[i] + iy * p.W + ix) * p.ldi + p.cioff + cc * EPC);
+            ga[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) gb[i] = wp[(int64_t)(co_tile * BN + r0 + 32 * i) * p.wld + ks * KC + cq];
+    };
+    auto store_lds = [&](int buf) {
+        u32x4* A = smem + buf * BUF;
+        u32x4* B = A + BM * KC;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) A[lds_slot(r0 + 32 * i, cq)] = ga[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) B[lds_slot(r0 + 32 * i, cq)] = gb[i];
+    };
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fchunk = lane >> 4;
+    if (ks_begin < ks_end) {
+        load_global(ks_begin);
+        store_lds(0);
+        __syncthreads();
+        for (int ks = ks_begin; ks < ks_end; ++ks) {
+            const int cur = (ks - ks_begin) & 1;
+            const bool more = ks + 1 < ks_end;
+            if (more) load_global(ks + 1);
+            const u32x4* A = smem + cur * BUF;
+            const u32x4* B = A + BM * KC;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x4 wf[TI], xf[TJ];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) wf[i] = B[lds_slot(wn * (BN / 2) + i * 16 + frow, kk * 4 + fchunk)];
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) xf[j] = A[lds_slot(wm * (BM / 2) + j * 16 + frow, kk * 4 + fchunk)];
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
+            }
+            if (more) store_lds(cur ^ 1);
+            __syncthreads();
+        }
+    }
+    epilogue_direct<T, TI, TJ, BN>(p, acc, co_tile, px_tile, wm, wn, lane, split);
+}
+
+// Fast addressing (stride-1 gathers, <= 64 taps: every forward conv and every stride-1 dgrad).
+//  * operands are fetched with BUFFER loads: one 32-bit byte offset per tile row, recomputed only when the tap changes;
+//    padding taps get an out-of-range offset and the hardware returns zeros; the k-offset inside a tap is a scalar.
+//    The resource base is moved to the first image of the tile so 32-bit offsets suffice for any tensor size.
+//  * prefetch distance 2 through two register sets; LDS double buffer; one barrier per k-step.
+//  * epilogue staged through LDS: bias/ReLU applied in registers, tile transposed in LDS, then 16-byte coalesced
+//    stores with vector loads for the ReLU-backward mask and the accumulate input.
+template <typename T, int BN>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) {
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int TI = BN / 32, TJ = BM / 32, PA = BM / 32, PB = BN / 32;
+    constexpr int BUF = (BM + BN) * KC;                      // 16-byte units per stage
+    constexpr int CPITCH = BN * (int)sizeof(T) + 16;         // epilogue tile row pitch (bytes): +16 B kills bank conflicts
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* smem = reinterpret_cast<u32x4*>(smem_raw);
+    int* tapdelta = reinterpret_cast<int*>(smem_raw + 2 * BUF * 16);   // [64] byte offset of tap (r,s) relative to tap (0,0)
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int co_tile = blockIdx.x % p.n_co_tiles, px_tile = blockIdx.x / p.n_co_tiles;
+    const int split = blockIdx.y;
+    const int ks_begin = split * p.ks_per_split;
+    int ks_end = ks_begin + p.ks_per_split;
+    if (ks_end > p.nk) ks_end = p.nk;
+    const int ntaps = p.kh * p.kw;
+    if (tid < 64) {
+        int r = tid / p.kw, s = tid - r * p.kw;
+        tapdelta[tid] = tid < ntaps ? (r * p.cy * p.W + s * p.cx) * p.ldi * (int)sizeof(T) : 0;
+    }
+
+    // ---- buffer resources ---------------------------------------------------------------------------------
+    const int m_first = px_tile * BM;
+    const int n_first = m_first / (p.OH * p.OW);                              // uniform
+    const long long img_bytes = (long long)p.H * p.W * p.ldi * (long long)sizeof(T);
+    const long long a_off = (long long)n_first * img_bytes;
+    long long a_rem = p.in_bytes - a_off;
+    if (a_rem > 0x7fffffffll) a_rem = 0x7fffffffll;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.in)) + a_off, 0, (int)a_rem, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+
+    // ---- per-row state --------------------------------------------------------------------------------------
+    const int cq = tid & 7, r0 = tid >> 3;
+    int pixoff[PA];                       // byte offset (from the resource base) of tap (0,0), channel cioff, chunk 0
+    unsigned long long vmask[PA];         // bit t set <=> tap t of this pixel lies inside the image
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        int m = m_first + r0 + 32 * i;
+        vmask[i] = 0ull; pixoff[i] = 0;
+        if (m < p.M) {
+            int n = m / (p.OH * p.OW);
+            int rem = m - n * (p.OH * p.OW);
+            int oy = rem / p.OW, ox = rem - oy * p.OW;
+            const int ty0 = oy * p.ay + p.by, tx0 = ox * p.ax + p.bx;
+            for (int r = 0; r < p.kh; ++r)
+                for (int s2 = 0; s2 < p.kw; ++s2) {
+                    int ty = ty0 + r * p.cy, tx = tx0 + s2 * p.cx;
+                    if (ty >= 0 && ty < p.H && tx >= 0 && tx < p.W) vmask[i] |= 1ull << (r * p.kw + s2);
+                }
+            pixoff[i] = (((n - n_first) * p.H + ty0) * p.W + tx0) * p.ldi * (int)sizeof(T) + p.cioff * (int)sizeof(T);
+        }
+    }
+    int voffB[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) voffB[i] = ((co_tile * BN + r0 + 32 * i) * p.wld + cq) * 16;
+    __syncthreads();                                                          // tapdelta visible
+
+    const bool tap_uniform = (p.cpt % KC) == 0;
+    // uniform-tap bookkeeping (scalar)
+    int tap_s = (ks_begin * KC) / p.cpt, cc_s = ks_begin * KC - tap_s * p.cpt;
+    unsigned voffA[PA];
+    auto refresh_uniform = [&]() {
+        const int td = tapdelta[tap_s < 64 ? tap_s : 0] + cq * 16;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) voffA[i] = (tap_s < ntaps && ((vmask[i] >> tap_s) & 1ull)) ? (unsigned)(pixoff[i] + td) : OOB;
+    };
+    // per-lane bookkeeping for k-steps that straddle taps
+    int tap_l = (ks_begin * KC + cq) / p.cpt, cc_l = ks_begin * KC + cq - tap_l * p.cpt;
+    if (tap_uniform) refresh_uniform();
+
+    auto load_global = [&](u32x4 (&ga)[PA], u32x4 (&gb)[PB], int ks) {
+        if (tap_uniform) {
+            const int soff = cc_s * 16;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) ga[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)voffA[i], soff, 0));
+            cc_s += KC;
+            if (cc_s >= p.cpt) { cc_s = 0; ++tap_s; refresh_uniform(); }
+        } else {
+            const bool ok = tap_l < ntaps;
+            const int td = tapdelta[ok ? tap_l : 0] + cc_l * 16;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                unsigned vo = (ok && ((vmask[i] >> tap_l) & 1ull)) ? (unsigned)(pixoff[i] + td) : OOB;
+                ga[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)vo, 0, 0));
+            }
+            cc_l += KC;
+            while (cc_l >= p.cpt) { cc_l -= p.cpt; ++tap_l; }
+        }
+        const int soffB = ks * KC * 16;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) gb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], soffB, 0));
+    };
+    auto store_lds = [&](const u32x4 (&ga)[PA], const u32x4 (&gb)[PB], int buf) {
+        u32x4* A = smem + buf * BUF;
+        u32x4* B = A + BM * KC;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) A[lds_slot(r0 + 32 * i, cq)] = ga[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) B[lds_slot(r0 + 32 * i, cq)] = gb[i];
+    };
+
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fchunk = lane >> 4;
+    auto compute = [&](int cur) {
+        const u32x4* A = smem + cur * BUF;
+        const u32x4* B = A + BM * KC;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4 wf[TI], xf[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) wf[i] = B[lds_slot(wn * (BN / 2) + i * 16 + frow, kk * 4 + fchunk)];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) xf[j] = A[lds_slot(wm * (BM / 2) + j * 16 + frow, kk * 4 + fchunk)];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
+        }
+    };
+
+    u32x4 ga0[PA], gb0[PB], ga1[PA], gb1[PB];
+    if (ks_begin < ks_end) {
+        load_global(ga0, gb0, ks_begin);
+        if (ks_begin + 1 < ks_end) load_global(ga1, gb1, ks_begin + 1);
+        store_lds(ga0, gb0, 0);
+        __syncthreads();
+        int ks = ks_begin;
+        while (ks < ks_end) {
+            if (ks + 2 < ks_end) load_global(ga0, gb0, ks + 2);
+            compute(0);
+            if (ks + 1 < ks_end) store_lds(ga1, gb1, 1);
+            __syncthreads();
+            if (++ks >= ks_end) break;
+            if (ks + 2 < ks_end) load_global(ga1, gb1, ks + 2);
+            compute(1);
+            if (ks + 1 < ks_end) store_lds(ga0, gb0, 0);
+            __syncthreads();
+            ++ks;
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------
+    const bool aligned = (p.Cout % EPC == 0) && (p.cooff % EPC == 0) && (p.ldo % EPC == 0) &&
+                         (!(p.flags & DIN_CONV_MASK) || ((p.ldm % EPC == 0) && (p.moff % EPC == 0)));
+    if (p.splitk > 1 || !aligned) {
+        epilogue_direct<T, TI, TJ, BN>(p, acc, co_tile, px_tile, wm, wn, lane, split);
+        return;
+    }
+    // (all waves passed the loop's final barrier: the stage buffers are free)
+    {
+        const int co_l = wn * (BN / 2) + (lane >> 4) * 4;          // channel inside the tile
+        const int px_l = wm * (BM / 2) + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            const int co = co_tile * BN + co_l + i * 16;
+            if ((p.flags & DIN_CONV_BIAS) && co < p.Cout) bv = *reinterpret_cast<const f32x4*>(p.bias + co);   // Cout % 4 == 0 here
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                f32x4 v = acc[i][j] + bv;
+                if (p.flags & DIN_CONV_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                unsigned char* dst = smem_raw + (px_l + j * 16) * CPITCH + (co_l + i * 16) * (int)sizeof(T);
+                if constexpr (sizeof(T) == 4) *reinterpret_cast<f32x4*>(dst) = v;
+                else *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int CPR = BN * (int)sizeof(T) / 16;                // 16-byte chunks per tile row
+        constexpr int RPP = NTHREADS / CPR;                          // rows per pass
+        const int c = tid % CPR, rr = tid / CPR;
+        const int co = co_tile * BN + c * EPC;
+        if (co < p.Cout) {
+            T* __restrict__ outp = reinterpret_cast<T*>(p.out);
+            const T* __restrict__ maskp = reinterpret_cast<const T*>(p.mask);
+            for (int row = rr; row < BM; row += RPP) {
+                const int m = m_first + row;
+                if (m >= p.M) break;
+                u32x4 v = *reinterpret_cast<const u32x4*>(smem_raw + row * CPITCH + c * 16);
+                const int64_t o = (int64_t)m * p.ldo + p.cooff + co;
+                if (p.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM)) {
+                    u32x4 mk = {0u, 0u, 0u, 0u}, old = {0u, 0u, 0u, 0u};
+                    if (p.flags & DIN_CONV_MASK) mk = *reinterpret_cast<const u32x4*>(maskp + (int64_t)m * p.ldm + p.moff + co);
+                    if (p.flags & DIN_CONV_ACCUM) old = *reinterpret_cast<const u32x4*>(outp + o);
+                    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = __uint_as_float(v[e]);
+                            if ((p.flags & DIN_CONV_MASK) && !(__uint_as_float(mk[e]) > 0.f)) x = 0.f;
+                            if (p.flags & DIN_CONV_ACCUM) x += __uint_as_float(old[e]);
+                            v[e] = __float_as_uint(x);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+                            if (p.flags & DIN_CONV_MASK) {
+                                if (!(__uint_as_float(mk[e] << 16) > 0.f)) lo = 0.f;
+                                if (!(__uint_as_float(mk[e] & 0xffff0000u) > 0.f)) hi = 0.f;
+                            }
+                            if (p.flags & DIN_CONV_ACCUM) { lo += __uint_as_float(old[e] << 16); hi += __uint_as_float(old[e] & 0xffff0000u); }
+                            v[e] = pack_bf16x2(lo, hi);
+                        }
+                    }
+                }
+                *reinterpret_cast<u32x4*>(outp + o) = v;
             }
         }
     }
@@ -601,6 +814,39 @@ __global__ void colsum_kernel(const T* __restrict__ g, float* __restrict__ out, 
     }
 }
 
+// vectorised form: thread = (row lane r, 4-channel group c); 8-/16-byte loads, LDS cross-row reduce, one atomic per column per block
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ g, float* __restrict__ out, int64_t M, int cout, int ld,
+                                                         int coff, int64_t rows_per_block) {
+    __shared__ f32x4 red[256];
+    const int ncg = cout >> 2;                       // <= 256
+    const int rows_pp = 256 / ncg;
+    const int r = threadIdx.x / ncg, c = threadIdx.x - r * ncg;
+    int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows_pp) {
+        for (int64_t row = r0 + r; row < r1; row += rows_pp) {
+            const T* src = g + row * ld + coff + c * 4;
+            if constexpr (sizeof(T) == 4) {
+                acc += *reinterpret_cast<const f32x4*>(src);
+            } else {
+                u32x2 v = *reinterpret_cast<const u32x2*>(src);
+                acc[0] += __uint_as_float(v[0] << 16); acc[1] += __uint_as_float(v[0] & 0xffff0000u);
+                acc[2] += __uint_as_float(v[1] << 16); acc[3] += __uint_as_float(v[1] & 0xffff0000u);
+            }
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < ncg) {
+        f32x4 t = red[threadIdx.x];
+        for (int k = 1; k < rows_pp; ++k) t += red[k * ncg + threadIdx.x];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(out + threadIdx.x * 4 + e, t[e]);
+    }
+}
+
 __global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                                float* scale, float* shift, int c) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -698,8 +944,17 @@ int check_desc(const din_conv_desc* d) {
 
 template <typename T, int BN>
 void launch_gather(const ConvK& k, int n_px_tiles, hipStream_t st) {
-    size_t lds = 2 * (BM + BN) * KC * 16;
-    hipLaunchKernelGGL((conv_gather_kernel<T, BN>), dim3(n_px_tiles * k.n_co_tiles, k.splitk), dim3(NTHREADS), lds, st, k);
+    const bool fast = k.divy == 1 && k.divx == 1 && k.kh * k.kw <= 64;
+    dim3 grid(n_px_tiles * k.n_co_tiles, k.splitk);
+    if (fast) {
+        size_t stage = 2 * (BM + BN) * KC * 16 + 256;                       // stage buffers + tap table
+        size_t epi = (size_t)BM * (BN * sizeof(T) + 16);
+        size_t lds = stage > epi ? stage : epi;
+        hipLaunchKernelGGL((conv_gather_fast_kernel<T, BN>), grid, dim3(NTHREADS), lds, st, k);
+    } else {
+        size_t lds = 2 * (BM + BN) * KC * 16;
+        hipLaunchKernelGGL((conv_gather_generic_kernel<T, BN>), grid, dim3(NTHREADS), lds, st, k);
+    }
 }
 
 int run_gather(ConvK& k, const GatherPlan& g, int dtype, void* workspace, int64_t ws_bytes, hipStream_t st, const char* what) {
@@ -781,6 +1036,8 @@ int din_conv_fwd(const din_conv_desc* d, const void* in, const void* wpk, const 
     k.ay = d->sh; k.by = -d->ph; k.cy = d->dh; k.divy = 1;
     k.ax = d->sw; k.bx = -d->pw; k.cx = d->dw; k.divx = 1;
     k.M = d->nb * d->oh * d->ow; k.flags = flags; k.ldm = 0; k.moff = 0;
+    k.in_bytes = (long long)d->nb * d->h * d->w * d->ldi * (d->dtype == DIN_F32 ? 4 : 2);
+    k.w_bytes = din_conv_packed_elems(d, 0) * (d->dtype == DIN_F32 ? 4 : 2);
     GatherPlan g = plan_gather(k.M, d->cin, d->cout, d->kh * d->kw, d->dtype);
     return run_gather(k, g, d->dtype, workspace, workspace_bytes, as_stream(stream), "conv_fwd");
 }
@@ -805,6 +1062,8 @@ int din_conv_dgrad(const din_conv_desc* d, const void* dout, const void* wpk_t, 
     k.ay = 1; k.by = d->ph; k.cy = -d->dh; k.divy = d->sh;
     k.ax = 1; k.bx = d->pw; k.cx = -d->dw; k.divx = d->sw;
     k.M = d->nb * d->h * d->w; k.flags = flags; k.ldm = ldm; k.moff = moff;
+    k.in_bytes = (long long)d->nb * d->oh * d->ow * d->ldo * (d->dtype == DIN_F32 ? 4 : 2);
+    k.w_bytes = din_conv_packed_elems(d, 1) * (d->dtype == DIN_F32 ? 4 : 2);
     GatherPlan g = plan_gather(k.M, d->cout, d->cin, d->kh * d->kw, d->dtype);
     return run_gather(k, g, d->dtype, workspace, workspace_bytes, as_stream(stream), "conv_dgrad");
 }
@@ -842,12 +1101,23 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
     if (dbias) {
         int64_t M = k.M;
         hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st);
-        int64_t rpb = 512;
-        int blocks = (int)ceil_div64(M, rpb);
-        if (d->dtype == DIN_F32)
-            hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dout, dbias, M, d->cout, d->ldo, d->cooff, rpb);
-        else
-            hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dout, dbias, M, d->cout, d->ldo, d->cooff, rpb);
+        if (d->cout % 4 == 0 && d->cout <= 1024) {
+            // ~2048 workgroups, each streaming a contiguous slab of rows
+            int64_t rpb = ceil_div64(M, 2048);
+            if (rpb < 64) rpb = 64;
+            int blocks = (int)ceil_div64(M, rpb);
+            if (d->dtype == DIN_F32)
+                hipLaunchKernelGGL(colsum_vec_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dout, dbias, M, d->cout, d->ldo, d->cooff, rpb);
+            else
+                hipLaunchKernelGGL(colsum_vec_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dout, dbias, M, d->cout, d->ldo, d->cooff, rpb);
+        } else {
+            int64_t rpb = 512;
+            int blocks = (int)ceil_div64(M, rpb);
+            if (d->dtype == DIN_F32)
+                hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dout, dbias, M, d->cout, d->ldo, d->cooff, rpb);
+            else
+                hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dout, dbias, M, d->cout, d->ldo, d->cooff, rpb);
+        }
         DIN_CHECK_LAUNCH("conv_colsum");
     }
     return DIN_OK;

@@ -53,7 +53,9 @@ __device__ __forceinline__ PoolK mk(const din_pool_desc& d) {
     return PoolK{d.nb, d.h, d.w, d.c, d.oh, d.ow, d.k, d.stride, d.pad, d.ldi, d.cioff, d.ldo, d.cooff, d.dtype};
 }
 
-__global__ void maxpool_fwd_kernel(din_pool_desc d, const void* __restrict__ in, void* __restrict__ out) {
+// Forward optionally records, per pooled element, which window tap won (first maximum in scan order = PyTorch's tie rule)
+// as one byte: tap index r*k+s, or 255 when the winner is <= 0 (the fused ReLU backward would zero its gradient anyway).
+__global__ void maxpool_fwd_kernel(din_pool_desc d, const void* __restrict__ in, void* __restrict__ out, uint8_t* __restrict__ amax) {
     const int c4 = d.c >> 2;
     int64_t total = (int64_t)d.nb * d.oh * d.ow * c4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -63,6 +65,7 @@ __global__ void maxpool_fwd_kernel(din_pool_desc d, const void* __restrict__ in,
         int64_t q = p / d.ow;
         int oy = (int)(q % d.oh), n = (int)(q / d.oh);
         f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int am[4] = {0, 0, 0, 0};
         for (int r = 0; r < d.k; ++r) {
             int iy = oy * d.stride - d.pad + r;
             if (iy < 0 || iy >= d.h) continue;
@@ -71,15 +74,55 @@ __global__ void maxpool_fwd_kernel(din_pool_desc d, const void* __restrict__ in,
                 if (ix < 0 || ix >= d.w) continue;
                 f32x4 v = ld4(in, d.dtype, ((int64_t)(n * d.h + iy) * d.w + ix) * d.ldi + d.cioff + cg * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];     // first max wins on ties
+                for (int e = 0; e < 4; ++e) if (v[e] > m[e]) { m[e] = v[e]; am[e] = r * d.k + s; }   // first max wins on ties
             }
         }
         st4(out, d.dtype, p * d.ldo + d.cooff + cg * 4, m);
+        if (amax) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk |= (uint32_t)(m[e] > 0.f ? am[e] : 255) << (8 * e);
+            *reinterpret_cast<uint32_t*>(amax + p * d.c + cg * 4) = pk;
+        }
     }
 }
 
-// Gather-form backward (no atomics): each INPUT element looks up the windows that contain it, recomputes each window's
-// arg-max (first maximal element in scan order, PyTorch's tie rule) and takes the gradient where it is the winner.
+// Backward from the saved map (gather form, no atomics, no re-read of the input): each input element visits the <= ceil(k/s)^2
+// windows that contain it and takes the gradient where the recorded tap is itself.
+__global__ void maxpool_bwd_amax_kernel(din_pool_desc d, const uint8_t* __restrict__ amax, const void* __restrict__ dout,
+                                        void* __restrict__ din_, int accumulate) {
+    const int c4 = d.c >> 2;
+    int64_t total = (int64_t)d.nb * d.h * d.w * c4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int cg = (int)(i % c4);
+        int64_t p = i / c4;
+        int ix = (int)(p % d.w);
+        int64_t q = p / d.w;
+        int iy = (int)(q % d.h), n = (int)(q / d.h);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        int oy_hi = (iy + d.pad) / d.stride, ox_hi = (ix + d.pad) / d.stride;
+        int oy_lo = (iy + d.pad - d.k + d.stride) / d.stride, ox_lo = (ix + d.pad - d.k + d.stride) / d.stride;
+        if (iy + d.pad - d.k + 1 < 0) oy_lo = 0;
+        if (ix + d.pad - d.k + 1 < 0) ox_lo = 0;
+        if (oy_hi >= d.oh) oy_hi = d.oh - 1;
+        if (ox_hi >= d.ow) ox_hi = d.ow - 1;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                const uint32_t tap = (uint32_t)((iy - (oy * d.stride - d.pad)) * d.k + (ix - (ox * d.stride - d.pad)));
+                int64_t po = (int64_t)(n * d.oh + oy) * d.ow + ox;
+                uint32_t pk = *reinterpret_cast<const uint32_t*>(amax + po * d.c + cg * 4);
+                if (((pk & 0xff) != tap) && (((pk >> 8) & 0xff) != tap) && (((pk >> 16) & 0xff) != tap) && ((pk >> 24) != tap)) continue;
+                f32x4 go = ld4(dout, d.dtype, po * d.ldo + d.cooff + cg * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] += ((pk >> (8 * e)) & 0xff) == tap ? go[e] : 0.f;
+            }
+        int64_t self_off = p * d.ldi + d.cioff + cg * 4;
+        if (accumulate) g += ld4(din_, d.dtype, self_off);
+        st4(din_, d.dtype, self_off, g);
+    }
+}
+
+// Map-free backward (recomputes each window's arg-max): kept for callers that did not save the map.
 __global__ void maxpool_bwd_kernel(din_pool_desc d, const void* __restrict__ in, const void* __restrict__ dout,
                                    void* __restrict__ din_, int relu_mask, int accumulate) {
     const int c4 = d.c >> 2;
@@ -93,7 +136,6 @@ __global__ void maxpool_bwd_kernel(din_pool_desc d, const void* __restrict__ in,
         int64_t self_off = p * d.ldi + d.cioff + cg * 4;
         f32x4 xv = ld4(in, d.dtype, self_off);
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
-        // windows (oy,ox) with oy*stride - pad <= iy < oy*stride - pad + k
         int oy_hi = (iy + d.pad) / d.stride, ox_hi = (ix + d.pad) / d.stride;
         int oy_lo = (iy + d.pad - d.k + d.stride) / d.stride, ox_lo = (ix + d.pad - d.k + d.stride) / d.stride;
         if (iy + d.pad - d.k + 1 < 0) oy_lo = 0;
@@ -102,7 +144,6 @@ __global__ void maxpool_bwd_kernel(din_pool_desc d, const void* __restrict__ in,
         if (ox_hi >= d.ow) ox_hi = d.ow - 1;
         for (int oy = oy_lo; oy <= oy_hi; ++oy)
             for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-                // is (iy,ix) the first maximum of this window?
                 bool win[4] = {true, true, true, true};
                 for (int r = 0; r < d.k; ++r) {
                     int yy = oy * d.stride - d.pad + r;
@@ -125,7 +166,6 @@ __global__ void maxpool_bwd_kernel(din_pool_desc d, const void* __restrict__ in,
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = xv[e] > 0.f ? g[e] : 0.f;
         }
-        // NOTE: din shares the geometry of `in` but is a separate buffer with the same (ldi, cioff)
         if (accumulate) { f32x4 o = ld4(din_, d.dtype, self_off); g += o; }
         st4(din_, d.dtype, self_off, g);
     }
@@ -385,19 +425,26 @@ int din_prep_images_nhwc(const void* in, int in_is_u8, void* out, int out_dtype,
     return DIN_OK;
 }
 
-int din_maxpool_fwd(const din_pool_desc* d, const void* in, void* out, void* stream) {
+int din_maxpool_fwd(const din_pool_desc* d, const void* in, void* out, uint8_t* argmax, void* stream) {
     if (int e = check_pool(d, "maxpool_fwd")) return e;
     DIN_REQUIRE(in && out, "maxpool_fwd: null pointer");
+    DIN_REQUIRE(d->k * d->k < 255, "maxpool_fwd: window too large for the byte arg-max map");
     int64_t total = (int64_t)d->nb * d->oh * d->ow * (d->c / 4);
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_1d(total, 256, 16384)), dim3(256), 0, as_stream(stream), *d, in, out);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_1d(total, 256, 16384)), dim3(256), 0, as_stream(stream), *d, in, out, argmax);
     DIN_CHECK_LAUNCH("maxpool_fwd");
     return DIN_OK;
 }
-int din_maxpool_bwd(const din_pool_desc* d, const void* in, const void* dout, void* din_, int relu_mask, int accumulate, void* stream) {
+int din_maxpool_bwd(const din_pool_desc* d, const void* in, const uint8_t* argmax, const void* dout, void* din_, int relu_mask,
+                    int accumulate, void* stream) {
     if (int e = check_pool(d, "maxpool_bwd")) return e;
-    DIN_REQUIRE(in && dout && din_, "maxpool_bwd: null pointer");
+    DIN_REQUIRE((in || argmax) && dout && din_, "maxpool_bwd: null pointer");
     int64_t total = (int64_t)d->nb * d->h * d->w * (d->c / 4);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_1d(total, 256, 16384)), dim3(256), 0, as_stream(stream), *d, in, dout, din_, relu_mask, accumulate);
+    if (argmax) {
+        DIN_REQUIRE(relu_mask, "maxpool_bwd: the arg-max map encodes the fused ReLU mask; relu_mask must be set");
+        hipLaunchKernelGGL(maxpool_bwd_amax_kernel, dim3(grid_1d(total, 256, 16384)), dim3(256), 0, as_stream(stream), *d, argmax, dout, din_, accumulate);
+    } else {
+        hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_1d(total, 256, 16384)), dim3(256), 0, as_stream(stream), *d, in, dout, din_, relu_mask, accumulate);
+    }
     DIN_CHECK_LAUNCH("maxpool_bwd");
     return DIN_OK;
 }

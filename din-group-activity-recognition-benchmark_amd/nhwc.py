@@ -234,7 +234,7 @@ def _pool_desc(g: Graph, op: Op, nb: int, dt: int) -> L.PoolDesc:
 BN_EPS = 1e-3      # torchvision BasicConv2d
 
 
-def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tensor], dt: int):
+def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tensor], dt: int, save_for_backward: bool = True):
     """Run the graph.  image_buf: NHWC [nb,h,w,cpad] of dtype dt.  Returns (bufs, aux) for backward."""
     lib = L.load()
     nb = image_buf.shape[0]
@@ -272,9 +272,17 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
                 L.check(lib.din_conv_fwd(C.byref(d), _ptr(src), _ptr(wpk), _ptr(bias), _ptr(dst), flags, _ptr(ws), wsb, st),
                         "conv_fwd " + op.name)
             aux.append((scale,))
-        elif op.kind in ("maxpool", "avgpool", "bilinear"):
+        elif op.kind == "maxpool":
             d = _pool_desc(g, op, nb, dt)
-            fn = {"maxpool": lib.din_maxpool_fwd, "avgpool": lib.din_avgpool_fwd, "bilinear": lib.din_bilinear_fwd}[op.kind]
+            # save the winning-tap map when the pooled tensor is a ReLU output: backward then never re-reads the input
+            amax = None
+            if save_for_backward and g.tensors[op.src.tid].relu_masked and op.src.tid != g.input_tid:
+                amax = torch.empty((nb, td.h, td.w, op.src.c), dtype=torch.uint8, device=dev)
+            L.check(lib.din_maxpool_fwd(C.byref(d), _ptr(src), _ptr(dst), _ptr(amax), st), "maxpool_fwd")
+            aux.append((amax,))
+        elif op.kind in ("avgpool", "bilinear"):
+            d = _pool_desc(g, op, nb, dt)
+            fn = {"avgpool": lib.din_avgpool_fwd, "bilinear": lib.din_bilinear_fwd}[op.kind]
             L.check(fn(C.byref(d), _ptr(src), _ptr(dst), st), op.kind + "_fwd")
             aux.append(())
         else:
@@ -365,8 +373,9 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
             gsrc, acc = grad_target(op.src)
             mask = _ptr(bufs[op.src.tid]) if ts.relu_masked else None
             if op.kind == "maxpool":
-                L.check(lib.din_maxpool_bwd(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(gsrc), int(ts.relu_masked),
-                                            int(acc), st), "maxpool_bwd")
+                (amax,) = aux[oi]
+                L.check(lib.din_maxpool_bwd(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(amax), _ptr(gout), _ptr(gsrc),
+                                            int(ts.relu_masked), int(acc), st), "maxpool_bwd")
             elif op.kind == "avgpool":
                 L.check(lib.din_avgpool_bwd(C.byref(d), _ptr(gout), _ptr(gsrc), mask, int(acc), st), "avgpool_bwd")
             else:
@@ -402,7 +411,7 @@ class NHWCGraphFunction(torch.autograd.Function):
                 L.check(lib.din_prep_images_nhwc(_ptr(images.float().contiguous()), 0, _ptr(img), dt, nb, h, w, ti.c, st),
                         "prep_nhwc")
         with torch.no_grad():
-            bufs, aux = graph_forward(graph, img, params, dt)
+            bufs, aux = graph_forward(graph, img, params, dt, save_for_backward=any(p.requires_grad for p in params))
         ctx.graph, ctx.dt, ctx.bufs, ctx.aux = graph, dt, bufs, aux
         ctx.params = params
         ctx.need = [p.requires_grad for p in params]

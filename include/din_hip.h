@@ -119,11 +119,15 @@ typedef struct din_pool_desc {
     int32_t ldi, cioff, ldo, cooff;
     int32_t dtype;
 } din_pool_desc;
-int din_maxpool_fwd(const din_pool_desc* d, const void* in, void* out, void* stream);
+/* argmax (nullable): uint8 [nb,oh,ow,c] map of the winning tap r*k+s (first maximum, PyTorch's tie rule), 255 when the
+ * winner is <= 0 -- i.e. the map already carries the fused ReLU-backward mask of the tensor being pooled.            */
+int din_maxpool_fwd(const din_pool_desc* d, const void* in, void* out, uint8_t* argmax, void* stream);
 /* din = scatter of dout to the first maximal element of each window; relu_mask!=0 additionally multiplies by
- * (in > 0) -- the fused backward of the ReLU that produced `in`.  accumulate!=0: din += ...             */
-int din_maxpool_bwd(const din_pool_desc* d, const void* in, const void* dout, void* din_, int relu_mask,
-                    int accumulate, void* stream);
+ * (in > 0) -- the fused backward of the ReLU that produced `in`.  accumulate!=0: din += ...
+ * With argmax (saved by the forward; requires relu_mask!=0) `in` is not read at all; without it the window arg-max
+ * is recomputed from `in`.                                                                                          */
+int din_maxpool_bwd(const din_pool_desc* d, const void* in, const uint8_t* argmax, const void* dout, void* din_,
+                    int relu_mask, int accumulate, void* stream);
 int din_avgpool_fwd(const din_pool_desc* d, const void* in, void* out, void* stream);   /* count_include_pad */
 int din_avgpool_bwd(const din_pool_desc* d, const void* dout, void* din_, const void* mask, int accumulate,
                     void* stream);

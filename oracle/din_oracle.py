@@ -285,12 +285,19 @@ def roi_align(fm: Tensor, boxes: Tensor, box_ind: Tensor, k: int, return_index: 
     bi = bot.long().clamp(0, hf - 1)
     li = left.long().clamp(0, wf - 1)
     ri = right.long().clamp(0, wf - 1)
-    src = fm[box_ind.long()]                                            # [M,C,Hf,Wf]
-    flat = src.reshape(m, c, hf * wf)
+    frames = box_ind.long()
+    flat_fm = fm.reshape(nb, c, hf * wf)
 
     def g(yi, xi):                                                       # -> [M,C,K,K]
-        lin = (yi[:, :, None] * wf + xi[:, None, :]).reshape(m, 1, k * k).expand(m, c, k * k)
-        return flat.gather(2, lin).reshape(m, c, k, k)
+        # gather per source frame (never materialises fm[box_ind]: M copies of the map)
+        lin = (yi[:, :, None] * wf + xi[:, None, :]).reshape(m, k * k)
+        out_ = fm.new_zeros((m, c, k * k))
+        for f in torch.unique(frames).tolist():
+            sel = (frames == f).nonzero(as_tuple=True)[0]
+            if 0 <= f < nb:
+                vals = flat_fm[f][:, lin[sel].reshape(-1)]               # [C, n_sel*K*K]
+                out_ = out_.index_copy(0, sel, vals.reshape(c, sel.numel(), k * k).permute(1, 0, 2))
+        return out_.reshape(m, c, k, k)
 
     tl, tr, bl, br = g(ti, li), g(ti, ri), g(bi, li), g(bi, ri)
     lxb = lx[:, None, None, :]

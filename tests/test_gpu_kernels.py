@@ -194,14 +194,22 @@ def test_pools(env, kind, k, s, p, dtype):
     d.dtype = L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
     xin = to_nhwc(x, tdt, 24, 4)
     out = torch.empty(2, y.shape[2], y.shape[3], 16, dtype=tdt, device="cuda")
-    fwd = lib.din_maxpool_fwd if kind == "maxpool" else lib.din_avgpool_fwd
-    L.check(fwd(C.byref(d), xin.data_ptr(), out.data_ptr(), None))
+    amax = torch.empty(2, y.shape[2], y.shape[3], 16, dtype=torch.uint8, device="cuda")
+    if kind == "maxpool":
+        L.check(lib.din_maxpool_fwd(C.byref(d), xin.data_ptr(), out.data_ptr(), amax.data_ptr(), None))
+    else:
+        L.check(lib.din_avgpool_fwd(C.byref(d), xin.data_ptr(), out.data_ptr(), None))
     tol = 1e-6 if dtype == "fp32" else 8e-3
     assert rel(from_nhwc(out, 16), y) <= tol
     gout = to_nhwc(cot, tdt)
     dx = torch.zeros_like(xin)
     if kind == "maxpool":
-        L.check(lib.din_maxpool_bwd(C.byref(d), xin.data_ptr(), gout.data_ptr(), dx.data_ptr(), 1, 0, None))
+        L.check(lib.din_maxpool_bwd(C.byref(d), xin.data_ptr(), None, gout.data_ptr(), dx.data_ptr(), 1, 0, None))
+        torch.cuda.synchronize()
+        want = xr.grad * (x > 0).float()
+        assert rel(from_nhwc(dx, 16, 4), want) <= (1e-6 if dtype == "fp32" else 1.5e-2)
+        dx.zero_()                                                        # same answer from the saved arg-max map
+        L.check(lib.din_maxpool_bwd(C.byref(d), None, amax.data_ptr(), gout.data_ptr(), dx.data_ptr(), 1, 0, None))
     else:
         L.check(lib.din_avgpool_bwd(C.byref(d), gout.data_ptr(), dx.data_ptr(), xin.data_ptr(), 0, None))
     torch.cuda.synchronize()
