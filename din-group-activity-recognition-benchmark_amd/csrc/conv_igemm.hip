@@ -498,7 +498,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, const float* __res
 // workspace [slice][cout_pad][kcols_pad] fp32, reduced (and un-permuted to [cout][cin][kh][kw]) afterwards.
 // ------------------------------------------------------------------------------------------------
 struct WgradK {
-    const void* in; const void* g; float* partial;
+    const void* in; const void* g; float* partial; float* dbias;
     int NB, H, W, Cin, ldi, cioff;
     int OH, OW, Cout, ldo, cooff;
     int kh, kw, sh, sw, ph, pw, dh, dw;
@@ -634,11 +634,192 @@ __device__ __forceinline__ u32x2 lds_tr_read(uint32_t byte_addr) {
     return r;
 }
 
+// v2: 64 pixels per k-step, buffer-resource loads (G: constant per-lane offset + scalar row offset; X: per-row offset
+// advanced incrementally, out-of-image taps -> hardware zero), prefetch distance 2 through two register sets, BCO = 128|64
+// filter rows per tile, and the bias gradient fused in: in the k_tile == 0 workgroups the kcol-half-0 waves also multiply
+// their G fragments with an all-ones operand, which yields sum_pix G[pix][co] without a second pass over dY.
+template <int BCO>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) {
+    constexpr int PK = 64;
+    constexpr int RSG = BCO * 2 + 32, RSX = WG_TILE * 2 + 32;   // row pitches (bytes): +32 B => 8 rows tile a 256-B bank row
+    constexpr int OPG = PK * RSG, OPX = PK * RSX, STAGE = OPG + OPX;
+    constexpr int TI = BCO / 32;                                  // 16-row filter tiles per wave (wave tile = BCO/2 x 64)
+    constexpr int CG = BCO / 8;                                   // 16-byte chunks per G row
+    constexpr int GP = PK * CG / NTHREADS;                        // G chunks per thread per k-step (4 | 2)
+    constexpr int GROWS = NTHREADS / CG;                          // rows covered per pass (16 | 32)
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int k_tile = blockIdx.x % p.n_k_tiles, co_tile = blockIdx.x / p.n_k_tiles;
+    const int slice = blockIdx.y;
+    const int m_begin = slice * p.m_per_slice;                   // multiple of PK
+    int m_end = m_begin + p.m_per_slice;
+    if (m_end > p.M) m_end = p.M;
+
+    // ---- buffer resources (base moved to the slice's first image / first pixel so 32-bit offsets always suffice) ----
+    const int ohw = p.OH * p.OW;
+    const int n_first = m_begin / ohw;
+    const long long img_bytes = (long long)p.H * p.W * p.ldi * 2ll;
+    const long long x_off = (long long)n_first * img_bytes;
+    long long x_rem = (long long)p.NB * img_bytes - x_off;
+    if (x_rem > 0x7fffffffll) x_rem = 0x7fffffffll;
+    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.in)) + x_off, 0, (int)x_rem, 0x00020000);
+    const long long g_off = (long long)m_begin * p.ldo * 2ll;
+    long long g_rem = (long long)p.M * p.ldo * 2ll - g_off;
+    if (g_rem > 0x7fffffffll) g_rem = 0x7fffffffll;
+    __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.g)) + g_off, 0, (int)g_rem, 0x00020000);
+
+    // ---- G loader: thread -> (row gr + GROWS*i, chunk gc); rows advance by PK per k-step (scalar offset) ----------------
+    const int gc = tid % CG, gr = tid / CG;
+    const int gco = co_tile * BCO + gc * 8;
+    const bool g_ok = gco + 7 < p.Cout;                            // Cout % 8 == 0 is enforced for this kernel
+    unsigned voffG[GP];
+#pragma unroll
+    for (int i = 0; i < GP; ++i) voffG[i] = g_ok ? (unsigned)(((gr + GROWS * i) * p.ldo + p.cooff + gco) * 2) : OOB;
+
+    // ---- X loader: thread -> (row xr + 16*i, chunk xc) with a fixed (tap, ci) ------------------------------------------
+    const int xc = tid & 15, xr = tid >> 4;
+    const int kcol = k_tile * WG_TILE + xc * 8;
+    const bool kok = kcol < p.kcols;
+    const int tap = kok ? kcol / p.cin_pad : 0;
+    const int ci = kcol - tap * p.cin_pad;
+    const int tr_ = tap / p.kw, ts_ = tap - tr_ * p.kw;
+    const bool ci_ok = kok && ci + 7 < p.Cin;                       // Cin % 8 == 0 enforced (conv1 uses the slow tail kernel)
+    const int dy0 = -p.ph + tr_ * p.dh, dx0 = -p.pw + ts_ * p.dw;   // iy = oy*sh + dy0, ix = ox*sw + dx0
+    const int step_bytes = p.sw * p.ldi * 2;                        // +1 output column
+    int px[4], py[4];            // output coordinates of this thread's 4 rows
+    int rowoff[4];               // byte offset of (n, iy, ix = dx0) for the current (n, oy): may be "virtual"
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m_begin + xr + 16 * i;
+        int n = m / ohw;
+        int rem = m - n * ohw;
+        py[i] = rem / p.OW; px[i] = rem - py[i] * p.OW;
+        rowoff[i] = (((n - n_first) * p.H + py[i] * p.sh + dy0) * p.W + dx0) * p.ldi * 2 + (p.cioff + ci) * 2;
+    }
+    const int row_jump = p.sh * p.W * p.ldi * 2;                    // +1 output row
+    const int img_jump = (p.H - p.OH * p.sh) * p.W * p.ldi * 2;     // extra when wrapping to the next image
+
+    u32x4 xa0[4], ga0[GP];
+    auto load_global = [&](u32x4 (&xa)[4], u32x4 (&ga)[GP], int m0) {
+        const int soffG = (m0 - m_begin) * p.ldo * 2;                // uniform
+#pragma unroll
+        for (int i = 0; i < GP; ++i) ga[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, (int)voffG[i], soffG, 0));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = py[i] * p.sh + dy0, ix = px[i] * p.sw + dx0;
+            const bool ok = ci_ok && (m0 + xr + 16 * i < m_end) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const unsigned vo = ok ? (unsigned)(rowoff[i] + px[i] * step_bytes) : OOB;
+            xa[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)vo, 0, 0));
+            // advance this row by PK output pixels
+            px[i] += PK;
+            while (px[i] >= p.OW) {
+                px[i] -= p.OW; rowoff[i] += row_jump;
+                if (++py[i] == p.OH) { py[i] = 0; rowoff[i] += img_jump; }
+            }
+        }
+    };
+    auto store_lds = [&](const u32x4 (&xa)[4], const u32x4 (&ga)[GP], int buf) {
+        unsigned char* G = smem_raw + buf * STAGE;
+        unsigned char* X = G + OPG;
+#pragma unroll
+        for (int i = 0; i < GP; ++i) *reinterpret_cast<u32x4*>(G + (gr + GROWS * i) * RSG + gc * 16) = ga[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(X + (xr + 16 * i) * RSX + xc * 16) = xa[i];
+    };
+
+    f32x4 acc[TI][4], accb[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = p.dbias != nullptr && k_tile == 0 && wn == 0;       // wave-uniform
+    const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+
+    // transpose-read addressing: lane i of a 16-lane group supplies the 8-byte piece (row i>>2, cols 4*(i&3)..+3)
+    const int li = lane & 15, lg = lane >> 4;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw;
+    const uint32_t pieceG = (uint32_t)((4 * lg + (li >> 2)) * RSG + (li & 3) * 8);
+    const uint32_t pieceX = (uint32_t)((4 * lg + (li >> 2)) * RSX + (li & 3) * 8);
+    auto compute = [&](int cur) {
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {                                       // two 32-pixel MFMA k-groups per stage
+            const uint32_t Gb = lds_base + cur * STAGE + kg * 32 * RSG + pieceG;
+            const uint32_t Xb = lds_base + cur * STAGE + OPG + kg * 32 * RSX + pieceX;
+            u32x4 gf[TI], xf[4];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                uint32_t a = Gb + (wm * (BCO / 2) + i * 16) * 2;
+                u32x2 lo = lds_tr_read(a), hi = lds_tr_read(a + 16 * RSG);
+                gf[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t a = Xb + (wn * 64 + j * 16) * 2;
+                u32x2 lo = lds_tr_read(a), hi = lds_tr_read(a + 16 * RSX);
+                xf[j] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gf[i]),
+                                                                        __builtin_bit_cast(bf16x8, xf[j]), acc[i][j], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gf[i]),
+                                                                      __builtin_bit_cast(bf16x8, ones), accb[i], 0, 0, 0);
+            }
+        }
+    };
+
+    if (m_begin < m_end) {
+        load_global(xa0, ga0, m_begin);
+        store_lds(xa0, ga0, 0);
+        __syncthreads();
+        int it = 0;
+        for (int m0 = m_begin; m0 < m_end; m0 += PK, ++it) {
+            const int cur = it & 1;
+            const bool more = m0 + PK < m_end;
+            if (more) load_global(xa0, ga0, m0 + PK);
+            compute(cur);
+            if (more) store_lds(xa0, ga0, cur ^ 1);
+            __syncthreads();
+        }
+    }
+    float* dst = p.partial + (int64_t)slice * p.cout_pad * p.kcols_pad;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int co = co_tile * BCO + wm * (BCO / 2) + i * 16 + (lane >> 4) * 4;
+            int kc = k_tile * WG_TILE + wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(int64_t)(co + e) * p.kcols_pad + kc] = acc[i][j][e];
+        }
+    if (do_bias && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            int co = co_tile * BCO + wm * (BCO / 2) + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (co + e < p.Cout) atomicAdd(p.dbias + co + e, accb[i][e]);
+        }
+    }
+}
+
+// tail kernel for channel counts that are not multiples of 8 (conv1: cin = 3): the round-1 32-pixel kernel
+__global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_tail_kernel(WgradK p) {
     constexpr int PK = 32;
     constexpr int RSB = WG_TILE * 2 + 32;          // row stride in bytes (288)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    // layout: [buf][ G: PK*RSB | X: PK*RSB ]
     constexpr int OPB = PK * RSB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -649,9 +830,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) 
     const int m_begin = slice * p.m_per_slice;
     int m_end = m_begin + p.m_per_slice;
     if (m_end > p.M) m_end = p.M;
-
-    // loader: 32 rows x 16 chunks (8 bf16) per operand -> 2 chunks per thread per operand
-    const int cc = tid & 15, rr = tid >> 4;         // chunk column 0..15, row 0..15 (+16)
+    const int cc = tid & 15, rr = tid >> 4;
     const int kcol = k_tile * WG_TILE + cc * 8;
     const bool kok = kcol < p.kcols;
     const int tap = kok ? kcol / p.cin_pad : 0;
@@ -661,7 +840,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) 
     const int gco = co_tile * WG_TILE + cc * 8;
     const bf16_t* __restrict__ inp = reinterpret_cast<const bf16_t*>(p.in);
     const bf16_t* __restrict__ gp = reinterpret_cast<const bf16_t*>(p.g);
-
     int pn[2], py[2], px[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -711,14 +889,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) 
             *reinterpret_cast<u32x4*>(X + (rr + 16 * i) * RSB + cc * 16) = xa[i];
         }
     };
-
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // transpose-read addressing: lane i of a 16-lane group supplies the 8-byte piece (row i>>2, cols 4*(i&3)..+3)
     const int li = lane & 15, lg = lane >> 4;
     const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw;
     const uint32_t piece = (uint32_t)((4 * lg + (li >> 2)) * RSB + (li & 3) * 8);
@@ -775,27 +950,29 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ partial, floa
                                          const float* __restrict__ scale, const float* __restrict__ w,
                                          float* __restrict__ wdot, int cout, int cin, int kh, int kw, int cin_pad,
                                          int cout_pad, int kcols_pad, int slices, int accumulate) {
-    // one workgroup per output filter co; partials are read in their own (coalesced) column order
+    // grid (co, kcol chunk of 256): partials are read in their own (coalesced) column order
     const int co = blockIdx.x;
     const int taps = kh * kw;
     const int per = cin * taps;
     float dot = 0.f;
-    for (int kc = threadIdx.x; kc < taps * cin_pad; kc += blockDim.x) {
+    const int kc = blockIdx.y * blockDim.x + threadIdx.x;
+    if (kc < taps * cin_pad) {
         int t = kc / cin_pad, ci = kc - t * cin_pad;            // t = r*kw + s
-        if (ci >= cin) continue;
-        float v = 0.f;
-        for (int s = 0; s < slices; ++s) v += partial[((int64_t)s * cout_pad + co) * kcols_pad + kc];
-        int64_t o = (int64_t)co * per + (int64_t)ci * taps + t;
-        if (wdot) dot += v * w[o];
-        if (scale) v *= scale[co];
-        dw[o] = accumulate ? dw[o] + v : v;
+        if (ci < cin) {
+            float v = 0.f;
+            for (int s = 0; s < slices; ++s) v += partial[((int64_t)s * cout_pad + co) * kcols_pad + kc];
+            int64_t o = (int64_t)co * per + (int64_t)ci * taps + t;
+            if (wdot) dot = v * w[o];
+            if (scale) v *= scale[co];
+            dw[o] = accumulate ? dw[o] + v : v;
+        }
     }
     if (wdot) {
         __shared__ float red[4];
         dot = wave_sum(dot);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
         __syncthreads();
-        if (threadIdx.x == 0) wdot[co] = red[0] + red[1] + red[2] + red[3];
+        if (threadIdx.x == 0) atomicAdd(wdot + co, red[0] + red[1] + red[2] + red[3]);
     }
 }
 
@@ -899,16 +1076,19 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype) {
     return g;
 }
 
-struct WgradPlan { int cin_pad, kcols, kcols_pad, cout_pad, n_co_tiles, n_k_tiles, slices, m_per_slice; int64_t ws_bytes; };
+struct WgradPlan { int cin_pad, kcols, kcols_pad, cout_pad, n_co_tiles, n_k_tiles, slices, m_per_slice, bco, v2; int64_t ws_bytes; };
 WgradPlan plan_wgrad(const din_conv_desc* d) {
     WgradPlan w;
     int epc = epc_of(d->dtype);
-    int pk = d->dtype == DIN_F32 ? 16 : 32;
+    // bf16 v2 kernel needs whole 16-byte channel chunks on both operands; otherwise the tail kernel (conv1: cin = 3)
+    w.v2 = d->dtype == DIN_BF16 && d->cin % 8 == 0 && d->cout % 8 == 0 && d->ldi % 8 == 0 && d->cioff % 8 == 0;
+    w.bco = (w.v2 && d->cout <= 64) ? 64 : 128;
+    int pk = d->dtype == DIN_F32 ? 16 : (w.v2 ? 64 : 32);
     w.cin_pad = pad_to(d->cin, epc);
     w.kcols = d->kh * d->kw * w.cin_pad;
     w.kcols_pad = pad_to(w.kcols, WG_TILE);
     w.cout_pad = pad_to(d->cout, WG_TILE);
-    w.n_co_tiles = w.cout_pad / WG_TILE;
+    w.n_co_tiles = (d->cout + w.bco - 1) / w.bco;
     w.n_k_tiles = w.kcols_pad / WG_TILE;
     int M = d->nb * d->oh * d->ow;
     int tiles = w.n_co_tiles * w.n_k_tiles;
@@ -1078,7 +1258,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
     if (workspace_bytes < wp.ws_bytes || !workspace)
         DIN_FAIL(DIN_E_WORKSPACE, "conv_wgrad: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)wp.ws_bytes);
     WgradK k{};
-    k.in = in; k.g = dout; k.partial = reinterpret_cast<float*>(workspace);
+    k.in = in; k.g = dout; k.partial = reinterpret_cast<float*>(workspace); k.dbias = nullptr;
     k.NB = d->nb; k.H = d->h; k.W = d->w; k.Cin = d->cin; k.ldi = d->ldi; k.cioff = d->cioff;
     k.OH = d->oh; k.OW = d->ow; k.Cout = d->cout; k.ldo = d->ldo; k.cooff = d->cooff;
     k.kh = d->kh; k.kw = d->kw; k.sh = d->sh; k.sw = d->sw; k.ph = d->ph; k.pw = d->pw; k.dh = d->dh; k.dw = d->dw;
@@ -1086,19 +1266,41 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
     k.M = d->nb * d->oh * d->ow; k.n_co_tiles = wp.n_co_tiles; k.n_k_tiles = wp.n_k_tiles;
     k.slices = wp.slices; k.m_per_slice = wp.m_per_slice;
     dim3 grid(wp.n_co_tiles * wp.n_k_tiles, wp.slices);
+    bool bias_fused = false;
     if (d->dtype == DIN_F32) {
         hipLaunchKernelGGL(conv_wgrad_f32_kernel, grid, dim3(NTHREADS), 0, st, k);
     } else {
         int epc = 8;
         DIN_REQUIRE(d->ldo % epc == 0 && d->cooff % epc == 0, "conv_wgrad: bf16 dout stride/offset must be multiples of 8");
-        size_t lds = 2 * 2 * 32 * (WG_TILE * 2 + 32);
-        hipLaunchKernelGGL(conv_wgrad_bf16_kernel, grid, dim3(NTHREADS), lds, st, k);
+        if (wp.v2) {
+            if (dbias) {
+                if (hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
+                k.dbias = dbias;
+                bias_fused = true;
+            }
+            if (wp.bco == 64) {
+                size_t lds = 2 * 64 * ((64 * 2 + 32) + (WG_TILE * 2 + 32));
+                hipLaunchKernelGGL(conv_wgrad_bf16_kernel<64>, grid, dim3(NTHREADS), lds, st, k);
+            } else {
+                size_t lds = 2 * 64 * ((128 * 2 + 32) + (WG_TILE * 2 + 32));
+                hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(conv_wgrad_bf16_kernel<128>, grid, dim3(NTHREADS), lds, st, k);
+            }
+        } else {
+            size_t lds = 2 * 2 * 32 * (WG_TILE * 2 + 32);
+            hipLaunchKernelGGL(conv_wgrad_bf16_tail_kernel, grid, dim3(NTHREADS), lds, st, k);
+        }
     }
     DIN_CHECK_LAUNCH("conv_wgrad");
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(d->cout), dim3(256), 0, st, k.partial, dw, scale, w, wdot,
-                       d->cout, d->cin, d->kh, d->kw, wp.cin_pad, wp.cout_pad, wp.kcols_pad, wp.slices, accumulate);
-    DIN_CHECK_LAUNCH("conv_wgrad_reduce");
-    if (dbias) {
+    if (wdot && hipMemsetAsync(wdot, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
+    {
+        int kc_total = d->kh * d->kw * wp.cin_pad;
+        dim3 rgrid(d->cout, (kc_total + 255) / 256);
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, rgrid, dim3(256), 0, st, k.partial, dw, scale, w, wdot,
+                           d->cout, d->cin, d->kh, d->kw, wp.cin_pad, wp.cout_pad, wp.kcols_pad, wp.slices, accumulate);
+        DIN_CHECK_LAUNCH("conv_wgrad_reduce");
+    }
+    if (dbias && !bias_fused) {
         int64_t M = k.M;
         hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st);
         if (d->cout % 4 == 0 && d->cout <= 1024) {
