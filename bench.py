@@ -70,11 +70,14 @@ def synth_weights(model, seed=3):
 
 
 def cpu_baseline(workload, T, N, H, W, budget_s=25.0):
-    """Oracle fwd+bwd on host cores for a bounded sample (B=1 clip per step)."""
+    """Oracle fwd+bwd on the host cores for a bounded sample (B=1 clip per step).
+
+    torch-CPU does not scale to every SMT thread of a 2-socket host (256 threads measured 40x SLOWER than 64 on the
+    2 x EPC 9575F box), so the baseline gets its best shot: one step at each of a few thread counts, then the remaining
+    budget at the fastest one; `cores` reports the thread count actually used for the quoted number."""
     from oracle import din_oracle as O
     backbone, _dt, (OH, OW), D = WORKLOADS[workload]
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     ocfg = O.OracleCfg(backbone=backbone, image_size=(H, W), out_size=(OH, OW), emb_features=D, num_boxes=N, num_frames=T)
     p = O.synth_params(O.model_param_shapes(ocfg), seed=3, din_std=0.02)
     p = {k: v.requires_grad_("running_" not in k) for k, v in p.items()}
@@ -88,16 +91,28 @@ def cpu_baseline(workload, T, N, H, W, budget_s=25.0):
         out = O.dynamic_volleyball_forward(ocfg, p, images, boxes)
         F.cross_entropy(out["activities"], labels).backward()
 
-    t0 = time.time()
-    step()                                   # warm-up (also sizes the budget)
-    warm = time.time() - t0
-    n = max(1, min(5, int(budget_s / max(warm, 1e-3)) - 1))
+    cands = sorted({max(1, min(ncpu, c)) for c in (ncpu // 4, ncpu // 8, 32)})
+    t_all = time.time()
+    best_t, best_th = None, None
+    for th in cands:
+        torch.set_num_threads(th)
+        t0 = time.time()
+        step()
+        dt = time.time() - t0
+        if best_t is None or dt < best_t:
+            best_t, best_th = dt, th
+        if time.time() - t_all > budget_s:
+            break
+    torch.set_num_threads(best_th)
+    n = max(1, min(4, int((budget_s - (time.time() - t_all)) / max(best_t, 1e-3))))
     t0 = time.time()
     for _ in range(n):
         step()
     dt = (time.time() - t0) / n
-    return {"value": B / dt, "unit": "clips/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} timed fwd+bwd step(s) of B={B} clip (T={T}, {H}x{W}, {backbone}, fp32 torch-CPU oracle) after 1 warm-up"}
+    dt = min(dt, best_t)
+    return {"value": B / dt, "unit": "clips/sec", "cores": best_th, "kind": "port", "host_logical_cpus": ncpu,
+            "sample": f"{n} timed fwd+bwd step(s) of B={B} clip (T={T}, {H}x{W}, {backbone}, fp32 torch-CPU oracle) at the fastest of "
+                      f"threads={cands} (1 probe step each)"}
 
 
 def main():
@@ -153,6 +168,28 @@ def main():
 
     for _ in range(a.warmup):
         step()
+
+    # calibrate what a HIP event pair adds around ONE launch (two marker packets; kernels otherwise run back to back):
+    # per-launch cost of a trivial kernel bracketed individually minus its cost inside one long bracket
+    from din_amd import ops as _ops
+    tiny = torch.zeros(64, device=dev)
+    def _tiny():
+        _ops.L.check(_ops.L.load().din_axpby(tiny.data_ptr(), None, tiny.data_ptr(), 1.0, 0.0, 64, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    singles = []
+    for _ in range(64):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); _tiny(); e1.record()
+        singles.append((e0, e1))
+    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    b0.record()
+    for _ in range(64):
+        _tiny()
+    b1.record()
+    torch.cuda.synchronize()
+    single_ms = sorted(x.elapsed_time(y) for x, y in singles)[len(singles) // 2]
+    event_overhead_ms = max(0.0, single_ms - b0.elapsed_time(b1) / 64)
+
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -175,15 +212,16 @@ def main():
     for kind, variant, flops, dt_, e0, e1 in prof:
         rec = agg.setdefault(variant, [0.0, 0.0, 0])
         rec[0] += flops
-        rec[1] += e0.elapsed_time(e1) * 1e-3
+        rec[1] += max(e0.elapsed_time(e1) - event_overhead_ms, 0.0) * 1e-3
         rec[2] += 1
     dom = "gather_bn128"
     fl, sec, cnt = agg.get(dom, [0.0, 1e-9, 1])
     achieved = fl / sec / 1e12
     peak = PEAK_TFLOPS[dtype]
-    roofline = {"bound": "mfma", "kernel": f"conv_gather_kernel<{'bf16' if dtype == 'bf16' else 'float'},128>",
+    roofline = {"bound": "mfma", "kernel": f"conv_gather_fast_kernel<{'bf16' if dtype == 'bf16' else 'float'},128>",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": None, "launches": cnt, "avg_launch_ms": round(sec / max(cnt, 1) * 1e3, 4),
+                "event_pair_overhead_ms_subtracted": round(event_overhead_ms, 4),
                 "flops_per_launch_avg": fl / max(cnt, 1),
                 "other_kernels": {k: {"TFLOP/s": round(v[0] / max(v[1], 1e-9) / 1e12, 2), "launches": v[2],
                                       "time_s": round(v[1], 4)} for k, v in agg.items() if k != dom}}
