@@ -215,7 +215,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_generic_kernel(ConvK 
     epilogue_direct<T, TI, TJ, BN>(p, acc, co_tile, px_tile, wm, wn, lane, split);
 }
 
-// Fast addressing (stride-1 gathers, <= 64 taps: every forward conv and every stride-1 dgrad).
+// Fast addressing (stride-1 gathers, <= 32 taps: every forward conv and every stride-1 dgrad).
 //  * operands are fetched with BUFFER loads: one 32-bit byte offset per tile row, recomputed only when the tap changes;
 //    padding taps get an out-of-range offset and the hardware returns zeros; the k-offset inside a tap is a scalar.
 //    The resource base is moved to the first image of the tile so 32-bit offsets suffice for any tensor size.
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* smem = reinterpret_cast<u32x4*>(smem_raw);
-    int* tapdelta = reinterpret_cast<int*>(smem_raw + 2 * BUF * 16);   // [64] byte offset of tap (r,s) relative to tap (0,0)
+    int* tapdelta = reinterpret_cast<int*>(smem_raw + 2 * BUF * 16);   // [64] (32 used) byte offset of tap (r,s) relative to tap (0,0)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -260,22 +260,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
     // ---- per-row state --------------------------------------------------------------------------------------
     const int cq = tid & 7, r0 = tid >> 3;
     int pixoff[PA];                       // byte offset (from the resource base) of tap (0,0), channel cioff, chunk 0
-    unsigned long long vmask[PA];         // bit t set <=> tap t of this pixel lies inside the image
+    unsigned vmask[PA];                   // bit t set <=> tap t of this pixel lies inside the image (<= 32 taps)
+    {
+        const unsigned full_row = p.kw >= 32 ? 0xffffffffu : ((1u << p.kw) - 1u);
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        int m = m_first + r0 + 32 * i;
-        vmask[i] = 0ull; pixoff[i] = 0;
-        if (m < p.M) {
-            int n = m / (p.OH * p.OW);
-            int rem = m - n * (p.OH * p.OW);
-            int oy = rem / p.OW, ox = rem - oy * p.OW;
-            const int ty0 = oy * p.ay + p.by, tx0 = ox * p.ax + p.bx;
-            for (int r = 0; r < p.kh; ++r)
+        for (int i = 0; i < PA; ++i) {
+            int m = m_first + r0 + 32 * i;
+            vmask[i] = 0u; pixoff[i] = 0;
+            if (m < p.M) {
+                int n = m / (p.OH * p.OW);
+                int rem = m - n * (p.OH * p.OW);
+                int oy = rem / p.OW, ox = rem - oy * p.OW;
+                const int ty0 = oy * p.ay + p.by, tx0 = ox * p.ax + p.bx;
+                // valid s: 0 <= tx0 + s*cx < W   (cx may be negative for dgrad) -- build the kw-bit column mask once
+                unsigned cmask = 0u;
                 for (int s2 = 0; s2 < p.kw; ++s2) {
-                    int ty = ty0 + r * p.cy, tx = tx0 + s2 * p.cx;
-                    if (ty >= 0 && ty < p.H && tx >= 0 && tx < p.W) vmask[i] |= 1ull << (r * p.kw + s2);
+                    int tx = tx0 + s2 * p.cx;
+                    cmask |= (tx >= 0 && tx < p.W) ? (1u << s2) : 0u;
                 }
-            pixoff[i] = (((n - n_first) * p.H + ty0) * p.W + tx0) * p.ldi * (int)sizeof(T) + p.cioff * (int)sizeof(T);
+                cmask &= full_row;
+                unsigned mk = 0u;
+                for (int r = 0; r < p.kh; ++r) {
+                    int ty = ty0 + r * p.cy;
+                    mk |= (ty >= 0 && ty < p.H) ? (cmask << (r * p.kw)) : 0u;
+                }
+                vmask[i] = mk;
+                pixoff[i] = (((n - n_first) * p.H + ty0) * p.W + tx0) * p.ldi * (int)sizeof(T) + p.cioff * (int)sizeof(T);
+            }
         }
     }
     int voffB[PB];
@@ -290,7 +301,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
     auto refresh_uniform = [&]() {
         const int td = tapdelta[tap_s < 64 ? tap_s : 0] + cq * 16;
 #pragma unroll
-        for (int i = 0; i < PA; ++i) voffA[i] = (tap_s < ntaps && ((vmask[i] >> tap_s) & 1ull)) ? (unsigned)(pixoff[i] + td) : OOB;
+        for (int i = 0; i < PA; ++i) voffA[i] = (tap_s < ntaps && ((vmask[i] >> tap_s) & 1u)) ? (unsigned)(pixoff[i] + td) : OOB;
     };
     // per-lane bookkeeping for k-steps that straddle taps
     int tap_l = (ks_begin * KC + cq) / p.cpt, cc_l = ks_begin * KC + cq - tap_l * p.cpt;
@@ -304,15 +315,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
             cc_s += KC;
             if (cc_s >= p.cpt) { cc_s = 0; ++tap_s; refresh_uniform(); }
         } else {
+            // k-step straddles taps: per-lane tap index; cost kept to ~5 VALU per row (bit-extract, add, select)
             const bool ok = tap_l < ntaps;
             const int td = tapdelta[ok ? tap_l : 0] + cc_l * 16;
+            const unsigned bit = ok ? (1u << tap_l) : 0u;
 #pragma unroll
             for (int i = 0; i < PA; ++i) {
-                unsigned vo = (ok && ((vmask[i] >> tap_l) & 1ull)) ? (unsigned)(pixoff[i] + td) : OOB;
+                unsigned vo = (vmask[i] & bit) ? (unsigned)(pixoff[i] + td) : OOB;
                 ga[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)vo, 0, 0));
             }
             cc_l += KC;
-            while (cc_l >= p.cpt) { cc_l -= p.cpt; ++tap_l; }
+            if (p.cpt >= KC) {                       // at most one tap boundary per k-step: branch-free
+                const bool wrap = cc_l >= p.cpt;
+                cc_l -= wrap ? p.cpt : 0;
+                tap_l += wrap ? 1 : 0;
+            } else {
+                while (cc_l >= p.cpt) { cc_l -= p.cpt; ++tap_l; }
+            }
         }
         const int soffB = ks * KC * 16;
 #pragma unroll
@@ -1124,7 +1143,7 @@ int check_desc(const din_conv_desc* d) {
 
 template <typename T, int BN>
 void launch_gather(const ConvK& k, int n_px_tiles, hipStream_t st) {
-    const bool fast = k.divy == 1 && k.divx == 1 && k.kh * k.kw <= 64;
+    const bool fast = k.divy == 1 && k.divx == 1 && k.kh * k.kw <= 32;
     dim3 grid(n_px_tiles * k.n_co_tiles, k.splitk);
     if (fast) {
         size_t stage = 2 * (BM + BN) * KC * 16 + 256;                       // stage buffers + tap table
