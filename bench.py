@@ -193,9 +193,13 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    nhwc.PROFILE = []
+    # Per-launch HIP events cost ~70 us of pipeline bubble each (two marker packets), i.e. ~10 % of a step if every conv launch
+    # of every step were bracketed.  They are therefore recorded during the LAST timed step only: still inside the timed region,
+    # while the headline number pays 1/K of that cost.
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for it in range(a.steps):
+        if it == a.steps - 1:
+            nhwc.PROFILE = []
         loss = step()
     if world > 1:
         dist.barrier()
@@ -221,7 +225,7 @@ def main():
     roofline = {"bound": "mfma", "kernel": f"conv_gather_fast_kernel<{'bf16' if dtype == 'bf16' else 'float'},128>",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": None, "launches": cnt, "avg_launch_ms": round(sec / max(cnt, 1) * 1e3, 4),
-                "event_pair_overhead_ms_subtracted": round(event_overhead_ms, 4),
+                "event_pair_overhead_ms_subtracted": round(event_overhead_ms, 4), "sampled_steps": 1,
                 "flops_per_launch_avg": fl / max(cnt, 1),
                 "other_kernels": {k: {"TFLOP/s": round(v[0] / max(v[1], 1e-9) / 1e12, 2), "launches": v[2],
                                       "time_s": round(v[1], 4)} for k, v in agg.items() if k != dom}}
@@ -240,7 +244,7 @@ def main():
                                    + ("" if a.no_adam else " + fused Adam"),
                        "bn_mode": "running statistics (set_bn_eval)" if backbone == "inv3" else "n/a"},
             "roofline": roofline,
-            "conv_time_frac": round(conv_time / elapsed, 4),
+            "conv_time_frac_sampled_step": round(conv_time / (elapsed / a.steps), 4),
             "final_loss": round(float(loss.item()), 5),
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -20,6 +20,20 @@ __device__ __forceinline__ void st4(void* base, int dtype, int64_t i, f32x4 v) {
     *reinterpret_cast<uint2*>((bf16_t*)base + i) = r;
 }
 
+// 8-channel (16-byte) bf16 vectors for the hot pool kernels
+struct f32x8 { f32x4 lo, hi; };
+__device__ __forceinline__ f32x8 ld8_bf16(const void* base, int64_t i) {
+    uint4 r = *reinterpret_cast<const uint4*>((const bf16_t*)base + i);
+    f32x8 o;
+    o.lo = f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+    o.hi = f32x4{__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u), __uint_as_float(r.w << 16), __uint_as_float(r.w & 0xffff0000u)};
+    return o;
+}
+__device__ __forceinline__ void st8_bf16(void* base, int64_t i, const f32x8& v) {
+    uint4 r = {pack_bf16x2(v.lo[0], v.lo[1]), pack_bf16x2(v.lo[2], v.lo[3]), pack_bf16x2(v.hi[0], v.hi[1]), pack_bf16x2(v.hi[2], v.hi[3])};
+    *reinterpret_cast<uint4*>((bf16_t*)base + i) = r;
+}
+
 // ---- Row P: prep_images (utils.py:8-19) --------------------------------------------------------------
 __device__ __forceinline__ float prep1(float x) {
     // three separately rounded fp32 operations, as in the reference (div, sub, mul)
@@ -192,6 +206,108 @@ __global__ void avgpool_fwd_kernel(din_pool_desc d, const void* __restrict__ in,
             }
         }
         st4(out, d.dtype, p * d.ldo + d.cooff + cg * 4, s4 * inv);
+    }
+}
+__global__ void avgpool_fwd8_kernel(din_pool_desc d, const void* __restrict__ in, void* __restrict__ out) {
+    const int c8 = d.c >> 3;
+    int64_t total = (int64_t)d.nb * d.oh * d.ow * c8;
+    const float inv = 1.f / (float)(d.k * d.k);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int cg = (int)(i % c8);
+        int64_t p = i / c8;
+        int ox = (int)(p % d.ow);
+        int64_t q = p / d.ow;
+        int oy = (int)(q % d.oh), n = (int)(q / d.oh);
+        f32x8 a; a.lo = f32x4{0.f, 0.f, 0.f, 0.f}; a.hi = a.lo;
+        for (int r = 0; r < d.k; ++r) {
+            int iy = oy * d.stride - d.pad + r;
+            if (iy < 0 || iy >= d.h) continue;
+            for (int s = 0; s < d.k; ++s) {
+                int ix = ox * d.stride - d.pad + s;
+                if (ix < 0 || ix >= d.w) continue;
+                f32x8 v = ld8_bf16(in, ((int64_t)(n * d.h + iy) * d.w + ix) * d.ldi + d.cioff + cg * 8);
+                a.lo += v.lo; a.hi += v.hi;
+            }
+        }
+        a.lo = a.lo * inv; a.hi = a.hi * inv;
+        st8_bf16(out, p * d.ldo + d.cooff + cg * 8, a);
+    }
+}
+__global__ void avgpool_bwd8_kernel(din_pool_desc d, const void* __restrict__ dout, void* __restrict__ din_,
+                                    const void* __restrict__ mask, int accumulate) {
+    const int c8 = d.c >> 3;
+    int64_t total = (int64_t)d.nb * d.h * d.w * c8;
+    const float inv = 1.f / (float)(d.k * d.k);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int cg = (int)(i % c8);
+        int64_t p = i / c8;
+        int ix = (int)(p % d.w);
+        int64_t q = p / d.w;
+        int iy = (int)(q % d.h), n = (int)(q / d.h);
+        f32x8 g; g.lo = f32x4{0.f, 0.f, 0.f, 0.f}; g.hi = g.lo;
+        for (int r = 0; r < d.k; ++r) {
+            int ty = iy + d.pad - r;
+            if (ty < 0 || ty % d.stride) continue;
+            int oy = ty / d.stride;
+            if (oy >= d.oh) continue;
+            for (int s = 0; s < d.k; ++s) {
+                int tx = ix + d.pad - s;
+                if (tx < 0 || tx % d.stride) continue;
+                int ox = tx / d.stride;
+                if (ox >= d.ow) continue;
+                f32x8 v = ld8_bf16(dout, ((int64_t)(n * d.oh + oy) * d.ow + ox) * d.ldo + d.cooff + cg * 8);
+                g.lo += v.lo; g.hi += v.hi;
+            }
+        }
+        g.lo = g.lo * inv; g.hi = g.hi * inv;
+        int64_t off = p * d.ldi + d.cioff + cg * 8;
+        if (mask) {
+            f32x8 y = ld8_bf16(mask, off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { g.lo[e] = y.lo[e] > 0.f ? g.lo[e] : 0.f; g.hi[e] = y.hi[e] > 0.f ? g.hi[e] : 0.f; }
+        }
+        if (accumulate) { f32x8 o = ld8_bf16(din_, off); g.lo += o.lo; g.hi += o.hi; }
+        st8_bf16(din_, off, g);
+    }
+}
+// 8-wide max-pool backward from the arg-max map
+__global__ void maxpool_bwd_amax8_kernel(din_pool_desc d, const uint8_t* __restrict__ amax, const void* __restrict__ dout,
+                                         void* __restrict__ din_, int accumulate) {
+    const int c8 = d.c >> 3;
+    int64_t total = (int64_t)d.nb * d.h * d.w * c8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int cg = (int)(i % c8);
+        int64_t p = i / c8;
+        int ix = (int)(p % d.w);
+        int64_t q = p / d.w;
+        int iy = (int)(q % d.h), n = (int)(q / d.h);
+        f32x8 g; g.lo = f32x4{0.f, 0.f, 0.f, 0.f}; g.hi = g.lo;
+        int oy_hi = (iy + d.pad) / d.stride, ox_hi = (ix + d.pad) / d.stride;
+        int oy_lo = (iy + d.pad - d.k + d.stride) / d.stride, ox_lo = (ix + d.pad - d.k + d.stride) / d.stride;
+        if (iy + d.pad - d.k + 1 < 0) oy_lo = 0;
+        if (ix + d.pad - d.k + 1 < 0) ox_lo = 0;
+        if (oy_hi >= d.oh) oy_hi = d.oh - 1;
+        if (ox_hi >= d.ow) ox_hi = d.ow - 1;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                const uint32_t tap = (uint32_t)((iy - (oy * d.stride - d.pad)) * d.k + (ix - (ox * d.stride - d.pad)));
+                int64_t po = (int64_t)(n * d.oh + oy) * d.ow + ox;
+                uint2 pk = *reinterpret_cast<const uint2*>(amax + po * d.c + cg * 8);
+                const uint32_t t4 = tap * 0x01010101u;
+                // any byte equal to tap?  (x ^ t4) has a zero byte
+                uint32_t xa = pk.x ^ t4, xb = pk.y ^ t4;
+                bool any = (((xa - 0x01010101u) & ~xa & 0x80808080u) | ((xb - 0x01010101u) & ~xb & 0x80808080u)) != 0u;
+                if (!any) continue;
+                f32x8 go = ld8_bf16(dout, po * d.ldo + d.cooff + cg * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    g.lo[e] += ((pk.x >> (8 * e)) & 0xff) == tap ? go.lo[e] : 0.f;
+                    g.hi[e] += ((pk.y >> (8 * e)) & 0xff) == tap ? go.hi[e] : 0.f;
+                }
+            }
+        int64_t self_off = p * d.ldi + d.cioff + cg * 8;
+        if (accumulate) { f32x8 o = ld8_bf16(din_, self_off); g.lo += o.lo; g.hi += o.hi; }
+        st8_bf16(din_, self_off, g);
     }
 }
 __global__ void avgpool_bwd_kernel(din_pool_desc d, const void* __restrict__ dout, void* __restrict__ din_,
@@ -395,6 +511,10 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+inline bool wide8(const din_pool_desc* d) {
+    return d->dtype == DIN_BF16 && d->c % 8 == 0 && d->ldi % 8 == 0 && d->ldo % 8 == 0 && d->cioff % 8 == 0 && d->cooff % 8 == 0;
+}
+
 int check_pool(const din_pool_desc* d, const char* what) {
     DIN_REQUIRE(d != nullptr, "%s: null descriptor", what);
     DIN_REQUIRE(d->dtype == DIN_F32 || d->dtype == DIN_BF16, "%s: bad dtype", what);
@@ -441,7 +561,8 @@ int din_maxpool_bwd(const din_pool_desc* d, const void* in, const uint8_t* argma
     int64_t total = (int64_t)d->nb * d->h * d->w * (d->c / 4);
     if (argmax) {
         DIN_REQUIRE(relu_mask, "maxpool_bwd: the arg-max map encodes the fused ReLU mask; relu_mask must be set");
-        hipLaunchKernelGGL(maxpool_bwd_amax_kernel, dim3(grid_1d(total, 256, 16384)), dim3(256), 0, as_stream(stream), *d, argmax, dout, din_, accumulate);
+        if (wide8(d)) hipLaunchKernelGGL(maxpool_bwd_amax8_kernel, dim3(grid_1d(total / 2, 256, 32768)), dim3(256), 0, as_stream(stream), *d, argmax, dout, din_, accumulate);
+        else hipLaunchKernelGGL(maxpool_bwd_amax_kernel, dim3(grid_1d(total, 256, 16384)), dim3(256), 0, as_stream(stream), *d, argmax, dout, din_, accumulate);
     } else {
         hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_1d(total, 256, 16384)), dim3(256), 0, as_stream(stream), *d, in, dout, din_, relu_mask, accumulate);
     }
@@ -452,7 +573,8 @@ int din_avgpool_fwd(const din_pool_desc* d, const void* in, void* out, void* str
     if (int e = check_pool(d, "avgpool_fwd")) return e;
     DIN_REQUIRE(in && out, "avgpool_fwd: null pointer");
     int64_t total = (int64_t)d->nb * d->oh * d->ow * (d->c / 4);
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_1d(total, 256, 16384)), dim3(256), 0, as_stream(stream), *d, in, out);
+    if (wide8(d)) hipLaunchKernelGGL(avgpool_fwd8_kernel, dim3(grid_1d(total / 2, 256, 32768)), dim3(256), 0, as_stream(stream), *d, in, out);
+    else hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_1d(total, 256, 16384)), dim3(256), 0, as_stream(stream), *d, in, out);
     DIN_CHECK_LAUNCH("avgpool_fwd");
     return DIN_OK;
 }
@@ -460,7 +582,8 @@ int din_avgpool_bwd(const din_pool_desc* d, const void* dout, void* din_, const 
     if (int e = check_pool(d, "avgpool_bwd")) return e;
     DIN_REQUIRE(dout && din_, "avgpool_bwd: null pointer");
     int64_t total = (int64_t)d->nb * d->h * d->w * (d->c / 4);
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_1d(total, 256, 16384)), dim3(256), 0, as_stream(stream), *d, dout, din_, mask, accumulate);
+    if (wide8(d)) hipLaunchKernelGGL(avgpool_bwd8_kernel, dim3(grid_1d(total / 2, 256, 32768)), dim3(256), 0, as_stream(stream), *d, dout, din_, mask, accumulate);
+    else hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_1d(total, 256, 16384)), dim3(256), 0, as_stream(stream), *d, dout, din_, mask, accumulate);
     DIN_CHECK_LAUNCH("avgpool_bwd");
     return DIN_OK;
 }

@@ -173,9 +173,10 @@ def test_bn_fold_and_wdot(env):
     assert rel(dw, wr.grad) <= 5e-5 and rel(dgamma, gr.grad) <= 5e-5 and rel(dbeta, br.grad) <= 5e-5
 
 
+@pytest.mark.parametrize("ldi,cioff", [(24, 4), (32, 8)])      # (32, 8) takes the 16-byte-vector bf16 kernels
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("kind,k,s,p", [("maxpool", 2, 2, 0), ("maxpool", 3, 2, 0), ("avgpool", 3, 1, 1)])
-def test_pools(env, kind, k, s, p, dtype):
+def test_pools(env, kind, k, s, p, dtype, ldi, cioff):
     lib, L, nhwc, ops = env
     tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
     g = torch.Generator().manual_seed(k * 10 + s)
@@ -190,9 +191,9 @@ def test_pools(env, kind, k, s, p, dtype):
     y.backward(cot)
     d = L.PoolDesc()
     d.nb, d.h, d.w, d.c, d.oh, d.ow = 2, 13, 15, 16, y.shape[2], y.shape[3]
-    d.k, d.stride, d.pad, d.ldi, d.cioff, d.ldo, d.cooff = k, s, p, 24, 4, 16, 0
+    d.k, d.stride, d.pad, d.ldi, d.cioff, d.ldo, d.cooff = k, s, p, ldi, cioff, 16, 0
     d.dtype = L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
-    xin = to_nhwc(x, tdt, 24, 4)
+    xin = to_nhwc(x, tdt, ldi, cioff)
     out = torch.empty(2, y.shape[2], y.shape[3], 16, dtype=tdt, device="cuda")
     amax = torch.empty(2, y.shape[2], y.shape[3], 16, dtype=torch.uint8, device="cuda")
     if kind == "maxpool":
@@ -207,14 +208,14 @@ def test_pools(env, kind, k, s, p, dtype):
         L.check(lib.din_maxpool_bwd(C.byref(d), xin.data_ptr(), None, gout.data_ptr(), dx.data_ptr(), 1, 0, None))
         torch.cuda.synchronize()
         want = xr.grad * (x > 0).float()
-        assert rel(from_nhwc(dx, 16, 4), want) <= (1e-6 if dtype == "fp32" else 1.5e-2)
+        assert rel(from_nhwc(dx, 16, cioff), want) <= (1e-6 if dtype == "fp32" else 1.5e-2)
         dx.zero_()                                                        # same answer from the saved arg-max map
         L.check(lib.din_maxpool_bwd(C.byref(d), None, amax.data_ptr(), gout.data_ptr(), dx.data_ptr(), 1, 0, None))
     else:
         L.check(lib.din_avgpool_bwd(C.byref(d), gout.data_ptr(), dx.data_ptr(), xin.data_ptr(), 0, None))
     torch.cuda.synchronize()
     want = xr.grad * (x > 0).float()
-    assert rel(from_nhwc(dx, 16, 4), want) <= (1e-6 if dtype == "fp32" else 1.5e-2)
+    assert rel(from_nhwc(dx, 16, cioff), want) <= (1e-6 if dtype == "fp32" else 1.5e-2)
 
 
 def test_bilinear_align_corners(env):
