@@ -41,7 +41,19 @@ struct ConvK {
     int flags, ldm, moff;
     int splitk, ks_per_split, n_co_tiles;
     long long in_bytes, w_bytes;    // extents for the buffer resources
+    // output pixel of tile row m=(n,a,b): ((n*out_H + a*out_sy + out_y0)*out_W + b*out_sx + out_x0); identity when out_sy==0
+    int out_sy, out_sx, out_y0, out_x0, out_H, out_W;
+    int remap;                      // 1: filter tap t of this launch is tap wtap[t] of the packed bank (tap subsets)
+    unsigned char wtap[32];
 };
+
+__device__ __forceinline__ int64_t out_pixel(const ConvK& p, int m) {
+    if (p.out_sy == 0) return m;
+    int n = m / (p.OH * p.OW);
+    int rem = m - n * (p.OH * p.OW);
+    int a = rem / p.OW, b = rem - a * p.OW;
+    return ((int64_t)n * p.out_H + a * p.out_sy + p.out_y0) * p.out_W + b * p.out_sx + p.out_x0;
+}
 
 __device__ __forceinline__ int lds_slot(int row, int chunk) { return row * KC + (chunk ^ ((row >> 1) & 7)); }
 
@@ -91,7 +103,8 @@ __device__ __forceinline__ void epilogue_direct(const ConvK& p, f32x4 (&acc)[TI]
             int co = co_base + i * 16;
             if (co >= p.Cout) continue;
             f32x4 v = acc[i][j];
-            int64_t o = (int64_t)m * p.ldo + p.cooff + co;
+            const int64_t opx = out_pixel(p, m);
+            int64_t o = opx * p.ldo + p.cooff + co;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (co + e >= p.Cout) break;
@@ -99,7 +112,7 @@ __device__ __forceinline__ void epilogue_direct(const ConvK& p, f32x4 (&acc)[TI]
                 if (p.flags & DIN_CONV_BIAS) x += p.bias[co + e];
                 if (p.flags & DIN_CONV_RELU) x = fmaxf(x, 0.f);
                 if (p.flags & DIN_CONV_MASK) {
-                    float y = Elem<T>::ld(maskp + (int64_t)m * p.ldm + p.moff + co + e);
+                    float y = Elem<T>::ld(maskp + opx * p.ldm + p.moff + co + e);
                     x = y > 0.f ? x : 0.f;
                 }
                 if (p.flags & DIN_CONV_ACCUM) x += Elem<T>::ld(outp + o + e);
@@ -241,9 +254,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
     int ks_end = ks_begin + p.ks_per_split;
     if (ks_end > p.nk) ks_end = p.nk;
     const int ntaps = p.kh * p.kw;
-    if (tid < 64) {
+    int* wtap_lds = tapdelta + 32;                                     // [32] tap -> tap of the packed filter bank
+    if (tid < 32) {
         int r = tid / p.kw, s = tid - r * p.kw;
         tapdelta[tid] = tid < ntaps ? (r * p.cy * p.W + s * p.cx) * p.ldi * (int)sizeof(T) : 0;
+        wtap_lds[tid] = (p.remap && tid < ntaps) ? (int)p.wtap[tid] : tid;
     }
 
     // ---- buffer resources ---------------------------------------------------------------------------------
@@ -291,7 +306,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
     }
     int voffB[PB];
 #pragma unroll
-    for (int i = 0; i < PB; ++i) voffB[i] = ((co_tile * BN + r0 + 32 * i) * p.wld + cq) * 16;
+    for (int i = 0; i < PB; ++i) voffB[i] = ((co_tile * BN + r0 + 32 * i) * p.wld + (p.remap ? 0 : cq)) * 16;
     __syncthreads();                                                          // tapdelta visible
 
     const bool tap_uniform = (p.cpt % KC) == 0;
@@ -299,7 +314,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
     int tap_s = (ks_begin * KC) / p.cpt, cc_s = ks_begin * KC - tap_s * p.cpt;
     unsigned voffA[PA];
     auto refresh_uniform = [&]() {
-        const int td = tapdelta[tap_s < 64 ? tap_s : 0] + cq * 16;
+        const int td = tapdelta[tap_s < 32 ? tap_s : 0] + cq * 16;
 #pragma unroll
         for (int i = 0; i < PA; ++i) voffA[i] = (tap_s < ntaps && ((vmask[i] >> tap_s) & 1u)) ? (unsigned)(pixoff[i] + td) : OOB;
     };
@@ -308,8 +323,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
     if (tap_uniform) refresh_uniform();
 
     auto load_global = [&](u32x4 (&ga)[PA], u32x4 (&gb)[PB], int ks) {
+        int remapB = 0;                                    // per-lane chunk offset (bytes) into the packed bank, remap mode only
         if (tap_uniform) {
             const int soff = cc_s * 16;
+            if (p.remap) remapB = ((tap_s < ntaps ? wtap_lds[tap_s] : 0) * p.cpt + cc_s + cq) * 16;
 #pragma unroll
             for (int i = 0; i < PA; ++i) ga[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)voffA[i], soff, 0));
             cc_s += KC;
@@ -319,6 +336,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
             const bool ok = tap_l < ntaps;
             const int td = tapdelta[ok ? tap_l : 0] + cc_l * 16;
             const unsigned bit = ok ? (1u << tap_l) : 0u;
+            if (p.remap) remapB = ok ? (wtap_lds[tap_l] * p.cpt + cc_l) * 16 : 0;
 #pragma unroll
             for (int i = 0; i < PA; ++i) {
                 unsigned vo = (vmask[i] & bit) ? (unsigned)(pixoff[i] + td) : OOB;
@@ -333,9 +351,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
                 while (cc_l >= p.cpt) { cc_l -= p.cpt; ++tap_l; }
             }
         }
-        const int soffB = ks * KC * 16;
+        if (p.remap) {
 #pragma unroll
-        for (int i = 0; i < PB; ++i) gb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], soffB, 0));
+            for (int i = 0; i < PB; ++i) gb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i] + remapB, 0, 0));
+        } else {
+            const int soffB = ks * KC * 16;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) gb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], soffB, 0));
+        }
     };
     auto store_lds = [&](const u32x4 (&ga)[PA], const u32x4 (&gb)[PB], int buf) {
         u32x4* A = smem + buf * BUF;
@@ -432,10 +455,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
                 const int m = m_first + row;
                 if (m >= p.M) break;
                 u32x4 v = *reinterpret_cast<const u32x4*>(smem_raw + row * CPITCH + c * 16);
-                const int64_t o = (int64_t)m * p.ldo + p.cooff + co;
+                const int64_t opx = out_pixel(p, m);
+                const int64_t o = opx * p.ldo + p.cooff + co;
                 if (p.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM)) {
                     u32x4 mk = {0u, 0u, 0u, 0u}, old = {0u, 0u, 0u, 0u};
-                    if (p.flags & DIN_CONV_MASK) mk = *reinterpret_cast<const u32x4*>(maskp + (int64_t)m * p.ldm + p.moff + co);
+                    if (p.flags & DIN_CONV_MASK) mk = *reinterpret_cast<const u32x4*>(maskp + opx * p.ldm + p.moff + co);
                     if (p.flags & DIN_CONV_ACCUM) old = *reinterpret_cast<const u32x4*>(outp + o);
                     if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -476,11 +500,12 @@ __global__ void conv_splitk_finish_kernel(ConvK p, int cpad) {
         for (int s = 0; s < p.splitk; ++s) x += p.partial[((int64_t)s * p.M + m) * cpad + co];
         if (p.flags & DIN_CONV_BIAS) x += p.bias[co];
         if (p.flags & DIN_CONV_RELU) x = fmaxf(x, 0.f);
+        const int64_t opx = out_pixel(p, m);
         if (p.flags & DIN_CONV_MASK) {
-            float y = Elem<T>::ld(maskp + (int64_t)m * p.ldm + p.moff + co);
+            float y = Elem<T>::ld(maskp + opx * p.ldm + p.moff + co);
             x = y > 0.f ? x : 0.f;
         }
-        int64_t o = (int64_t)m * p.ldo + p.cooff + co;
+        int64_t o = opx * p.ldo + p.cooff + co;
         if (p.flags & DIN_CONV_ACCUM) x += Elem<T>::ld(outp + o);
         Elem<T>::st(outp + o, x);
     }
@@ -1090,7 +1115,8 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype) {
         if (g.splitk > 64) g.splitk = 64;
     }
     g.ks_per_split = (g.nk + g.splitk - 1) / g.splitk;
-    g.splitk = (g.nk + g.ks_per_split - 1) / g.ks_per_split;
+    if (g.ks_per_split < 1) g.ks_per_split = 1;                    // nk == 0: launch still runs its epilogue (zeros / accumulate)
+    g.splitk = g.nk > 0 ? (g.nk + g.ks_per_split - 1) / g.ks_per_split : 1;
     g.ws_bytes = g.splitk > 1 ? (int64_t)g.splitk * M * (g.n_co_tiles * g.bn) * 4 : 0;
     return g;
 }
@@ -1157,7 +1183,8 @@ void launch_gather(const ConvK& k, int n_px_tiles, hipStream_t st) {
 }
 
 int run_gather(ConvK& k, const GatherPlan& g, int dtype, void* workspace, int64_t ws_bytes, hipStream_t st, const char* what) {
-    k.cpt = g.cpt; k.Q = g.Q; k.nk = g.nk; k.wld = g.nk * KC;
+    k.cpt = g.cpt; k.Q = g.Q; k.nk = g.nk;
+    if (!k.remap) k.wld = g.nk * KC;
     k.splitk = g.splitk; k.ks_per_split = g.ks_per_split; k.n_co_tiles = g.n_co_tiles;
     if (g.splitk > 1) {
         if (ws_bytes < g.ws_bytes || workspace == nullptr)
@@ -1217,7 +1244,23 @@ int din_conv_pack_weights(const din_conv_desc* d, const float* w, const float* s
 int64_t din_conv_workspace_bytes(const din_conv_desc* d, int which) {
     if (!d) return 0;
     if (which == 0) return plan_gather(d->nb * d->oh * d->ow, d->cin, d->cout, d->kh * d->kw, d->dtype).ws_bytes;
-    if (which == 1) return plan_gather(d->nb * d->h * d->w, d->cout, d->cin, d->kh * d->kw, d->dtype).ws_bytes;
+    if (which == 1) {
+        if ((d->sh > 1 || d->sw > 1) && d->dh == 1 && d->dw == 1 && d->kh * d->kw <= 32) {
+            int64_t mx = 0;
+            for (int py = 0; py < d->sh; ++py)
+                for (int px = 0; px < d->sw; ++px) {
+                    const int Ha = (d->h - py + d->sh - 1) / d->sh, Wa = (d->w - px + d->sw - 1) / d->sw;
+                    if (Ha <= 0 || Wa <= 0) continue;
+                    const int r0c = (py + d->ph) % d->sh, s0c = (px + d->pw) % d->sw;
+                    const int khs = r0c < d->kh ? (d->kh - r0c + d->sh - 1) / d->sh : 0;
+                    const int kws = s0c < d->kw ? (d->kw - s0c + d->sw - 1) / d->sw : 0;
+                    int64_t b = plan_gather(d->nb * Ha * Wa, d->cout, d->cin, khs * kws, d->dtype).ws_bytes;
+                    if (b > mx) mx = b;
+                }
+            return mx;
+        }
+        return plan_gather(d->nb * d->h * d->w, d->cout, d->cin, d->kh * d->kw, d->dtype).ws_bytes;
+    }
     return plan_wgrad(d).ws_bytes;
 }
 
@@ -1257,14 +1300,44 @@ int din_conv_dgrad(const din_conv_desc* d, const void* dout, const void* wpk_t, 
     k.NB = d->nb; k.H = d->oh; k.W = d->ow; k.Cin = d->cout; k.ldi = d->ldo; k.cioff = d->cooff;
     k.OH = d->h; k.OW = d->w; k.Cout = d->cin; k.ldo = d->ldi; k.cooff = d->cioff;
     k.kh = d->kh; k.kw = d->kw;
-    // y_in = oy*sh - ph + r*dh  =>  oy = (y_in + ph - r*dh) / sh
-    k.ay = 1; k.by = d->ph; k.cy = -d->dh; k.divy = d->sh;
-    k.ax = 1; k.bx = d->pw; k.cx = -d->dw; k.divx = d->sw;
-    k.M = d->nb * d->h * d->w; k.flags = flags; k.ldm = ldm; k.moff = moff;
+    k.flags = flags; k.ldm = ldm; k.moff = moff;
     k.in_bytes = (long long)d->nb * d->oh * d->ow * d->ldo * (d->dtype == DIN_F32 ? 4 : 2);
     k.w_bytes = din_conv_packed_elems(d, 1) * (d->dtype == DIN_F32 ? 4 : 2);
-    GatherPlan g = plan_gather(k.M, d->cout, d->cin, d->kh * d->kw, d->dtype);
-    return run_gather(k, g, d->dtype, workspace, workspace_bytes, as_stream(stream), "conv_dgrad");
+    const bool strided = d->sh > 1 || d->sw > 1;
+    if (!strided || d->dh != 1 || d->dw != 1 || d->kh * d->kw > 32) {
+        // y_in = oy*sh - ph + r*dh  =>  oy = (y_in + ph - r*dh) / sh
+        k.ay = 1; k.by = d->ph; k.cy = -d->dh; k.divy = d->sh;
+        k.ax = 1; k.bx = d->pw; k.cx = -d->dw; k.divx = d->sw;
+        k.M = d->nb * d->h * d->w;
+        GatherPlan g = plan_gather(k.M, d->cout, d->cin, d->kh * d->kw, d->dtype);
+        return run_gather(k, g, d->dtype, workspace, workspace_bytes, as_stream(stream), "conv_dgrad");
+    }
+    // Strided dgrad: decompose by output parity (py,px).  Class (py,px) only sees the taps r = r0 + sh*r', s = s0 + sw*s'
+    // with r0 = (py+ph) % sh: a stride-1 gather oy = a + (py+ph-r0)/sh - r' over the sub-grid y = sh*a + py -- no structurally
+    // zero taps are multiplied, and it runs on the fast (buffer-addressed) kernel.
+    const int epc2 = epc_of(d->dtype);
+    const int cpt_full = pad_to(d->cout, epc2) / epc2;
+    const int wld_full = (d->kh * d->kw * cpt_full + KC - 1) / KC * KC;
+    for (int py = 0; py < d->sh; ++py)
+        for (int px = 0; px < d->sw; ++px) {
+            const int Ha = (d->h - py + d->sh - 1) / d->sh, Wa = (d->w - px + d->sw - 1) / d->sw;
+            if (Ha <= 0 || Wa <= 0) continue;
+            const int r0c = (py + d->ph) % d->sh, s0c = (px + d->pw) % d->sw;
+            const int khs = r0c < d->kh ? (d->kh - r0c + d->sh - 1) / d->sh : 0;
+            const int kws = s0c < d->kw ? (d->kw - s0c + d->sw - 1) / d->sw : 0;
+            ConvK c = k;
+            c.kh = khs > 0 && kws > 0 ? khs : 0; c.kw = khs > 0 && kws > 0 ? kws : 1;
+            c.ay = 1; c.by = (py + d->ph - r0c) / d->sh; c.cy = -1; c.divy = 1;
+            c.ax = 1; c.bx = (px + d->pw - s0c) / d->sw; c.cx = -1; c.divx = 1;
+            c.OH = Ha; c.OW = Wa; c.M = d->nb * Ha * Wa;
+            c.out_sy = d->sh; c.out_sx = d->sw; c.out_y0 = py; c.out_x0 = px; c.out_H = d->h; c.out_W = d->w;
+            c.remap = 1; c.wld = wld_full;
+            for (int rr = 0; rr < khs; ++rr)
+                for (int ss = 0; ss < kws; ++ss) c.wtap[rr * kws + ss] = (unsigned char)((r0c + d->sh * rr) * d->kw + (s0c + d->sw * ss));
+            GatherPlan g = plan_gather(c.M, d->cout, d->cin, c.kh * c.kw, d->dtype);
+            if (int e = run_gather(c, g, d->dtype, workspace, workspace_bytes, as_stream(stream), "conv_dgrad(strided)")) return e;
+        }
+    return DIN_OK;
 }
 
 int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, float* dw, float* dbias, const float* scale,
