@@ -75,10 +75,10 @@ template <> struct Mma<bf16_t> {
 // fwd / dgrad gather kernels
 // ------------------------------------------------------------------------------------------------
 // direct (un-staged) epilogue shared by both kernels: lane holds D[co0 + i*16 + (lane>>4)*4 + e][pix0 + j*16 + (lane&15)]
-template <typename T, int TI, int TJ, int BN>
+template <typename T, int TI, int TJ, int BN, int BMT = BM, int WM = 2, int WN = 2>
 __device__ __forceinline__ void epilogue_direct(const ConvK& p, f32x4 (&acc)[TI][TJ], int co_tile, int px_tile, int wm, int wn, int lane, int split) {
-    const int co_base = co_tile * BN + wn * (BN / 2) + (lane >> 4) * 4;
-    const int px_base = px_tile * BM + wm * (BM / 2) + (lane & 15);
+    const int co_base = co_tile * BN + wn * (BN / WN) + (lane >> 4) * 4;
+    const int px_base = px_tile * BMT + wm * (BMT / WM) + (lane & 15);
     if (p.splitk > 1) {
         // raw fp32 partial sums: partial[split][pix][cout_pad]   (cout_pad = n_co_tiles*BN)
         const int cpad = p.n_co_tiles * BN;
@@ -235,31 +235,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_generic_kernel(ConvK 
 //  * prefetch distance 2 through two register sets; LDS double buffer; one barrier per k-step.
 //  * epilogue staged through LDS: bias/ReLU applied in registers, tile transposed in LDS, then 16-byte coalesced
 //    stores with vector loads for the ReLU-backward mask and the accumulate input.
-template <typename T, int BN>
+// Tile variants <BMT, BN, WM x WN waves, DEEP>: 128x128 (2x2), 128x64 (2x2) and 256x64 (4x1; twice the work per barrier for the
+// short-K, latency-bound 64-filter layers; single register set to stay under 256 VGPRs, no LDS tables so two workgroups fit a CU).
+template <typename T, int BMT, int BN, int WM, int WN, bool DEEP>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) {
     constexpr int EPC = Elem<T>::EPC;
-    constexpr int TI = BN / 32, TJ = BM / 32, PA = BM / 32, PB = BN / 32;
+    constexpr int BM = BMT;                                  // shadows the file-level default inside this kernel
+    constexpr int TI = BN / WN / 16, TJ = BM / WM / 16, PA = BM / 32, PB = BN / 32;
     constexpr int BUF = (BM + BN) * KC;                      // 16-byte units per stage
     constexpr int CPITCH = BN * (int)sizeof(T) + 16;         // epilogue tile row pitch (bytes): +16 B kills bank conflicts
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* smem = reinterpret_cast<u32x4*>(smem_raw);
-    int* tapdelta = reinterpret_cast<int*>(smem_raw + 2 * BUF * 16);   // [64] (32 used) byte offset of tap (r,s) relative to tap (0,0)
+    int* wtap_lds = reinterpret_cast<int*>(smem_raw + 2 * BUF * 16);   // [32] tap -> tap of the packed bank (remap launches only)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WN, wn = wid % WN;
     const int co_tile = blockIdx.x % p.n_co_tiles, px_tile = blockIdx.x / p.n_co_tiles;
     const int split = blockIdx.y;
     const int ks_begin = split * p.ks_per_split;
     int ks_end = ks_begin + p.ks_per_split;
     if (ks_end > p.nk) ks_end = p.nk;
     const int ntaps = p.kh * p.kw;
-    int* wtap_lds = tapdelta + 32;                                     // [32] tap -> tap of the packed filter bank
-    if (tid < 32) {
-        int r = tid / p.kw, s = tid - r * p.kw;
-        tapdelta[tid] = tid < ntaps ? (r * p.cy * p.W + s * p.cx) * p.ldi * (int)sizeof(T) : 0;
-        wtap_lds[tid] = (p.remap && tid < ntaps) ? (int)p.wtap[tid] : tid;
-    }
+    if (p.remap && tid < 32) wtap_lds[tid] = tid < ntaps ? (int)p.wtap[tid] : 0;
+    // byte offset of tap t = (r,s) relative to tap (0,0): r*dA + s*dB, r = t / kw by an exact multiply-shift (t < 32)
+    const int dA = p.cy * p.W * p.ldi * (int)sizeof(T), dB = p.cx * p.ldi * (int)sizeof(T);
+    const int inv_kw = 65536 / p.kw + 1;
+    auto tapdelta = [&](int t) { int r = (t * inv_kw) >> 16; return r * dA + (t - r * p.kw) * dB; };
 
     // ---- buffer resources ---------------------------------------------------------------------------------
     const int m_first = px_tile * BM;
@@ -307,14 +309,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
     int voffB[PB];
 #pragma unroll
     for (int i = 0; i < PB; ++i) voffB[i] = ((co_tile * BN + r0 + 32 * i) * p.wld + (p.remap ? 0 : cq)) * 16;
-    __syncthreads();                                                          // tapdelta visible
+    if (p.remap) __syncthreads();                                             // wtap table visible (uniform branch)
 
     const bool tap_uniform = (p.cpt % KC) == 0;
     // uniform-tap bookkeeping (scalar)
     int tap_s = (ks_begin * KC) / p.cpt, cc_s = ks_begin * KC - tap_s * p.cpt;
     unsigned voffA[PA];
     auto refresh_uniform = [&]() {
-        const int td = tapdelta[tap_s < 32 ? tap_s : 0] + cq * 16;
+        const int td = tapdelta(tap_s) + cq * 16;
 #pragma unroll
         for (int i = 0; i < PA; ++i) voffA[i] = (tap_s < ntaps && ((vmask[i] >> tap_s) & 1u)) ? (unsigned)(pixoff[i] + td) : OOB;
     };
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
         } else {
             // k-step straddles taps: per-lane tap index; cost kept to ~5 VALU per row (bit-extract, add, select)
             const bool ok = tap_l < ntaps;
-            const int td = tapdelta[ok ? tap_l : 0] + cc_l * 16;
+            const int td = tapdelta(tap_l) + cc_l * 16;
             const unsigned bit = ok ? (1u << tap_l) : 0u;
             if (p.remap) remapB = ok ? (wtap_lds[tap_l] * p.cpt + cc_l) * 16 : 0;
 #pragma unroll
@@ -382,9 +384,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
         for (int kk = 0; kk < 2; ++kk) {
             u32x4 wf[TI], xf[TJ];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) wf[i] = B[lds_slot(wn * (BN / 2) + i * 16 + frow, kk * 4 + fchunk)];
+            for (int i = 0; i < TI; ++i) wf[i] = B[lds_slot(wn * (BN / WN) + i * 16 + frow, kk * 4 + fchunk)];
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) xf[j] = A[lds_slot(wm * (BM / 2) + j * 16 + frow, kk * 4 + fchunk)];
+            for (int j = 0; j < TJ; ++j) xf[j] = A[lds_slot(wm * (BM / WM) + j * 16 + frow, kk * 4 + fchunk)];
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -392,24 +394,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
         }
     };
 
-    u32x4 ga0[PA], gb0[PB], ga1[PA], gb1[PB];
-    if (ks_begin < ks_end) {
-        load_global(ga0, gb0, ks_begin);
-        if (ks_begin + 1 < ks_end) load_global(ga1, gb1, ks_begin + 1);
-        store_lds(ga0, gb0, 0);
-        __syncthreads();
-        int ks = ks_begin;
-        while (ks < ks_end) {
-            if (ks + 2 < ks_end) load_global(ga0, gb0, ks + 2);
-            compute(0);
-            if (ks + 1 < ks_end) store_lds(ga1, gb1, 1);
+    if constexpr (DEEP) {
+        // prefetch distance 2 through two named register sets (static indexing)
+        u32x4 ga0[PA], gb0[PB], ga1[PA], gb1[PB];
+        if (ks_begin < ks_end) {
+            load_global(ga0, gb0, ks_begin);
+            if (ks_begin + 1 < ks_end) load_global(ga1, gb1, ks_begin + 1);
+            store_lds(ga0, gb0, 0);
             __syncthreads();
-            if (++ks >= ks_end) break;
-            if (ks + 2 < ks_end) load_global(ga1, gb1, ks + 2);
-            compute(1);
-            if (ks + 1 < ks_end) store_lds(ga0, gb0, 0);
+            int ks = ks_begin;
+            while (ks < ks_end) {
+                if (ks + 2 < ks_end) load_global(ga0, gb0, ks + 2);
+                compute(0);
+                if (ks + 1 < ks_end) store_lds(ga1, gb1, 1);
+                __syncthreads();
+                if (++ks >= ks_end) break;
+                if (ks + 2 < ks_end) load_global(ga1, gb1, ks + 2);
+                compute(1);
+                if (ks + 1 < ks_end) store_lds(ga0, gb0, 0);
+                __syncthreads();
+                ++ks;
+            }
+        }
+    } else {
+        u32x4 ga0[PA], gb0[PB];
+        if (ks_begin < ks_end) {
+            load_global(ga0, gb0, ks_begin);
+            store_lds(ga0, gb0, 0);
             __syncthreads();
-            ++ks;
+            for (int ks = ks_begin; ks < ks_end; ++ks) {
+                const int cur = (ks - ks_begin) & 1;
+                const bool more = ks + 1 < ks_end;
+                if (more) load_global(ga0, gb0, ks + 1);
+                compute(cur);
+                if (more) store_lds(ga0, gb0, cur ^ 1);
+                __syncthreads();
+            }
         }
     }
 
@@ -417,13 +437,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
     const bool aligned = (p.Cout % EPC == 0) && (p.cooff % EPC == 0) && (p.ldo % EPC == 0) &&
                          (!(p.flags & DIN_CONV_MASK) || ((p.ldm % EPC == 0) && (p.moff % EPC == 0)));
     if (p.splitk > 1 || !aligned) {
-        epilogue_direct<T, TI, TJ, BN>(p, acc, co_tile, px_tile, wm, wn, lane, split);
+        epilogue_direct<T, TI, TJ, BN, BM, WM, WN>(p, acc, co_tile, px_tile, wm, wn, lane, split);
         return;
     }
     // (all waves passed the loop's final barrier: the stage buffers are free)
     {
-        const int co_l = wn * (BN / 2) + (lane >> 4) * 4;          // channel inside the tile
-        const int px_l = wm * (BM / 2) + (lane & 15);
+        const int co_l = wn * (BN / WN) + (lane >> 4) * 4;         // channel inside the tile
+        const int px_l = wm * (BM / WM) + (lane & 15);
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -1091,7 +1111,7 @@ __global__ void bn_fold_bwd_kernel(const float* wdot, const float* dshift, const
 inline int epc_of(int dtype) { return dtype == DIN_F32 ? 4 : 8; }
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 
-struct GatherPlan { int bn, n_co_tiles, n_px_tiles, cpt, Q, nk, splitk, ks_per_split, cout_pad; int64_t ws_bytes; };
+struct GatherPlan { int bm, bn, n_co_tiles, n_px_tiles, cpt, Q, nk, splitk, ks_per_split, cout_pad; int64_t ws_bytes; };
 
 // geometry of a gather launch whose reduction runs over `cred` channels x taps and produces `cprod` channels
 GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype) {
@@ -1101,9 +1121,12 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype) {
     g.Q = taps * g.cpt;
     g.nk = (g.Q + KC - 1) / KC;
     g.bn = cprod <= 64 ? 64 : 128;
+    // 64-filter launches over many pixels are latency-bound with 128-pixel tiles: use 256-pixel tiles when that still leaves
+    // >= 4 workgroups per CU (the caller downgrades to 128 for strided/remap/generic launches)
+    g.bm = (g.bn == 64 && M >= 256 * 1024) ? 256 : 128;
     g.cout_pad = pad_to(cprod, 128);
     g.n_co_tiles = (cprod + g.bn - 1) / g.bn;
-    g.n_px_tiles = (M + BM - 1) / BM;
+    g.n_px_tiles = (M + g.bm - 1) / g.bm;
     // split-K only when the launch cannot fill the chip and the reduction is long
     int tiles = g.n_co_tiles * g.n_px_tiles;
     g.splitk = 1;
@@ -1168,21 +1191,34 @@ int check_desc(const din_conv_desc* d) {
 }
 
 template <typename T, int BN>
-void launch_gather(const ConvK& k, int n_px_tiles, hipStream_t st) {
+void launch_gather(const ConvK& k, int n_px_tiles, int bm, hipStream_t st) {
     const bool fast = k.divy == 1 && k.divx == 1 && k.kh * k.kw <= 32;
     dim3 grid(n_px_tiles * k.n_co_tiles, k.splitk);
     if (fast) {
-        size_t stage = 2 * (BM + BN) * KC * 16 + 256;                       // stage buffers + tap table
+        if constexpr (BN == 64) {
+            if (bm == 256) {
+                size_t lds = 2 * (256 + 64) * KC * 16;                          // exactly 80 KiB: two workgroups per CU
+                auto kern = conv_gather_fast_kernel<T, 256, 64, 4, 1, false>;
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, k);
+                return;
+            }
+        }
+        size_t stage = 2 * (BM + BN) * KC * 16 + 128;                          // stage buffers + remap table
         size_t epi = (size_t)BM * (BN * sizeof(T) + 16);
         size_t lds = stage > epi ? stage : epi;
-        hipLaunchKernelGGL((conv_gather_fast_kernel<T, BN>), grid, dim3(NTHREADS), lds, st, k);
+        auto kern = conv_gather_fast_kernel<T, 128, BN, 2, 2, true>;
+        if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, k);
     } else {
         size_t lds = 2 * (BM + BN) * KC * 16;
         hipLaunchKernelGGL((conv_gather_generic_kernel<T, BN>), grid, dim3(NTHREADS), lds, st, k);
     }
 }
 
-int run_gather(ConvK& k, const GatherPlan& g, int dtype, void* workspace, int64_t ws_bytes, hipStream_t st, const char* what) {
+int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_bytes, hipStream_t st, const char* what) {
+    const bool fast = k.divy == 1 && k.divx == 1 && k.kh * k.kw <= 32;
+    if (g.bm == 256 && (!fast || k.remap || g.splitk > 1)) { g.bm = 128; g.n_px_tiles = (k.M + 127) / 128; }
     k.cpt = g.cpt; k.Q = g.Q; k.nk = g.nk;
     if (!k.remap) k.wld = g.nk * KC;
     k.splitk = g.splitk; k.ks_per_split = g.ks_per_split; k.n_co_tiles = g.n_co_tiles;
@@ -1192,9 +1228,9 @@ int run_gather(ConvK& k, const GatherPlan& g, int dtype, void* workspace, int64_
         k.partial = reinterpret_cast<float*>(workspace);
     }
     if (dtype == DIN_F32) {
-        if (g.bn == 128) launch_gather<float, 128>(k, g.n_px_tiles, st); else launch_gather<float, 64>(k, g.n_px_tiles, st);
+        if (g.bn == 128) launch_gather<float, 128>(k, g.n_px_tiles, g.bm, st); else launch_gather<float, 64>(k, g.n_px_tiles, g.bm, st);
     } else {
-        if (g.bn == 128) launch_gather<bf16_t, 128>(k, g.n_px_tiles, st); else launch_gather<bf16_t, 64>(k, g.n_px_tiles, st);
+        if (g.bn == 128) launch_gather<bf16_t, 128>(k, g.n_px_tiles, g.bm, st); else launch_gather<bf16_t, 64>(k, g.n_px_tiles, g.bm, st);
     }
     DIN_CHECK_LAUNCH(what);
     if (g.splitk > 1) {
