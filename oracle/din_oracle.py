@@ -469,6 +469,7 @@ class OracleCfg:
         self.hierarchical_inference = False
         self.train_dropout_prob = 0.3
         self.head_mode = "vgg16"       # which residual/LN order (infer_model.py:203-216)
+        self.collective = False        # Dynamic_collective parameter layout (bare DPI, dpi_nl [T,C])
         for k, v in kw.items():
             setattr(self, k, v)
 
@@ -491,6 +492,14 @@ def model_param_shapes(cfg: OracleCfg) -> Dict[str, Tuple[int, ...]]:
         shapes["point_conv.bias"] = (c,)
         shapes["point_ln.weight"] = (t, n, c)
         shapes["point_ln.bias"] = (t, n, c)
+    if getattr(cfg, "collective", False):
+        k0 = cfg.ST_kernel_size[0] if isinstance(cfg.ST_kernel_size, list) else cfg.ST_kernel_size
+        shapes.update(din_param_shapes("DPI.", c, tuple(k0), cfg.sampling_ratio, cfg.scale_factor, cfg.beta_factor))
+        shapes["dpi_nl.weight"] = (t, c)
+        shapes["dpi_nl.bias"] = (t, c)
+        shapes["fc_activities.weight"] = (cfg.num_activities, c)
+        shapes["fc_activities.bias"] = (cfg.num_activities,)
+        return shapes
     if cfg.hierarchical_inference:
         for i, sub in enumerate(("DPI.DPI_1.", "DPI.DPI_2.")):
             shapes.update(din_param_shapes(sub, c, tuple(cfg.ST_kernel_size[i]), cfg.sampling_ratio,

@@ -15,6 +15,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
+def golden_dir():
+    return os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
 def gpu():
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
@@ -154,3 +159,54 @@ def test_bf16_backbone_tracks_fp32(gpu):
             got = outs["bf16"][1][k]
             cos = float((got.flatten() @ ref.flatten()) / (got.norm() * ref.norm()))
             assert cos >= 0.85, (k, cos)
+
+
+def test_hierarchical_din_matches_reference_golden(gpu, golden_dir):
+    """row D7: DPI_1 -> LN -> ReLU -> (dropout off) -> DPI_2 at the only shape the reference allows (T=10, N=12, C=1024)"""
+    from din_amd.infer_module.dynamic_infer_module import Hierarchical_Dynamic_Inference
+    from tests.test_oracle_golden import load_hier_case
+    z, p, x, cot, kernels, ratios = load_hier_case(golden_dir)
+    mod = Hierarchical_Dynamic_Inference(in_dim=1024, person_mat_shape=(10, 12), kernel_size=kernels, dynamic_sampling=True,
+                                         sampling_ratio=ratios, scale_factor=True, beta_factor=False)
+    mod.load_state_dict(p, strict=True)
+    mod.deterministic = True                    # golden was captured with the functional dropout neutralised
+    mod = mod.to(gpu)
+    xd = x.to(gpu).requires_grad_(True)
+    out, _ = mod(xd)
+    (out * cot.to(gpu)).sum().backward()
+    assert rel(out, z["out"]) <= 1e-4 and rel(xd.grad, z["gx"]) <= 2e-4
+    named = dict(mod.named_parameters())
+    for k in z.files:
+        if k.startswith("gsum."):
+            got = named[k[5:]].grad.double()
+            assert abs(got.sum().item() - float(z[k])) <= 1e-3 * float(z["gabs." + k[5:]]) + 1e-6, k
+    # and the training-mode dropout (p = 0.5, always on in the reference: dynamic_infer_module.py:495) really drops
+    mod.deterministic = False
+    out2, _ = mod(x.to(gpu))
+    assert rel(out2, out) > 1e-2
+
+
+def test_collective_model_matches_reference_golden(gpu, golden_dir):
+    """row C: Dynamic_collective with variable actors per clip (6, 1, 4) and zero padding boxes"""
+    from din_amd.config import Config
+    from din_amd.infer_model import Dynamic_collective
+    from tests.test_oracle_golden import load_collective_case
+    z, ocfg, p, images, boxes, labels, counts = load_collective_case(golden_dir)
+    cfg = Config("collective")
+    cfg.backbone, cfg.image_size, cfg.out_size, cfg.emb_features = "vgg16", ocfg.image_size, ocfg.out_size, 512
+    cfg.num_boxes, cfg.num_frames, cfg.num_activities = ocfg.num_boxes, ocfg.num_frames, ocfg.num_activities
+    cfg.num_features_boxes = cfg.num_features_gcn = ocfg.num_features_boxes
+    cfg.ST_kernel_size, cfg.sampling_ratio, cfg.beta_factor, cfg.train_backbone = (3, 3), [1], False, True
+    model = Dynamic_collective(cfg)
+    model.load_state_dict(p, strict=True)
+    model = model.to(gpu).eval()
+    ret = model((images.to(gpu), boxes.to(gpu), counts.to(gpu)))
+    loss = F.cross_entropy(ret["activities"], labels.to(gpu))
+    loss.backward()
+    assert rel(ret["activities"], z["logits"]) <= 1e-4
+    assert abs(loss.item() - float(z["loss"])) <= 1e-4 * max(1.0, abs(float(z["loss"])))
+    named = dict(model.named_parameters())
+    for k in z.files:
+        if k.startswith("gsum."):
+            got = named[k[5:]].grad.double()
+            assert abs(got.sum().item() - float(z[k])) <= 2e-3 * float(z["gabs." + k[5:]]) + 1e-6, k

@@ -156,3 +156,68 @@ def test_din_clamp_double_count_quirk():
     # interior columns: mean of three ones = 1; last time row doubled -> 2; edge columns lose one neighbour
     assert torch.allclose(z[0, 3, 2], torch.full((2,), 2.0))
     assert torch.allclose(z[0, 1, 2], torch.full((2,), 1.0))
+
+
+def load_hier_case(golden_dir):
+    z = np.load(os.path.join(golden_dir, "hier_k13_k31_t10_c1024.npz"))
+    T, N, C = 10, 12, 1024
+    kernels, ratios = [(1, 3), (3, 1)], [1]
+    w_seed, x_seed = int(z["w_seed"]), int(z["x_seed"])
+    shapes = {}
+    for i, sub in enumerate(("DPI_1.", "DPI_2.")):
+        shapes.update(O.din_param_shapes(sub, C, kernels[i], ratios, True, False))
+    shapes["hier_LN.weight"] = (T, N, C)
+    shapes["hier_LN.bias"] = (T, N, C)
+    p = O.synth_params(shapes, seed=w_seed, din_std=0.02)
+    g = torch.Generator().manual_seed(w_seed + 1)
+    p["hier_LN.weight"] = 0.75 + 0.5 * torch.rand((T, N, C), generator=g)
+    p["hier_LN.bias"] = 0.1 * torch.randn((T, N, C), generator=g)
+    x = seeded((1, T, N, C), x_seed)
+    cot = seeded((1, T, N, C), x_seed + 1)
+    return z, p, x, cot, kernels, ratios
+
+
+def test_hierarchical_oracle_matches_reference(golden_dir):
+    """row D7 (reference crashes as shipped; golden captured with the SURVEY 8c no-source-patch recipe, dropout neutralised)"""
+    z, p, x, cot, kernels, ratios = load_hier_case(golden_dir)
+    po = {("DPI." + k): v.clone().requires_grad_(True) for k, v in p.items()}
+    xo = x.clone().requires_grad_(True)
+    out, _ = O.din_hierarchical_inference(xo, po, "DPI.", kernels, ratios, True, False)
+    (out * cot).sum().backward()
+    assert _rel(out.detach(), z["out"]) <= 1e-5 and _rel(xo.grad, z["gx"]) <= 1e-4
+    for k in z.files:
+        if k.startswith("gsum."):
+            gq = po["DPI." + k[5:]].grad.double()
+            assert abs(gq.sum().item() - float(z[k])) <= 1e-3 * float(z["gabs." + k[5:]]) + 1e-6, k
+
+
+def load_collective_case(golden_dir):
+    z = np.load(os.path.join(golden_dir, "collective_vgg16_96x160.npz"))
+    H_, W_, OH, OW, B, T, MAXN, NFB, A = 96, 160, 3, 5, 3, 3, 6, 64, 4
+    seed = int(z["seed"])
+    ocfg = O.OracleCfg(image_size=(H_, W_), out_size=(OH, OW), num_boxes=MAXN, num_frames=T, num_features_boxes=NFB,
+                       ST_kernel_size=(3, 3), sampling_ratio=[1], num_activities=A, collective=True)
+    p = O.synth_params(O.model_param_shapes(ocfg), seed=seed + 3, din_std=0.05)
+    g = torch.Generator().manual_seed(seed + 5)
+    p["dpi_nl.weight"] = 0.75 + 0.5 * torch.rand((T, NFB), generator=g)
+    p["dpi_nl.bias"] = 0.1 * torch.randn((T, NFB), generator=g)
+    images, boxes, labels = O.synth_inputs(B, T, MAXN, H_, W_, OH, OW, A, seed=seed)
+    counts = torch.from_numpy(z["counts"])
+    for b in range(B):
+        boxes[b, :, int(counts[b, 0]):] = 0.0
+    return z, ocfg, p, images, boxes, labels, counts
+
+
+def test_collective_oracle_matches_reference(golden_dir):
+    """row C: variable actors per clip (incl. N=1), zero padding boxes"""
+    z, ocfg, p, images, boxes, labels, counts = load_collective_case(golden_dir)
+    assert np.array_equal(labels.numpy(), z["labels"])
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    out = O.dynamic_collective_forward(ocfg, po, images.float(), boxes, counts)
+    loss = F.cross_entropy(out["activities"], labels)
+    loss.backward()
+    assert _rel(out["activities"].detach(), z["logits"]) <= 2e-4
+    for k in z.files:
+        if k.startswith("gsum."):
+            gq = po[k[5:]].grad.double()
+            assert abs(gq.sum().item() - float(z[k])) <= 2e-3 * float(z["gabs." + k[5:]]) + 1e-6, k

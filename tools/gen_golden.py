@@ -333,6 +333,110 @@ def model_case(name, refim, refcfg, out_dir, *, backbone, H, W, OH, OW, D, B, T,
     print(f"[model] {name}: logits rel err {e:.2e}, worst grad rel err {eg:.2e}, loss {loss.item():.6f}")
 
 
+class _First(nn.Module):
+    """SURVEY 8c oracle recipe: the reference feeds DPI's (ft, MAD) tuple where a tensor is expected
+    (dynamic_infer_module.py:492-493, infer_model.py:1294); wrap the sub-module so only `ft` flows on."""
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+
+    def forward(self, x):
+        return self.m(x)[0]
+
+
+def hier_case(name, refmod, out_dir, x_seed=51, w_seed=61):
+    """Hierarchical_Dynamic_Inference (dynamic_infer_module.py:446-498) with the no-source-patch recipe:
+    DPI_1 wrapped to return ft; the always-on functional dropout (:495) neutralised by rebinding the module-global `F`."""
+    T, N, C = 10, 12, 1024                      # forced by hier_LN = LayerNorm(person_mat_shape + (1024,))
+    kernels, ratios = [(1, 3), (3, 1)], [1]
+    torch.manual_seed(0)
+    H = refmod.Hierarchical_Dynamic_Inference(in_dim=C, person_mat_shape=(T, N), kernel_size=kernels, dynamic_sampling=True,
+                                              sampling_ratio=ratios, scale_factor=True, beta_factor=False, cfg=None)
+    shapes = {}
+    for i, sub in enumerate(("DPI_1.", "DPI_2.")):
+        shapes.update(O.din_param_shapes(sub, C, kernels[i], ratios, True, False))
+    shapes["hier_LN.weight"] = (T, N, C)
+    shapes["hier_LN.bias"] = (T, N, C)
+    p = O.synth_params(shapes, seed=w_seed, din_std=0.02)
+    g = torch.Generator().manual_seed(w_seed + 1)
+    p["hier_LN.weight"] = 0.75 + 0.5 * torch.rand((T, N, C), generator=g)
+    p["hier_LN.bias"] = 0.1 * torch.randn((T, N, C), generator=g)
+    missing, unexpected = H.load_state_dict(p, strict=False)
+    assert not unexpected and not [k for k in missing if "zero_padding" not in k], (missing, unexpected)
+    H.DPI_1 = _First(H.DPI_1)
+    realF = refmod.F
+    shim = types.SimpleNamespace(**{k: getattr(realF, k) for k in dir(realF) if not k.startswith("__")})
+    shim.dropout = lambda x, *a, **k: x
+    refmod.F = shim
+    try:
+        x = seeded((1, T, N, C), x_seed).requires_grad_(True)
+        cot = seeded((1, T, N, C), x_seed + 1)
+        out, _mad = H(x)
+        (out * cot).sum().backward()
+    finally:
+        refmod.F = realF
+    po = {("DPI." + k): v.clone().requires_grad_(True) for k, v in p.items()}
+    xo = x.detach().clone().requires_grad_(True)
+    oo, _ = O.din_hierarchical_inference(xo, po, "DPI.", kernels, ratios, True, False)
+    (oo * cot).sum().backward()
+    e = close(oo, out, 1e-5, name + ".out")
+    eg = close(xo.grad, x.grad, 1e-4, name + ".gx")
+    rec = dict(out=out.detach().numpy(), gx=x.grad.numpy(), x_seed=np.int64(x_seed), w_seed=np.int64(w_seed))
+    for k, v in H.named_parameters():
+        kk = k.replace("DPI_1.m.", "DPI_1.")
+        eg = max(eg, close(po["DPI." + kk].grad, v.grad, 1e-4, name + ".g_" + kk))
+        rec["gsum." + kk] = np.float64(v.grad.double().sum().item())
+        rec["gabs." + kk] = np.float64(v.grad.double().abs().sum().item())
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
+    print(f"[hier] {name}: oracle-vs-reference out {e:.2e}, worst grad {eg:.2e}")
+
+
+def collective_case(name, refim, refcfg, out_dir, seed=200):
+    """Dynamic_collective.forward (infer_model.py:1226-1319), variable actors per clip, DPI wrapped per the recipe."""
+    H_, W_, OH, OW, B, T, MAXN, NFB, A = 96, 160, 3, 5, 3, 3, 6, 64, 4
+    cfg = refcfg.Config("collective")
+    cfg.log_path = None
+    cfg.backbone, cfg.image_size, cfg.out_size, cfg.emb_features = "vgg16", (H_, W_), (OH, OW), 512
+    cfg.num_boxes, cfg.num_frames, cfg.batch_size, cfg.num_activities = MAXN, T, B, A
+    cfg.num_features_boxes = cfg.num_features_gcn = NFB
+    cfg.ST_kernel_size, cfg.sampling_ratio = (3, 3), [1]
+    cfg.dynamic_sampling, cfg.scale_factor, cfg.beta_factor = True, True, False
+    cfg.lite_dim, cfg.hierarchical_inference, cfg.train_backbone = None, False, True
+    torch.manual_seed(0)
+    model = refim.Dynamic_collective(cfg)
+    model.eval()
+    ocfg = O.OracleCfg(image_size=(H_, W_), out_size=(OH, OW), num_boxes=MAXN, num_frames=T, num_features_boxes=NFB,
+                       ST_kernel_size=(3, 3), sampling_ratio=[1], num_activities=A, collective=True)
+    p = O.synth_params(O.model_param_shapes(ocfg), seed=seed + 3, din_std=0.05)
+    g = torch.Generator().manual_seed(seed + 5)
+    p["dpi_nl.weight"] = 0.75 + 0.5 * torch.rand((T, NFB), generator=g)
+    p["dpi_nl.bias"] = 0.1 * torch.randn((T, NFB), generator=g)
+    missing, unexpected = model.load_state_dict(p, strict=False)
+    assert not unexpected and not [k for k in missing if "zero_padding" not in k], (missing, unexpected)
+    model.DPI = _First(model.DPI)
+    images, boxes, labels = O.synth_inputs(B, T, MAXN, H_, W_, OH, OW, A, seed=seed)
+    counts = torch.tensor([[6] * T, [1] * T, [4] * T], dtype=torch.int32)      # variable N incl. a single-actor clip
+    for b in range(B):
+        boxes[b, :, int(counts[b, 0]):] = 0.0                                  # zero padding boxes (collective.py:201-203)
+    ret = model((images.float(), boxes, counts))
+    loss = F.cross_entropy(ret["activities"], labels)
+    loss.backward()
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    oret = O.dynamic_collective_forward(ocfg, po, images.float(), boxes, counts)
+    F.cross_entropy(oret["activities"], labels).backward()
+    e = close(oret["activities"], ret["activities"], 2e-4, name + ".logits")
+    rec = dict(logits=ret["activities"].detach().numpy(), loss=np.float64(loss.item()), labels=labels.numpy(),
+               counts=counts.numpy(), seed=np.int64(seed))
+    eg = 0.0
+    for k, v in model.named_parameters():
+        kk = k.replace("DPI.m.", "DPI.")
+        eg = max(eg, close(po[kk].grad, v.grad, 2e-3, name + ".g_" + kk))
+        rec["gsum." + kk] = np.float64(v.grad.double().sum().item())
+        rec["gabs." + kk] = np.float64(v.grad.double().abs().sum().item())
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
+    print(f"[collective] {name}: logits {e:.2e}, worst grad {eg:.2e}, loss {loss.item():.6f}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -383,6 +487,9 @@ def main():
         # Inception-v3: 299x299-ish small frame; OHxOW follows the layer arithmetic
         model_case("model_inv3_139x203_nfb64", refim, refcfg, a.out, backbone="inv3", H=139, W=203, OH=15, OW=23,
                    D=1056, B=1, T=3, N=6, NFB=64, kernels=[(3, 3)], ratios=[1], seed=104)
+    if not a.skip_big:
+        hier_case("hier_k13_k31_t10_c1024", refdin, a.out)
+    collective_case("collective_vgg16_96x160", refim, refcfg, a.out)
     print("golden vectors written to", a.out)
 
 
