@@ -23,12 +23,17 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # DIN_DIST_BACKEND=gloo + DIN_SINGLE_DEVICE=1: debugging aid to exercise the N>1 control flow on a 1-GPU box
+            backend = os.environ.get("DIN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if os.environ.get("DIN_SINGLE_DEVICE") == "1":
+            local = 0
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif os.environ.get("DIN_SINGLE_DEVICE") == "1":
+        local = 0
     return rank, local, world
 
 
