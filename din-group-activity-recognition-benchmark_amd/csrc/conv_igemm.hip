@@ -18,6 +18,7 @@
 // Replaces the arithmetic of torch.nn.Conv2d / nn.Linear reached from the reference at
 // backbone/backbone.py:44-99, infer_model.py:184,190,226 and infer_module/dynamic_infer_module.py:149,191,195.
 #include "din_common.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -237,11 +238,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_generic_kernel(ConvK 
 //    stores with vector loads for the ReLU-backward mask and the accumulate input.
 // Tile variants <BMT, BN, WM x WN waves, DEEP>: 128x128 (2x2), 128x64 (2x2) and 256x64 (4x1; twice the work per barrier for the
 // short-K, latency-bound 64-filter layers; single register set to stay under 256 VGPRs, no LDS tables so two workgroups fit a CU).
+// 512-thread variants 256x128 (4x2 waves) and 256x256 (4x2 waves, 64x128 wave tiles) raise the FLOPs per byte pulled from L2
+// from 64 to 85 / 128 -- the 128x128 tile saturates the L2->CU path at ~770 TFLOP/s.
 template <typename T, int BMT, int BN, int WM, int WN, bool DEEP>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK p) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BM = BMT;                                  // shadows the file-level default inside this kernel
-    constexpr int TI = BN / WN / 16, TJ = BM / WM / 16, PA = BM / 32, PB = BN / 32;
+    constexpr int NT = 64 * WM * WN;                         // threads per workgroup
+    constexpr int LR = NT / 8;                               // tile rows covered by one loader pass (8 chunk lanes per row)
+    constexpr int TI = BN / WN / 16, TJ = BM / WM / 16, PA = BM / LR, PB = BN / LR;
     constexpr int BUF = (BM + BN) * KC;                      // 16-byte units per stage
     constexpr int CPITCH = BN * (int)sizeof(T) + 16;         // epilogue tile row pitch (bytes): +16 B kills bank conflicts
     constexpr unsigned OOB = 0x80000000u;
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
         const unsigned full_row = p.kw >= 32 ? 0xffffffffu : ((1u << p.kw) - 1u);
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            int m = m_first + r0 + 32 * i;
+            int m = m_first + r0 + LR * i;
             vmask[i] = 0u; pixoff[i] = 0;
             if (m < p.M) {
                 int n = m / (p.OH * p.OW);
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
     }
     int voffB[PB];
 #pragma unroll
-    for (int i = 0; i < PB; ++i) voffB[i] = ((co_tile * BN + r0 + 32 * i) * p.wld + (p.remap ? 0 : cq)) * 16;
+    for (int i = 0; i < PB; ++i) voffB[i] = ((co_tile * BN + r0 + LR * i) * p.wld + (p.remap ? 0 : cq)) * 16;
     if (p.remap) __syncthreads();                                             // wtap table visible (uniform branch)
 
     const bool tap_uniform = (p.cpt % KC) == 0;
@@ -366,9 +371,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
         u32x4* A = smem + buf * BUF;
         u32x4* B = A + BM * KC;
 #pragma unroll
-        for (int i = 0; i < PA; ++i) A[lds_slot(r0 + 32 * i, cq)] = ga[i];
+        for (int i = 0; i < PA; ++i) A[lds_slot(r0 + LR * i, cq)] = ga[i];
 #pragma unroll
-        for (int i = 0; i < PB; ++i) B[lds_slot(r0 + 32 * i, cq)] = gb[i];
+        for (int i = 0; i < PB; ++i) B[lds_slot(r0 + LR * i, cq)] = gb[i];
     };
 
     f32x4 acc[TI][TJ];
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_fast_kernel(ConvK p) 
     __syncthreads();
     {
         constexpr int CPR = BN * (int)sizeof(T) / 16;                // 16-byte chunks per tile row
-        constexpr int RPP = NTHREADS / CPR;                          // rows per pass
+        constexpr int RPP = NT / CPR;                                // rows per pass
         const int c = tid % CPR, rr = tid / CPR;
         const int co = co_tile * BN + c * EPC;
         if (co < p.Cout) {
@@ -1121,9 +1126,22 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype) {
     g.Q = taps * g.cpt;
     g.nk = (g.Q + KC - 1) / KC;
     g.bn = cprod <= 64 ? 64 : 128;
-    // 64-filter launches over many pixels are latency-bound with 128-pixel tiles: use 256-pixel tiles when that still leaves
-    // >= 4 workgroups per CU (the caller downgrades to 128 for strided/remap/generic launches)
-    g.bm = (g.bn == 64 && M >= 256 * 1024) ? 256 : 128;
+    g.bm = 128;
+    // Tile choice (measured on MI355X, tools/conv_bench.py).  The L2->CU operand stream limits the 128x128
+    // tile to ~770 TFLOP/s (64 FLOP per byte pulled from L2):
+    //   64-filter launches over many pixels              -> 256x64  (256 threads, 2 workgroups / CU: 2x work per barrier)
+    //   bf16, filters fill 256-wide tiles, long reduction -> 256x256 (512 threads, 128 FLOP/B; +12..16 % on VGG conv3/conv4)
+    //   everything else                                   -> 128x128 / 128x64 at 2 workgroups / CU (a 256x128 tile at one
+    //                                                        workgroup / CU measured 8..25 % SLOWER: no prologue/epilogue overlap)
+    g.nk = (taps * g.cpt + KC - 1) / KC;
+    const int64_t tiles256 = ((int64_t)M + 255) / 256;
+    const char* force = getenv("DIN_CONV_TILE");
+    if (g.bn == 64) {
+        if (M >= 256 * 1024) g.bm = 256;
+    } else if (!(force && atoi(force) == 128)) {
+        const int nco256 = (cprod + 255) / 256;
+        if (dtype == DIN_BF16 && cprod >= 224 && nco256 * 256 * 100 <= cprod * 115 && g.nk >= 24 && tiles256 * nco256 >= 768) { g.bm = 256; g.bn = 256; }
+    }
     g.cout_pad = pad_to(cprod, 128);
     g.n_co_tiles = (cprod + g.bn - 1) / g.bn;
     g.n_px_tiles = (M + g.bm - 1) / g.bm;
@@ -1190,35 +1208,40 @@ int check_desc(const din_conv_desc* d) {
     return DIN_OK;
 }
 
-template <typename T, int BN>
-void launch_gather(const ConvK& k, int n_px_tiles, int bm, hipStream_t st) {
+template <typename T, int BMT, int BN, int WM, int WN, bool DEEP>
+void launch_fast(const ConvK& k, dim3 grid, hipStream_t st) {
+    size_t stage = 2 * (size_t)(BMT + BN) * KC * 16 + (k.remap ? 128 : 0);     // stage buffers (+ remap table)
+    size_t epi = (size_t)BMT * (BN * sizeof(T) + 16);
+    size_t lds = stage > epi ? stage : epi;
+    auto kern = conv_gather_fast_kernel<T, BMT, BN, WM, WN, DEEP>;
+    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, st, k);
+}
+
+template <typename T>
+void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t st) {
     const bool fast = k.divy == 1 && k.divx == 1 && k.kh * k.kw <= 32;
     dim3 grid(n_px_tiles * k.n_co_tiles, k.splitk);
-    if (fast) {
-        if constexpr (BN == 64) {
-            if (bm == 256) {
-                size_t lds = 2 * (256 + 64) * KC * 16;                          // exactly 80 KiB: two workgroups per CU
-                auto kern = conv_gather_fast_kernel<T, 256, 64, 4, 1, false>;
-                hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, k);
-                return;
-            }
-        }
-        size_t stage = 2 * (BM + BN) * KC * 16 + 128;                          // stage buffers + remap table
-        size_t epi = (size_t)BM * (BN * sizeof(T) + 16);
-        size_t lds = stage > epi ? stage : epi;
-        auto kern = conv_gather_fast_kernel<T, 128, BN, 2, 2, true>;
-        if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, k);
-    } else {
-        size_t lds = 2 * (BM + BN) * KC * 16;
-        hipLaunchKernelGGL((conv_gather_generic_kernel<T, BN>), grid, dim3(NTHREADS), lds, st, k);
+    if (!fast) {
+        size_t lds = 2 * (BM + 128) * KC * 16;
+        if (bn == 64) hipLaunchKernelGGL((conv_gather_generic_kernel<T, 64>), grid, dim3(NTHREADS), lds, st, k);
+        else hipLaunchKernelGGL((conv_gather_generic_kernel<T, 128>), grid, dim3(NTHREADS), lds, st, k);
+        return;
     }
+    if (bm == 256 && bn == 64) launch_fast<T, 256, 64, 4, 1, false>(k, grid, st);
+    else if (bm == 256 && bn == 256) {
+        if constexpr (sizeof(T) == 2) launch_fast<T, 256, 256, 4, 2, false>(k, grid, st);
+    }
+    else if (bn == 64) launch_fast<T, 128, 64, 2, 2, true>(k, grid, st);
+    else launch_fast<T, 128, 128, 2, 2, true>(k, grid, st);
 }
 
 int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_bytes, hipStream_t st, const char* what) {
     const bool fast = k.divy == 1 && k.divx == 1 && k.kh * k.kw <= 32;
-    if (g.bm == 256 && (!fast || k.remap || g.splitk > 1)) { g.bm = 128; g.n_px_tiles = (k.M + 127) / 128; }
+    if (g.bm == 256 && (!fast || k.remap || g.splitk > 1)) {
+        g.bm = 128; if (g.bn == 256) g.bn = 128;
+        g.n_px_tiles = (k.M + 127) / 128; g.n_co_tiles = (k.Cout + g.bn - 1) / g.bn;
+    }
     k.cpt = g.cpt; k.Q = g.Q; k.nk = g.nk;
     if (!k.remap) k.wld = g.nk * KC;
     k.splitk = g.splitk; k.ks_per_split = g.ks_per_split; k.n_co_tiles = g.n_co_tiles;
@@ -1227,11 +1250,8 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
             DIN_FAIL(DIN_E_WORKSPACE, "%s: workspace %lld < %lld bytes", what, (long long)ws_bytes, (long long)g.ws_bytes);
         k.partial = reinterpret_cast<float*>(workspace);
     }
-    if (dtype == DIN_F32) {
-        if (g.bn == 128) launch_gather<float, 128>(k, g.n_px_tiles, g.bm, st); else launch_gather<float, 64>(k, g.n_px_tiles, g.bm, st);
-    } else {
-        if (g.bn == 128) launch_gather<bf16_t, 128>(k, g.n_px_tiles, g.bm, st); else launch_gather<bf16_t, 64>(k, g.n_px_tiles, g.bm, st);
-    }
+    if (dtype == DIN_F32) launch_gather<float>(k, g.n_px_tiles, g.bm, g.bn, st);
+    else launch_gather<bf16_t>(k, g.n_px_tiles, g.bm, g.bn, st);
     DIN_CHECK_LAUNCH(what);
     if (g.splitk > 1) {
         int64_t total = (int64_t)k.M * k.Cout;
@@ -1253,7 +1273,7 @@ int64_t din_conv_packed_elems(const din_conv_desc* d, int transposed) {
     int cred = transposed ? d->cout : d->cin, cprod = transposed ? d->cin : d->cout;
     int cpt = pad_to(cred, epc) / epc;
     int nk = (d->kh * d->kw * cpt + KC - 1) / KC;
-    return (int64_t)pad_to(cprod, 128) * nk * KC * epc;
+    return (int64_t)pad_to(cprod, 256) * nk * KC * epc;
 }
 
 int din_conv_pack_weights(const din_conv_desc* d, const float* w, const float* scale, void* wpk, int transposed, void* stream) {
@@ -1264,7 +1284,7 @@ int din_conv_pack_weights(const din_conv_desc* d, const float* w, const float* s
     int cpt = inner_pad / epc;
     int nk = (d->kh * d->kw * cpt + KC - 1) / KC;
     int kelems = nk * KC * epc;
-    int rows_pad = pad_to(cprod, 128);
+    int rows_pad = pad_to(cprod, 256);
     int64_t total = (int64_t)rows_pad * kelems;
     hipStream_t st = as_stream(stream);
     if (d->dtype == DIN_F32)

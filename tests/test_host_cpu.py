@@ -35,7 +35,7 @@ def test_conv_planning_is_callable_without_gpu():
     d.sh = d.sw = d.ph = d.pw = d.dh = d.dw = 1
     d.ldi = d.ldo = 64
     d.dtype = _lib.DIN_BF16
-    assert lib.din_conv_packed_elems(ctypes.byref(d), 0) == 128 * 576
+    assert lib.din_conv_packed_elems(ctypes.byref(d), 0) == 256 * 576        # rows padded to the widest tile
     assert lib.din_conv_workspace_bytes(ctypes.byref(d), 0) == 0          # big launch: no split-K
     assert lib.din_conv_workspace_bytes(ctypes.byref(d), 2) > 0
     # error path: null pointers give a status code + message, never a crash
