@@ -44,6 +44,8 @@ struct ConvK {
     long long in_bytes, w_bytes;    // extents for the buffer resources
     // output pixel of tile row m=(n,a,b): ((n*out_H + a*out_sy + out_y0)*out_W + b*out_sx + out_x0); identity when out_sy==0
     int out_sy, out_sx, out_y0, out_x0, out_H, out_W;
+    int korder;                     // 1: reduction runs channel-chunk outer / tap inner (uniform taps only): consecutive k-steps
+                                    //    re-read nearly the same pixels (shifted by one tap) -> L1 hits instead of L2 traffic
     int remap;                      // 1: filter tap t of this launch is tap wtap[t] of the packed bank (tap subsets)
     unsigned char wtap[32];
 };
@@ -242,6 +244,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_generic_kernel(ConvK 
 // from 64 to 85 / 128 -- the 128x128 tile saturates the L2->CU path at ~770 TFLOP/s.
 template <typename T, int BMT, int BN, int WM, int WN, bool DEEP>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK p) {
+#if defined(__HIP_DEVICE_COMPILE__)      // the host pass only needs the launch stub (the LDS-DMA builtin is device-only)
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BM = BMT;                                  // shadows the file-level default inside this kernel
     constexpr int NT = 64 * WM * WN;                         // threads per workgroup
@@ -280,7 +283,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
     __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
 
     // ---- per-row state --------------------------------------------------------------------------------------
-    const int cq = tid & 7, r0 = tid >> 3;
+    // LDS-DMA writes lane-linearly (wave base + lane*16 B; measured: profiles/r01_probe_lds_dma.txt), i.e. lane -> (row lane>>3,
+    // slot lane&7).  The XOR swizzle of the LDS image is therefore applied to the SOURCE: the lane fetches logical chunk
+    // cq = slot ^ swizzle(row) (guide rule 21: linear destination + permuted source + same permutation on the read).
+    const int r0 = tid >> 3;
+    const int cq = (tid & 7) ^ ((r0 >> 1) & 7);
     int pixoff[PA];                       // byte offset (from the resource base) of tap (0,0), channel cioff, chunk 0
     unsigned vmask[PA];                   // bit t set <=> tap t of this pixel lies inside the image (<= 32 taps)
     {
@@ -317,8 +324,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
     if (p.remap) __syncthreads();                                             // wtap table visible (uniform branch)
 
     const bool tap_uniform = (p.cpt % KC) == 0;
-    // uniform-tap bookkeeping (scalar)
-    int tap_s = (ks_begin * KC) / p.cpt, cc_s = ks_begin * KC - tap_s * p.cpt;
+    // uniform-tap bookkeeping (scalar).  korder: ks = cchunk * ntaps + tap
+    int tap_s, cc_s;
+    if (p.korder) { const int cch = ks_begin / ntaps; tap_s = ks_begin - cch * ntaps; cc_s = cch * KC; }
+    else { tap_s = (ks_begin * KC) / p.cpt; cc_s = ks_begin * KC - tap_s * p.cpt; }
     unsigned voffA[PA];
     auto refresh_uniform = [&]() {
         const int td = tapdelta(tap_s) + cq * 16;
@@ -329,17 +338,29 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
     int tap_l = (ks_begin * KC + cq) / p.cpt, cc_l = ks_begin * KC + cq - tap_l * p.cpt;
     if (tap_uniform) refresh_uniform();
 
-    auto load_global = [&](u32x4 (&ga)[PA], u32x4 (&gb)[PB], int ks) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    // issue the DMA of k-step ks into stage `buf`: PA + PB wave-level 1-KiB transfers per wave, no VGPRs, no ds_write
+    auto issue_dma = [&](int buf, int ks) {
+        u32x4* A = smem + buf * BUF + (wid * 8) * KC;             // this wave's 8 rows of pass 0 (wave-uniform)
+        u32x4* B = smem + buf * BUF + BM * KC + (wid * 8) * KC;
         int remapB = 0;                                    // per-lane chunk offset (bytes) into the packed bank, remap mode only
+        int korderB = 0;                                   // scalar chunk offset of this k-step in the packed bank (korder mode)
         if (tap_uniform) {
             const int soff = cc_s * 16;
             if (p.remap) remapB = ((tap_s < ntaps ? wtap_lds[tap_s] : 0) * p.cpt + cc_s + cq) * 16;
+            korderB = (tap_s * p.cpt + cc_s) * 16;
 #pragma unroll
-            for (int i = 0; i < PA; ++i) ga[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)voffA[i], soff, 0));
-            cc_s += KC;
-            if (cc_s >= p.cpt) { cc_s = 0; ++tap_s; refresh_uniform(); }
+            for (int i = 0; i < PA; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(A + LR * i * KC), 16, (int)voffA[i], soff, 0, 0);
+            if (p.korder) {
+                if (++tap_s == ntaps) { tap_s = 0; cc_s += KC; }
+                refresh_uniform();
+            } else {
+                cc_s += KC;
+                if (cc_s >= p.cpt) { cc_s = 0; ++tap_s; refresh_uniform(); }
+            }
         } else {
-            // k-step straddles taps: per-lane tap index; cost kept to ~5 VALU per row (bit-extract, add, select)
+            // k-step straddles taps: per-lane tap index; cost kept to ~5 VALU per row (bit test, add, select)
             const bool ok = tap_l < ntaps;
             const int td = tapdelta(tap_l) + cc_l * 16;
             const unsigned bit = ok ? (1u << tap_l) : 0u;
@@ -347,7 +368,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
 #pragma unroll
             for (int i = 0; i < PA; ++i) {
                 unsigned vo = (vmask[i] & bit) ? (unsigned)(pixoff[i] + td) : OOB;
-                ga[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)vo, 0, 0));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(A + LR * i * KC), 16, (int)vo, 0, 0, 0);
             }
             cc_l += KC;
             if (p.cpt >= KC) {                       // at most one tap boundary per k-step: branch-free
@@ -360,20 +381,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
         }
         if (p.remap) {
 #pragma unroll
-            for (int i = 0; i < PB; ++i) gb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i] + remapB, 0, 0));
+            for (int i = 0; i < PB; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(B + LR * i * KC), 16, voffB[i] + remapB, 0, 0, 0);
         } else {
-            const int soffB = ks * KC * 16;
+            const int soffB = p.korder ? korderB : ks * KC * 16;
 #pragma unroll
-            for (int i = 0; i < PB; ++i) gb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], soffB, 0));
+            for (int i = 0; i < PB; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(B + LR * i * KC), 16, voffB[i], soffB, 0, 0);
         }
-    };
-    auto store_lds = [&](const u32x4 (&ga)[PA], const u32x4 (&gb)[PB], int buf) {
-        u32x4* A = smem + buf * BUF;
-        u32x4* B = A + BM * KC;
-#pragma unroll
-        for (int i = 0; i < PA; ++i) A[lds_slot(r0 + LR * i, cq)] = ga[i];
-#pragma unroll
-        for (int i = 0; i < PB; ++i) B[lds_slot(r0 + LR * i, cq)] = gb[i];
     };
 
     f32x4 acc[TI][TJ];
@@ -399,42 +414,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
         }
     };
 
-    if constexpr (DEEP) {
-        // prefetch distance 2 through two named register sets (static indexing)
-        u32x4 ga0[PA], gb0[PB], ga1[PA], gb1[PB];
-        if (ks_begin < ks_end) {
-            load_global(ga0, gb0, ks_begin);
-            if (ks_begin + 1 < ks_end) load_global(ga1, gb1, ks_begin + 1);
-            store_lds(ga0, gb0, 0);
+    // Two LDS stages: the DMA of k-step ks+1 lands in the other stage while ks is multiplied.  vmcnt(0) before the barrier makes
+    // every wave's transfers visible to all readers (an LDS-DMA is a pending LDS write on the VM counter).
+    if (ks_begin < ks_end) {
+        issue_dma(0, ks_begin);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int ks = ks_begin; ks < ks_end; ++ks) {
+            const int cur = (ks - ks_begin) & 1;
+            if (ks + 1 < ks_end) issue_dma(cur ^ 1, ks + 1);
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            int ks = ks_begin;
-            while (ks < ks_end) {
-                if (ks + 2 < ks_end) load_global(ga0, gb0, ks + 2);
-                compute(0);
-                if (ks + 1 < ks_end) store_lds(ga1, gb1, 1);
-                __syncthreads();
-                if (++ks >= ks_end) break;
-                if (ks + 2 < ks_end) load_global(ga1, gb1, ks + 2);
-                compute(1);
-                if (ks + 1 < ks_end) store_lds(ga0, gb0, 0);
-                __syncthreads();
-                ++ks;
-            }
-        }
-    } else {
-        u32x4 ga0[PA], gb0[PB];
-        if (ks_begin < ks_end) {
-            load_global(ga0, gb0, ks_begin);
-            store_lds(ga0, gb0, 0);
-            __syncthreads();
-            for (int ks = ks_begin; ks < ks_end; ++ks) {
-                const int cur = (ks - ks_begin) & 1;
-                const bool more = ks + 1 < ks_end;
-                if (more) load_global(ga0, gb0, ks + 1);
-                compute(cur);
-                if (more) store_lds(ga0, gb0, cur ^ 1);
-                __syncthreads();
-            }
         }
     }
 
@@ -511,6 +502,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
             }
         }
     }
+#endif
 }
 
 // split-K finish: out = epilogue(sum_s partial[s])
@@ -1244,6 +1236,11 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
     }
     k.cpt = g.cpt; k.Q = g.Q; k.nk = g.nk;
     if (!k.remap) k.wld = g.nk * KC;
+    {
+        const char* ko = getenv("DIN_CONV_KORDER");
+        const bool want = ko ? atoi(ko) != 0 : true;
+        k.korder = (want && fast && !k.remap && g.splitk == 1 && (g.cpt % KC) == 0 && k.kh * k.kw > 1) ? 1 : 0;
+    }
     k.splitk = g.splitk; k.ks_per_split = g.ks_per_split; k.n_co_tiles = g.n_co_tiles;
     if (g.splitk > 1) {
         if (ws_bytes < g.ws_bytes || workspace == nullptr)
