@@ -77,6 +77,17 @@ template <> struct Mma<bf16_t> {
 // ------------------------------------------------------------------------------------------------
 // fwd / dgrad gather kernels
 // ------------------------------------------------------------------------------------------------
+// One wave-level LDS-DMA: 64 lanes x 16 B land at LDS byte address `lds_addr` + lane*16 (lane-linear; out-of-range lanes write
+// zeros -- measured, profiles/r01_probe_lds_dma.txt).  Issued through inline asm on purpose: with the builtin, hipcc tracks the LDS
+// write, cannot tell the ring stages apart and drains vmcnt(0) before the next barrier/ds_read, which serialises the pipeline.
+// Here the compiler does not see the transfer at all; completion is counted by hand (s_waitcnt vmcnt(N) + s_barrier in the loop).
+// M0 carries the LDS destination and is saved/restored inside the same statement (it is compiler-reserved).
+__device__ __forceinline__ void lds_dma16(uint32_t lds_addr, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+
 // direct (un-staged) epilogue shared by both kernels: lane holds D[co0 + i*16 + (lane>>4)*4 + e][pix0 + j*16 + (lane&15)]
 template <typename T, int TI, int TJ, int BN, int BMT = BM, int WM = 2, int WN = 2>
 __device__ __forceinline__ void epilogue_direct(const ConvK& p, f32x4 (&acc)[TI][TJ], int co_tile, int px_tile, int wm, int wn, int lane, int split) {
@@ -242,28 +253,39 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_generic_kernel(ConvK 
 // short-K, latency-bound 64-filter layers; single register set to stay under 256 VGPRs, no LDS tables so two workgroups fit a CU).
 // 512-thread variants 256x128 (4x2 waves) and 256x256 (4x2 waves, 64x128 wave tiles) raise the FLOPs per byte pulled from L2
 // from 64 to 85 / 128 -- the 128x128 tile saturates the L2->CU path at ~770 TFLOP/s.
-template <typename T, int BMT, int BN, int WM, int WN, bool DEEP>
+// Pipeline: an NS-stage ring of LDS stages of KCS 16-byte chunks per row, filled by LDS-DMA.  Bytes in flight (not MFMA rate) bound
+// this kernel (Little: ~2 us loaded latency), so the ring keeps NS-1 stages in flight: per stage ONE counted s_waitcnt vmcnt(N)
+// (VMEM completes in order: N = DMAs of the younger stages) + ONE raw s_barrier (every wave's share of the stage landed, and
+// every wave is done reading the stage about to be refilled).
+template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the host pass only needs the launch stub (the LDS-DMA builtin is device-only)
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BM = BMT;                                  // shadows the file-level default inside this kernel
+    constexpr int KC = KCS;                                  // chunks per stage row (shadows the packing granularity of 8)
     constexpr int NT = 64 * WM * WN;                         // threads per workgroup
-    constexpr int LR = NT / 8;                               // tile rows covered by one loader pass (8 chunk lanes per row)
+    constexpr int LR = NT / KC;                              // tile rows covered by one loader pass (KC chunk lanes per row)
+    constexpr int RW = 64 / KC;                              // rows written by one wave-level DMA (1 KiB)
     constexpr int TI = BN / WN / 16, TJ = BM / WM / 16, PA = BM / LR, PB = BN / LR;
     constexpr int BUF = (BM + BN) * KC;                      // 16-byte units per stage
+    auto lds_slot = [](int row, int chunk) { return row * KCS + (chunk ^ ((row >> 1) & (KCS - 1))); };   // conflict-free for 4 and 8
     constexpr int CPITCH = BN * (int)sizeof(T) + 16;         // epilogue tile row pitch (bytes): +16 B kills bank conflicts
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* smem = reinterpret_cast<u32x4*>(smem_raw);
-    int* wtap_lds = reinterpret_cast<int*>(smem_raw + 2 * BUF * 16);   // [32] tap -> tap of the packed bank (remap launches only)
+    int* wtap_lds = reinterpret_cast<int*>(smem_raw + NS * BUF * 16);  // [32] tap -> tap of the packed bank (remap launches only)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int co_tile = blockIdx.x % p.n_co_tiles, px_tile = blockIdx.x / p.n_co_tiles;
     const int split = blockIdx.y;
-    const int ks_begin = split * p.ks_per_split;
-    int ks_end = ks_begin + p.ks_per_split;
-    if (ks_end > p.nk) ks_end = p.nk;
+    // host counts k-steps in units of 8 chunks (the packing granularity); this kernel steps KCS chunks
+    const int ks_begin = split * p.ks_per_split * (8 / KCS);
+    int ks_end = ks_begin + p.ks_per_split * (8 / KCS);
+    {
+        const int nk_s = (p.Q + KCS - 1) / KCS;
+        if (ks_end > nk_s) ks_end = nk_s;
+    }
     const int ntaps = p.kh * p.kw;
     if (p.remap && tid < 32) wtap_lds[tid] = tid < ntaps ? (int)p.wtap[tid] : 0;
     // byte offset of tap t = (r,s) relative to tap (0,0): r*dA + s*dB, r = t / kw by an exact multiply-shift (t < 32)
@@ -286,8 +308,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
     // LDS-DMA writes lane-linearly (wave base + lane*16 B; measured: profiles/r01_probe_lds_dma.txt), i.e. lane -> (row lane>>3,
     // slot lane&7).  The XOR swizzle of the LDS image is therefore applied to the SOURCE: the lane fetches logical chunk
     // cq = slot ^ swizzle(row) (guide rule 21: linear destination + permuted source + same permutation on the read).
-    const int r0 = tid >> 3;
-    const int cq = (tid & 7) ^ ((r0 >> 1) & 7);
+    const int r0 = tid / KC;
+    const int cq = (tid % KC) ^ ((r0 >> 1) & (KC - 1));
     int pixoff[PA];                       // byte offset (from the resource base) of tap (0,0), channel cioff, chunk 0
     unsigned vmask[PA];                   // bit t set <=> tap t of this pixel lies inside the image (<= 32 taps)
     {
@@ -338,11 +360,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
     int tap_l = (ks_begin * KC + cq) / p.cpt, cc_l = ks_begin * KC + cq - tap_l * p.cpt;
     if (tap_uniform) refresh_uniform();
 
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    // LDS byte address of this wave's RW rows of pass 0 in stage 0 (wave-uniform -> SGPR)
+    const uint32_t ldsA0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(smem + (wid * RW) * KC));
     // issue the DMA of k-step ks into stage `buf`: PA + PB wave-level 1-KiB transfers per wave, no VGPRs, no ds_write
     auto issue_dma = [&](int buf, int ks) {
-        u32x4* A = smem + buf * BUF + (wid * 8) * KC;             // this wave's 8 rows of pass 0 (wave-uniform)
-        u32x4* B = smem + buf * BUF + BM * KC + (wid * 8) * KC;
+        const uint32_t A = ldsA0 + (uint32_t)(buf * BUF * 16);
+        const uint32_t B = A + (uint32_t)(BM * KC * 16);
         int remapB = 0;                                    // per-lane chunk offset (bytes) into the packed bank, remap mode only
         int korderB = 0;                                   // scalar chunk offset of this k-step in the packed bank (korder mode)
         if (tap_uniform) {
@@ -351,7 +374,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
             korderB = (tap_s * p.cpt + cc_s) * 16;
 #pragma unroll
             for (int i = 0; i < PA; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(A + LR * i * KC), 16, (int)voffA[i], soff, 0, 0);
+                lds_dma16(A + (uint32_t)(LR * i * KC * 16), rsA, (int)voffA[i], soff);
             if (p.korder) {
                 if (++tap_s == ntaps) { tap_s = 0; cc_s += KC; }
                 refresh_uniform();
@@ -368,7 +391,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
 #pragma unroll
             for (int i = 0; i < PA; ++i) {
                 unsigned vo = (vmask[i] & bit) ? (unsigned)(pixoff[i] + td) : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(A + LR * i * KC), 16, (int)vo, 0, 0, 0);
+                lds_dma16(A + (uint32_t)(LR * i * KC * 16), rsA, (int)vo, 0);
             }
             cc_l += KC;
             if (p.cpt >= KC) {                       // at most one tap boundary per k-step: branch-free
@@ -382,12 +405,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
         if (p.remap) {
 #pragma unroll
             for (int i = 0; i < PB; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(B + LR * i * KC), 16, voffB[i] + remapB, 0, 0, 0);
+                lds_dma16(B + (uint32_t)(LR * i * KC * 16), rsB, voffB[i] + remapB, 0);
         } else {
             const int soffB = p.korder ? korderB : ks * KC * 16;
 #pragma unroll
             for (int i = 0; i < PB; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(B + LR * i * KC), 16, voffB[i], soffB, 0, 0);
+                lds_dma16(B + (uint32_t)(LR * i * KC * 16), rsB, voffB[i], soffB);
         }
     };
 
@@ -401,7 +424,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
         const u32x4* A = smem + cur * BUF;
         const u32x4* B = A + BM * KC;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < KCS / 4; ++kk) {
             u32x4 wf[TI], xf[TJ];
 #pragma unroll
             for (int i = 0; i < TI; ++i) wf[i] = B[lds_slot(wn * (BN / WN) + i * 16 + frow, kk * 4 + fchunk)];
@@ -414,20 +437,29 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
         }
     };
 
-    // Two LDS stages: the DMA of k-step ks+1 lands in the other stage while ks is multiplied.  vmcnt(0) before the barrier makes
-    // every wave's transfers visible to all readers (an LDS-DMA is a pending LDS write on the VM counter).
+    constexpr int NDMA = PA + PB;                                  // wave-level DMAs per stage per wave (issued unconditionally)
+    static_assert((NS - 2) * NDMA <= 63, "vmcnt field");
     if (ks_begin < ks_end) {
-        issue_dma(0, ks_begin);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+#pragma unroll
+        for (int s0 = 0; s0 < NS - 1; ++s0)
+            if (ks_begin + s0 < ks_end) issue_dma(s0, ks_begin + s0);
+        int cur = 0, nxt = NS - 1;                                 // stage of ks / stage the next DMA goes to
         for (int ks = ks_begin; ks < ks_end; ++ks) {
-            const int cur = (ks - ks_begin) & 1;
-            if (ks + 1 < ks_end) issue_dma(cur ^ 1, ks + 1);
+            // stage ks must have landed; younger stages (at most NS-2, fewer at the tail) may stay in flight
+            int younger = ks_end - 1 - ks;
+            if (younger > NS - 2) younger = NS - 2;
+            if constexpr (NS >= 4) { if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory"); }
+            if constexpr (NS >= 3) { if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * NDMA) : "memory"); }
+            if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");                       // LDS contents changed behind the compiler's back
+            if (ks + NS - 1 < ks_end) issue_dma(nxt, ks + NS - 1);
             compute(cur);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            cur = cur + 1 == NS ? 0 : cur + 1;
+            nxt = nxt + 1 == NS ? 0 : nxt + 1;
         }
     }
+    __syncthreads();                                                // all waves done with the stages: the epilogue reuses them
 
     // ---- epilogue ---------------------------------------------------------------------------------------------
     const bool aligned = (p.Cout % EPC == 0) && (p.cooff % EPC == 0) && (p.ldo % EPC == 0) &&
@@ -436,7 +468,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
         epilogue_direct<T, TI, TJ, BN, BM, WM, WN>(p, acc, co_tile, px_tile, wm, wn, lane, split);
         return;
     }
-    // (all waves passed the loop's final barrier: the stage buffers are free)
     {
         const int co_l = wn * (BN / WN) + (lane >> 4) * 4;         // channel inside the tile
         const int px_l = wm * (BM / WM) + (lane & 15);
@@ -1200,12 +1231,12 @@ int check_desc(const din_conv_desc* d) {
     return DIN_OK;
 }
 
-template <typename T, int BMT, int BN, int WM, int WN, bool DEEP>
+template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS>
 void launch_fast(const ConvK& k, dim3 grid, hipStream_t st) {
-    size_t stage = 2 * (size_t)(BMT + BN) * KC * 16 + (k.remap ? 128 : 0);     // stage buffers (+ remap table)
+    size_t stage = (size_t)NS * (BMT + BN) * KCS * 16 + (k.remap ? 128 : 0);     // stage ring (+ remap table)
     size_t epi = (size_t)BMT * (BN * sizeof(T) + 16);
     size_t lds = stage > epi ? stage : epi;
-    auto kern = conv_gather_fast_kernel<T, BMT, BN, WM, WN, DEEP>;
+    auto kern = conv_gather_fast_kernel<T, BMT, BN, WM, WN, KCS, NS>;
     if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, st, k);
 }
@@ -1220,12 +1251,17 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
         else hipLaunchKernelGGL((conv_gather_generic_kernel<T, 128>), grid, dim3(NTHREADS), lds, st, k);
         return;
     }
-    if (bm == 256 && bn == 64) launch_fast<T, 256, 64, 4, 1, false>(k, grid, st);
+    // ring geometry per tile, from A/B runs of tools/conv_bench.py (DIN_CONV_PIPE=0/1 switches the alternatives):
+    //   256x64  : 4 stages x 4 chunks (80 KiB)  -- short-K, latency-bound launches gain 9 % from the deeper ring
+    //   others  : 2 stages x 8 chunks           -- MFMA-dense tiles lose 8-10 % when the stage (and the barrier interval) is halved
+    const char* pv = getenv("DIN_CONV_PIPE");
+    const int pipe = pv ? atoi(pv) : -1;
+    if (bm == 256 && bn == 64) { if (pipe != 0) launch_fast<T, 256, 64, 4, 1, 4, 4>(k, grid, st); else launch_fast<T, 256, 64, 4, 1, 8, 2>(k, grid, st); }
     else if (bm == 256 && bn == 256) {
-        if constexpr (sizeof(T) == 2) launch_fast<T, 256, 256, 4, 2, false>(k, grid, st);
+        if constexpr (sizeof(T) == 2) { if (pipe == 1) launch_fast<T, 256, 256, 4, 2, 4, 4>(k, grid, st); else launch_fast<T, 256, 256, 4, 2, 8, 2>(k, grid, st); }
     }
-    else if (bn == 64) launch_fast<T, 128, 64, 2, 2, true>(k, grid, st);
-    else launch_fast<T, 128, 128, 2, 2, true>(k, grid, st);
+    else if (bn == 64) { if (pipe == 1) launch_fast<T, 128, 64, 2, 2, 8, 3>(k, grid, st); else launch_fast<T, 128, 64, 2, 2, 8, 2>(k, grid, st); }
+    else { if (pipe == 1) launch_fast<T, 128, 128, 2, 2, 4, 4>(k, grid, st); else launch_fast<T, 128, 128, 2, 2, 8, 2>(k, grid, st); }
 }
 
 int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_bytes, hipStream_t st, const char* what) {
