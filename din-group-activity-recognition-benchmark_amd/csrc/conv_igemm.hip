@@ -492,10 +492,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
     __syncthreads();
     {
         constexpr int CPR = BN * (int)sizeof(T) / 16;                // 16-byte chunks per tile row
-        constexpr int RPP = NT / CPR;                                // rows per pass
+        constexpr int RPP = NT / CPR;                                // rows per pass (threads beyond RPP*CPR idle when CPR !| NT)
         const int c = tid % CPR, rr = tid / CPR;
         const int co = co_tile * BN + c * EPC;
-        if (co < p.Cout) {
+        if (co < p.Cout && rr < RPP) {
             T* __restrict__ outp = reinterpret_cast<T*>(p.out);
             const T* __restrict__ maskp = reinterpret_cast<const T*>(p.mask);
             for (int row = rr; row < BM; row += RPP) {
@@ -1150,6 +1150,17 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype) {
     g.nk = (g.Q + KC - 1) / KC;
     g.bn = cprod <= 64 ? 64 : 128;
     g.bm = 128;
+    if (cprod > 64 && !(getenv("DIN_CONV_BN") && atoi(getenv("DIN_CONV_BN")) == 128)) {
+        // filter-tile width in {96,128,160,192}: least padded filters, ties to the wider tile (fewer re-reads of the pixel tile).
+        // Inception's 96/160/192/288/384-filter layers otherwise waste 25-37 % of a 128-wide tile.
+        int best = 128, best_pad = ((cprod + 127) / 128) * 128;
+        const int cands[4] = {96, 160, 192, 128};
+        for (int ci = 0; ci < 4; ++ci) {
+            int bnc = cands[ci], pad = ((cprod + bnc - 1) / bnc) * bnc;
+            if (pad < best_pad || (pad == best_pad && bnc > best)) { best = bnc; best_pad = pad; }
+        }
+        g.bn = best;
+    }
     // Tile choice (measured on MI355X, tools/conv_bench.py).  The L2->CU operand stream limits the 128x128
     // tile to ~770 TFLOP/s (64 FLOP per byte pulled from L2):
     //   64-filter launches over many pixels              -> 256x64  (256 threads, 2 workgroups / CU: 2x work per barrier)
@@ -1261,11 +1272,15 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
         if constexpr (sizeof(T) == 2) { if (pipe == 1) launch_fast<T, 256, 256, 4, 2, 4, 4>(k, grid, st); else launch_fast<T, 256, 256, 4, 2, 8, 2>(k, grid, st); }
     }
     else if (bn == 64) { if (pipe == 1) launch_fast<T, 128, 64, 2, 2, 8, 3>(k, grid, st); else launch_fast<T, 128, 64, 2, 2, 8, 2>(k, grid, st); }
+    else if (bn == 96) launch_fast<T, 128, 96, 2, 2, 8, 2>(k, grid, st);
+    else if (bn == 160) launch_fast<T, 128, 160, 2, 2, 8, 2>(k, grid, st);
+    else if (bn == 192) launch_fast<T, 128, 192, 2, 2, 8, 2>(k, grid, st);
     else { if (pipe == 1) launch_fast<T, 128, 128, 2, 2, 4, 4>(k, grid, st); else launch_fast<T, 128, 128, 2, 2, 8, 2>(k, grid, st); }
 }
 
 int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_bytes, hipStream_t st, const char* what) {
     const bool fast = k.divy == 1 && k.divx == 1 && k.kh * k.kw <= 32;
+    if (!fast && g.bn != 64 && g.bn != 128) { g.bn = 128; g.n_co_tiles = (k.Cout + 127) / 128; }
     if (g.bm == 256 && (!fast || k.remap || g.splitk > 1)) {
         g.bm = 128; if (g.bn == 256) g.bn = 128;
         g.n_px_tiles = (k.M + 127) / 128; g.n_co_tiles = (k.Cout + g.bn - 1) / g.bn;
