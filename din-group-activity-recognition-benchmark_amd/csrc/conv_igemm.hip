@@ -736,9 +736,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) 
     constexpr int RSG = BCO * 2 + 32, RSX = WG_TILE * 2 + 32;   // row pitches (bytes): +32 B => 8 rows tile a 256-B bank row
     constexpr int OPG = PK * RSG, OPX = PK * RSX, STAGE = OPG + OPX;
     constexpr int TI = BCO / 32;                                  // 16-row filter tiles per wave (wave tile = BCO/2 x 64)
-    constexpr int CG = BCO / 8;                                   // 16-byte chunks per G row
-    constexpr int GP = PK * CG / NTHREADS;                        // G chunks per thread per k-step (4 | 2)
-    constexpr int GROWS = NTHREADS / CG;                          // rows covered per pass (16 | 32)
+    constexpr int CG = BCO / 8;                                   // 16-byte chunks per G row (BCO in {64,96,128,160})
+    constexpr int GP = PK * CG / NTHREADS;                        // G chunks per thread per k-step (= BCO/32)
+    static_assert(PK * CG % NTHREADS == 0, "BCO must be a multiple of 32");
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -764,13 +764,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) 
     __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.g)) + g_off, 0, (int)g_rem, 0x00020000);
 
-    // ---- G loader: thread -> (row gr + GROWS*i, chunk gc); rows advance by PK per k-step (scalar offset) ----------------
-    const int gc = tid % CG, gr = tid / CG;
-    const int gco = co_tile * BCO + gc * 8;
-    const bool g_ok = gco + 7 < p.Cout;                            // Cout % 8 == 0 is enforced for this kernel
+    // ---- G loader: chunk id = tid + 256*i -> (row id / CG, chunk id % CG); rows advance by PK per k-step (scalar offset) -----
     unsigned voffG[GP];
+    int ldsG[GP];
 #pragma unroll
-    for (int i = 0; i < GP; ++i) voffG[i] = g_ok ? (unsigned)(((gr + GROWS * i) * p.ldo + p.cooff + gco) * 2) : OOB;
+    for (int i = 0; i < GP; ++i) {
+        const int id = tid + NTHREADS * i;
+        const int grow = id / CG, gc = id - grow * CG;              // CG is a compile-time constant
+        const int gco = co_tile * BCO + gc * 8;
+        voffG[i] = (gco + 7 < p.Cout) ? (unsigned)((grow * p.ldo + p.cooff + gco) * 2) : OOB;   // Cout % 8 == 0 enforced
+        ldsG[i] = grow * RSG + gc * 16;
+    }
 
     // ---- X loader: thread -> (row xr + 16*i, chunk xc) with a fixed (tap, ci) ------------------------------------------
     const int xc = tid & 15, xr = tid >> 4;
@@ -818,7 +822,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) 
         unsigned char* G = smem_raw + buf * STAGE;
         unsigned char* X = G + OPG;
 #pragma unroll
-        for (int i = 0; i < GP; ++i) *reinterpret_cast<u32x4*>(G + (gr + GROWS * i) * RSG + gc * 16) = ga[i];
+        for (int i = 0; i < GP; ++i) *reinterpret_cast<u32x4*>(G + ldsG[i]) = ga[i];
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(X + (xr + 16 * i) * RSX + xc * 16) = xa[i];
     };
@@ -1153,11 +1157,12 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype) {
     if (cprod > 64 && !(getenv("DIN_CONV_BN") && atoi(getenv("DIN_CONV_BN")) == 128)) {
         // filter-tile width in {96,128,160,192}: least padded filters, ties to the wider tile (fewer re-reads of the pixel tile).
         // Inception's 96/160/192/288/384-filter layers otherwise waste 25-37 % of a 128-wide tile.
-        int best = 128, best_pad = ((cprod + 127) / 128) * 128;
-        const int cands[4] = {96, 160, 192, 128};
-        for (int ci = 0; ci < 4; ++ci) {
-            int bnc = cands[ci], pad = ((cprod + bnc - 1) / bnc) * bnc;
-            if (pad < best_pad || (pad == best_pad && bnc > best)) { best = bnc; best_pad = pad; }
+        // fewest filter tiles first (each tile re-reads the pixel tile), then least padding
+        int best = 128, best_tiles = (cprod + 127) / 128, best_pad = best_tiles * 128;
+        const int cands[3] = {96, 160, 192};
+        for (int ci = 0; ci < 3; ++ci) {
+            int bnc = cands[ci], tl = (cprod + bnc - 1) / bnc, pad = tl * bnc;
+            if (tl < best_tiles || (tl == best_tiles && pad < best_pad)) { best = bnc; best_tiles = tl; best_pad = pad; }
         }
         g.bn = best;
     }
@@ -1202,13 +1207,28 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
     int epc = epc_of(d->dtype);
     // bf16 v2 kernel needs whole 16-byte channel chunks on both operands; otherwise the tail kernel (conv1: cin = 3)
     w.v2 = d->dtype == DIN_BF16 && d->cin % 8 == 0 && d->cout % 8 == 0 && d->ldi % 8 == 0 && d->cioff % 8 == 0;
-    w.bco = (w.v2 && d->cout <= 64) ? 64 : 128;
+    w.bco = 128;
+    if (w.v2) {
+        // filter-tile width in {64,96,128,160}: least padding, ties to the wider tile (192 -> 2 x 96, 288 -> 3 x 96, 384 -> 3 x 128)
+        if (d->cout <= 64) w.bco = 64;
+        else if (!(getenv("DIN_CONV_BN") && atoi(getenv("DIN_CONV_BN")) == 128)) {
+            // fewest filter tiles first; on a tie keep 128 when cout > 128 (measured: 192 as 2 x 96 is slower than 2 x 128),
+            // otherwise the least padded width
+            int best = 128, best_tiles = (d->cout + 127) / 128, best_pad = best_tiles * 128;
+            const int cands[2] = {96, 160};
+            for (int ci = 0; ci < 2; ++ci) {
+                int bc = cands[ci], tl = (d->cout + bc - 1) / bc, pad = tl * bc;
+                if (tl < best_tiles || (tl == best_tiles && d->cout <= 128 && pad < best_pad)) { best = bc; best_tiles = tl; best_pad = pad; }
+            }
+            w.bco = best;
+        }
+    }
     int pk = d->dtype == DIN_F32 ? 16 : (w.v2 ? 64 : 32);
     w.cin_pad = pad_to(d->cin, epc);
     w.kcols = d->kh * d->kw * w.cin_pad;
     w.kcols_pad = pad_to(w.kcols, WG_TILE);
-    w.cout_pad = pad_to(d->cout, WG_TILE);
     w.n_co_tiles = (d->cout + w.bco - 1) / w.bco;
+    w.cout_pad = pad_to(w.n_co_tiles * w.bco, WG_TILE);            // partial-sum rows cover every filter tile
     w.n_k_tiles = w.kcols_pad / WG_TILE;
     int M = d->nb * d->oh * d->ow;
     int tiles = w.n_co_tiles * w.n_k_tiles;
@@ -1474,14 +1494,15 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
                 k.dbias = dbias;
                 bias_fused = true;
             }
-            if (wp.bco == 64) {
-                size_t lds = 2 * 64 * ((64 * 2 + 32) + (WG_TILE * 2 + 32));
-                hipLaunchKernelGGL(conv_wgrad_bf16_kernel<64>, grid, dim3(NTHREADS), lds, st, k);
-            } else {
-                size_t lds = 2 * 64 * ((128 * 2 + 32) + (WG_TILE * 2 + 32));
-                hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL(conv_wgrad_bf16_kernel<128>, grid, dim3(NTHREADS), lds, st, k);
-            }
+            size_t lds = 2 * 64 * ((size_t)(wp.bco * 2 + 32) + (WG_TILE * 2 + 32));
+            auto launch = [&](auto kern) {
+                if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, k);
+            };
+            if (wp.bco == 64) launch(conv_wgrad_bf16_kernel<64>);
+            else if (wp.bco == 96) launch(conv_wgrad_bf16_kernel<96>);
+            else if (wp.bco == 160) launch(conv_wgrad_bf16_kernel<160>);
+            else launch(conv_wgrad_bf16_kernel<128>);
         } else {
             size_t lds = 2 * 2 * 32 * (WG_TILE * 2 + 32);
             hipLaunchKernelGGL(conv_wgrad_bf16_tail_kernel, grid, dim3(NTHREADS), lds, st, k);
