@@ -36,6 +36,10 @@ class PoolDesc(C.Structure):
         "nb", "h", "w", "c", "oh", "ow", "k", "stride", "pad", "ldi", "cioff", "ldo", "cooff", "dtype")]
 
 
+class ConvSrc(C.Structure):
+    _fields_ = [("dout", C.c_void_p), ("wpk_t", C.c_void_p), ("cout", C.c_int32), ("ldo", C.c_int32), ("cooff", C.c_int32)]
+
+
 _P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 _CD, _PD = C.POINTER(ConvDesc), C.POINTER(PoolDesc)
 
@@ -51,6 +55,7 @@ SIGNATURES: Dict[str, tuple] = {
     "din_conv_workspace_bytes": (_L, [_CD, _I]),
     "din_conv_fwd": (_I, [_CD, _P, _P, _P, _P, _I, _P, _L, _P]),
     "din_conv_dgrad": (_I, [_CD, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P]),
+    "din_conv1x1_dgrad_multi": (_I, [_I, C.POINTER(ConvSrc), _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
     "din_conv_wgrad": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P]),
     "din_bn_fold": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "din_bn_fold_bwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),

@@ -48,6 +48,10 @@ struct ConvK {
                                     //    re-read nearly the same pixels (shifted by one tap) -> L1 hits instead of L2 traffic
     int remap;                      // 1: filter tap t of this launch is tap wtap[t] of the packed bank (tap subsets)
     unsigned char wtap[32];
+    // multi-source 1x1 gather (fused dgrad of several 1x1 convs that read the same tensor): the reduction runs over the
+    // concatenation of the sources' channels; source b = its own tensor (pixel stride, channel offset) + its own filter bank
+    int nsrc;
+    struct Src { const void* in; const void* w; long long in_bytes, w_bytes; int cpt, ld, coff, wld; } src[4];
 };
 
 __device__ __forceinline__ int64_t out_pixel(const ConvK& p, int m) {
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_generic_kernel(ConvK 
 // this kernel (Little: ~2 us loaded latency), so the ring keeps NS-1 stages in flight: per stage ONE counted s_waitcnt vmcnt(N)
 // (VMEM completes in order: N = DMAs of the younger stages) + ONE raw s_barrier (every wave's share of the stage landed, and
 // every wave is done reading the stage about to be refilled).
-template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS>
+template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS, bool MULTI = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the host pass only needs the launch stub (the LDS-DMA builtin is device-only)
     constexpr int EPC = Elem<T>::EPC;
@@ -311,6 +315,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
     const int r0 = tid / KC;
     const int cq = (tid % KC) ^ ((r0 >> 1) & (KC - 1));
     int pixoff[PA];                       // byte offset (from the resource base) of tap (0,0), channel cioff, chunk 0
+                                          // (MULTI: pixel index relative to the first image of the tile, -1 = row beyond M)
     unsigned vmask[PA];                   // bit t set <=> tap t of this pixel lies inside the image (<= 32 taps)
     {
         const unsigned full_row = p.kw >= 32 ? 0xffffffffu : ((1u << p.kw) - 1u);
@@ -337,7 +342,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
                 }
                 vmask[i] = mk;
                 pixoff[i] = (((n - n_first) * p.H + ty0) * p.W + tx0) * p.ldi * (int)sizeof(T) + p.cioff * (int)sizeof(T);
-            }
+                if constexpr (MULTI) pixoff[i] = m - n_first * (p.OH * p.OW);      // 1x1, stride 1: output pixel == input pixel
+            } else if constexpr (MULTI) pixoff[i] = -1;
         }
     }
     int voffB[PB];
@@ -360,6 +366,30 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
     int tap_l = (ks_begin * KC + cq) / p.cpt, cc_l = ks_begin * KC + cq - tap_l * p.cpt;
     if (tap_uniform) refresh_uniform();
 
+    // ---- multi-source bookkeeping (uniform): current source, chunk position inside it ----------------------------------------
+    int sb = 0, cc_m = 0;
+    [[maybe_unused]] auto open_source = [&](int bsrc) {
+        const ConvK::Src& sr = p.src[bsrc];
+        const long long imgb = (long long)p.H * p.W * sr.ld * (long long)sizeof(T);
+        long long rem = sr.in_bytes - (long long)n_first * imgb;
+        if (rem > 0x7fffffffll) rem = 0x7fffffffll;
+        rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(sr.in)) + (long long)n_first * imgb, 0, (int)rem, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(sr.w), 0, (int)sr.w_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) voffB[i] = ((co_tile * BN + r0 + LR * i) * sr.wld + cq) * 16;
+    };
+    if constexpr (MULTI) {
+        // position at this split's first k-step (split-K is never used with MULTI, but keep the walk general)
+        int skip = ks_begin;
+        while (sb < p.nsrc) {
+            const int steps = (p.src[sb].cpt + KC - 1) / KC;
+            if (skip < steps) break;
+            skip -= steps; ++sb;
+        }
+        cc_m = skip * KC;
+        if (sb < p.nsrc) open_source(sb);
+    }
+
     // LDS byte address of this wave's RW rows of pass 0 in stage 0 (wave-uniform -> SGPR)
     const uint32_t ldsA0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(smem + (wid * RW) * KC));
     // issue the DMA of k-step ks into stage `buf`: PA + PB wave-level 1-KiB transfers per wave, no VGPRs, no ds_write
@@ -368,6 +398,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
         const uint32_t B = A + (uint32_t)(BM * KC * 16);
         int remapB = 0;                                    // per-lane chunk offset (bytes) into the packed bank, remap mode only
         int korderB = 0;                                   // scalar chunk offset of this k-step in the packed bank (korder mode)
+        if constexpr (MULTI) {
+            const ConvK::Src& sr = p.src[sb < p.nsrc ? sb : 0];
+            const bool cok = sb < p.nsrc && (cc_m + cq) < sr.cpt;         // chunk inside this source's channels
+            const int chan = sr.coff * (int)sizeof(T) + (cc_m + cq) * 16;
+            const int ldb = sr.ld * (int)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                unsigned vo = (cok && pixoff[i] >= 0) ? (unsigned)(pixoff[i] * ldb + chan) : OOB;
+                lds_dma16(A + (uint32_t)(LR * i * KC * 16), rsA, (int)vo, 0);
+            }
+            const int soffB = cc_m * 16;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) lds_dma16(B + (uint32_t)(LR * i * KC * 16), rsB, voffB[i], soffB);
+            cc_m += KC;
+            if (sb < p.nsrc && cc_m >= sr.cpt) { cc_m = 0; ++sb; if (sb < p.nsrc) open_source(sb); }
+            return;
+        }
         if (tap_uniform) {
             const int soff = cc_s * 16;
             if (p.remap) remapB = ((tap_s < ntaps ? wtap_lds[tap_s] : 0) * p.cpt + cc_s + cq) * 16;
@@ -1272,8 +1319,27 @@ void launch_fast(const ConvK& k, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, st, k);
 }
 
+template <typename T, int BN>
+void launch_fast_multi(const ConvK& k, dim3 grid, hipStream_t st) {
+    size_t stage = (size_t)2 * (128 + BN) * 8 * 16;
+    size_t epi = (size_t)128 * (BN * sizeof(T) + 16);
+    size_t lds = stage > epi ? stage : epi;
+    auto kern = conv_gather_fast_kernel<T, 128, BN, 2, 2, 8, 2, true>;
+    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k);
+}
+
 template <typename T>
 void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t st) {
+    if (k.nsrc > 0) {
+        dim3 mgrid(n_px_tiles * k.n_co_tiles, 1);
+        if (bn == 64) launch_fast_multi<T, 64>(k, mgrid, st);
+        else if (bn == 96) launch_fast_multi<T, 96>(k, mgrid, st);
+        else if (bn == 160) launch_fast_multi<T, 160>(k, mgrid, st);
+        else if (bn == 192) launch_fast_multi<T, 192>(k, mgrid, st);
+        else launch_fast_multi<T, 128>(k, mgrid, st);
+        return;
+    }
     const bool fast = k.divy == 1 && k.divx == 1 && k.kh * k.kw <= 32;
     dim3 grid(n_px_tiles * k.n_co_tiles, k.splitk);
     if (!fast) {
@@ -1461,6 +1527,48 @@ int din_conv_dgrad(const din_conv_desc* d, const void* dout, const void* wpk_t, 
             GatherPlan g = plan_gather(c.M, d->cout, d->cin, c.kh * c.kw, d->dtype);
             if (int e = run_gather(c, g, d->dtype, workspace, workspace_bytes, as_stream(stream), "conv_dgrad(strided)")) return e;
         }
+    return DIN_OK;
+}
+
+int din_conv1x1_dgrad_multi(int nsrc, const din_conv_src* srcs, int dtype, int nb, int h, int w, int cin, int ldi, int cioff,
+                            void* din_, const void* mask, int ldm, int moff, int flags, void* stream) {
+    DIN_REQUIRE(nsrc >= 1 && nsrc <= 4 && srcs && din_, "conv1x1_dgrad_multi: 1..4 sources");
+    DIN_REQUIRE(dtype == DIN_F32 || dtype == DIN_BF16, "conv1x1_dgrad_multi: bad dtype");
+    DIN_REQUIRE(!(flags & (DIN_CONV_BIAS | DIN_CONV_RELU)), "conv1x1_dgrad_multi: BIAS/RELU are fwd-only flags");
+    DIN_REQUIRE(!(flags & DIN_CONV_MASK) || mask, "conv1x1_dgrad_multi: MASK flag without mask");
+    const int epc = epc_of(dtype), esz = dtype == DIN_F32 ? 4 : 2;
+    DIN_REQUIRE(nb > 0 && h > 0 && w > 0 && cin > 0 && ldi % 4 == 0 && cioff % 4 == 0 && ldi >= cioff + cin, "conv1x1_dgrad_multi: bad output geometry");
+    DIN_REQUIRE((int64_t)nb * h * w < (1ll << 31), "conv1x1_dgrad_multi: too many pixels");
+    ConvK k{};
+    k.out = din_; k.mask = mask; k.bias = nullptr; k.partial = nullptr;
+    k.NB = nb; k.H = h; k.W = w; k.OH = h; k.OW = w; k.Cout = cin; k.ldo = ldi; k.cooff = cioff;
+    k.kh = k.kw = 1; k.ay = k.ax = 1; k.by = k.bx = 0; k.cy = k.cx = 1; k.divy = k.divx = 1;
+    k.M = nb * h * w; k.flags = flags; k.ldm = ldm; k.moff = moff;
+    int steps = 0;
+    for (int b = 0; b < nsrc; ++b) {
+        const din_conv_src& sc = srcs[b];
+        DIN_REQUIRE(sc.dout && sc.wpk_t && sc.cout > 0, "conv1x1_dgrad_multi: null source %d", b);
+        DIN_REQUIRE(sc.ldo % epc == 0 && sc.cooff % epc == 0 && sc.ldo >= sc.cooff + pad_to(sc.cout, epc),
+                    "conv1x1_dgrad_multi: source %d stride/offset must be multiples of %d and cover cout (+zero pad)", b, epc);
+        ConvK::Src& o = k.src[b];
+        o.in = sc.dout; o.w = sc.wpk_t; o.ld = sc.ldo; o.coff = sc.cooff;
+        o.cpt = pad_to(sc.cout, epc) / epc;
+        o.wld = (o.cpt + KC - 1) / KC * KC;
+        o.in_bytes = (long long)nb * h * w * sc.ldo * esz;
+        o.w_bytes = (long long)pad_to(cin, 256) * o.wld * 16;
+        steps += (o.cpt + KC - 1) / KC;
+    }
+    k.nsrc = nsrc;
+    k.in = srcs[0].dout; k.w = srcs[0].wpk_t; k.in_bytes = k.src[0].in_bytes; k.w_bytes = k.src[0].w_bytes;
+    k.Cin = srcs[0].cout; k.ldi = srcs[0].ldo; k.cioff = srcs[0].cooff;
+    GatherPlan g = plan_gather(k.M, 64, cin, 1, dtype);
+    if (g.bn == 256) g.bn = 128;
+    g.bm = 128; g.n_px_tiles = (k.M + 127) / 128; g.n_co_tiles = (cin + g.bn - 1) / g.bn;
+    k.cpt = KC; k.Q = steps * KC; k.nk = steps; k.wld = k.src[0].wld;
+    k.splitk = 1; k.ks_per_split = steps; k.n_co_tiles = g.n_co_tiles; k.remap = 0; k.korder = 0;
+    if (dtype == DIN_F32) launch_gather<float>(k, g.n_px_tiles, 128, g.bn, as_stream(stream));
+    else launch_gather<bf16_t>(k, g.n_px_tiles, 128, g.bn, as_stream(stream));
+    DIN_CHECK_LAUNCH("conv1x1_dgrad_multi");
     return DIN_OK;
 }
 

@@ -55,6 +55,8 @@ def require_gpu(*tensors: torch.Tensor) -> None:
 # (kind, flops, start_event, end_event) recorded on the stream the kernel is launched on.
 # ------------------------------------------------------------------------------------------------
 PROFILE = None
+import os as _os
+FUSE_1X1_DGRAD = _os.environ.get("DIN_FUSE_1X1", "1") != "0"     # fuse the dgrads of 1x1 convs that read the same tensor
 
 
 def _conv_flops(d) -> float:
@@ -321,9 +323,51 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
             offsets.append(-1)
     grads: List[Optional[torch.Tensor]] = [None] * len(params)
 
+    # 1x1 / stride-1 convs that read the same view (branch-entry convs of the Inception blocks): their dgrads are fused into ONE
+    # multi-source launch, issued when the last member (first in program order) has been visited
+    groups: Dict[Tuple[int, int, int], List[int]] = {}
+    if FUSE_1X1_DGRAD:
+        for oi, op in enumerate(g.ops):
+            if op.kind == "conv" and op.k == (1, 1) and op.s == (1, 1) and op.p == (0, 0) and op.src.tid != g.input_tid:
+                groups.setdefault((op.src.tid, op.src.coff, op.src.c), []).append(oi)
+    groups = {k: v for k, v in groups.items() if 2 <= len(v) <= 4}
+    member_of = {oi: key for key, v in groups.items() for oi in v}
+    remaining = {key: len(v) for key, v in groups.items()}
+    pending: Dict[Tuple[int, int, int], list] = {key: [] for key in groups}
+
+    def flush_group(key):
+        items = pending[key]
+        if not items:
+            return
+        op0 = g.ops[items[0][0]]
+        ts0 = g.tensors[op0.src.tid]
+        gsrc, acc = grad_target(op0.src)
+        srcs = (L.ConvSrc * len(items))()
+        keep = []
+        for j, (oi_, gout_, w_, scale_) in enumerate(items):
+            opj = g.ops[oi_]
+            dj = _conv_desc(g, opj, nb, dt)
+            wpt = torch.empty(lib.din_conv_packed_elems(C.byref(dj), 1), dtype=tdt, device=dev)
+            L.check(lib.din_conv_pack_weights(C.byref(dj), _ptr(w_), _ptr(scale_), _ptr(wpt), 1, st), "conv_pack_t")
+            keep.append(wpt)
+            srcs[j].dout, srcs[j].wpk_t = gout_.data_ptr(), wpt.data_ptr()
+            srcs[j].cout, srcs[j].ldo, srcs[j].cooff = opj.dst.c, g.tensors[opj.dst.tid].c, opj.dst.coff
+        flags = (L.CONV_ACCUM if acc else 0) | (L.CONV_MASK if ts0.relu_masked else 0)
+        d0 = _conv_desc(g, op0, nb, dt)
+        d0.cout = sum(g.ops[it[0]].dst.c for it in items)          # FLOP accounting of the fused launch
+        with _timed("dgrad", d0):
+            L.check(lib.din_conv1x1_dgrad_multi(len(items), srcs, dt, nb, ts0.h, ts0.w, op0.src.c, ts0.c, op0.src.coff, _ptr(gsrc),
+                                                _ptr(bufs[op0.src.tid]) if ts0.relu_masked else None, ts0.c, op0.src.coff, flags, st),
+                    "conv1x1_dgrad_multi")
+        pending[key] = []
+
     for oi in range(len(g.ops) - 1, -1, -1):
         op = g.ops[oi]
         if op.dst.tid not in gbufs:
+            if oi in member_of:                       # a group member without gradient still counts as visited
+                remaining[member_of[oi]] -= 1
+                if remaining[member_of[oi]] == 0:
+                    flush_group(member_of[oi])
             continue                                  # nothing flows back through this op
         gout = gbufs[op.dst.tid]
         src_needs_grad = op.src.tid != g.input_tid
@@ -358,7 +402,13 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 if op.bias:
                     grads[po + 1] = db
             # ---- dgrad
-            if src_needs_grad:
+            if src_needs_grad and oi in member_of:
+                key = member_of[oi]
+                pending[key].append((oi, gout, w, scale))
+                remaining[key] -= 1
+                if remaining[key] == 0:
+                    flush_group(key)
+            elif src_needs_grad:
                 gsrc, acc = grad_target(op.src)
                 wpt = torch.empty(lib.din_conv_packed_elems(C.byref(d), 1), dtype=tdt, device=dev)
                 L.check(lib.din_conv_pack_weights(C.byref(d), _ptr(w), _ptr(scale), _ptr(wpt), 1, st), "conv_pack_t")

@@ -94,6 +94,17 @@ int din_conv_fwd(const din_conv_desc* d, const void* in, const void* wpk, const 
 int din_conv_dgrad(const din_conv_desc* d, const void* dout, const void* wpk_t, void* din,
                    const void* mask, int ldm, int moff, int flags,
                    void* workspace, int64_t workspace_bytes, void* stream);
+/* Fused dgrad of up to four 1x1 / stride-1 convolutions that read the SAME tensor (the branch-entry convs of torchvision's
+ * InceptionA/C blocks, backbone.py:61-77): din = sum_b dout_b . W_b^T computed as ONE contraction over the concatenated
+ * channels, so the (write-bound) gradient tensor is written once instead of once per branch with read-modify-write.
+ * Source b: dout_b [nb,h,w,cout_b] (pixel stride ldo, offset cooff), wpk_t = its bank packed with transposed=1.       */
+typedef struct din_conv_src {
+    const void* dout;
+    const void* wpk_t;
+    int32_t cout, ldo, cooff;
+} din_conv_src;
+int din_conv1x1_dgrad_multi(int nsrc, const din_conv_src* srcs, int dtype, int nb, int h, int w, int cin, int ldi,
+                            int cioff, void* din, const void* mask, int ldm, int moff, int flags, void* stream);
 /* dw: [cout][cin][kh][kw] fp32, overwritten (or += when accumulate!=0), multiplied by scale[cout] when scale
  * is given.  dbias (nullable) [cout] fp32 = column sums of dout.  wdot (nullable) [cout] fp32 =
  * <w[co,:], dw_raw[co,:]> (needs w) -- the BatchNorm-eval scale gradient.                                */

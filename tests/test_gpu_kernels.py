@@ -344,3 +344,50 @@ def test_head_and_adam(env):
         opt.step()
         ops.adam_step(pd, gr.cuda(), m, v, 1e-2, 0.9, 0.999, 1e-8, 0.01, step)
     assert rel(pd, pr) <= 1e-5
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_conv1x1_dgrad_multi_source(env, dtype):
+    """fused dgrad of three 1x1 convs reading the same tensor == sum of the three separate dgrads (+ mask, + accumulate)"""
+    lib, L, nhwc, ops = env
+    dt = L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
+    tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    g = torch.Generator().manual_seed(21)
+    nb, h, w, cin = 2, 9, 13, 288
+    couts = [64, 48, 104]
+    x = torch.randn(nb, cin, h, w, generator=g)
+    if dtype == "bf16":
+        x = x.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    total = 0
+    srcs = (L.ConvSrc * 3)()
+    keep = []
+    for j, co in enumerate(couts):
+        wt = torch.randn(co, cin, 1, 1, generator=g) * 0.1
+        gz = torch.randn(nb, co, h, w, generator=g)
+        if dtype == "bf16":
+            wt, gz = wt.bfloat16().float(), gz.bfloat16().float()
+        total = total + (F.conv2d(xr, wt) * gz).sum()
+        d = L.ConvDesc()
+        d.nb, d.h, d.w, d.cin, d.oh, d.ow, d.cout = nb, h, w, cin, h, w, co
+        d.kh = d.kw = d.sh = d.sw = d.dh = d.dw = 1
+        d.ph = d.pw = 0
+        ldo = (co + 7) // 8 * 8 + 8
+        d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = cin, 0, ldo, 8, dt
+        wdev = wt.cuda()
+        wpt = torch.empty(lib.din_conv_packed_elems(C.byref(d), 1), dtype=tdt, device="cuda")
+        L.check(lib.din_conv_pack_weights(C.byref(d), wdev.data_ptr(), None, wpt.data_ptr(), 1, None))
+        gdev = to_nhwc(gz, tdt, ldo, 8)
+        keep += [wdev, wpt, gdev]
+        srcs[j].dout, srcs[j].wpk_t, srcs[j].cout, srcs[j].ldo, srcs[j].cooff = gdev.data_ptr(), wpt.data_ptr(), co, ldo, 8
+    total.backward()
+    xin = to_nhwc(x, tdt)
+    dx = torch.zeros(nb, h, w, cin, dtype=tdt, device="cuda")
+    L.check(lib.din_conv1x1_dgrad_multi(3, srcs, dt, nb, h, w, cin, cin, 0, dx.data_ptr(), None, 0, 0, 0, None))
+    torch.cuda.synchronize()
+    tol = 5e-5 if dtype == "fp32" else 2e-2
+    assert rel(from_nhwc(dx, cin), xr.grad) <= tol
+    L.check(lib.din_conv1x1_dgrad_multi(3, srcs, dt, nb, h, w, cin, cin, 0, dx.data_ptr(), xin.data_ptr(), cin, 0,
+                                        L.CONV_MASK | L.CONV_ACCUM, None))
+    torch.cuda.synchronize()
+    assert rel(from_nhwc(dx, cin), xr.grad + xr.grad * (x > 0).float()) <= 2 * tol
