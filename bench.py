@@ -218,17 +218,20 @@ def main():
         rec[0] += flops
         rec[1] += max(e0.elapsed_time(e1) - event_overhead_ms, 0.0) * 1e-3
         rec[2] += 1
-    dom = "gather_bn128"
+    # dominant kernel = the kernel (as rocprofv3 names it, tile template included) with the largest summed launch time
+    dom = max(agg, key=lambda kname: agg[kname][1]) if agg else "none"
     fl, sec, cnt = agg.get(dom, [0.0, 1e-9, 1])
     achieved = fl / sec / 1e12
     peak = PEAK_TFLOPS[dtype]
-    roofline = {"bound": "mfma", "kernel": f"conv_gather_fast_kernel<{'bf16' if dtype == 'bf16' else 'float'},128>",
+    roofline = {"bound": "mfma", "kernel": dom,
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": None, "launches": cnt, "avg_launch_ms": round(sec / max(cnt, 1) * 1e3, 4),
                 "event_pair_overhead_ms_subtracted": round(event_overhead_ms, 4), "sampled_steps": 1,
                 "flops_per_launch_avg": fl / max(cnt, 1),
-                "other_kernels": {k: {"TFLOP/s": round(v[0] / max(v[1], 1e-9) / 1e12, 2), "launches": v[2],
-                                      "time_s": round(v[1], 4)} for k, v in agg.items() if k != dom}}
+                "all_conv_launches": {"TFLOP/s": round(sum(v[0] for v in agg.values()) / max(sum(v[1] for v in agg.values()), 1e-9) / 1e12, 2),
+                                      "time_s": round(sum(v[1] for v in agg.values()), 4)},
+                "other_kernels": {kname: {"TFLOP/s": round(v[0] / max(v[1], 1e-9) / 1e12, 2), "launches": v[2],
+                                          "time_s": round(v[1], 4)} for kname, v in sorted(agg.items(), key=lambda kv: -kv[1][1]) if kname != dom}}
     conv_time = sum(v[1] for v in agg.values())
 
     if rank == 0:

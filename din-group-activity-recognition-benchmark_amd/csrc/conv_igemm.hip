@@ -1431,6 +1431,18 @@ int din_conv_pack_weights(const din_conv_desc* d, const float* w, const float* s
     return DIN_OK;
 }
 
+int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t* bn) {
+    DIN_REQUIRE(d && bm && bn && which >= 0 && which <= 2, "conv_kernel_tile: bad argument");
+    if (which == 2) { WgradPlan wp = plan_wgrad(d); *bm = wp.bco; *bn = WG_TILE; return DIN_OK; }
+    const bool strided = which == 1 && (d->sh > 1 || d->sw > 1);
+    GatherPlan g = which == 0 ? plan_gather(d->nb * d->oh * d->ow, d->cin, d->cout, d->kh * d->kw, d->dtype)
+                              : plan_gather(d->nb * (strided ? (d->h + d->sh - 1) / d->sh * ((d->w + d->sw - 1) / d->sw) : d->h * d->w),
+                                            d->cout, d->cin, d->kh * d->kw, d->dtype);
+    if (g.bm == 256 && (strided || g.splitk > 1)) { g.bm = 128; if (g.bn == 256) g.bn = 128; }
+    *bm = g.bm; *bn = g.bn;
+    return DIN_OK;
+}
+
 int64_t din_conv_workspace_bytes(const din_conv_desc* d, int which) {
     if (!d) return 0;
     if (which == 0) return plan_gather(d->nb * d->oh * d->ow, d->cin, d->cout, d->kh * d->kw, d->dtype).ws_bytes;

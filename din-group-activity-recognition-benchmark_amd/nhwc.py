@@ -78,8 +78,14 @@ class _timed:
         if PROFILE is not None:
             self.e1.record(torch.cuda.current_stream())
             d = self.d
-            cprod = d.cin if self.kind == "dgrad" else d.cout          # channels the launch produces (tile variant)
-            variant = "wgrad" if self.kind == "wgrad" else ("gather_bn64" if cprod <= 64 else "gather_bn128")
+            bm, bn = C.c_int32(0), C.c_int32(0)
+            which = {"fwd": 0, "dgrad": 1, "wgrad": 2}[self.kind]
+            L.load().din_conv_kernel_tile(C.byref(d), which, C.byref(bm), C.byref(bn))
+            tn = "unsigned short" if d.dtype == L.DIN_BF16 else "float"
+            if self.kind == "wgrad":
+                variant = f"conv_wgrad_bf16_kernel<{bm.value}>" if d.dtype == L.DIN_BF16 else "conv_wgrad_f32_kernel"
+            else:
+                variant = f"conv_gather_fast_kernel<{tn}, {bm.value}, {bn.value}, ...>"
             PROFILE.append((self.kind, variant, _conv_flops(d), int(d.dtype), self.e0, self.e1))
         return False
 

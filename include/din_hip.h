@@ -85,6 +85,9 @@ int64_t din_conv_packed_elems(const din_conv_desc* d, int transposed);
  * (BatchNorm-eval: backbone.py BasicConv2d).  transposed=0 -> [cout_pad][(r,s,ci)], =1 -> [cin_pad][(r,s,co)] */
 int din_conv_pack_weights(const din_conv_desc* d, const float* w, const float* scale, void* wpk,
                           int transposed, void* stream);
+/* which tile variant the planner picks (which: 0 fwd, 1 dgrad -> pixels x filters of conv_gather_*_kernel; 2 wgrad -> filter rows x
+ * k columns of conv_wgrad_*_kernel): lets a profiler-side caller name the kernel a launch resolves to */
+int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t* bn);
 /* workspace bytes needed by fwd / dgrad / wgrad for this descriptor (split-K partial sums) */
 int64_t din_conv_workspace_bytes(const din_conv_desc* d, int which /*0 fwd,1 dgrad,2 wgrad*/);
 

@@ -137,7 +137,7 @@ ref(clips).pow(2).mean().backward()
 for p, q in zip(lin.parameters(), ref.parameters()):
     assert torch.allclose(p.grad, q.grad, atol=1e-6), (p.grad - q.grad).abs().max()
 dist.barrier()
-print("RANK_OK", rank)
+sys.stdout.write(f"RANK_OK_{rank}\n"); sys.stdout.flush()
 """
 
 
@@ -149,4 +149,4 @@ def test_gloo_world2_gradient_allreduce(tmp_path):
            "--master-port", "29517", str(script), ROOT]
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-3000:]
-    assert "RANK_OK 0" in res.stdout and "RANK_OK 1" in res.stdout
+    assert "RANK_OK_0" in res.stdout and "RANK_OK_1" in res.stdout
