@@ -773,19 +773,22 @@ __device__ __forceinline__ u32x2 lds_tr_read(uint32_t byte_addr) {
     return r;
 }
 
-// v2: 64 pixels per k-step, buffer-resource loads (G: constant per-lane offset + scalar row offset; X: per-row offset
-// advanced incrementally, out-of-image taps -> hardware zero), prefetch distance 2 through two register sets, BCO = 128|64
-// filter rows per tile, and the bias gradient fused in: in the k_tile == 0 workgroups the kcol-half-0 waves also multiply
-// their G fragments with an all-ones operand, which yields sum_pix G[pix][co] without a second pass over dY.
+// v3: 64 pixels per k-step; operands arrive by LDS-DMA (buffer_load ... lds, issued through inline asm and counted by hand like the
+// gather kernel): G: constant per-lane offset + scalar row offset; X: per-row offset advanced incrementally, out-of-image taps ->
+// hardware zero.  LDS-DMA is lane-linear, so the tiles are UNPADDED [pixel][channel] images; bank conflicts of the transpose reads
+// are avoided by rotating each row's 16-byte chunks by 2*(row & 7) -- applied on the SOURCE side (the lane fetches the logical chunk
+// that belongs at its slot) and in the read addresses.  BCO in {64,96,128,160} filter rows x 128 k columns per workgroup; the bias
+// gradient is fused in: the k_tile == 0 workgroups' kcol-half-0 waves also multiply their G fragments with an all-ones operand.
 template <int BCO>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) {
+#if defined(__HIP_DEVICE_COMPILE__)
     constexpr int PK = 64;
-    constexpr int RSG = BCO * 2 + 32, RSX = WG_TILE * 2 + 32;   // row pitches (bytes): +32 B => 8 rows tile a 256-B bank row
-    constexpr int OPG = PK * RSG, OPX = PK * RSX, STAGE = OPG + OPX;
+    constexpr int CG = BCO / 8, CX = WG_TILE / 8;                 // 16-byte chunks per G / X row
+    constexpr int RBG = BCO * 2, RBX = WG_TILE * 2;               // row bytes (unpadded)
+    constexpr int OPG = PK * RBG, OPX = PK * RBX, STAGE = OPG + OPX;
     constexpr int TI = BCO / 32;                                  // 16-row filter tiles per wave (wave tile = BCO/2 x 64)
-    constexpr int CG = BCO / 8;                                   // 16-byte chunks per G row (BCO in {64,96,128,160})
-    constexpr int GP = PK * CG / NTHREADS;                        // G chunks per thread per k-step (= BCO/32)
-    static_assert(PK * CG % NTHREADS == 0, "BCO must be a multiple of 32");
+    constexpr int GP = PK * CG / NTHREADS;                        // G DMA chunks per thread per stage (= BCO/32)
+    constexpr int XP = PK * CX / NTHREADS;                        // X DMA chunks per thread per stage (= 4)
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -811,67 +814,65 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) 
     __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.g)) + g_off, 0, (int)g_rem, 0x00020000);
 
-    // ---- G loader: chunk id = tid + 256*i -> (row id / CG, chunk id % CG); rows advance by PK per k-step (scalar offset) -----
+    // ---- G DMA: wave-level transfer t of this wave covers chunk ids [(wid + 4 t) * 64, +64): id -> (row id / CG, slot id % CG);
+    //      the lane fetches logical chunk (slot - 2*(row & 7)) mod CG of that row ---------------------------------------------
     unsigned voffG[GP];
-    int ldsG[GP];
 #pragma unroll
-    for (int i = 0; i < GP; ++i) {
-        const int id = tid + NTHREADS * i;
-        const int grow = id / CG, gc = id - grow * CG;              // CG is a compile-time constant
+    for (int t = 0; t < GP; ++t) {
+        const int id = (wid + 4 * t) * 64 + lane;
+        const int grow = id / CG, slot = id - grow * CG;
+        int gc = slot - 2 * (grow & 7);
+        gc += gc < 0 ? CG : 0;
+        gc += gc < 0 ? CG : 0;                                      // 2*(row&7) <= 14 may exceed CG = 8 or 12 once
         const int gco = co_tile * BCO + gc * 8;
-        voffG[i] = (gco + 7 < p.Cout) ? (unsigned)((grow * p.ldo + p.cooff + gco) * 2) : OOB;   // Cout % 8 == 0 enforced
-        ldsG[i] = grow * RSG + gc * 16;
+        voffG[t] = (gco + 7 < p.Cout) ? (unsigned)((grow * p.ldo + p.cooff + gco) * 2) : OOB;   // Cout % 8 == 0 enforced
     }
-
-    // ---- X loader: thread -> (row xr + 16*i, chunk xc) with a fixed (tap, ci) ------------------------------------------
-    const int xc = tid & 15, xr = tid >> 4;
+    // ---- X DMA: transfer t covers rows (wid + 4 t) * 4 + (lane >> 4); rotation 2*(row & 7) is the same for all t, so the lane's
+    //      logical chunk -- hence its (tap, ci) -- is fixed -------------------------------------------------------------------
+    const int xrow0 = wid * 4 + (lane >> 4);                       // rows xrow0 + 16 t
+    int xc = (lane & 15) - 2 * (xrow0 & 7);
+    xc += xc < 0 ? CX : 0;
     const int kcol = k_tile * WG_TILE + xc * 8;
     const bool kok = kcol < p.kcols;
     const int tap = kok ? kcol / p.cin_pad : 0;
     const int ci = kcol - tap * p.cin_pad;
     const int tr_ = tap / p.kw, ts_ = tap - tr_ * p.kw;
-    const bool ci_ok = kok && ci + 7 < p.Cin;                       // Cin % 8 == 0 enforced (conv1 uses the slow tail kernel)
+    const bool ci_ok = kok && ci + 7 < p.Cin;                       // Cin % 8 == 0 enforced (conv1 uses the tail kernel)
     const int dy0 = -p.ph + tr_ * p.dh, dx0 = -p.pw + ts_ * p.dw;   // iy = oy*sh + dy0, ix = ox*sw + dx0
     const int step_bytes = p.sw * p.ldi * 2;                        // +1 output column
-    int px[4], py[4];            // output coordinates of this thread's 4 rows
-    int rowoff[4];               // byte offset of (n, iy, ix = dx0) for the current (n, oy): may be "virtual"
+    int px[XP], py[XP];          // output coordinates of this thread's rows
+    int rowoff[XP];              // byte offset of (n, iy, ix = dx0) for the current (n, oy): may be "virtual"
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int m = m_begin + xr + 16 * i;
+    for (int t = 0; t < XP; ++t) {
+        int m = m_begin + xrow0 + 16 * t;
         int n = m / ohw;
         int rem = m - n * ohw;
-        py[i] = rem / p.OW; px[i] = rem - py[i] * p.OW;
-        rowoff[i] = (((n - n_first) * p.H + py[i] * p.sh + dy0) * p.W + dx0) * p.ldi * 2 + (p.cioff + ci) * 2;
+        py[t] = rem / p.OW; px[t] = rem - py[t] * p.OW;
+        rowoff[t] = (((n - n_first) * p.H + py[t] * p.sh + dy0) * p.W + dx0) * p.ldi * 2 + (p.cioff + ci) * 2;
     }
     const int row_jump = p.sh * p.W * p.ldi * 2;                    // +1 output row
     const int img_jump = (p.H - p.OH * p.sh) * p.W * p.ldi * 2;     // extra when wrapping to the next image
 
-    u32x4 xa0[4], ga0[GP];
-    auto load_global = [&](u32x4 (&xa)[4], u32x4 (&ga)[GP], int m0) {
+    const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw;
+    const uint32_t ldsW = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(wid * 1024));   // this wave's first 1-KiB slot
+    auto issue_dma = [&](int buf, int m0) {
+        const uint32_t Gd = ldsW + (uint32_t)(buf * STAGE), Xd = Gd + (uint32_t)OPG;
         const int soffG = (m0 - m_begin) * p.ldo * 2;                // uniform
 #pragma unroll
-        for (int i = 0; i < GP; ++i) ga[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, (int)voffG[i], soffG, 0));
+        for (int t = 0; t < GP; ++t) lds_dma16(Gd + (uint32_t)(t * 4096), rsG, (int)voffG[t], soffG);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int iy = py[i] * p.sh + dy0, ix = px[i] * p.sw + dx0;
-            const bool ok = ci_ok && (m0 + xr + 16 * i < m_end) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const unsigned vo = ok ? (unsigned)(rowoff[i] + px[i] * step_bytes) : OOB;
-            xa[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)vo, 0, 0));
+        for (int t = 0; t < XP; ++t) {
+            const int iy = py[t] * p.sh + dy0, ix = px[t] * p.sw + dx0;
+            const bool ok = ci_ok && (m0 + xrow0 + 16 * t < m_end) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const unsigned vo = ok ? (unsigned)(rowoff[t] + px[t] * step_bytes) : OOB;
+            lds_dma16(Xd + (uint32_t)(t * 4096), rsX, (int)vo, 0);
             // advance this row by PK output pixels
-            px[i] += PK;
-            while (px[i] >= p.OW) {
-                px[i] -= p.OW; rowoff[i] += row_jump;
-                if (++py[i] == p.OH) { py[i] = 0; rowoff[i] += img_jump; }
+            px[t] += PK;
+            while (px[t] >= p.OW) {
+                px[t] -= p.OW; rowoff[t] += row_jump;
+                if (++py[t] == p.OH) { py[t] = 0; rowoff[t] += img_jump; }
             }
         }
-    };
-    auto store_lds = [&](const u32x4 (&xa)[4], const u32x4 (&ga)[GP], int buf) {
-        unsigned char* G = smem_raw + buf * STAGE;
-        unsigned char* X = G + OPG;
-#pragma unroll
-        for (int i = 0; i < GP; ++i) *reinterpret_cast<u32x4*>(G + ldsG[i]) = ga[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(X + (xr + 16 * i) * RSX + xc * 16) = xa[i];
     };
 
     f32x4 acc[TI][4], accb[TI];
@@ -884,27 +885,39 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) 
     const bool do_bias = p.dbias != nullptr && k_tile == 0 && wn == 0;       // wave-uniform
     const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
 
-    // transpose-read addressing: lane i of a 16-lane group supplies the 8-byte piece (row i>>2, cols 4*(i&3)..+3)
+    // transpose-read addressing: lane i of a 16-lane group supplies the 8-byte piece (row 4*lg + (i>>2), cols 4*(i&3)..+3) of a
+    // 16-column tile, i.e. chunk (tile_chunk + ((i&3)>>1)), half (i&1); rows of the second read are +16 (same row & 7 -> same rotation)
     const int li = lane & 15, lg = lane >> 4;
-    const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw;
-    const uint32_t pieceG = (uint32_t)((4 * lg + (li >> 2)) * RSG + (li & 3) * 8);
-    const uint32_t pieceX = (uint32_t)((4 * lg + (li >> 2)) * RSX + (li & 3) * 8);
+    const int prow = 4 * lg + (li >> 2);
+    const int rot = 2 * (prow & 7);
+    uint32_t colG[TI], colX[4];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        int ch = (wm * (BCO / 2) + i * 16) / 8 + rot;                         // even
+        ch -= ch >= CG ? CG : 0;
+        ch -= ch >= CG ? CG : 0;
+        colG[i] = (uint32_t)(prow * RBG + (ch + ((li & 3) >> 1)) * 16 + (li & 1) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int ch = (wn * 64 + j * 16) / 8 + rot;
+        ch -= ch >= CX ? CX : 0;
+        colX[j] = (uint32_t)(prow * RBX + (ch + ((li & 3) >> 1)) * 16 + (li & 1) * 8);
+    }
     auto compute = [&](int cur) {
 #pragma unroll
         for (int kg = 0; kg < 2; ++kg) {                                       // two 32-pixel MFMA k-groups per stage
-            const uint32_t Gb = lds_base + cur * STAGE + kg * 32 * RSG + pieceG;
-            const uint32_t Xb = lds_base + cur * STAGE + OPG + kg * 32 * RSX + pieceX;
+            const uint32_t Gb = lds_base + cur * STAGE + kg * 32 * RBG;
+            const uint32_t Xb = lds_base + cur * STAGE + OPG + kg * 32 * RBX;
             u32x4 gf[TI], xf[4];
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
-                uint32_t a = Gb + (wm * (BCO / 2) + i * 16) * 2;
-                u32x2 lo = lds_tr_read(a), hi = lds_tr_read(a + 16 * RSG);
+                u32x2 lo = lds_tr_read(Gb + colG[i]), hi = lds_tr_read(Gb + colG[i] + 16 * RBG);
                 gf[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                uint32_t a = Xb + (wn * 64 + j * 16) * 2;
-                u32x2 lo = lds_tr_read(a), hi = lds_tr_read(a + 16 * RSX);
+                u32x2 lo = lds_tr_read(Xb + colX[j]), hi = lds_tr_read(Xb + colX[j] + 16 * RBX);
                 xf[j] = u32x4{lo[0], lo[1], hi[0], hi[1]};
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -925,17 +938,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) 
     };
 
     if (m_begin < m_end) {
-        load_global(xa0, ga0, m_begin);
-        store_lds(xa0, ga0, 0);
-        __syncthreads();
+        issue_dma(0, m_begin);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         int it = 0;
         for (int m0 = m_begin; m0 < m_end; m0 += PK, ++it) {
             const int cur = it & 1;
-            const bool more = m0 + PK < m_end;
-            if (more) load_global(xa0, ga0, m0 + PK);
+            if (m0 + PK < m_end) issue_dma(cur ^ 1, m0 + PK);
             compute(cur);
-            if (more) store_lds(xa0, ga0, cur ^ 1);
-            __syncthreads();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
     }
     float* dst = p.partial + (int64_t)slice * p.cout_pad * p.kcols_pad;
@@ -956,6 +970,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) 
             for (int e = 0; e < 4; ++e) if (co + e < p.Cout) atomicAdd(p.dbias + co + e, accb[i][e]);
         }
     }
+#endif
 }
 
 // tail kernel for channel counts that are not multiples of 8 (conv1: cin = 3): the round-1 32-pixel kernel
@@ -1614,7 +1629,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
                 k.dbias = dbias;
                 bias_fused = true;
             }
-            size_t lds = 2 * 64 * ((size_t)(wp.bco * 2 + 32) + (WG_TILE * 2 + 32));
+            size_t lds = 2 * 64 * ((size_t)(wp.bco * 2) + (WG_TILE * 2));        // two unpadded stages
             auto launch = [&](auto kern) {
                 if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, k);
