@@ -583,6 +583,210 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small-channel 3x3 (stem) convolution: filters stationary in LDS + input HALO tiles, persistent workgroups.
+// For layers with 32/64 reduction channels and <= 64 produced channels over millions of pixels (Inception Conv2d_2a/2b, fwd and
+// dgrad) the implicit-GEMM kernel is bound by the L2->CU operand stream: im2col pulls every input pixel kh*kw times.  Here
+//   * the whole filter bank of the launch (<= 36 KiB) is loaded into LDS once per workgroup and stays there;
+//   * per 8x32 output tile the (8+kh-1) x (32+kw-1) input halo is brought in ONCE by LDS-DMA (1.33x the unique bytes instead of 9x),
+//     out-of-image pixels as hardware zeros; all taps are formed from LDS with a swizzle that is conflict-free at every pixel
+//     offset ((hp>>1)&3 for 64-byte pixels, hp&7 for 128-byte pixels; brute-forced against the ds_read_b128 lane groups);
+//   * workgroups are persistent (grid = 2 per CU) and walk the tiles; with 64-byte pixels the next halo is in flight while the
+//     current tile is multiplied; the epilogue is staged through the just-consumed halo buffer -> 16-byte coalesced stores with the
+//     usual fused bias / ReLU / ReLU-backward mask / accumulate.
+// bf16 only; stride 1, dilation 1; the gather geometry (ay = 1, by, cy = +-1) covers forward and (stride-1) dgrad.
+// ------------------------------------------------------------------------------------------------
+template <int CPP, int BN, int NBUF, int KH, int KW>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_small_kernel(ConvK p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef bf16_t T;
+    constexpr int TH = 8, TW = 32, NPX = TH * TW;
+    constexpr int TI = BN / 16, TJ = 4, SL = CPP / 4, NTAPS = KH * KW;
+    constexpr int CPITCH = BN * 2 + 16;
+    constexpr int HWW = TW + KW - 1, HWH = TH + KH - 1, HPX = HWW * HWH, HC = HPX * CPP;  // halo geometry (pixels, chunks)
+    constexpr int WBYTES = NTAPS * BN * CPP * 16;
+    constexpr int HBYTES = (HC * 16 + 1023) / 1024 * 1024;                                // whole 1-KiB DMA slots
+    constexpr int NSLOT = HBYTES / 1024, NTR = (NSLOT + 3) / 4;
+    constexpr int NPASS = HBYTES / CPITCH >= NPX ? 1 : 2;                                  // epilogue passes through the staging buffer
+    static_assert(HBYTES / CPITCH >= NPX / NPASS, "staging does not fit the halo buffer");
+    constexpr int JN = TJ / NPASS;                                                         // pixel segments per wave per pass
+    constexpr int CPR = BN / 8;                                                            // 16-byte chunks per produced pixel
+    constexpr int NST = (NPX / NPASS) * CPR / NTHREADS * NPASS;                            // store instructions per wave per tile
+    static_assert((NPX / NPASS) * CPR % NTHREADS == 0, "store loop must be uniform");
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    u32x4* Wl = reinterpret_cast<u32x4*>(smem_raw);
+    auto swz = [](int row) { return CPP == 4 ? ((row >> 1) & 3) : (row & 7); };
+
+    // ---- filters: [tap][co][chunk ^ swz(co)] ------------------------------------------------------------------------------
+    {
+        const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(p.w);
+        for (int id = tid; id < NTAPS * BN * CPP; id += NTHREADS) {
+            const int row = id / CPP, slot = id - row * CPP;
+            const int tap = row / BN, co = row - tap * BN;
+            const int cc = slot ^ swz(co);
+            Wl[id] = wp[(int64_t)co * p.wld + tap * CPP + cc];
+        }
+    }
+    // ---- halo DMA plan: transfer i of this wave covers chunk ids [(wid + 4 i) * 64, +64) ------------------------------------
+    int rel[NTR];                                      // byte offset relative to the halo origin pixel (chunk already permuted)
+    short hyv[NTR], hxv[NTR];
+#pragma unroll
+    for (int i = 0; i < NTR; ++i) {
+        const int id = (wid + 4 * i) * 64 + lane;
+        const int hp = id / CPP, slot = id - hp * CPP;
+        const int cc = slot ^ swz(hp);
+        const int hy = hp / HWW, hx = hp - hy * HWW;
+        rel[i] = id < HC ? (hy * p.W + hx) * p.ldi * 2 + cc * 16 : -1;
+        hyv[i] = (short)hy; hxv[i] = (short)hx;
+    }
+    const int hy0 = p.by + (p.cy < 0 ? (KH - 1) * p.cy : 0), hx0 = p.bx + (p.cx < 0 ? (KW - 1) * p.cx : 0);   // halo origin - tile origin
+    const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + TH - 1) / TH;
+    const int tiles_img = tiles_x * tiles_y, ntiles = tiles_img * p.NB;
+    const long long img_bytes = (long long)p.H * p.W * p.ldi * 2ll;
+    const long long oimg_bytes = (long long)p.OH * p.OW * p.ldo * 2ll, mimg_bytes = (long long)p.OH * p.OW * p.ldm * 2ll;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw;
+    const uint32_t ldsH0 = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)WBYTES + (uint32_t)(wid * 1024));
+
+    auto issue_halo = [&](int buf, int tile) {
+        const int n = tile / tiles_img;
+        const int tr = tile - n * tiles_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int gy0 = ty * TH + hy0, gx0 = tx * TW + hx0;
+        // one image per resource: 32-bit offsets always suffice; out-of-image pixels get the out-of-range offset -> zeros
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(p.in)) + (long long)n * img_bytes, 0, (int)img_bytes, 0x00020000);
+        const int base = (gy0 * p.W + gx0) * p.ldi * 2 + p.cioff * 2;
+        const uint32_t dst = ldsH0 + (uint32_t)(buf * HBYTES);
+#pragma unroll
+        for (int i = 0; i < NTR; ++i) {
+            if (wid + 4 * i < NSLOT) {                                                  // uniform: slot inside the halo buffer
+                const int gy = gy0 + hyv[i], gx = gx0 + hxv[i];
+                const bool ok = rel[i] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                lds_dma16(dst + (uint32_t)(i * 4096), rs, ok ? base + rel[i] : (int)OOB, 0);
+            }
+        }
+    };
+
+    const int frow = lane & 15, g4 = lane >> 4;
+    int cur = 0;
+    int tile = blockIdx.x;
+    bool first = true;
+    if (tile < ntiles) issue_halo(0, tile);
+    __syncthreads();                                                                   // filters visible
+    for (; tile < ntiles; tile += gridDim.x) {
+        // in-order completion: the halo transfers of this tile are older than the (always NST) stores of the previous tile when
+        // double-buffered, so the stores may stay in flight; single-buffered the transfers are the youngest -> drain everything
+        if (NBUF == 2 && !first) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        first = false;
+        __builtin_amdgcn_s_barrier();                                                  // halo(tile) landed; everyone left the previous tile
+        asm volatile("" ::: "memory");
+        if (NBUF == 2 && tile + (int)gridDim.x < ntiles) issue_halo(cur ^ 1, tile + gridDim.x);
+        const u32x4* Hl = reinterpret_cast<const u32x4*>(smem_raw + WBYTES + cur * HBYTES);
+
+        f32x4 acc[TI][TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int ysgn = p.cy > 0 ? 1 : -1, xsgn = p.cx > 0 ? 1 : -1;
+        const int yb = p.cy > 0 ? 0 : KH - 1, xb = p.cx > 0 ? 0 : KW - 1;
+#pragma unroll
+        for (int tap = 0; tap < NTAPS; ++tap) {
+            const int r = tap / KW, s2 = tap - r * KW;
+            const int dy = yb + ysgn * r, dx = xb + xsgn * s2;
+#pragma unroll
+            for (int sl = 0; sl < SL; ++sl) {
+                u32x4 wf[TI], xf[TJ];
+                const int chunk = sl * 4 + g4;
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    const int co = i * 16 + frow;
+                    wf[i] = Wl[(tap * BN + co) * CPP + (chunk ^ swz(co))];
+                }
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const int q = wid * 4 + j;                                         // 16-pixel segment of the tile
+                    const int hp = ((q >> 1) + dy) * HWW + (q & 1) * 16 + frow + dx;
+                    xf[j] = Hl[hp * CPP + (chunk ^ swz(hp))];
+                }
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
+            }
+        }
+        __syncthreads();                                                               // all waves done reading halo(cur)
+        // ---- epilogue: stage through the consumed halo buffer, then 16-byte coalesced buffer stores (always NST per wave) -----
+        const int n = tile / tiles_img;
+        const int trm = tile - n * tiles_img;
+        const int ty = trm / tiles_x, tx = trm - ty * tiles_x;
+        unsigned char* stg = smem_raw + WBYTES + cur * HBYTES;
+        __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + (long long)n * oimg_bytes, 0, (int)oimg_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>((p.flags & DIN_CONV_MASK) ? p.mask : p.out)) + (long long)n * mimg_bytes, 0,
+            (p.flags & DIN_CONV_MASK) ? (int)mimg_bytes : 0, 0x00020000);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                const int co = i * 16 + g4 * 4;
+                if ((p.flags & DIN_CONV_BIAS) && co < p.Cout) bv = *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+                for (int j = ps * JN; j < (ps + 1) * JN; ++j) {
+                    f32x4 v = acc[i][j] + bv;
+                    if (p.flags & DIN_CONV_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    const int srow = (wid * JN + (j - ps * JN)) * 16 + frow;             // staging row of this pixel
+                    *reinterpret_cast<u32x2*>(stg + srow * CPITCH + co * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < (NPX / NPASS) * CPR / NTHREADS; ++it) {
+                const int idx = it * NTHREADS + tid;
+                const int srow = idx / CPR, c = idx - srow * CPR;
+                const int w_ = srow / (JN * 16), rem = srow - w_ * (JN * 16);
+                const int q = w_ * 4 + ps * JN + rem / 16;                                // segment of the tile
+                const int gy = ty * TH + (q >> 1), gx = tx * TW + (q & 1) * 16 + (rem & 15);
+                const int co = c * 8;
+                const bool ok = gy < p.OH && gx < p.OW && co < p.Cout;
+                u32x4 v = *reinterpret_cast<const u32x4*>(stg + srow * CPITCH + c * 16);
+                const int opx = gy * p.OW + gx;
+                const int o = ok ? (opx * p.ldo + p.cooff + co) * 2 : (int)OOB;
+                if (p.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM)) {
+                    u32x4 mk = {0u, 0u, 0u, 0u}, old = {0u, 0u, 0u, 0u};
+                    if (p.flags & DIN_CONV_MASK) mk = __builtin_amdgcn_raw_buffer_load_b128(rsM, ok ? (opx * p.ldm + p.moff + co) * 2 : (int)OOB, 0, 0);
+                    if (p.flags & DIN_CONV_ACCUM) old = __builtin_amdgcn_raw_buffer_load_b128(rsO, o, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+                        if (p.flags & DIN_CONV_MASK) {
+                            if (!(__uint_as_float(mk[e] << 16) > 0.f)) lo = 0.f;
+                            if (!(__uint_as_float(mk[e] & 0xffff0000u) > 0.f)) hi = 0.f;
+                        }
+                        if (p.flags & DIN_CONV_ACCUM) { lo += __uint_as_float(old[e] << 16); hi += __uint_as_float(old[e] & 0xffff0000u); }
+                        v[e] = pack_bf16x2(lo, hi);
+                    }
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsO, o, 0, 0);                  // out-of-range offset -> dropped, still counted
+            }
+            if (ps + 1 < NPASS) __syncthreads();
+        }
+        if (NBUF == 2) cur ^= 1;
+        else {
+            __syncthreads();                                                            // staging buffer free again
+            if (tile + (int)gridDim.x < ntiles) issue_halo(0, tile + gridDim.x);
+        }
+    }
+#endif
+}
+
 // split-K finish: out = epilogue(sum_s partial[s])
 template <typename T>
 __global__ void conv_splitk_finish_kernel(ConvK p, int cpad) {
@@ -1398,6 +1602,38 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
         if (ws_bytes < g.ws_bytes || workspace == nullptr)
             DIN_FAIL(DIN_E_WORKSPACE, "%s: workspace %lld < %lld bytes", what, (long long)ws_bytes, (long long)g.ws_bytes);
         k.partial = reinterpret_cast<float*>(workspace);
+    }
+    {
+        // stem layers: stationary filters + halo tiles (conv_small_kernel)
+        const char* sv = getenv("DIN_CONV_SMALL");
+        const bool want = sv ? atoi(sv) != 0 : true;
+        const int taps = k.kh * k.kw;
+        const bool small = want && dtype == DIN_BF16 && fast && !k.remap && k.nsrc == 0 && g.splitk == 1 && k.kh == 3 && k.kw == 3 &&
+                           (g.cpt == 4 || g.cpt == 8) && g.cpt * 8 == k.Cin && k.Cout <= 64 && k.Cout % 8 == 0 &&
+                           k.cooff % 8 == 0 && k.ldo % 8 == 0 && (!(k.flags & DIN_CONV_MASK) || (k.ldm % 8 == 0 && k.moff % 8 == 0)) &&
+                           k.ay == 1 && k.ax == 1 && (k.cy == 1 || k.cy == -1) && (k.cx == 1 || k.cx == -1) &&
+                           (long long)k.H * k.W * k.ldi * 2 < 0x7fffffffll && (long long)k.OH * k.OW * k.ldo * 2 < 0x7fffffffll &&
+                           (long long)k.OH * k.OW * (k.ldm > 0 ? k.ldm : 1) * 2 < 0x7fffffffll && k.out_sy == 0 && (int64_t)k.M >= 256 * 1024;
+        if (small) {
+            const int bnS = k.Cout <= 32 ? 32 : 64;
+            const int hpx = (8 + k.kh - 1) * (32 + k.kw - 1);
+            const int hbytes = (hpx * g.cpt * 16 + 1023) / 1024 * 1024;
+            const int nbuf = g.cpt == 4 ? 2 : 1;
+            const size_t lds = (size_t)taps * bnS * g.cpt * 16 + (size_t)nbuf * hbytes;
+            const bool fits = lds <= 80 * 1024 && !(g.cpt == 8 && bnS == 64);
+            if (fits) {
+                dim3 grid(512);
+                auto launch = [&](auto kern) {
+                    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, k);
+                };
+                if (g.cpt == 4 && bnS == 32) launch(conv_small_kernel<4, 32, 2, 3, 3>);
+                else if (g.cpt == 4) launch(conv_small_kernel<4, 64, 2, 3, 3>);
+                else launch(conv_small_kernel<8, 32, 1, 3, 3>);
+                DIN_CHECK_LAUNCH(what);
+                return DIN_OK;
+            }
+        }
     }
     if (dtype == DIN_F32) launch_gather<float>(k, g.n_px_tiles, g.bm, g.bn, st);
     else launch_gather<bf16_t>(k, g.n_px_tiles, g.bm, g.bn, st);

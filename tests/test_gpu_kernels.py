@@ -52,6 +52,9 @@ CONV_CASES = [
     ("dil3_grid", 2, 32, 10, 12, 27, (3, 3), (1, 1), (3, 3), 3),
     ("big_tile", 1, 128, 40, 48, 256, (3, 3), (1, 1), (1, 1), 1),
     ("linear_splitk", 1, 1600, 1, 72, 128, (1, 1), (1, 1), (0, 0), 1),
+    # stem shapes (>= 256K pixels): bf16 runs the stationary-filter halo kernel (fwd cpt4, dgrad cpt4 / cpt8), ragged tile edges
+    ("stem_32_32_p0", 1, 32, 515, 517, 32, (3, 3), (1, 1), (0, 0), 1),
+    ("stem_32_64_p1", 2, 32, 363, 365, 64, (3, 3), (1, 1), (1, 1), 1),
 ]
 
 
