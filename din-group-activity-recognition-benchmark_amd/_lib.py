@@ -58,11 +58,12 @@ SIGNATURES: Dict[str, tuple] = {
     "din_conv_dgrad": (_I, [_CD, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P]),
     "din_conv1x1_dgrad_multi": (_I, [_I, C.POINTER(ConvSrc), _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
     "din_conv_wgrad": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P]),
+    "din_colsum": (_I, [_P, _I, _L, _I, _I, _I, _P, _P]),
     "din_bn_fold": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "din_bn_fold_bwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "din_maxpool_fwd": (_I, [_PD, _P, _P, _P, _P]),
     "din_maxpool_bwd": (_I, [_PD, _P, _P, _P, _P, _I, _I, _P]),
-    "din_avgpool_fwd": (_I, [_PD, _P, _P, _P]),
+    "din_avgpool_fwd": (_I, [_PD, _P, _P, _P, _I, _P]),
     "din_avgpool_bwd": (_I, [_PD, _P, _P, _P, _I, _P]),
     "din_bilinear_fwd": (_I, [_PD, _P, _P, _P]),
     "din_bilinear_bwd": (_I, [_PD, _P, _P, _P, _I, _P]),

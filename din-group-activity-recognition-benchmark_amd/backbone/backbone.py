@@ -10,6 +10,8 @@ weights drop in through load_state_dict (key names are identical).
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Dict, List, Tuple
 
@@ -176,9 +178,18 @@ class MyInception_v3(_GraphBackbone):
         gb = GraphBuilder(h, w, _cpad_image(dt))
         spec = {s[0]: s for s in self._specs}
 
-        def bc(name, src: View, dst=None) -> View:
+        def bc(name, src: View, dst=None, pooled=None) -> View:
             _, _cin, cout, k, s, p = spec[name]
-            return gb.conv(name, src, cout, k, s, p, relu=True, bn=True, dst=dst)
+            return gb.conv(name, src, cout, k, s, p, relu=True, bn=True, dst=dst, pooled=pooled)
+
+        # branch_pool = BasicConv2d_1x1(avg_pool2d(x, 3, 1, 1)) (torchvision InceptionA/C.forward): run as conv1x1 -> avgpool so the
+        # pool moves cout (32..192) instead of cin (192..768) channels.  DIN_POOL_COMMUTE=0 keeps the reference's op order.
+        commute = os.environ.get("DIN_POOL_COMMUTE", "1") != "0"
+
+        def branch_pool(name, src: View, dst: View):
+            if commute:
+                return bc(name, src, dst, pooled=(3, 1, 1))
+            return bc(name, gb.pool("avgpool", src, 3, 1, 1), dst)
 
         v = gb.full(gb.g.input_tid)
         v = bc("Conv2d_1a_3x3", v)
@@ -205,8 +216,7 @@ class MyInception_v3(_GraphBackbone):
             t = bc(blk + "branch3x3dbl_1", v)
             t = bc(blk + "branch3x3dbl_2", t)
             bc(blk + "branch3x3dbl_3", t, View(out_tid, base + 128, 96))
-            t = gb.pool("avgpool", v, 3, 1, 1)
-            bc(blk + "branch_pool", t, View(out_tid, base + 224, pf))
+            branch_pool(blk + "branch_pool", v, View(out_tid, base + 224, pf))
             v = View(out_tid, base, ctot)
         v5d = v
         # Mixed_6a (InceptionB)
@@ -230,8 +240,7 @@ class MyInception_v3(_GraphBackbone):
             t = bc(blk + "branch7x7dbl_3", t)
             t = bc(blk + "branch7x7dbl_4", t)
             bc(blk + "branch7x7dbl_5", t, View(out_tid, 384, 192))
-            t = gb.pool("avgpool", v, 3, 1, 1)
-            bc(blk + "branch_pool", t, View(out_tid, 576, 192))
+            branch_pool(blk + "branch_pool", v, View(out_tid, 576, 192))
             v = View(out_tid, 0, 768)
         # multiscale fuse (infer_model.py:165-172): resize Mixed_6e to the Mixed_5d grid into channels [288, 1056)
         gb.bilinear(v, View(fused_tid, 288, 768))

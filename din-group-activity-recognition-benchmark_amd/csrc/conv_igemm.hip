@@ -1312,17 +1312,38 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ partial, floa
                                          const float* __restrict__ scale, const float* __restrict__ w,
                                          float* __restrict__ wdot, int cout, int cin, int kh, int kw, int cin_pad,
                                          int cout_pad, int kcols_pad, int slices, int accumulate) {
-    // grid (co, kcol chunk of 256): partials are read in their own (coalesced) column order
+    // grid (co, 64-column chunk), block (64 columns, SG slice groups): every wave reads 256 contiguous bytes of one slice per step
+    // (partials keep their own column order), the SG partial sums meet in LDS in a fixed order (deterministic result)
+    __shared__ float red[16][64];
     const int co = blockIdx.x;
     const int taps = kh * kw;
     const int per = cin * taps;
+    const int kc = blockIdx.y * 64 + threadIdx.x;
+    const int sg = threadIdx.y, nsg = blockDim.y;
+    const bool col_ok = kc < taps * cin_pad;
+    float v = 0.f;
+    if (col_ok) {
+        const float* __restrict__ pp = partial + (int64_t)co * kcols_pad + kc;
+        const int64_t sstride = (int64_t)cout_pad * kcols_pad;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int s = sg;
+        for (; s + 3 * nsg < slices; s += 4 * nsg) {
+            v0 += pp[(int64_t)s * sstride];
+            v1 += pp[(int64_t)(s + nsg) * sstride];
+            v2 += pp[(int64_t)(s + 2 * nsg) * sstride];
+            v3 += pp[(int64_t)(s + 3 * nsg) * sstride];
+        }
+        for (; s < slices; s += nsg) v0 += pp[(int64_t)s * sstride];
+        v = (v0 + v1) + (v2 + v3);
+    }
+    red[sg][threadIdx.x] = v;
+    __syncthreads();
+    if (sg != 0) return;
+    for (int g = 1; g < nsg; ++g) v += red[g][threadIdx.x];
     float dot = 0.f;
-    const int kc = blockIdx.y * blockDim.x + threadIdx.x;
-    if (kc < taps * cin_pad) {
+    if (col_ok) {
         int t = kc / cin_pad, ci = kc - t * cin_pad;            // t = r*kw + s
         if (ci < cin) {
-            float v = 0.f;
-            for (int s = 0; s < slices; ++s) v += partial[((int64_t)s * cout_pad + co) * kcols_pad + kc];
             int64_t o = (int64_t)co * per + (int64_t)ci * taps + t;
             if (wdot) dot = v * w[o];
             if (scale) v *= scale[co];
@@ -1330,11 +1351,8 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ partial, floa
         }
     }
     if (wdot) {
-        __shared__ float red[4];
         dot = wave_sum(dot);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
-        __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(wdot + co, red[0] + red[1] + red[2] + red[3]);
+        if (threadIdx.x == 0) atomicAdd(wdot + co, dot);
     }
 }
 
@@ -1648,6 +1666,30 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
     return DIN_OK;
 }
 
+// column sums of a pixel-major tensor view -> out[c] (zeroed here, fp32 atomics across row slabs)
+static int launch_colsum(int dtype, const void* g, float* out, int64_t M, int c, int ld, int coff, hipStream_t st) {
+    hipMemsetAsync(out, 0, sizeof(float) * c, st);
+    if (c % 4 == 0 && c <= 1024 && ld % 4 == 0 && coff % 4 == 0) {
+        // ~2048 workgroups, each streaming a contiguous slab of rows
+        int64_t rpb = ceil_div64(M, 2048);
+        if (rpb < 64) rpb = 64;
+        int blocks = (int)ceil_div64(M, rpb);
+        if (dtype == DIN_F32)
+            hipLaunchKernelGGL(colsum_vec_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)g, out, M, c, ld, coff, rpb);
+        else
+            hipLaunchKernelGGL(colsum_vec_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)g, out, M, c, ld, coff, rpb);
+    } else {
+        int64_t rpb = 512;
+        int blocks = (int)ceil_div64(M, rpb);
+        if (dtype == DIN_F32)
+            hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)g, out, M, c, ld, coff, rpb);
+        else
+            hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)g, out, M, c, ld, coff, rpb);
+    }
+    DIN_CHECK_LAUNCH("colsum");
+    return DIN_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1691,6 +1733,14 @@ int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t
                                             d->cout, d->cin, d->kh * d->kw, d->dtype);
     if (g.bm == 256 && (strided || g.splitk > 1)) { g.bm = 128; if (g.bn == 256) g.bn = 128; }
     *bm = g.bm; *bn = g.bn;
+    {   // stem layers run conv_small_kernel (same conditions as run_gather, for tensors with 16-byte aligned channel offsets): bm = 0
+        const int cred = which == 0 ? d->cin : d->cout, cprod = which == 0 ? d->cout : d->cin;
+        const int64_t M = which == 0 ? (int64_t)d->nb * d->oh * d->ow : (int64_t)d->nb * d->h * d->w;
+        const char* sv = getenv("DIN_CONV_SMALL");
+        if ((sv ? atoi(sv) != 0 : true) && d->dtype == DIN_BF16 && d->kh == 3 && d->kw == 3 && d->sh == 1 && d->sw == 1 && d->dh == 1 &&
+            d->dw == 1 && (cred == 32 || cred == 64) && cprod <= 64 && cprod % 8 == 0 && !(cred == 64 && cprod > 32) && g.splitk == 1 &&
+            M >= 256 * 1024) { *bm = 0; *bn = cprod <= 32 ? 32 : 64; }
+    }
     return DIN_OK;
 }
 
@@ -1883,34 +1933,22 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
     if (wdot && hipMemsetAsync(wdot, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
     {
         int kc_total = d->kh * d->kw * wp.cin_pad;
-        dim3 rgrid(d->cout, (kc_total + 255) / 256);
-        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, rgrid, dim3(256), 0, st, k.partial, dw, scale, w, wdot,
+        dim3 rgrid(d->cout, (kc_total + 63) / 64);
+        const int nsg = wp.slices >= 64 ? 16 : wp.slices >= 8 ? 4 : 1;
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, rgrid, dim3(64, nsg), 0, st, k.partial, dw, scale, w, wdot,
                            d->cout, d->cin, d->kh, d->kw, wp.cin_pad, wp.cout_pad, wp.kcols_pad, wp.slices, accumulate);
         DIN_CHECK_LAUNCH("conv_wgrad_reduce");
     }
     if (dbias && !bias_fused) {
-        int64_t M = k.M;
-        hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st);
-        if (d->cout % 4 == 0 && d->cout <= 1024) {
-            // ~2048 workgroups, each streaming a contiguous slab of rows
-            int64_t rpb = ceil_div64(M, 2048);
-            if (rpb < 64) rpb = 64;
-            int blocks = (int)ceil_div64(M, rpb);
-            if (d->dtype == DIN_F32)
-                hipLaunchKernelGGL(colsum_vec_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dout, dbias, M, d->cout, d->ldo, d->cooff, rpb);
-            else
-                hipLaunchKernelGGL(colsum_vec_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dout, dbias, M, d->cout, d->ldo, d->cooff, rpb);
-        } else {
-            int64_t rpb = 512;
-            int blocks = (int)ceil_div64(M, rpb);
-            if (d->dtype == DIN_F32)
-                hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dout, dbias, M, d->cout, d->ldo, d->cooff, rpb);
-            else
-                hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dout, dbias, M, d->cout, d->ldo, d->cooff, rpb);
-        }
-        DIN_CHECK_LAUNCH("conv_colsum");
+        if (int e = launch_colsum(d->dtype, dout, dbias, k.M, d->cout, d->ldo, d->cooff, st)) return e;
     }
     return DIN_OK;
+}
+
+int din_colsum(const void* g, int dtype, int64_t rows, int c, int ld, int coff, float* out, void* stream) {
+    DIN_REQUIRE(g && out && rows > 0 && c > 0 && ld >= coff + c && coff >= 0, "colsum: bad argument");
+    DIN_REQUIRE(dtype == DIN_F32 || dtype == DIN_BF16, "colsum: bad dtype");
+    return launch_colsum(dtype, g, out, rows, c, ld, coff, as_stream(stream));
 }
 
 int din_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,

@@ -185,7 +185,10 @@ __global__ void maxpool_bwd_kernel(din_pool_desc d, const void* __restrict__ in,
     }
 }
 
-__global__ void avgpool_fwd_kernel(din_pool_desc d, const void* __restrict__ in, void* __restrict__ out) {
+// flags: DIN_CONV_BIAS adds bias[c] after the average, DIN_CONV_RELU clamps -- the epilogue of a 1x1 conv that was commuted in
+// front of the pool (avgpool(conv1x1(x)) == conv1x1(avgpool(x)): both linear, zero padding maps to zero)
+__global__ void avgpool_fwd_kernel(din_pool_desc d, const void* __restrict__ in, void* __restrict__ out,
+                                   const float* __restrict__ bias, int flags) {
     const int c4 = d.c >> 2;
     int64_t total = (int64_t)d.nb * d.oh * d.ow * c4;
     const float inv = 1.f / (float)(d.k * d.k);                       // count_include_pad=True
@@ -205,10 +208,17 @@ __global__ void avgpool_fwd_kernel(din_pool_desc d, const void* __restrict__ in,
                 s4 += ld4(in, d.dtype, ((int64_t)(n * d.h + iy) * d.w + ix) * d.ldi + d.cioff + cg * 4);
             }
         }
-        st4(out, d.dtype, p * d.ldo + d.cooff + cg * 4, s4 * inv);
+        s4 = s4 * inv;
+        if (flags & DIN_CONV_BIAS) s4 += *reinterpret_cast<const f32x4*>(bias + cg * 4);
+        if (flags & DIN_CONV_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s4[e] = fmaxf(s4[e], 0.f);
+        }
+        st4(out, d.dtype, p * d.ldo + d.cooff + cg * 4, s4);
     }
 }
-__global__ void avgpool_fwd8_kernel(din_pool_desc d, const void* __restrict__ in, void* __restrict__ out) {
+__global__ void avgpool_fwd8_kernel(din_pool_desc d, const void* __restrict__ in, void* __restrict__ out,
+                                    const float* __restrict__ bias, int flags) {
     const int c8 = d.c >> 3;
     int64_t total = (int64_t)d.nb * d.oh * d.ow * c8;
     const float inv = 1.f / (float)(d.k * d.k);
@@ -230,6 +240,14 @@ __global__ void avgpool_fwd8_kernel(din_pool_desc d, const void* __restrict__ in
             }
         }
         a.lo = a.lo * inv; a.hi = a.hi * inv;
+        if (flags & DIN_CONV_BIAS) {
+            a.lo += *reinterpret_cast<const f32x4*>(bias + cg * 8);
+            a.hi += *reinterpret_cast<const f32x4*>(bias + cg * 8 + 4);
+        }
+        if (flags & DIN_CONV_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a.lo[e] = fmaxf(a.lo[e], 0.f); a.hi[e] = fmaxf(a.hi[e], 0.f); }
+        }
         st8_bf16(out, p * d.ldo + d.cooff + cg * 8, a);
     }
 }
@@ -569,12 +587,14 @@ int din_maxpool_bwd(const din_pool_desc* d, const void* in, const uint8_t* argma
     DIN_CHECK_LAUNCH("maxpool_bwd");
     return DIN_OK;
 }
-int din_avgpool_fwd(const din_pool_desc* d, const void* in, void* out, void* stream) {
+int din_avgpool_fwd(const din_pool_desc* d, const void* in, void* out, const float* bias, int flags, void* stream) {
     if (int e = check_pool(d, "avgpool_fwd")) return e;
     DIN_REQUIRE(in && out, "avgpool_fwd: null pointer");
+    DIN_REQUIRE(!(flags & ~(DIN_CONV_BIAS | DIN_CONV_RELU)), "avgpool_fwd: only BIAS / RELU flags");
+    DIN_REQUIRE(!(flags & DIN_CONV_BIAS) || bias, "avgpool_fwd: BIAS flag without bias");
     int64_t total = (int64_t)d->nb * d->oh * d->ow * (d->c / 4);
-    if (wide8(d)) hipLaunchKernelGGL(avgpool_fwd8_kernel, dim3(grid_1d(total / 2, 256, 32768)), dim3(256), 0, as_stream(stream), *d, in, out);
-    else hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_1d(total, 256, 16384)), dim3(256), 0, as_stream(stream), *d, in, out);
+    if (wide8(d)) hipLaunchKernelGGL(avgpool_fwd8_kernel, dim3(grid_1d(total / 2, 256, 32768)), dim3(256), 0, as_stream(stream), *d, in, out, bias, flags);
+    else hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_1d(total, 256, 16384)), dim3(256), 0, as_stream(stream), *d, in, out, bias, flags);
     DIN_CHECK_LAUNCH("avgpool_fwd");
     return DIN_OK;
 }

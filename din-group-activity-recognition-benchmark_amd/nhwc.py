@@ -84,6 +84,8 @@ class _timed:
             tn = "unsigned short" if d.dtype == L.DIN_BF16 else "float"
             if self.kind == "wgrad":
                 variant = f"conv_wgrad_bf16_kernel<{bm.value}>" if d.dtype == L.DIN_BF16 else "conv_wgrad_f32_kernel"
+            elif bm.value == 0:
+                variant = f"conv_small_kernel<..., {bn.value}, ...>"
             else:
                 variant = f"conv_gather_fast_kernel<{tn}, {bm.value}, {bn.value}, ...>"
             PROFILE.append((self.kind, variant, _conv_flops(d), int(d.dtype), self.e0, self.e1))
@@ -137,6 +139,8 @@ class Op:
     relu: bool = False
     bias: bool = False      # conv has its own bias parameter (VGG)
     bn: bool = False        # conv followed by BatchNorm (Inception BasicConv2d)
+    pooled: Optional[Tuple[int, int, int]] = None   # (k, s, p): the reference runs avg_pool2d(k, s, p) on src BEFORE this 1x1 conv
+                                                    # (InceptionA/C branch_pool); executed as conv1x1 -> avgpool(+shift, ReLU) on cout channels
 
 
 @dataclass
@@ -185,15 +189,18 @@ class GraphBuilder:
         return View(tid, 0, self.g.tensors[tid].c)
 
     def conv(self, name, src: View, cout, k, s=(1, 1), p=(0, 0), relu=True, bias=False, bn=False,
-             dst: Optional[View] = None) -> View:
+             dst: Optional[View] = None, pooled: Optional[Tuple[int, int, int]] = None) -> View:
         ts = self.g.tensors[src.tid]
         oh, ow = conv_out(ts.h, k[0], s[0], p[0]), conv_out(ts.w, k[1], s[1], p[1])
+        if pooled is not None:
+            assert tuple(k) == (1, 1) and tuple(s) == (1, 1) and tuple(p) == (0, 0) and pooled[1] == 1 and cout % 8 == 0
+            assert conv_out(ts.h, pooled[0], 1, pooled[2]) == ts.h, "commuted pool must keep the grid"
         if dst is None:
             dst = self.full(self.tensor(oh, ow, cout))
         td = self.g.tensors[dst.tid]
         assert (td.h, td.w) == (oh, ow) and dst.c == cout, (name, td, oh, ow)
         td.relu_masked = td.relu_masked or relu
-        self.g.ops.append(Op("conv", src, dst, name, tuple(k), tuple(s), tuple(p), relu, bias, bn))
+        self.g.ops.append(Op("conv", src, dst, name, tuple(k), tuple(s), tuple(p), relu, bias, bn, pooled))
         return dst
 
     def pool(self, kind, src: View, k, s, p, dst: Optional[View] = None) -> View:
@@ -239,6 +246,19 @@ def _pool_desc(g: Graph, op: Op, nb: int, dt: int) -> L.PoolDesc:
     return d
 
 
+def _pooled_descs(g: Graph, op: Op, nb: int, dt: int) -> Tuple[L.ConvDesc, L.PoolDesc]:
+    """conv1x1 src -> tmp [nb,h,w,cout] and avgpool tmp -> dst view for a conv whose pool was commuted behind it"""
+    ts, td = g.tensors[op.src.tid], g.tensors[op.dst.tid]
+    d = _conv_desc(g, op, nb, dt)
+    d.ldo, d.cooff = op.dst.c, 0
+    pd = L.PoolDesc()
+    pd.nb, pd.h, pd.w, pd.c, pd.oh, pd.ow = nb, ts.h, ts.w, op.dst.c, td.h, td.w
+    pd.k, pd.stride, pd.pad = op.pooled
+    pd.ldi, pd.cioff, pd.ldo, pd.cooff = op.dst.c, 0, td.c, op.dst.coff
+    pd.dtype = dt
+    return d, pd
+
+
 BN_EPS = 1e-3      # torchvision BasicConv2d
 
 
@@ -274,11 +294,19 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
                 bias = next(it) if op.bias else None
             wpk = torch.empty(lib.din_conv_packed_elems(C.byref(d), 0), dtype=tdt, device=dev)
             L.check(lib.din_conv_pack_weights(C.byref(d), _ptr(w), _ptr(scale), _ptr(wpk), 0, st), "conv_pack")
-            ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 0), dev)
             flags = (L.CONV_BIAS if bias is not None else 0) | (L.CONV_RELU if op.relu else 0)
-            with _timed("fwd", d):
-                L.check(lib.din_conv_fwd(C.byref(d), _ptr(src), _ptr(wpk), _ptr(bias), _ptr(dst), flags, _ptr(ws), wsb, st),
-                        "conv_fwd " + op.name)
+            if op.pooled is not None:
+                d, pd = _pooled_descs(g, op, nb, dt)
+                tmp = torch.empty((nb, pd.h, pd.w, pd.c), dtype=tdt, device=dev)
+                ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 0), dev)
+                with _timed("fwd", d):
+                    L.check(lib.din_conv_fwd(C.byref(d), _ptr(src), _ptr(wpk), None, _ptr(tmp), 0, _ptr(ws), wsb, st), "conv_fwd " + op.name)
+                L.check(lib.din_avgpool_fwd(C.byref(pd), _ptr(tmp), _ptr(dst), _ptr(bias), flags, st), "avgpool_fwd(epilogue)")
+            else:
+                ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 0), dev)
+                with _timed("fwd", d):
+                    L.check(lib.din_conv_fwd(C.byref(d), _ptr(src), _ptr(wpk), _ptr(bias), _ptr(dst), flags, _ptr(ws), wsb, st),
+                            "conv_fwd " + op.name)
             aux.append((scale,))
         elif op.kind == "maxpool":
             d = _pool_desc(g, op, nb, dt)
@@ -290,8 +318,10 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
             aux.append((amax,))
         elif op.kind in ("avgpool", "bilinear"):
             d = _pool_desc(g, op, nb, dt)
-            fn = {"avgpool": lib.din_avgpool_fwd, "bilinear": lib.din_bilinear_fwd}[op.kind]
-            L.check(fn(C.byref(d), _ptr(src), _ptr(dst), st), op.kind + "_fwd")
+            if op.kind == "avgpool":
+                L.check(lib.din_avgpool_fwd(C.byref(d), _ptr(src), _ptr(dst), None, 0, st), "avgpool_fwd")
+            else:
+                L.check(lib.din_bilinear_fwd(C.byref(d), _ptr(src), _ptr(dst), st), "bilinear_fwd")
             aux.append(())
         else:
             raise L.DinError("unknown op " + op.kind)
@@ -350,14 +380,14 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
         gsrc, acc = grad_target(op0.src)
         srcs = (L.ConvSrc * len(items))()
         keep = []
-        for j, (oi_, gout_, w_, scale_) in enumerate(items):
+        for j, (oi_, gout_, w_, scale_, ldj, coffj) in enumerate(items):
             opj = g.ops[oi_]
             dj = _conv_desc(g, opj, nb, dt)
             wpt = torch.empty(lib.din_conv_packed_elems(C.byref(dj), 1), dtype=tdt, device=dev)
             L.check(lib.din_conv_pack_weights(C.byref(dj), _ptr(w_), _ptr(scale_), _ptr(wpt), 1, st), "conv_pack_t")
             keep.append(wpt)
             srcs[j].dout, srcs[j].wpk_t = gout_.data_ptr(), wpt.data_ptr()
-            srcs[j].cout, srcs[j].ldo, srcs[j].cooff = opj.dst.c, g.tensors[opj.dst.tid].c, opj.dst.coff
+            srcs[j].cout, srcs[j].ldo, srcs[j].cooff = opj.dst.c, ldj, coffj
         flags = (L.CONV_ACCUM if acc else 0) | (L.CONV_MASK if ts0.relu_masked else 0)
         d0 = _conv_desc(g, op0, nb, dt)
         d0.cout = sum(g.ops[it[0]].dst.c for it in items)          # FLOP accounting of the fused launch
@@ -384,25 +414,39 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
             po = offsets[oi]
             w = params[po]
             (scale,) = aux[oi]
+            g_ld, g_coff = g.tensors[op.dst.tid].c, op.dst.coff        # where the gradient at the conv output lives
+            dshift_pre = None
+            if op.pooled is not None:
+                # y = relu(avgpool(conv1x1(x)) + shift): shift gradient = column sums of gout, conv-output gradient = avgpool^T(gout)
+                d, pd = _pooled_descs(g, op, nb, dt)
+                td_ = g.tensors[op.dst.tid]
+                if op.bn or op.bias:
+                    dshift_pre = torch.empty(op.dst.c, dtype=torch.float32, device=dev)
+                    L.check(lib.din_colsum(_ptr(gout), dt, nb * td_.h * td_.w, op.dst.c, td_.c, op.dst.coff, _ptr(dshift_pre), st), "colsum")
+                gtmp = torch.empty((nb, pd.h, pd.w, pd.c), dtype=tdt, device=dev)
+                L.check(lib.din_avgpool_bwd(C.byref(pd), _ptr(gout), _ptr(gtmp), None, 0, st), "avgpool_bwd(epilogue)")
+                gout, g_ld, g_coff = gtmp, pd.c, 0
             # ---- wgrad (+ bias / BN parameter gradients)
             dw = torch.empty_like(w)
             if op.bn:
                 gamma, beta, mean, var = params[po + 1:po + 5]
-                dshift = torch.empty_like(gamma)
+                dshift = dshift_pre if dshift_pre is not None else torch.empty_like(gamma)
                 wdot = torch.empty_like(gamma)
                 ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 2), dev)
                 with _timed("wgrad", d):
-                    L.check(lib.din_conv_wgrad(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dw), _ptr(dshift), _ptr(scale),
+                    L.check(lib.din_conv_wgrad(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dw),
+                                               None if dshift_pre is not None else _ptr(dshift), _ptr(scale),
                                                _ptr(w), _ptr(wdot), 0, _ptr(ws), wsb, st), "conv_wgrad " + op.name)
                 dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
                 L.check(lib.din_bn_fold_bwd(_ptr(wdot), _ptr(dshift), _ptr(mean), _ptr(var), BN_EPS, _ptr(dgamma), _ptr(dbeta),
                                             gamma.numel(), st), "bn_fold_bwd")
                 grads[po], grads[po + 1], grads[po + 2] = dw, dgamma, dbeta
             else:
-                db = torch.empty_like(params[po + 1]) if op.bias else None
+                db = (dshift_pre if dshift_pre is not None else torch.empty_like(params[po + 1])) if op.bias else None
                 ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 2), dev)
                 with _timed("wgrad", d):
-                    L.check(lib.din_conv_wgrad(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dw), _ptr(db), None, None, None, 0,
+                    L.check(lib.din_conv_wgrad(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dw),
+                                               None if dshift_pre is not None else _ptr(db), None, None, None, 0,
                                                _ptr(ws), wsb, st), "conv_wgrad " + op.name)
                 grads[po] = dw
                 if op.bias:
@@ -410,7 +454,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
             # ---- dgrad
             if src_needs_grad and oi in member_of:
                 key = member_of[oi]
-                pending[key].append((oi, gout, w, scale))
+                pending[key].append((oi, gout, w, scale, g_ld, g_coff))
                 remaining[key] -= 1
                 if remaining[key] == 0:
                     flush_group(key)

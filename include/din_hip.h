@@ -86,7 +86,8 @@ int64_t din_conv_packed_elems(const din_conv_desc* d, int transposed);
 int din_conv_pack_weights(const din_conv_desc* d, const float* w, const float* scale, void* wpk,
                           int transposed, void* stream);
 /* which tile variant the planner picks (which: 0 fwd, 1 dgrad -> pixels x filters of conv_gather_*_kernel; 2 wgrad -> filter rows x
- * k columns of conv_wgrad_*_kernel): lets a profiler-side caller name the kernel a launch resolves to */
+ * k columns of conv_wgrad_*_kernel; bm = 0 -> the stationary-filter stem kernel conv_small_kernel with bn filters): lets a
+ * profiler-side caller name the kernel a launch resolves to */
 int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t* bn);
 /* workspace bytes needed by fwd / dgrad / wgrad for this descriptor (split-K partial sums) */
 int64_t din_conv_workspace_bytes(const din_conv_desc* d, int which /*0 fwd,1 dgrad,2 wgrad*/);
@@ -115,6 +116,9 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
                    const float* scale, const float* w, float* wdot, int accumulate,
                    void* workspace, int64_t workspace_bytes, void* stream);
 
+/* out[c] = sum over rows of g[row*ld + coff + c] (fp32 result; BatchNorm shift gradient of a conv whose epilogue ran in the pool) */
+int din_colsum(const void* g, int dtype, int64_t rows, int c, int ld, int coff, float* out, void* stream);
+
 /* BatchNorm(eval) folding helpers (torchvision BasicConv2d, eps=1e-3; train_net_dynamic.py:17-20 set_bn_eval)
  * scale = gamma*rsqrt(var+eps); shift = beta - mean*scale                                                */
 int din_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
@@ -142,7 +146,10 @@ int din_maxpool_fwd(const din_pool_desc* d, const void* in, void* out, uint8_t* 
  * is recomputed from `in`.                                                                                          */
 int din_maxpool_bwd(const din_pool_desc* d, const void* in, const uint8_t* argmax, const void* dout, void* din_,
                     int relu_mask, int accumulate, void* stream);
-int din_avgpool_fwd(const din_pool_desc* d, const void* in, void* out, void* stream);   /* count_include_pad */
+/* F.avg_pool2d(x, k, stride, pad) with count_include_pad (backbone: torchvision InceptionA/C branch_pool).  flags: DIN_CONV_BIAS adds
+ * bias[c] (fp32) after the average, DIN_CONV_RELU clamps: the epilogue of a 1x1 conv commuted in front of the pool
+ * (avgpool(conv1x1(x)) == conv1x1(avgpool(x)), both linear, zero padding maps to zero) -- the pool then runs on cout channels */
+int din_avgpool_fwd(const din_pool_desc* d, const void* in, void* out, const float* bias, int flags, void* stream);
 int din_avgpool_bwd(const din_pool_desc* d, const void* dout, void* din_, const void* mask, int accumulate,
                     void* stream);
 int din_bilinear_fwd(const din_pool_desc* d, const void* in, void* out, void* stream); /* align_corners=True */

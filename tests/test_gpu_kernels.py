@@ -204,9 +204,16 @@ def test_pools(env, kind, k, s, p, dtype, ldi, cioff):
     if kind == "maxpool":
         L.check(lib.din_maxpool_fwd(C.byref(d), xin.data_ptr(), out.data_ptr(), amax.data_ptr(), None))
     else:
-        L.check(lib.din_avgpool_fwd(C.byref(d), xin.data_ptr(), out.data_ptr(), None))
+        L.check(lib.din_avgpool_fwd(C.byref(d), xin.data_ptr(), out.data_ptr(), None, 0, None))
     tol = 1e-6 if dtype == "fp32" else 8e-3
     assert rel(from_nhwc(out, 16), y) <= tol
+    if kind == "avgpool":                                                 # fused bias + ReLU epilogue (commuted 1x1 conv) and colsum
+        bias = torch.randn(16, generator=g).cuda()
+        L.check(lib.din_avgpool_fwd(C.byref(d), xin.data_ptr(), out.data_ptr(), bias.data_ptr(), L.CONV_BIAS | L.CONV_RELU, None))
+        assert rel(from_nhwc(out, 16), F.relu(y + bias.cpu().view(1, -1, 1, 1))) <= tol
+        cs = torch.empty(16, device="cuda")
+        L.check(lib.din_colsum(xin.data_ptr(), d.dtype, 2 * 13 * 15, 16, ldi, cioff, cs.data_ptr(), None))
+        assert rel(cs, x.sum(dim=(0, 2, 3))) <= (1e-5 if dtype == "fp32" else 1e-5)
     gout = to_nhwc(cot, tdt)
     dx = torch.zeros_like(xin)
     if kind == "maxpool":
