@@ -160,8 +160,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_generic_kernel(ConvK 
     constexpr int BUF = (BM + BN) * KC;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int co_tile = blockIdx.x % p.n_co_tiles, px_tile = blockIdx.x / p.n_co_tiles;
-    const int split = blockIdx.y;
+    int bx_, by_;
+    xcd_block(bx_, by_);
+    const int co_tile = bx_ % p.n_co_tiles, px_tile = bx_ / p.n_co_tiles;
+    const int split = by_;
     const int ks_begin = split * p.ks_per_split;
     int ks_end = ks_begin + p.ks_per_split;
     if (ks_end > p.nk) ks_end = p.nk;
@@ -281,8 +283,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int co_tile = blockIdx.x % p.n_co_tiles, px_tile = blockIdx.x / p.n_co_tiles;
-    const int split = blockIdx.y;
+    int bx_, by_;
+    xcd_block(bx_, by_);
+    const int co_tile = bx_ % p.n_co_tiles, px_tile = bx_ / p.n_co_tiles;
+    const int split = by_;
     // host counts k-steps in units of 8 chunks (the packing granularity); this kernel steps KCS chunks
     const int ks_begin = split * p.ks_per_split * (8 / KCS);
     int ks_end = ks_begin + p.ks_per_split * (8 / KCS);
@@ -671,7 +675,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_small_kernel(ConvK p) {
 
     const int frow = lane & 15, g4 = lane >> 4;
     int cur = 0;
-    int tile = blockIdx.x;
+    // persistent walk: round i covers tiles [i*G, (i+1)*G); inside a round every XCD takes a contiguous run (shared halo rows hit L2)
+    int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     bool first = true;
     if (tile < ntiles) issue_halo(0, tile);
     __syncthreads();                                                                   // filters visible
@@ -859,10 +864,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_f32_kernel(WgradK p) {
     __shared__ float Xs[2][PK][RS];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    int bid = blockIdx.x;
+    int bid, slice_;
+    xcd_block(bid, slice_);
     const int k_tile = bid % p.n_k_tiles;
     const int co_tile = bid / p.n_k_tiles;
-    const int slice = blockIdx.y;
+    const int slice = slice_;
     const int m_begin = slice * p.m_per_slice;
     int m_end = m_begin + p.m_per_slice;
     if (m_end > p.M) m_end = p.M;
@@ -997,8 +1003,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int k_tile = blockIdx.x % p.n_k_tiles, co_tile = blockIdx.x / p.n_k_tiles;
-    const int slice = blockIdx.y;
+    int bx_, by_;
+    xcd_block(bx_, by_);
+    const int k_tile = bx_ % p.n_k_tiles, co_tile = bx_ / p.n_k_tiles;
+    const int slice = by_;
     const int m_begin = slice * p.m_per_slice;                   // multiple of PK
     int m_end = m_begin + p.m_per_slice;
     if (m_end > p.M) m_end = p.M;
@@ -1185,10 +1193,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_tail_kernel(Wgrad
     constexpr int OPB = PK * RSB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    int bid = blockIdx.x;
+    int bid, slice_;
+    xcd_block(bid, slice_);
     const int k_tile = bid % p.n_k_tiles;
     const int co_tile = bid / p.n_k_tiles;
-    const int slice = blockIdx.y;
+    const int slice = slice_;
     const int m_begin = slice * p.m_per_slice;
     int m_end = m_begin + p.m_per_slice;
     if (m_end > p.M) m_end = p.M;
