@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--frames", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adam", action="store_true")
+    ap.add_argument("--per-layer", default="", help="write the per-layer conv launch table of the sampled step to this file")
     a = ap.parse_args()
 
     from din_amd import nhwc, parallel
@@ -213,7 +214,13 @@ def main():
 
     # ---- roofline of the dominant kernel from the live HIP events -------------------------------------------
     agg = {}
-    for kind, variant, flops, dt_, e0, e1 in prof:
+    if a.per_layer and rank == 0:
+        rows = sorted(((max(e0.elapsed_time(e1) - event_overhead_ms, 0.0), kind, name, variant, flops) for kind, variant, flops, dt_, e0, e1, name in prof),
+                      reverse=True)
+        with open(a.per_layer, "w") as f:
+            for ms, kind, name, variant, flops in rows:
+                f.write(f"{ms * 1e3:9.1f} us  {flops / max(ms, 1e-6) / 1e9:7.1f} TF  {kind:5s} {name:60s} {variant}\n")
+    for kind, variant, flops, dt_, e0, e1, _name in prof:
         rec = agg.setdefault(variant, [0.0, 0.0, 0])
         rec[0] += flops
         rec[1] += max(e0.elapsed_time(e1) - event_overhead_ms, 0.0) * 1e-3

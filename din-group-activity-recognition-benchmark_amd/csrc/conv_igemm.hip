@@ -1380,36 +1380,50 @@ __global__ void colsum_kernel(const T* __restrict__ g, float* __restrict__ out, 
     }
 }
 
-// vectorised form: thread = (row lane r, 4-channel group c); 8-/16-byte loads, LDS cross-row reduce, one atomic per column per block
+// vectorised form: thread = (row lane r, 16-byte channel chunk c); four rows in flight per thread, LDS cross-row reduce, one atomic
+// per column per block
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ g, float* __restrict__ out, int64_t M, int cout, int ld,
                                                          int coff, int64_t rows_per_block) {
-    __shared__ f32x4 red[256];
-    const int ncg = cout >> 2;                       // <= 256
+    constexpr int EPC = 16 / sizeof(T);
+    __shared__ float red[256][EPC + 1];
+    const int ncg = cout / EPC;                      // <= 256
     const int rows_pp = 256 / ncg;
     const int r = threadIdx.x / ncg, c = threadIdx.x - r * ncg;
-    int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block;
+    int64_t r0 = (int64_t)xcd_remap((int)blockIdx.x, (int)gridDim.x) * rows_per_block, r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (r < rows_pp) {
-        for (int64_t row = r0 + r; row < r1; row += rows_pp) {
-            const T* src = g + row * ld + coff + c * 4;
-            if constexpr (sizeof(T) == 4) {
-                acc += *reinterpret_cast<const f32x4*>(src);
-            } else {
-                u32x2 v = *reinterpret_cast<const u32x2*>(src);
-                acc[0] += __uint_as_float(v[0] << 16); acc[1] += __uint_as_float(v[0] & 0xffff0000u);
-                acc[2] += __uint_as_float(v[1] << 16); acc[3] += __uint_as_float(v[1] & 0xffff0000u);
-            }
-        }
-    }
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    if (threadIdx.x < ncg) {
-        f32x4 t = red[threadIdx.x];
-        for (int k = 1; k < rows_pp; ++k) t += red[k * ncg + threadIdx.x];
+    float acc[EPC];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(out + threadIdx.x * 4 + e, t[e]);
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    auto add = [&](const u32x4& v) {
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += __uint_as_float(v[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[2 * e] += __uint_as_float(v[e] << 16); acc[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u); }
+        }
+    };
+    if (r < rows_pp) {
+        const T* base = g + coff + c * EPC;
+        int64_t row = r0 + r;
+        for (; row + 3 * rows_pp < r1; row += 4 * rows_pp) {
+            const u32x4 v0 = *reinterpret_cast<const u32x4*>(base + row * ld);
+            const u32x4 v1 = *reinterpret_cast<const u32x4*>(base + (row + rows_pp) * ld);
+            const u32x4 v2 = *reinterpret_cast<const u32x4*>(base + (row + 2 * rows_pp) * ld);
+            const u32x4 v3 = *reinterpret_cast<const u32x4*>(base + (row + 3 * rows_pp) * ld);
+            add(v0); add(v1); add(v2); add(v3);
+        }
+        for (; row < r1; row += rows_pp) add(*reinterpret_cast<const u32x4*>(base + row * ld));
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) red[threadIdx.x][e] = acc[e];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < ncg * EPC; idx += 256) {
+        const int cc = idx / EPC, e = idx - cc * EPC;
+        float t = 0.f;
+        for (int k = 0; k < rows_pp; ++k) t += red[k * ncg + cc][e];
+        atomicAdd(out + idx, t);
     }
 }
 
@@ -1678,9 +1692,10 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
 // column sums of a pixel-major tensor view -> out[c] (zeroed here, fp32 atomics across row slabs)
 static int launch_colsum(int dtype, const void* g, float* out, int64_t M, int c, int ld, int coff, hipStream_t st) {
     hipMemsetAsync(out, 0, sizeof(float) * c, st);
-    if (c % 4 == 0 && c <= 1024 && ld % 4 == 0 && coff % 4 == 0) {
-        // ~2048 workgroups, each streaming a contiguous slab of rows
-        int64_t rpb = ceil_div64(M, 2048);
+    const int epc = dtype == DIN_F32 ? 4 : 8;
+    if (c % epc == 0 && c / epc <= 256 && ld % epc == 0 && coff % epc == 0) {
+        // ~1024 workgroups, each streaming a contiguous slab of rows (XCD-contiguous order)
+        int64_t rpb = ceil_div64(M, 1024);
         if (rpb < 64) rpb = 64;
         int blocks = (int)ceil_div64(M, rpb);
         if (dtype == DIN_F32)

@@ -1,0 +1,572 @@
+// Pools and bilinear resize of the DIN stage-2 backbone path for gfx950 (HBM-bound; no MFMA work here).
+//   max_pool2d (backbone.py MyVGG16 / torchvision Inception3 stem + InceptionB), avg_pool2d count_include_pad (InceptionA/C
+//   branch_pool), F.interpolate(bilinear, align_corners=True) (infer_model.py:165-172 multiscale fuse).
+// All tensors are NHWC views (pixel stride, channel offset).  One thread = V channels of one pixel: V = 8 (16-byte bf16 vectors) when
+// the view allows it, else V = 4 (8-/16-byte vectors, either storage type).  What makes these kernels run at the memory system's
+// speed rather than the ALU's / the latency's:
+//   * the linear index -> (n, y, x, channel group) decode uses host-precomputed multiply-shift reciprocals (three 64-bit
+//     divisions per element cost more than the element's memory traffic);
+//   * the 3x3 / 2x2 windows are template constants: all taps are issued as independent, predicated loads (clamped address +
+//     select) instead of a data-dependent loop with one load in flight;
+//   * workgroups walk the tensor in XCD-contiguous order (din_common.h xcd_remap) so the rows a window shares with its
+//     neighbours are L2 hits.
+#include "din_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// ---- index decode ---------------------------------------------------------------------------------------------------------------
+struct FastDiv { uint32_t mul; int shift; int d; };      // q = n / d for 0 <= n < 2^31:  mul == 0 -> d == 1
+FastDiv make_fastdiv(int d) {
+    FastDiv f{0u, 0, d};
+    if (d <= 1) return f;
+    int l = 0;
+    while ((1ll << l) < d) ++l;                           // ceil(log2 d) >= 1
+    f.mul = (uint32_t)(((1ull << (31 + l)) + (uint64_t)d - 1) / (uint64_t)d);   // ceil(2^(31+l) / d) <= 2^32 - 1 for d >= 2
+    f.shift = l - 1;
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) { return f.mul ? (__umulhi(n, f.mul) >> f.shift) : n; }
+
+struct Dec3 { FastDiv c, w, h; int fast; };              // element id -> (channel group, x, y, n); fast: total < 2^31
+Dec3 make_dec(int cgroups, int w, int h, int64_t total) { return Dec3{make_fastdiv(cgroups), make_fastdiv(w), make_fastdiv(h), total < (1ll << 31) ? 1 : 0}; }
+__device__ __forceinline__ void decode(const Dec3& dd, int64_t i, int& cg, int& x, int& y, int& n, int64_t& p) {
+    if (dd.fast) {
+        const uint32_t ii = (uint32_t)i;
+        const uint32_t pp = fdiv(ii, dd.c);
+        cg = (int)(ii - pp * (uint32_t)dd.c.d);
+        const uint32_t q = fdiv(pp, dd.w);
+        x = (int)(pp - q * (uint32_t)dd.w.d);
+        const uint32_t nn = fdiv(q, dd.h);
+        y = (int)(q - nn * (uint32_t)dd.h.d);
+        n = (int)nn; p = (int64_t)pp;
+    } else {
+        p = i / dd.c.d; cg = (int)(i - p * dd.c.d);
+        int64_t q = p / dd.w.d; x = (int)(p - q * dd.w.d);
+        n = (int)(q / dd.h.d); y = (int)(q - (int64_t)n * dd.h.d);
+    }
+}
+#define DIN_GRID_STRIDE(i, total) \
+    for (int64_t i = (int64_t)xcd_remap((int)blockIdx.x, (int)gridDim.x) * blockDim.x + threadIdx.x; i < (total); i += (int64_t)gridDim.x * blockDim.x)
+
+// ---- V-channel vectors ----------------------------------------------------------------------------------------------------------
+template <int V> struct Vec { float v[V]; };
+template <int V> __device__ __forceinline__ Vec<V> vzero() { Vec<V> r; for (int e = 0; e < V; ++e) r.v[e] = 0.f; return r; }
+template <int V> __device__ __forceinline__ Vec<V> vload(const void* base, int dtype, int64_t i);
+template <> __device__ __forceinline__ Vec<4> vload<4>(const void* base, int dtype, int64_t i) {
+    Vec<4> o;
+    if (dtype == DIN_F32) {
+        f32x4 t = *reinterpret_cast<const f32x4*>((const float*)base + i);
+        o.v[0] = t[0]; o.v[1] = t[1]; o.v[2] = t[2]; o.v[3] = t[3];
+    } else {
+        uint2 r = *reinterpret_cast<const uint2*>((const bf16_t*)base + i);
+        o.v[0] = __uint_as_float(r.x << 16); o.v[1] = __uint_as_float(r.x & 0xffff0000u);
+        o.v[2] = __uint_as_float(r.y << 16); o.v[3] = __uint_as_float(r.y & 0xffff0000u);
+    }
+    return o;
+}
+template <> __device__ __forceinline__ Vec<8> vload<8>(const void* base, int, int64_t i) {       // bf16 only
+    uint4 r = *reinterpret_cast<const uint4*>((const bf16_t*)base + i);
+    Vec<8> o;
+    o.v[0] = __uint_as_float(r.x << 16); o.v[1] = __uint_as_float(r.x & 0xffff0000u);
+    o.v[2] = __uint_as_float(r.y << 16); o.v[3] = __uint_as_float(r.y & 0xffff0000u);
+    o.v[4] = __uint_as_float(r.z << 16); o.v[5] = __uint_as_float(r.z & 0xffff0000u);
+    o.v[6] = __uint_as_float(r.w << 16); o.v[7] = __uint_as_float(r.w & 0xffff0000u);
+    return o;
+}
+template <int V> __device__ __forceinline__ void vstore(void* base, int dtype, int64_t i, const Vec<V>& a);
+template <> __device__ __forceinline__ void vstore<4>(void* base, int dtype, int64_t i, const Vec<4>& a) {
+    if (dtype == DIN_F32) { *reinterpret_cast<f32x4*>((float*)base + i) = f32x4{a.v[0], a.v[1], a.v[2], a.v[3]}; return; }
+    *reinterpret_cast<uint2*>((bf16_t*)base + i) = uint2{pack_bf16x2(a.v[0], a.v[1]), pack_bf16x2(a.v[2], a.v[3])};
+}
+template <> __device__ __forceinline__ void vstore<8>(void* base, int, int64_t i, const Vec<8>& a) {
+    *reinterpret_cast<uint4*>((bf16_t*)base + i) =
+        uint4{pack_bf16x2(a.v[0], a.v[1]), pack_bf16x2(a.v[2], a.v[3]), pack_bf16x2(a.v[4], a.v[5]), pack_bf16x2(a.v[6], a.v[7])};
+}
+// V arg-max bytes
+template <int V> __device__ __forceinline__ void amax_load(const uint8_t* p, uint32_t (&w)[V / 4]);
+template <> __device__ __forceinline__ void amax_load<4>(const uint8_t* p, uint32_t (&w)[1]) { w[0] = *reinterpret_cast<const uint32_t*>(p); }
+template <> __device__ __forceinline__ void amax_load<8>(const uint8_t* p, uint32_t (&w)[2]) {
+    uint2 t = *reinterpret_cast<const uint2*>(p); w[0] = t.x; w[1] = t.y;
+}
+
+// ---- max pool -------------------------------------------------------------------------------------------------------------------
+// Forward optionally records, per pooled element, which window tap won (first maximum in scan order = PyTorch's tie rule) as one
+// byte: tap index r*k+s, or 255 when the winner is <= 0 (the fused ReLU backward would zero its gradient anyway).
+// K = 0: runtime window size (loop form).
+template <int V, int K>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(din_pool_desc d, Dec3 dd, const void* __restrict__ in, void* __restrict__ out,
+                                                          uint8_t* __restrict__ amax) {
+    const int64_t total = (int64_t)d.nb * d.oh * d.ow * (d.c / V);
+    const int k = K ? K : d.k;
+    DIN_GRID_STRIDE(i, total) {
+        int cg, ox, oy, n; int64_t p;
+        decode(dd, i, cg, ox, oy, n, p);
+        Vec<V> m; int am[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) { m.v[e] = -INFINITY; am[e] = 0; }
+        const int y0 = oy * d.stride - d.pad, x0 = ox * d.stride - d.pad;
+        const int64_t img = (int64_t)n * d.h;
+        if (K) {
+            Vec<V> t[K ? K * K : 1];
+#pragma unroll
+            for (int r = 0; r < K; ++r)
+#pragma unroll
+                for (int s = 0; s < K; ++s) {
+                    const int iy = min(max(y0 + r, 0), d.h - 1), ix = min(max(x0 + s, 0), d.w - 1);
+                    t[r * K + s] = vload<V>(in, d.dtype, ((img + iy) * d.w + ix) * d.ldi + d.cioff + cg * V);
+                }
+#pragma unroll
+            for (int r = 0; r < K; ++r)
+#pragma unroll
+                for (int s = 0; s < K; ++s) {
+                    const bool ok = y0 + r >= 0 && y0 + r < d.h && x0 + s >= 0 && x0 + s < d.w;
+#pragma unroll
+                    for (int e = 0; e < V; ++e)
+                        if (ok && t[r * K + s].v[e] > m.v[e]) { m.v[e] = t[r * K + s].v[e]; am[e] = r * K + s; }   // first max wins on ties
+                }
+        } else {
+            for (int r = 0; r < k; ++r) {
+                const int iy = y0 + r;
+                if (iy < 0 || iy >= d.h) continue;
+                for (int s = 0; s < k; ++s) {
+                    const int ix = x0 + s;
+                    if (ix < 0 || ix >= d.w) continue;
+                    Vec<V> t = vload<V>(in, d.dtype, ((img + iy) * d.w + ix) * d.ldi + d.cioff + cg * V);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) if (t.v[e] > m.v[e]) { m.v[e] = t.v[e]; am[e] = r * k + s; }
+                }
+            }
+        }
+        vstore<V>(out, d.dtype, p * d.ldo + d.cooff + cg * V, m);
+        if (amax) {
+            uint32_t pk[V / 4];
+#pragma unroll
+            for (int q = 0; q < V / 4; ++q) {
+                pk[q] = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[q] |= (uint32_t)(m.v[q * 4 + e] > 0.f ? am[q * 4 + e] : 255) << (8 * e);
+            }
+            if (V == 4) *reinterpret_cast<uint32_t*>(amax + p * d.c + cg * V) = pk[0];
+            else *reinterpret_cast<uint2*>(amax + p * d.c + cg * V) = uint2{pk[0], pk[V / 4 - 1]};
+        }
+    }
+}
+
+// Backward from the saved map (gather form, no atomics, no re-read of the input): each input element visits the <= ceil(k/s)^2
+// windows that contain it and takes the gradient where the recorded tap is itself.  NW = windows per axis (template) or 0 (loop).
+template <int V, int NW>
+__global__ __launch_bounds__(256) void maxpool_bwd_amax_kernel(din_pool_desc d, Dec3 dd, const uint8_t* __restrict__ amax,
+                                                               const void* __restrict__ dout, void* __restrict__ din_, int accumulate) {
+    const int64_t total = (int64_t)d.nb * d.h * d.w * (d.c / V);
+    DIN_GRID_STRIDE(i, total) {
+        int cg, ix, iy, n; int64_t p;
+        decode(dd, i, cg, ix, iy, n, p);
+        Vec<V> g = vzero<V>();
+        int oy_hi = (iy + d.pad) / d.stride, ox_hi = (ix + d.pad) / d.stride;
+        int oy_lo = (iy + d.pad - d.k + d.stride) / d.stride, ox_lo = (ix + d.pad - d.k + d.stride) / d.stride;
+        if (iy + d.pad - d.k + 1 < 0) oy_lo = 0;
+        if (ix + d.pad - d.k + 1 < 0) ox_lo = 0;
+        if (oy_hi >= d.oh) oy_hi = d.oh - 1;
+        if (ox_hi >= d.ow) ox_hi = d.ow - 1;
+        const int64_t img = (int64_t)n * d.oh;
+        auto visit = [&](int oy, int ox, bool ok, uint32_t (&pk)[V / 4], Vec<V>& go, uint32_t& tap) {
+            const int oyc = min(max(oy, 0), d.oh - 1), oxc = min(max(ox, 0), d.ow - 1);
+            const int64_t po = (img + oyc) * d.ow + oxc;
+            amax_load<V>(amax + po * d.c + cg * V, pk);
+            go = vload<V>(dout, d.dtype, po * d.ldo + d.cooff + cg * V);
+            tap = ok ? (uint32_t)((iy - (oy * d.stride - d.pad)) * d.k + (ix - (ox * d.stride - d.pad))) : 254u;   // 254: never recorded
+        };
+        if (NW) {
+            uint32_t pk[NW ? NW * NW : 1][V / 4], tap[NW ? NW * NW : 1];
+            Vec<V> go[NW ? NW * NW : 1];
+#pragma unroll
+            for (int a = 0; a < NW; ++a)
+#pragma unroll
+                for (int b = 0; b < NW; ++b) {
+                    const int oy = oy_hi - a, ox = ox_hi - b;
+                    visit(oy, ox, oy >= oy_lo && ox >= ox_lo, pk[a * NW + b], go[a * NW + b], tap[a * NW + b]);
+                }
+#pragma unroll
+            for (int t = 0; t < NW * NW; ++t)
+#pragma unroll
+                for (int e = 0; e < V; ++e) g.v[e] += ((pk[t][e / 4] >> (8 * (e & 3))) & 0xff) == tap[t] ? go[t].v[e] : 0.f;
+        } else {
+            for (int oy = oy_lo; oy <= oy_hi; ++oy)
+                for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                    uint32_t pk[V / 4], tap; Vec<V> go;
+                    visit(oy, ox, true, pk, go, tap);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) g.v[e] += ((pk[e / 4] >> (8 * (e & 3))) & 0xff) == tap ? go.v[e] : 0.f;
+                }
+        }
+        const int64_t self_off = p * d.ldi + d.cioff + cg * V;
+        if (accumulate) { Vec<V> o = vload<V>(din_, d.dtype, self_off);
+#pragma unroll
+            for (int e = 0; e < V; ++e) g.v[e] += o.v[e]; }
+        vstore<V>(din_, d.dtype, self_off, g);
+    }
+}
+
+// Map-free backward (recomputes each window's arg-max): for callers that did not save the map.
+__global__ void maxpool_bwd_kernel(din_pool_desc d, Dec3 dd, const void* __restrict__ in, const void* __restrict__ dout,
+                                   void* __restrict__ din_, int relu_mask, int accumulate) {
+    constexpr int V = 4;
+    const int64_t total = (int64_t)d.nb * d.h * d.w * (d.c / V);
+    DIN_GRID_STRIDE(i, total) {
+        int cg, ix, iy, n; int64_t p;
+        decode(dd, i, cg, ix, iy, n, p);
+        const int64_t self_off = p * d.ldi + d.cioff + cg * V;
+        Vec<V> xv = vload<V>(in, d.dtype, self_off);
+        Vec<V> g = vzero<V>();
+        int oy_hi = (iy + d.pad) / d.stride, ox_hi = (ix + d.pad) / d.stride;
+        int oy_lo = (iy + d.pad - d.k + d.stride) / d.stride, ox_lo = (ix + d.pad - d.k + d.stride) / d.stride;
+        if (iy + d.pad - d.k + 1 < 0) oy_lo = 0;
+        if (ix + d.pad - d.k + 1 < 0) ox_lo = 0;
+        if (oy_hi >= d.oh) oy_hi = d.oh - 1;
+        if (ox_hi >= d.ow) ox_hi = d.ow - 1;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                bool win[V] = {true, true, true, true};
+                for (int r = 0; r < d.k; ++r) {
+                    int yy = oy * d.stride - d.pad + r;
+                    if (yy < 0 || yy >= d.h) continue;
+                    for (int s = 0; s < d.k; ++s) {
+                        int xx = ox * d.stride - d.pad + s;
+                        if (xx < 0 || xx >= d.w) continue;
+                        if (yy == iy && xx == ix) continue;
+                        Vec<V> v = vload<V>(in, d.dtype, ((int64_t)(n * d.h + yy) * d.w + xx) * d.ldi + d.cioff + cg * V);
+                        bool before = (yy < iy) || (yy == iy && xx < ix);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) win[e] = win[e] && (before ? v.v[e] < xv.v[e] : v.v[e] <= xv.v[e]);
+                    }
+                }
+                Vec<V> go = vload<V>(dout, d.dtype, ((int64_t)(n * d.oh + oy) * d.ow + ox) * d.ldo + d.cooff + cg * V);
+#pragma unroll
+                for (int e = 0; e < V; ++e) g.v[e] += win[e] ? go.v[e] : 0.f;
+            }
+        if (relu_mask) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) g.v[e] = xv.v[e] > 0.f ? g.v[e] : 0.f;
+        }
+        if (accumulate) { Vec<V> o = vload<V>(din_, d.dtype, self_off);
+#pragma unroll
+            for (int e = 0; e < V; ++e) g.v[e] += o.v[e]; }
+        vstore<V>(din_, d.dtype, self_off, g);
+    }
+}
+
+// ---- average pool (count_include_pad) -------------------------------------------------------------------------------------------
+// BOX3: k = 3, stride 1, pad 1 (the only shape the backbones use): forward and backward are the same zero-padded box filter.
+// The box rows are summed top-to-bottom, taps left-to-right (the order of the loop form), so both forms give identical bits.
+template <int V>
+__device__ __forceinline__ Vec<V> box3(const void* __restrict__ src, int dtype, int64_t img, int h, int w, int y, int x, int ld, int off) {
+    Vec<V> t[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int yy = min(max(y + r - 1, 0), h - 1), xx = min(max(x + s - 1, 0), w - 1);
+            t[r * 3 + s] = vload<V>(src, dtype, ((img + yy) * w + xx) * ld + off);
+        }
+    Vec<V> a = vzero<V>();
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const bool ok = y + r - 1 >= 0 && y + r - 1 < h && x + s - 1 >= 0 && x + s - 1 < w;
+#pragma unroll
+            for (int e = 0; e < V; ++e) a.v[e] += ok ? t[r * 3 + s].v[e] : 0.f;
+        }
+    return a;
+}
+// flags: DIN_CONV_BIAS adds bias[c] after the average, DIN_CONV_RELU clamps -- the epilogue of a 1x1 conv that was commuted in
+// front of the pool (avgpool(conv1x1(x)) == conv1x1(avgpool(x)): both linear, zero padding maps to zero)
+template <int V, bool BOX3>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(din_pool_desc d, Dec3 dd, const void* __restrict__ in, void* __restrict__ out,
+                                                          const float* __restrict__ bias, int flags) {
+    const int64_t total = (int64_t)d.nb * d.oh * d.ow * (d.c / V);
+    const float inv = 1.f / (float)(d.k * d.k);
+    DIN_GRID_STRIDE(i, total) {
+        int cg, ox, oy, n; int64_t p;
+        decode(dd, i, cg, ox, oy, n, p);
+        Vec<V> a;
+        if (BOX3) {
+            a = box3<V>(in, d.dtype, (int64_t)n * d.h, d.h, d.w, oy, ox, d.ldi, d.cioff + cg * V);
+        } else {
+            a = vzero<V>();
+            for (int r = 0; r < d.k; ++r) {
+                int iy = oy * d.stride - d.pad + r;
+                if (iy < 0 || iy >= d.h) continue;
+                for (int s = 0; s < d.k; ++s) {
+                    int ix = ox * d.stride - d.pad + s;
+                    if (ix < 0 || ix >= d.w) continue;
+                    Vec<V> t = vload<V>(in, d.dtype, ((int64_t)(n * d.h + iy) * d.w + ix) * d.ldi + d.cioff + cg * V);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) a.v[e] += t.v[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float v = a.v[e] * inv;
+            if (flags & DIN_CONV_BIAS) v += bias[cg * V + e];
+            if (flags & DIN_CONV_RELU) v = fmaxf(v, 0.f);
+            a.v[e] = v;
+        }
+        vstore<V>(out, d.dtype, p * d.ldo + d.cooff + cg * V, a);
+    }
+}
+template <int V, bool BOX3>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(din_pool_desc d, Dec3 dd, const void* __restrict__ dout, void* __restrict__ din_,
+                                                          const void* __restrict__ mask, int accumulate) {
+    const int64_t total = (int64_t)d.nb * d.h * d.w * (d.c / V);
+    const float inv = 1.f / (float)(d.k * d.k);
+    DIN_GRID_STRIDE(i, total) {
+        int cg, ix, iy, n; int64_t p;
+        decode(dd, i, cg, ix, iy, n, p);
+        Vec<V> g;
+        if (BOX3) {
+            // taps r = 0..2 of the loop form visit output rows iy+1, iy, iy-1: mirror the box so the summation order is unchanged
+            Vec<V> t[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int yy = min(max(iy + 1 - r, 0), d.oh - 1), xx = min(max(ix + 1 - s, 0), d.ow - 1);
+                    t[r * 3 + s] = vload<V>(dout, d.dtype, (((int64_t)n * d.oh + yy) * d.ow + xx) * d.ldo + d.cooff + cg * V);
+                }
+            g = vzero<V>();
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const bool ok = iy + 1 - r >= 0 && iy + 1 - r < d.oh && ix + 1 - s >= 0 && ix + 1 - s < d.ow;
+#pragma unroll
+                    for (int e = 0; e < V; ++e) g.v[e] += ok ? t[r * 3 + s].v[e] : 0.f;
+                }
+        } else {
+            g = vzero<V>();
+            for (int r = 0; r < d.k; ++r) {
+                int ty = iy + d.pad - r;
+                if (ty < 0 || ty % d.stride) continue;
+                int oy = ty / d.stride;
+                if (oy >= d.oh) continue;
+                for (int s = 0; s < d.k; ++s) {
+                    int tx = ix + d.pad - s;
+                    if (tx < 0 || tx % d.stride) continue;
+                    int ox = tx / d.stride;
+                    if (ox >= d.ow) continue;
+                    Vec<V> t = vload<V>(dout, d.dtype, ((int64_t)(n * d.oh + oy) * d.ow + ox) * d.ldo + d.cooff + cg * V);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) g.v[e] += t.v[e];
+                }
+            }
+        }
+        const int64_t off = p * d.ldi + d.cioff + cg * V;
+#pragma unroll
+        for (int e = 0; e < V; ++e) g.v[e] *= inv;
+        if (mask) { Vec<V> y = vload<V>(mask, d.dtype, off);
+#pragma unroll
+            for (int e = 0; e < V; ++e) g.v[e] = y.v[e] > 0.f ? g.v[e] : 0.f; }
+        if (accumulate) { Vec<V> o = vload<V>(din_, d.dtype, off);
+#pragma unroll
+            for (int e = 0; e < V; ++e) g.v[e] += o.v[e]; }
+        vstore<V>(din_, d.dtype, off, g);
+    }
+}
+
+// ---- bilinear resize, align_corners=True (infer_model.py:169): src = dst*(in-1)/(out-1) -----------------------------------------
+__device__ __forceinline__ void bil_coord(int o, int in, int out, int& i0, int& i1, float& l) {
+    float sc = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    float src = sc * (float)o;
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + 1 < in ? i0 + 1 : in - 1;
+    l = src - (float)i0;
+}
+template <int V>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(din_pool_desc d, Dec3 dd, const void* __restrict__ in, void* __restrict__ out) {
+    const int64_t total = (int64_t)d.nb * d.oh * d.ow * (d.c / V);
+    DIN_GRID_STRIDE(i, total) {
+        int cg, ox, oy, n; int64_t p;
+        decode(dd, i, cg, ox, oy, n, p);
+        int y0, y1, x0, x1; float ly, lx;
+        bil_coord(oy, d.h, d.oh, y0, y1, ly);
+        bil_coord(ox, d.w, d.ow, x0, x1, lx);
+        auto at = [&](int y, int x) { return vload<V>(in, d.dtype, ((int64_t)(n * d.h + y) * d.w + x) * d.ldi + d.cioff + cg * V); };
+        const Vec<V> a = at(y0, x0), b = at(y0, x1), c = at(y1, x0), e2 = at(y1, x1);
+        Vec<V> o;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float top = a.v[e] * (1.f - lx) + b.v[e] * lx;
+            const float bot = c.v[e] * (1.f - lx) + e2.v[e] * lx;
+            o.v[e] = top * (1.f - ly) + bot * ly;
+        }
+        vstore<V>(out, d.dtype, p * d.ldo + d.cooff + cg * V, o);
+    }
+}
+// gather-form backward: each input cell sums the contributions of the output cells whose 2x2 footprint touches it.  Because the map
+// is monotone, candidate outputs for input row y are those with source coordinate in (y-1, y+1): a short output range per axis.
+template <int V>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(din_pool_desc d, Dec3 dd, const void* __restrict__ dout, void* __restrict__ din_,
+                                                           const void* __restrict__ mask, int accumulate) {
+    const int64_t total = (int64_t)d.nb * d.h * d.w * (d.c / V);
+    const float scy = d.oh > 1 ? (float)(d.h - 1) / (float)(d.oh - 1) : 0.f;
+    const float scx = d.ow > 1 ? (float)(d.w - 1) / (float)(d.ow - 1) : 0.f;
+    DIN_GRID_STRIDE(i, total) {
+        int cg, ix, iy, n; int64_t p;
+        decode(dd, i, cg, ix, iy, n, p);
+        int oy_lo = scy > 0.f ? (int)floorf((float)(iy - 1) / scy) : 0, oy_hi = scy > 0.f ? (int)ceilf((float)(iy + 1) / scy) : d.oh - 1;
+        int ox_lo = scx > 0.f ? (int)floorf((float)(ix - 1) / scx) : 0, ox_hi = scx > 0.f ? (int)ceilf((float)(ix + 1) / scx) : d.ow - 1;
+        if (oy_lo < 0) oy_lo = 0;
+        if (ox_lo < 0) ox_lo = 0;
+        if (oy_hi > d.oh - 1) oy_hi = d.oh - 1;
+        if (ox_hi > d.ow - 1) ox_hi = d.ow - 1;
+        Vec<V> g = vzero<V>();
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int y0, y1; float ly;
+            bil_coord(oy, d.h, d.oh, y0, y1, ly);
+            float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int x0, x1; float lx;
+                bil_coord(ox, d.w, d.ow, x0, x1, lx);
+                float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+                if (wx == 0.f) continue;
+                Vec<V> t = vload<V>(dout, d.dtype, ((int64_t)(n * d.oh + oy) * d.ow + ox) * d.ldo + d.cooff + cg * V);
+                const float wgt = wy * wx;
+#pragma unroll
+                for (int e = 0; e < V; ++e) g.v[e] += t.v[e] * wgt;
+            }
+        }
+        const int64_t off = p * d.ldi + d.cioff + cg * V;
+        if (mask) { Vec<V> y = vload<V>(mask, d.dtype, off);
+#pragma unroll
+            for (int e = 0; e < V; ++e) g.v[e] = y.v[e] > 0.f ? g.v[e] : 0.f; }
+        if (accumulate) { Vec<V> o = vload<V>(din_, d.dtype, off);
+#pragma unroll
+            for (int e = 0; e < V; ++e) g.v[e] += o.v[e]; }
+        vstore<V>(din_, d.dtype, off, g);
+    }
+}
+
+inline bool wide8(const din_pool_desc* d) {
+    return d->dtype == DIN_BF16 && d->c % 8 == 0 && d->ldi % 8 == 0 && d->ldo % 8 == 0 && d->cioff % 8 == 0 && d->cooff % 8 == 0;
+}
+int check_pool(const din_pool_desc* d, const char* what) {
+    DIN_REQUIRE(d != nullptr, "%s: null descriptor", what);
+    DIN_REQUIRE(d->dtype == DIN_F32 || d->dtype == DIN_BF16, "%s: bad dtype", what);
+    DIN_REQUIRE(d->c % 4 == 0 && d->ldi % 4 == 0 && d->ldo % 4 == 0 && d->cioff % 4 == 0 && d->cooff % 4 == 0,
+                "%s: channels/strides/offsets must be multiples of 4", what);
+    DIN_REQUIRE(d->nb > 0 && d->h > 0 && d->w > 0 && d->oh > 0 && d->ow > 0 && d->c > 0, "%s: empty tensor", what);
+    return DIN_OK;
+}
+inline bool is_box3(const din_pool_desc* d) { return d->k == 3 && d->stride == 1 && d->pad == 1 && d->oh == d->h && d->ow == d->w; }
+constexpr int POOL_GRID_CAP = 32768;
+
+}  // namespace
+
+#define POOL_LAUNCH(kern, total, ...) hipLaunchKernelGGL(kern, dim3(grid_1d(total, 256, POOL_GRID_CAP)), dim3(256), 0, as_stream(stream), __VA_ARGS__)
+
+extern "C" {
+
+int din_maxpool_fwd(const din_pool_desc* d, const void* in, void* out, uint8_t* argmax, void* stream) {
+    if (int e = check_pool(d, "maxpool_fwd")) return e;
+    DIN_REQUIRE(in && out, "maxpool_fwd: null pointer");
+    DIN_REQUIRE(d->k * d->k < 254, "maxpool_fwd: window too large for the byte arg-max map");
+    const int v = wide8(d) ? 8 : 4;
+    const int64_t total = (int64_t)d->nb * d->oh * d->ow * (d->c / v);
+    const Dec3 dd = make_dec(d->c / v, d->ow, d->oh, total);
+    if (v == 8) {
+        if (d->k == 3) POOL_LAUNCH((maxpool_fwd_kernel<8, 3>), total, *d, dd, in, out, argmax);
+        else if (d->k == 2) POOL_LAUNCH((maxpool_fwd_kernel<8, 2>), total, *d, dd, in, out, argmax);
+        else POOL_LAUNCH((maxpool_fwd_kernel<8, 0>), total, *d, dd, in, out, argmax);
+    } else {
+        if (d->k == 3) POOL_LAUNCH((maxpool_fwd_kernel<4, 3>), total, *d, dd, in, out, argmax);
+        else if (d->k == 2) POOL_LAUNCH((maxpool_fwd_kernel<4, 2>), total, *d, dd, in, out, argmax);
+        else POOL_LAUNCH((maxpool_fwd_kernel<4, 0>), total, *d, dd, in, out, argmax);
+    }
+    DIN_CHECK_LAUNCH("maxpool_fwd");
+    return DIN_OK;
+}
+int din_maxpool_bwd(const din_pool_desc* d, const void* in, const uint8_t* argmax, const void* dout, void* din_, int relu_mask,
+                    int accumulate, void* stream) {
+    if (int e = check_pool(d, "maxpool_bwd")) return e;
+    DIN_REQUIRE((in || argmax) && dout && din_, "maxpool_bwd: null pointer");
+    DIN_REQUIRE(d->stride >= 1 && d->k >= 1, "maxpool_bwd: bad window");
+    if (argmax) {
+        DIN_REQUIRE(relu_mask, "maxpool_bwd: the arg-max map encodes the fused ReLU mask; relu_mask must be set");
+        const int v = wide8(d) ? 8 : 4;
+        const int64_t total = (int64_t)d->nb * d->h * d->w * (d->c / v);
+        const Dec3 dd = make_dec(d->c / v, d->w, d->h, total);
+        const int nw = (d->k + d->stride - 1) / d->stride;       // windows per axis that can contain one input element
+        if (v == 8) {
+            if (nw == 2) POOL_LAUNCH((maxpool_bwd_amax_kernel<8, 2>), total, *d, dd, argmax, dout, din_, accumulate);
+            else if (nw == 1) POOL_LAUNCH((maxpool_bwd_amax_kernel<8, 1>), total, *d, dd, argmax, dout, din_, accumulate);
+            else POOL_LAUNCH((maxpool_bwd_amax_kernel<8, 0>), total, *d, dd, argmax, dout, din_, accumulate);
+        } else {
+            if (nw == 2) POOL_LAUNCH((maxpool_bwd_amax_kernel<4, 2>), total, *d, dd, argmax, dout, din_, accumulate);
+            else if (nw == 1) POOL_LAUNCH((maxpool_bwd_amax_kernel<4, 1>), total, *d, dd, argmax, dout, din_, accumulate);
+            else POOL_LAUNCH((maxpool_bwd_amax_kernel<4, 0>), total, *d, dd, argmax, dout, din_, accumulate);
+        }
+    } else {
+        const int64_t total = (int64_t)d->nb * d->h * d->w * (d->c / 4);
+        const Dec3 dd = make_dec(d->c / 4, d->w, d->h, total);
+        POOL_LAUNCH(maxpool_bwd_kernel, total, *d, dd, in, dout, din_, relu_mask, accumulate);
+    }
+    DIN_CHECK_LAUNCH("maxpool_bwd");
+    return DIN_OK;
+}
+int din_avgpool_fwd(const din_pool_desc* d, const void* in, void* out, const float* bias, int flags, void* stream) {
+    if (int e = check_pool(d, "avgpool_fwd")) return e;
+    DIN_REQUIRE(in && out, "avgpool_fwd: null pointer");
+    DIN_REQUIRE(!(flags & ~(DIN_CONV_BIAS | DIN_CONV_RELU)), "avgpool_fwd: only BIAS / RELU flags");
+    DIN_REQUIRE(!(flags & DIN_CONV_BIAS) || bias, "avgpool_fwd: BIAS flag without bias");
+    const int v = wide8(d) ? 8 : 4;
+    const int64_t total = (int64_t)d->nb * d->oh * d->ow * (d->c / v);
+    const Dec3 dd = make_dec(d->c / v, d->ow, d->oh, total);
+    const bool b3 = is_box3(d);
+    if (v == 8) { if (b3) POOL_LAUNCH((avgpool_fwd_kernel<8, true>), total, *d, dd, in, out, bias, flags); else POOL_LAUNCH((avgpool_fwd_kernel<8, false>), total, *d, dd, in, out, bias, flags); }
+    else { if (b3) POOL_LAUNCH((avgpool_fwd_kernel<4, true>), total, *d, dd, in, out, bias, flags); else POOL_LAUNCH((avgpool_fwd_kernel<4, false>), total, *d, dd, in, out, bias, flags); }
+    DIN_CHECK_LAUNCH("avgpool_fwd");
+    return DIN_OK;
+}
+int din_avgpool_bwd(const din_pool_desc* d, const void* dout, void* din_, const void* mask, int accumulate, void* stream) {
+    if (int e = check_pool(d, "avgpool_bwd")) return e;
+    DIN_REQUIRE(dout && din_, "avgpool_bwd: null pointer");
+    DIN_REQUIRE(d->stride >= 1, "avgpool_bwd: bad stride");
+    const int v = wide8(d) ? 8 : 4;
+    const int64_t total = (int64_t)d->nb * d->h * d->w * (d->c / v);
+    const Dec3 dd = make_dec(d->c / v, d->w, d->h, total);
+    const bool b3 = is_box3(d);
+    if (v == 8) { if (b3) POOL_LAUNCH((avgpool_bwd_kernel<8, true>), total, *d, dd, dout, din_, mask, accumulate); else POOL_LAUNCH((avgpool_bwd_kernel<8, false>), total, *d, dd, dout, din_, mask, accumulate); }
+    else { if (b3) POOL_LAUNCH((avgpool_bwd_kernel<4, true>), total, *d, dd, dout, din_, mask, accumulate); else POOL_LAUNCH((avgpool_bwd_kernel<4, false>), total, *d, dd, dout, din_, mask, accumulate); }
+    DIN_CHECK_LAUNCH("avgpool_bwd");
+    return DIN_OK;
+}
+int din_bilinear_fwd(const din_pool_desc* d, const void* in, void* out, void* stream) {
+    if (int e = check_pool(d, "bilinear_fwd")) return e;
+    DIN_REQUIRE(in && out, "bilinear_fwd: null pointer");
+    const int v = wide8(d) ? 8 : 4;
+    const int64_t total = (int64_t)d->nb * d->oh * d->ow * (d->c / v);
+    const Dec3 dd = make_dec(d->c / v, d->ow, d->oh, total);
+    if (v == 8) POOL_LAUNCH(bilinear_fwd_kernel<8>, total, *d, dd, in, out);
+    else POOL_LAUNCH(bilinear_fwd_kernel<4>, total, *d, dd, in, out);
+    DIN_CHECK_LAUNCH("bilinear_fwd");
+    return DIN_OK;
+}
+int din_bilinear_bwd(const din_pool_desc* d, const void* dout, void* din_, const void* mask, int accumulate, void* stream) {
+    if (int e = check_pool(d, "bilinear_bwd")) return e;
+    DIN_REQUIRE(dout && din_, "bilinear_bwd: null pointer");
+    const int v = wide8(d) ? 8 : 4;
+    const int64_t total = (int64_t)d->nb * d->h * d->w * (d->c / v);
+    const Dec3 dd = make_dec(d->c / v, d->w, d->h, total);
+    if (v == 8) POOL_LAUNCH(bilinear_bwd_kernel<8>, total, *d, dd, dout, din_, mask, accumulate);
+    else POOL_LAUNCH(bilinear_bwd_kernel<4>, total, *d, dd, dout, din_, mask, accumulate);
+    DIN_CHECK_LAUNCH("bilinear_bwd");
+    return DIN_OK;
+}
+
+}  // extern "C"

@@ -64,8 +64,8 @@ def _conv_flops(d) -> float:
 
 
 class _timed:
-    def __init__(self, kind, d):
-        self.kind, self.d = kind, d
+    def __init__(self, kind, d, name=""):
+        self.kind, self.d, self.name = kind, d, name
 
     def __enter__(self):
         if PROFILE is not None:
@@ -88,7 +88,7 @@ class _timed:
                 variant = f"conv_small_kernel<..., {bn.value}, ...>"
             else:
                 variant = f"conv_gather_fast_kernel<{tn}, {bm.value}, {bn.value}, ...>"
-            PROFILE.append((self.kind, variant, _conv_flops(d), int(d.dtype), self.e0, self.e1))
+            PROFILE.append((self.kind, variant, _conv_flops(d), int(d.dtype), self.e0, self.e1, self.name))
         return False
 
 
@@ -299,12 +299,12 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
                 d, pd = _pooled_descs(g, op, nb, dt)
                 tmp = torch.empty((nb, pd.h, pd.w, pd.c), dtype=tdt, device=dev)
                 ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 0), dev)
-                with _timed("fwd", d):
+                with _timed("fwd", d, op.name):
                     L.check(lib.din_conv_fwd(C.byref(d), _ptr(src), _ptr(wpk), None, _ptr(tmp), 0, _ptr(ws), wsb, st), "conv_fwd " + op.name)
                 L.check(lib.din_avgpool_fwd(C.byref(pd), _ptr(tmp), _ptr(dst), _ptr(bias), flags, st), "avgpool_fwd(epilogue)")
             else:
                 ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 0), dev)
-                with _timed("fwd", d):
+                with _timed("fwd", d, op.name):
                     L.check(lib.din_conv_fwd(C.byref(d), _ptr(src), _ptr(wpk), _ptr(bias), _ptr(dst), flags, _ptr(ws), wsb, st),
                             "conv_fwd " + op.name)
             aux.append((scale,))
@@ -391,7 +391,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
         flags = (L.CONV_ACCUM if acc else 0) | (L.CONV_MASK if ts0.relu_masked else 0)
         d0 = _conv_desc(g, op0, nb, dt)
         d0.cout = sum(g.ops[it[0]].dst.c for it in items)          # FLOP accounting of the fused launch
-        with _timed("dgrad", d0):
+        with _timed("dgrad", d0, "+".join(g.ops[it[0]].name for it in items)):
             L.check(lib.din_conv1x1_dgrad_multi(len(items), srcs, dt, nb, ts0.h, ts0.w, op0.src.c, ts0.c, op0.src.coff, _ptr(gsrc),
                                                 _ptr(bufs[op0.src.tid]) if ts0.relu_masked else None, ts0.c, op0.src.coff, flags, st),
                     "conv1x1_dgrad_multi")
@@ -433,7 +433,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 dshift = dshift_pre if dshift_pre is not None else torch.empty_like(gamma)
                 wdot = torch.empty_like(gamma)
                 ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 2), dev)
-                with _timed("wgrad", d):
+                with _timed("wgrad", d, op.name):
                     L.check(lib.din_conv_wgrad(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dw),
                                                None if dshift_pre is not None else _ptr(dshift), _ptr(scale),
                                                _ptr(w), _ptr(wdot), 0, _ptr(ws), wsb, st), "conv_wgrad " + op.name)
@@ -444,7 +444,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
             else:
                 db = (dshift_pre if dshift_pre is not None else torch.empty_like(params[po + 1])) if op.bias else None
                 ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 2), dev)
-                with _timed("wgrad", d):
+                with _timed("wgrad", d, op.name):
                     L.check(lib.din_conv_wgrad(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dw),
                                                None if dshift_pre is not None else _ptr(db), None, None, None, 0,
                                                _ptr(ws), wsb, st), "conv_wgrad " + op.name)
@@ -464,7 +464,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 L.check(lib.din_conv_pack_weights(C.byref(d), _ptr(w), _ptr(scale), _ptr(wpt), 1, st), "conv_pack_t")
                 flags = (L.CONV_ACCUM if acc else 0) | (L.CONV_MASK if ts.relu_masked else 0)
                 ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 1), dev)
-                with _timed("dgrad", d):
+                with _timed("dgrad", d, op.name):
                     L.check(lib.din_conv_dgrad(C.byref(d), _ptr(gout), _ptr(wpt), _ptr(gsrc),
                                                _ptr(bufs[op.src.tid]) if ts.relu_masked else None, ts.c, op.src.coff, flags,
                                                _ptr(ws), wsb, st), "conv_dgrad " + op.name)
