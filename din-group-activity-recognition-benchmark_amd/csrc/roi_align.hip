@@ -7,6 +7,8 @@
 // (floor/ceil indices, out-of-range tests) are bit-exact with the CPU oracle.
 #include "din_common.h"
 
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
 namespace {
 
 struct Sample { float in; int lo, hi; float l; bool oob; };
@@ -102,6 +104,156 @@ __global__ void roi_align_bwd_kernel(const float* __restrict__ dout, int nb, int
     }
 }
 
+
+// Gather-form backward, written straight into the feature map's gradient tensor (storage type T, NHWC view, channels [0, c)):
+//   gfm[n, y, x, ch] = (mask: fm > 0) * sum over boxes b of frame n, samples (ky, kx):  wy(b,ky,y) * wx(b,kx,x) * dout[b, ch, ky, kx]
+// with wy = (lo == y ? 1-l : 0) + (hi == y ? l : 0) -- the same four corner weights the scatter form adds, but no atomics, no fp32
+// staging tensor, no zero-fill and no separate cast/mask pass: every element of the view is written exactly once (zeros outside
+// the boxes' footprints, ~90 % of the map).  Deterministic: contributions are summed in (box, ky, kx) order.
+// One workgroup per (frame, row).  LDS: the frame's boxes (ascending), their k x-samples and this row's k y-weights.  Wave w owns
+// pixels x = w, w+4, ...: the (wave-uniform) scan over the row's active boxes finds the samples touching x, lanes stream 16-byte
+// channel chunks.  `cap` boxes of a frame are handled per batch; later batches (frames with more than `cap` boxes) re-read the
+// partial result, which is then rounded to T once per batch.
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* __restrict__ dout, int nb, int hf, int wf, int c,
+                                                                   const float* __restrict__ boxes, const int32_t* __restrict__ box_ind,
+                                                                   int m, int k, const T* __restrict__ fm, int ldf, T* __restrict__ gfm,
+                                                                   int ldg, int cap) {
+    constexpr int V = 16 / sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* boxid = reinterpret_cast<int*>(smem);                         // [cap] boxes of this frame (batch), ascending
+    int* xlo = boxid + cap;                                            // [cap * k] x-sample low / high cell (-2: out of range)
+    int* xhi = xlo + cap * k;
+    float* xl = reinterpret_cast<float*>(xhi + cap * k);               // [cap * k] x-sample lerp
+    float* wyv = xl + cap * k;                                         // [cap * k] y-weight of sample ky on this row (0: none)
+    int* xmin = reinterpret_cast<int*>(wyv + cap * k);                 // [cap] x extent of the box's samples
+    int* xmax = xmin + cap;
+    int* act = xmax + cap;                                             // [cap] slots of the boxes that touch this row
+    __shared__ int wtot[4];
+    __shared__ int nact_s, nfound_s;
+    const int n = blockIdx.x / hf, y = blockIdx.x - n * hf;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kk = k * k;
+    int scan_from = 0;                                                 // next box id to look at (uniform)
+    for (int batch = 0;; ++batch) {
+        // ---- the next <= cap boxes of frame n, in ascending id order (ballot compaction, 256 ids per round) ----
+        int found = 0;
+        while (scan_from < m && found < cap) {
+            const int b = scan_from + tid;
+            const bool hit = b < m && box_ind[b] == n;
+            const unsigned long long bal = __ballot(hit);
+            if (lane == 0) wtot[wave] = __popcll(bal);
+            __syncthreads();
+            int off = found;
+            for (int w = 0; w < wave; ++w) off += wtot[w];
+            const int tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+            const int slot = off + __popcll(bal & ((1ull << lane) - 1ull));
+            // a round that would overflow the batch is cut at the first id that does not fit; the scan resumes there
+            __shared__ int cut_s;
+            if (tid == 0) cut_s = scan_from + 256;
+            __syncthreads();
+            if (hit && slot == cap) cut_s = b;                         // exactly one thread
+            if (hit && slot < cap) boxid[slot] = b;
+            __syncthreads();
+            found = min(found + tot, cap);
+            scan_from = cut_s;
+            __syncthreads();
+        }
+        if (batch > 0 && found == 0) break;
+        // ---- per box: x samples, this row's y weights, x extent ----
+        for (int t = tid; t < found * k; t += 256) {
+            const int j = t / k, q = t - j * k;
+            const int b = boxid[j];
+            const Sample sx = roi_sample(boxes[b * 4 + 0], boxes[b * 4 + 2], wf, k, q);
+            xlo[t] = sx.oob ? -2 : sx.lo; xhi[t] = sx.oob ? -2 : sx.hi; xl[t] = sx.l;
+            const Sample sy = roi_sample(boxes[b * 4 + 1], boxes[b * 4 + 3], hf, k, q);
+            wyv[t] = sy.oob ? 0.f : ((sy.lo == y ? 1.f - sy.l : 0.f) + (sy.hi == y ? sy.l : 0.f));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int na = 0;
+            for (int j = 0; j < found; ++j) {
+                bool any = false; int lo = 1 << 30, hi = -1;
+                for (int q = 0; q < k; ++q) {
+                    any = any || wyv[j * k + q] != 0.f;
+                    if (xlo[j * k + q] >= 0) { lo = min(lo, xlo[j * k + q]); hi = max(hi, xhi[j * k + q]); }
+                }
+                xmin[j] = lo; xmax[j] = hi;
+                if (any && hi >= 0) act[na++] = j;
+            }
+            nact_s = na; nfound_s = found;
+        }
+        __syncthreads();
+        const int nact = nact_s;
+        // ---- pixels of the row ----
+        const int nchunk = c / V;
+        for (int x = wave; x < wf; x += 4) {
+            const int64_t pix = ((int64_t)n * hf + y) * wf + x;
+            for (int ch0 = lane; ch0 - lane < nchunk; ch0 += 64) {
+                const bool lane_ok = ch0 < nchunk;
+                float acc[V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] = 0.f;
+                bool any = false;
+                for (int a = 0; a < nact; ++a) {
+                    const int j = act[a];
+                    if (x < xmin[j] || x > xmax[j]) continue;
+                    const int b = boxid[j];
+                    for (int qy = 0; qy < k; ++qy) {
+                        const float wy = wyv[j * k + qy];
+                        if (wy == 0.f) continue;
+                        for (int qx = 0; qx < k; ++qx) {
+                            const int lo = xlo[j * k + qx], hi = xhi[j * k + qx];
+                            const float l = xl[j * k + qx];
+                            const float wx = (lo == x ? 1.f - l : 0.f) + (hi == x ? l : 0.f);
+                            if (wx == 0.f) continue;
+                            any = true;
+                            if (lane_ok) {
+                                const float w = wy * wx;
+                                const float* src = dout + ((int64_t)b * c + ch0 * V) * kk + qy * k + qx;
+#pragma unroll
+                                for (int e = 0; e < V; ++e) acc[e] += w * src[(int64_t)e * kk];
+                            }
+                        }
+                    }
+                }
+                if (!lane_ok) continue;
+                T* dst = gfm + pix * ldg + ch0 * V;
+                if (any && fm != nullptr) {
+                    const u32x4_t mv = *reinterpret_cast<const u32x4_t*>(fm + pix * ldf + ch0 * V);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        float yv;
+                        if constexpr (sizeof(T) == 4) yv = __uint_as_float(mv[e]);
+                        else yv = (e & 1) ? __uint_as_float(mv[e >> 1] & 0xffff0000u) : __uint_as_float(mv[e >> 1] << 16);
+                        acc[e] = yv > 0.f ? acc[e] : 0.f;
+                    }
+                }
+                if (batch > 0) {
+                    if (!any) continue;                                // nothing to add to the earlier batches' result
+                    const u32x4_t ov = *reinterpret_cast<const u32x4_t*>(dst);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        if constexpr (sizeof(T) == 4) acc[e] += __uint_as_float(ov[e]);
+                        else acc[e] += (e & 1) ? __uint_as_float(ov[e >> 1] & 0xffff0000u) : __uint_as_float(ov[e >> 1] << 16);
+                    }
+                }
+                u32x4_t o;
+                if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(acc[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(acc[2 * e], acc[2 * e + 1]);
+                }
+                *reinterpret_cast<u32x4_t*>(dst) = o;
+            }
+        }
+        if (nfound_s < cap || scan_from >= m) break;                   // the frame had no more boxes than this batch
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -125,6 +277,30 @@ int din_roi_align_bwd(const float* dout, int nb, int hf, int wf, int c, const fl
     if (m == 0) return DIN_OK;
     hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(m * k), dim3(256), 0, as_stream(stream), dout, nb, hf, wf, c, boxes, box_ind, m, k, dfm);
     DIN_CHECK_LAUNCH("roi_align_bwd");
+    return DIN_OK;
+}
+
+int din_roi_align_bwd_nhwc(const float* dout, int nb, int hf, int wf, int c, const float* boxes, const int32_t* box_ind, int m,
+                           int k, const void* fm_mask, int dtype, int ldf, void* gfm, int ldg, void* stream) {
+    DIN_REQUIRE(dout && boxes && box_ind && gfm, "roi_align_bwd_nhwc: null pointer");
+    DIN_REQUIRE(nb > 0 && hf > 1 && wf > 1 && c > 0 && k > 0 && k <= 64 && m >= 0, "roi_align_bwd_nhwc: bad shape");
+    DIN_REQUIRE(dtype == DIN_F32 || dtype == DIN_BF16, "roi_align_bwd_nhwc: bad dtype");
+    const int v = dtype == DIN_F32 ? 4 : 8;
+    DIN_REQUIRE(c % v == 0 && ldg % v == 0 && ldg >= c && (!fm_mask || (ldf % v == 0 && ldf >= c)),
+                "roi_align_bwd_nhwc: channels / pixel strides must be multiples of %d", v);
+    // boxes of one frame handled per batch: LDS = cap * (16 + 16 k) bytes, at most 48 KiB
+    int cap = m < 1 ? 1 : m;
+    const int cap_max = (48 * 1024) / (16 + 16 * k);
+    if (cap > cap_max) cap = cap_max;
+    if (cap > 256) cap = 256;
+    const size_t lds = (size_t)cap * (16 + 16 * k);
+    if (dtype == DIN_F32)
+        hipLaunchKernelGGL(roi_align_bwd_gather_kernel<float>, dim3(nb * hf), dim3(256), lds, as_stream(stream), dout, nb, hf, wf, c, boxes,
+                           box_ind, m, k, (const float*)fm_mask, ldf, (float*)gfm, ldg, cap);
+    else
+        hipLaunchKernelGGL(roi_align_bwd_gather_kernel<bf16_t>, dim3(nb * hf), dim3(256), lds, as_stream(stream), dout, nb, hf, wf, c, boxes,
+                           box_ind, m, k, (const bf16_t*)fm_mask, ldf, (bf16_t*)gfm, ldg, cap);
+    DIN_CHECK_LAUNCH("roi_align_bwd_nhwc");
     return DIN_OK;
 }
 

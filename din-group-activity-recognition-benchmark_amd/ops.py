@@ -69,13 +69,12 @@ class RoIAlignFunction(torch.autograd.Function):
         k, c = ctx.k, ctx.c
         gout = gout.contiguous()
         st = _stream()
-        g32 = torch.zeros((nb, hf, wf, c), dtype=torch.float32, device=fm.device)
-        L.check(lib.din_roi_align_bwd(_ptr(gout), nb, hf, wf, c, _ptr(boxes), _ptr(box_ind), boxes.shape[0], k, _ptr(g32), st),
-                "roi_align_bwd")
-        # fp32 scatter buffer -> storage dtype of the feature map, fused with the ReLU mask of the cropped tensor
+        # gather form: the gradient tensor is written once, in the feature map's storage type, already multiplied by the ReLU mask
+        # of the cropped tensor (no fp32 scatter buffer, no zero-fill, no cast pass)
         gfm = torch.zeros_like(fm) if ld != c else torch.empty_like(fm)
-        L.check(lib.din_grad_cast_mask(_ptr(g32), _ptr(fm), _ptr(gfm), din_dtype(fm), nb * hf * wf, c, ld, 0, ld, 0,
-                                       int(ctx.relu_masked), st), "grad_cast_mask")
+        L.check(lib.din_roi_align_bwd_nhwc(_ptr(gout.float()), nb, hf, wf, c, _ptr(boxes), _ptr(box_ind), boxes.shape[0], k,
+                                           _ptr(fm) if ctx.relu_masked else None, din_dtype(fm), ld, _ptr(gfm), ld, st),
+                "roi_align_bwd_nhwc")
         return gfm, None, None, None, None, None, None
 
 

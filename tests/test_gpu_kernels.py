@@ -295,6 +295,36 @@ def test_roi_align_index_bit_exact_and_values(env, k):
     assert torch.equal(ops.boxes_frame_index(nb, n, "cuda").cpu(), ind)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_roi_align_bwd_gather_matches_scatter(env, dtype):
+    """gather-form backward (any box order, > 256 boxes in one frame -> two batches, ReLU mask) == atomic scatter + cast/mask"""
+    lib, L, nhwc, ops = env
+    g = torch.Generator().manual_seed(21)
+    nb, c, hf, wf, k, m = 3, 64, 22, 40, 5, 330
+    tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    dt = L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
+    x1 = torch.rand(m, generator=g) * (wf - 8); y1 = torch.rand(m, generator=g) * (hf - 8)
+    boxes = torch.stack([x1, y1, x1 + 1 + torch.rand(m, generator=g) * 9, y1 + 1 + torch.rand(m, generator=g) * 9], 1)
+    boxes[3] = 0.0
+    boxes[4] = torch.tensor([-3.0, 2.0, 50.0, 30.0])
+    ind = torch.zeros(m, dtype=torch.int32)                       # 300 boxes in frame 0 (two batches), the rest interleaved
+    ind[300:] = torch.randint(1, nb, (m - 300,), generator=g, dtype=torch.int32)
+    perm = torch.randperm(m, generator=g)
+    boxes, ind = boxes[perm].contiguous(), ind[perm].contiguous()
+    fm = torch.randn(nb, hf, wf, c, generator=g).to(tdt).cuda()
+    gout = torch.randn(m, c, k, k, generator=g).cuda()
+    bd, idv = boxes.cuda(), ind.cuda()
+    g32 = torch.zeros(nb, hf, wf, c, device="cuda")
+    L.check(lib.din_roi_align_bwd(gout.data_ptr(), nb, hf, wf, c, bd.data_ptr(), idv.data_ptr(), m, k, g32.data_ptr(), None))
+    want = g32 * (fm.float() > 0).float()
+    got = torch.full((nb, hf, wf, c), 9.0, dtype=tdt, device="cuda")
+    L.check(lib.din_roi_align_bwd_nhwc(gout.data_ptr(), nb, hf, wf, c, bd.data_ptr(), idv.data_ptr(), m, k, fm.data_ptr(), dt, c,
+                                       got.data_ptr(), c, None))
+    torch.cuda.synchronize()
+    assert rel(got.float(), want) <= (1e-5 if dtype == "fp32" else 1e-2)      # bf16: one rounding per batch
+    assert bool(((want == 0) == (got.float() == 0)).all()), "footprint (zeros outside the boxes, mask) must match"
+
+
 def test_layernorm_variants(env):
     lib, L, nhwc, ops = env
     g = torch.Generator().manual_seed(11)
