@@ -600,15 +600,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
 //     usual fused bias / ReLU / ReLU-backward mask / accumulate.
 // bf16 only; stride 1, dilation 1; the gather geometry (ay = 1, by, cy = +-1) covers forward and (stride-1) dgrad.
 // ------------------------------------------------------------------------------------------------
-template <int CPP, int BN, int NBUF, int KH, int KW>
+template <int CPP, int BN, int NBUF, int KH, int KW, int ST>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_small_kernel(ConvK p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef bf16_t T;
     constexpr int TH = 8, TW = 32, NPX = TH * TW;
-    constexpr int TI = BN / 16, TJ = 4, SL = CPP / 4, NTAPS = KH * KW;
+    constexpr int TI = BN / 16, TJ = 4, NTAPS = KH * KW;
+    // MFMA k-slices (32 channels-of-taps each): CPP >= 4: SL slices per tap; CPP == 1 (image layer, 8 padded channels per pixel):
+    // four taps share one slice, lane group g4 carries tap 4*slice + g4 (taps >= NTAPS hit zero filter chunks of the packed bank)
+    constexpr int SL = CPP >= 4 ? CPP / 4 : 1, NSL = CPP >= 4 ? NTAPS * SL : (NTAPS + 3) / 4;
     constexpr int CPITCH = BN * 2 + 16;
-    constexpr int HWW = TW + KW - 1, HWH = TH + KH - 1, HPX = HWW * HWH, HC = HPX * CPP;  // halo geometry (pixels, chunks)
-    constexpr int WBYTES = NTAPS * BN * CPP * 16;
+    constexpr int HWW = (TW - 1) * ST + KW, HWH = (TH - 1) * ST + KH, HPX = HWW * HWH, HC = HPX * CPP;  // halo geometry (pixels, chunks)
+    constexpr int WBYTES = NSL * BN * 4 * 16;
     constexpr int HBYTES = (HC * 16 + 1023) / 1024 * 1024;                                // whole 1-KiB DMA slots
     constexpr int NSLOT = HBYTES / 1024, NTR = (NSLOT + 3) / 4;
     constexpr int NPASS = HBYTES / CPITCH >= NPX ? 1 : 2;                                  // epilogue passes through the staging buffer
@@ -621,16 +624,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_small_kernel(ConvK p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     u32x4* Wl = reinterpret_cast<u32x4*>(smem_raw);
-    auto swz = [](int row) { return CPP == 4 ? ((row >> 1) & 3) : (row & 7); };
+    auto swz = [](int row) { return CPP == 1 ? 0 : CPP == 4 ? ((row >> 1) & 3) : (row & 7); };
 
-    // ---- filters: [tap][co][chunk ^ swz(co)] ------------------------------------------------------------------------------
+    // ---- filters: [tap][co][chunk ^ swz(co)]  (CPP == 1: [slice][co][tap & 3]) ---------------------------------------------
     {
         const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(p.w);
-        for (int id = tid; id < NTAPS * BN * CPP; id += NTHREADS) {
-            const int row = id / CPP, slot = id - row * CPP;
-            const int tap = row / BN, co = row - tap * BN;
-            const int cc = slot ^ swz(co);
-            Wl[id] = wp[(int64_t)co * p.wld + tap * CPP + cc];
+        if (CPP >= 4) {
+            for (int id = tid; id < NTAPS * BN * CPP; id += NTHREADS) {
+                const int row = id / CPP, slot = id - row * CPP;
+                const int tap = row / BN, co = row - tap * BN;
+                const int cc = slot ^ swz(co);
+                Wl[id] = wp[(int64_t)co * p.wld + tap * CPP + cc];
+            }
+        } else {
+            for (int id = tid; id < NSL * BN * 4; id += NTHREADS) {
+                const int row = id >> 2, g = id & 3;
+                const int sl = row / BN, co = row - sl * BN;
+                Wl[id] = wp[(int64_t)co * p.wld + sl * 4 + g];          // sl*4+g < wld: the packed row is zero beyond the last tap
+            }
         }
     }
     // ---- halo DMA plan: transfer i of this wave covers chunk ids [(wid + 4 i) * 64, +64) ------------------------------------
@@ -657,7 +668,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_small_kernel(ConvK p) {
         const int n = tile / tiles_img;
         const int tr = tile - n * tiles_img;
         const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
-        const int gy0 = ty * TH + hy0, gx0 = tx * TW + hx0;
+        const int gy0 = ty * TH * ST + hy0, gx0 = tx * TW * ST + hx0;
         // one image per resource: 32-bit offsets always suffice; out-of-image pixels get the out-of-range offset -> zeros
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char*>(reinterpret_cast<const char*>(p.in)) + (long long)n * img_bytes, 0, (int)img_bytes, 0x00020000);
@@ -698,24 +709,45 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_small_kernel(ConvK p) {
             for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int ysgn = p.cy > 0 ? 1 : -1, xsgn = p.cx > 0 ? 1 : -1;
         const int yb = p.cy > 0 ? 0 : KH - 1, xb = p.cx > 0 ? 0 : KW - 1;
+        if (CPP >= 4) {
 #pragma unroll
-        for (int tap = 0; tap < NTAPS; ++tap) {
-            const int r = tap / KW, s2 = tap - r * KW;
-            const int dy = yb + ysgn * r, dx = xb + xsgn * s2;
+            for (int tap = 0; tap < NTAPS; ++tap) {
+                const int r = tap / KW, s2 = tap - r * KW;
+                const int dy = yb + ysgn * r, dx = xb + xsgn * s2;
 #pragma unroll
-            for (int sl = 0; sl < SL; ++sl) {
-                u32x4 wf[TI], xf[TJ];
-                const int chunk = sl * 4 + g4;
+                for (int sl = 0; sl < SL; ++sl) {
+                    u32x4 wf[TI], xf[TJ];
+                    const int chunk = sl * 4 + g4;
 #pragma unroll
-                for (int i = 0; i < TI; ++i) {
-                    const int co = i * 16 + frow;
-                    wf[i] = Wl[(tap * BN + co) * CPP + (chunk ^ swz(co))];
+                    for (int i = 0; i < TI; ++i) {
+                        const int co = i * 16 + frow;
+                        wf[i] = Wl[(tap * BN + co) * CPP + (chunk ^ swz(co))];
+                    }
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) {
+                        const int q = wid * 4 + j;                                     // 16-pixel segment of the tile
+                        const int hp = ((q >> 1) * ST + dy) * HWW + ((q & 1) * 16 + frow) * ST + dx;
+                        xf[j] = Hl[hp * CPP + (chunk ^ swz(hp))];
+                    }
+#pragma unroll
+                    for (int i = 0; i < TI; ++i)
+#pragma unroll
+                        for (int j = 0; j < TJ; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
                 }
+            }
+        } else {
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl) {
+                u32x4 wf[TI], xf[TJ];
+                const int tap = min(sl * 4 + g4, NTAPS - 1);                           // surplus taps: finite data x zero filter
+                const int r = tap / KW, s2 = tap - r * KW;
+                const int dy = yb + ysgn * r, dx = xb + xsgn * s2;
+#pragma unroll
+                for (int i = 0; i < TI; ++i) wf[i] = Wl[(sl * BN + i * 16 + frow) * 4 + g4];
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
-                    const int q = wid * 4 + j;                                         // 16-pixel segment of the tile
-                    const int hp = ((q >> 1) + dy) * HWW + (q & 1) * 16 + frow + dx;
-                    xf[j] = Hl[hp * CPP + (chunk ^ swz(hp))];
+                    const int q = wid * 4 + j;
+                    xf[j] = Hl[((q >> 1) * ST + dy) * HWW + ((q & 1) * 16 + frow) * ST + dx];
                 }
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
@@ -1185,6 +1217,187 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) 
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad of the stem layers (3x3; 32 -> 32/64 channels stride 1, and the image layer <= 8 padded channels -> 32, stride 2): millions of
+// pixels, a few thousand filter gradients.  The general kernel re-pulls every input pixel once per tap and every G pixel once per
+// k-column tile; here each 8x32 output tile brings its G tile and its input HALO in once (LDS-DMA, out-of-image -> hardware zeros),
+// all (tap, ci) columns are formed from LDS by transpose reads, and persistent workgroups keep the whole dW block
+// (BN x 9*cin_pad fp32) in registers across their tiles: HBM traffic = the two tensors once.
+//   k (pixel) assignment inside a 32-pixel k-step = one tile row: read rd, lane group g4, sub-row q -> x = 16 rd + 4 g4 + q; each
+//   32-lane half of a ds_read_b64_tr_b16 then covers 8 consecutive pixels, conflict-free with the unit swizzles below.
+//   wave w owns the 16-column tiles w, w+4, ... of the (tap, ci) axis and all BN filter rows; wave 0 also forms the bias gradient
+//   (G^T x ones).  Result: one fp32 partial slab per workgroup in the layout conv_wgrad_reduce_kernel expects.
+// ------------------------------------------------------------------------------------------------
+template <int CPP, int BN, int ST>
+__global__ __launch_bounds__(NTHREADS, (CPP == 4 && BN == 64) ? 1 : 2) void conv_wgrad_small_kernel(WgradK p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TH = 8, TW = 32, NPX = TH * TW, KH = 3, KW = 3;
+    constexpr int HWW = (TW - 1) * ST + KW, HWH = (TH - 1) * ST + KH, HPX = HWW * HWH, HC = HPX * CPP;
+    constexpr int HBYTES = (HC * 16 + 1023) / 1024 * 1024, NSLOT_H = HBYTES / 1024, NTR_H = (NSLOT_H + 3) / 4;
+    constexpr int CG = BN / 8, GBYTES = NPX * CG * 16, NTR_G = GBYTES / 4096;
+    constexpr int STAGE = HBYTES + GBYTES;
+    constexpr int NCT = CPP == 4 ? 18 : 5, TI = BN / 16, TJ = (NCT + 3) / 4;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    auto swzX = [](int hp) { return CPP == 4 ? ((hp >> 2) & 1) * 2 : 0; };
+    auto swzG = [](int t) { return BN == 32 ? ((t >> 2) & 1) * 2 : ((t >> 1) & 3) * 2; };
+
+    // ---- DMA plans (per lane, tile independent) ----------------------------------------------------------------------------
+    int relH[NTR_H]; short hyv[NTR_H], hxv[NTR_H];
+#pragma unroll
+    for (int i = 0; i < NTR_H; ++i) {
+        const int id = (wid + 4 * i) * 64 + lane;
+        const int hp = id / CPP, slot = id - hp * CPP;
+        const int cc = slot ^ swzX(hp);
+        const int hy = hp / HWW, hx = hp - hy * HWW;
+        relH[i] = id < HC ? (hy * p.W + hx) * p.ldi * 2 + cc * 16 : -1;
+        hyv[i] = (short)hy; hxv[i] = (short)hx;
+    }
+    int relG[NTR_G]; short gyv[NTR_G], gxv[NTR_G];
+#pragma unroll
+    for (int i = 0; i < NTR_G; ++i) {
+        const int id = (wid + 4 * i) * 64 + lane;
+        const int t = id / CG, slot = id - t * CG;
+        const int cc = slot ^ swzG(t);
+        gyv[i] = (short)(t >> 5); gxv[i] = (short)(t & 31);
+        relG[i] = (cc * 8 + 7 < p.Cout) ? ((t >> 5) * p.OW + (t & 31)) * p.ldo * 2 + cc * 16 : -1;     // Cout % 8 == 0
+    }
+    const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + TH - 1) / TH;
+    const int tiles_img = tiles_x * tiles_y, ntiles = tiles_img * p.NB;
+    const long long ximg = (long long)p.H * p.W * p.ldi * 2ll, gimg = (long long)p.OH * p.OW * p.ldo * 2ll;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw;
+    const uint32_t ldsW = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(wid * 1024));
+
+    auto issue = [&](int buf, int tile) {
+        const int n = tile / tiles_img;
+        const int tr = tile - n * tiles_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int gy0 = ty * TH * ST - p.ph, gx0 = tx * TW * ST - p.pw;
+        __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(p.in)) + (long long)n * ximg, 0, (int)ximg, 0x00020000);
+        __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(p.g)) + (long long)n * gimg, 0, (int)gimg, 0x00020000);
+        const int baseX = (gy0 * p.W + gx0) * p.ldi * 2 + p.cioff * 2;
+        const int baseG = ((ty * TH) * p.OW + tx * TW) * p.ldo * 2 + p.cooff * 2;
+        const uint32_t dH = ldsW + (uint32_t)(buf * STAGE), dG = dH + (uint32_t)HBYTES;
+#pragma unroll
+        for (int i = 0; i < NTR_H; ++i) {
+            if (wid + 4 * i < NSLOT_H) {
+                const int gy = gy0 + hyv[i], gx = gx0 + hxv[i];
+                const bool ok = relH[i] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                lds_dma16(dH + (uint32_t)(i * 4096), rsX, ok ? baseX + relH[i] : (int)OOB, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NTR_G; ++i) {
+            const bool ok = relG[i] >= 0 && ty * TH + gyv[i] < p.OH && tx * TW + gxv[i] < p.OW;
+            lds_dma16(dG + (uint32_t)(i * 4096), rsG, ok ? baseG + relG[i] : (int)OOB, 0);
+        }
+    };
+
+    f32x4 acc[TI][TJ], accb[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = p.dbias != nullptr && wid == 0;
+    const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+
+    // ---- transpose-read addressing (per lane, tile independent): lane i16 of a 16-lane group supplies the 8-byte piece
+    //      (k row = i16 >> 2, columns 4*(i16&3)..+3) and receives column i16 ---------------------------------------------------
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int xq = g4 * 4 + (i16 >> 2);                                 // x inside the 16-pixel read (add 16 * rd)
+    const int csel = (i16 & 3) >> 1, chalf = (i16 & 1) * 8;
+    int tapoff[TJ];                                                     // halo pixel offset of this lane's tap for its column tiles
+    int unitX[TJ];
+#pragma unroll
+    for (int jj = 0; jj < TJ; ++jj) {
+        const int j = min(wid + 4 * jj, NCT - 1);
+        const int tap = CPP == 4 ? (j >> 1) : min(2 * j + csel, KH * KW - 1);
+        const int r = tap / KW, s2 = tap - r * KW;
+        tapoff[jj] = r * HWW + s2;
+        unitX[jj] = j & 1;
+    }
+
+    int cur = 0;
+    int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    if (tile < ntiles) issue(0, tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                   // stage(cur) landed; everyone finished reading stage(cur^1)
+        asm volatile("" ::: "memory");
+        if (tile + (int)gridDim.x < ntiles) issue(cur ^ 1, tile + gridDim.x);
+        const uint32_t Hb = lds_base + (uint32_t)(cur * STAGE), Gb = Hb + (uint32_t)HBYTES;
+#pragma unroll 2
+        for (int ks = 0; ks < TH; ++ks) {
+            u32x4 gf[TI], xf[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                u32x2 rr[2];
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) {
+                    const int t = ks * 32 + rd * 16 + xq;
+                    const int ch = (i * 2) ^ swzG(t);
+                    rr[rd] = lds_tr_read(Gb + (uint32_t)((t * CG + ch + csel) * 16 + chalf));
+                }
+                gf[i] = u32x4{rr[0][0], rr[0][1], rr[1][0], rr[1][1]};
+            }
+#pragma unroll
+            for (int jj = 0; jj < TJ; ++jj) {
+                u32x2 rr[2];
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) {
+                    const int hp = ks * ST * HWW + (rd * 16 + xq) * ST + tapoff[jj];
+                    uint32_t a;
+                    if (CPP == 4) a = (uint32_t)((hp * 4 + ((unitX[jj] * 2) ^ swzX(hp)) + csel) * 16 + chalf);
+                    else a = (uint32_t)(hp * 16 + chalf);
+                    rr[rd] = lds_tr_read(Hb + a);
+                }
+                xf[jj] = u32x4{rr[0][0], rr[0][1], rr[1][0], rr[1][1]};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int jj = 0; jj < TJ; ++jj)
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gf[i]), __builtin_bit_cast(bf16x8, xf[jj]),
+                                                                         acc[i][jj], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gf[i]), __builtin_bit_cast(bf16x8, ones), accb[i], 0, 0, 0);
+            }
+        }
+        cur ^= 1;
+    }
+    // ---- this workgroup's partial slab: [BN][NCT * 16] fp32 ------------------------------------------------------------------
+    float* dst = p.partial + (int64_t)blockIdx.x * p.cout_pad * p.kcols_pad;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TJ; ++jj) {
+            const int j = wid + 4 * jj;
+            if (j < NCT) {
+                const int co = i * 16 + g4 * 4, kc = j * 16 + i16;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[(int64_t)(co + e) * p.kcols_pad + kc] = acc[i][jj][e];
+            }
+        }
+    if (do_bias && i16 == 0) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int co = i * 16 + g4 * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (co + e < p.Cout) atomicAdd(p.dbias + co + e, accb[i][e]);
+        }
+    }
+#endif
+}
+
 // tail kernel for channel counts that are not multiples of 8 (conv1: cin = 3): the round-1 32-pixel kernel
 __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_tail_kernel(WgradK p) {
     constexpr int PK = 32;
@@ -1508,7 +1721,8 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype) {
     return g;
 }
 
-struct WgradPlan { int cin_pad, kcols, kcols_pad, cout_pad, n_co_tiles, n_k_tiles, slices, m_per_slice, bco, v2; int64_t ws_bytes; };
+struct WgradPlan { int cin_pad, kcols, kcols_pad, cout_pad, n_co_tiles, n_k_tiles, slices, m_per_slice, bco, v2, small; int64_t ws_bytes; };
+constexpr int WGRAD_SMALL_GRID = 512;
 WgradPlan plan_wgrad(const din_conv_desc* d) {
     WgradPlan w;
     int epc = epc_of(d->dtype);
@@ -1529,6 +1743,28 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
             }
             w.bco = best;
         }
+    }
+    // stem layers (conv_wgrad_small_kernel): small = 1: 32 -> <=32, 2: 32 -> <=64 (stride 1), 3: image layer (<= 8 channels, stride 2)
+    w.small = 0;
+    {
+        const char* sv = getenv("DIN_CONV_SMALL");
+        const bool want = sv ? atoi(sv) != 0 : true;
+        const int64_t M = (int64_t)d->nb * d->oh * d->ow;
+        const bool common = want && d->dtype == DIN_BF16 && d->kh == 3 && d->kw == 3 && d->dh == 1 && d->dw == 1 && d->cout % 8 == 0 &&
+                            d->ldi % 8 == 0 && d->cioff % 8 == 0 && d->ldo % 8 == 0 && d->cooff % 8 == 0 && M >= 256 * 1024 &&
+                            (long long)d->h * d->w * d->ldi * 2 < 0x7fffffffll && (long long)d->oh * d->ow * d->ldo * 2 < 0x7fffffffll;
+        if (common && d->sh == 1 && d->sw == 1 && d->cin == 32 && d->cout <= 64) w.small = d->cout <= 32 ? 1 : 2;
+        else if (common && d->sh == 2 && d->sw == 2 && d->cin <= 8 && d->ldi >= d->cioff + 8 && d->cout <= 32) w.small = 3;
+    }
+    if (w.small) {
+        w.v2 = 0; w.bco = w.small == 2 ? 64 : 32;
+        w.cin_pad = pad_to(d->cin, 8);
+        w.kcols = 9 * w.cin_pad;
+        w.kcols_pad = (w.small == 3 ? 5 : 18) * 16;
+        w.cout_pad = w.bco; w.n_co_tiles = 1; w.n_k_tiles = 1;
+        w.slices = WGRAD_SMALL_GRID; w.m_per_slice = 0;
+        w.ws_bytes = (int64_t)w.slices * w.cout_pad * w.kcols_pad * 4;
+        return w;
     }
     int pk = d->dtype == DIN_F32 ? 16 : (w.v2 ? 64 : 32);
     w.cin_pad = pad_to(d->cin, epc);
@@ -1648,32 +1884,35 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
         // stem layers: stationary filters + halo tiles (conv_small_kernel)
         const char* sv = getenv("DIN_CONV_SMALL");
         const bool want = sv ? atoi(sv) != 0 : true;
-        const int taps = k.kh * k.kw;
-        const bool small = want && dtype == DIN_BF16 && fast && !k.remap && k.nsrc == 0 && g.splitk == 1 && k.kh == 3 && k.kw == 3 &&
-                           (g.cpt == 4 || g.cpt == 8) && g.cpt * 8 == k.Cin && k.Cout <= 64 && k.Cout % 8 == 0 &&
-                           k.cooff % 8 == 0 && k.ldo % 8 == 0 && (!(k.flags & DIN_CONV_MASK) || (k.ldm % 8 == 0 && k.moff % 8 == 0)) &&
-                           k.ay == 1 && k.ax == 1 && (k.cy == 1 || k.cy == -1) && (k.cx == 1 || k.cx == -1) &&
-                           (long long)k.H * k.W * k.ldi * 2 < 0x7fffffffll && (long long)k.OH * k.OW * k.ldo * 2 < 0x7fffffffll &&
-                           (long long)k.OH * k.OW * (k.ldm > 0 ? k.ldm : 1) * 2 < 0x7fffffffll && k.out_sy == 0 && (int64_t)k.M >= 256 * 1024;
-        if (small) {
+        const bool common = want && dtype == DIN_BF16 && fast && !k.remap && k.nsrc == 0 && g.splitk == 1 && k.kh == 3 && k.kw == 3 &&
+                            k.Cout <= 64 && k.Cout % 8 == 0 && k.cooff % 8 == 0 && k.ldo % 8 == 0 && k.ldi % 8 == 0 && k.cioff % 8 == 0 &&
+                            (!(k.flags & DIN_CONV_MASK) || (k.ldm % 8 == 0 && k.moff % 8 == 0)) &&
+                            (long long)k.H * k.W * k.ldi * 2 < 0x7fffffffll && (long long)k.OH * k.OW * k.ldo * 2 < 0x7fffffffll &&
+                            (long long)k.OH * k.OW * (k.ldm > 0 ? k.ldm : 1) * 2 < 0x7fffffffll && k.out_sy == 0 && (int64_t)k.M >= 256 * 1024;
+        // 32/64-channel 3x3 stride-1 layers (fwd and dgrad) ...
+        const bool stem = common && (g.cpt == 4 || g.cpt == 8) && g.cpt * 8 == k.Cin && k.ay == 1 && k.ax == 1 &&
+                          (k.cy == 1 || k.cy == -1) && (k.cx == 1 || k.cx == -1) && !(g.cpt == 8 && k.Cout > 32);
+        // ... and the image layer: <= 8 (zero-padded) channels per pixel, stride 2, forward only
+        const bool image = common && g.cpt == 1 && k.Cin <= 8 && k.ldi >= 8 && k.Cout <= 32 && k.ay == 2 && k.ax == 2 && k.cy == 1 && k.cx == 1 &&
+                           k.wld >= 12;
+        if (stem || image) {
             const int bnS = k.Cout <= 32 ? 32 : 64;
-            const int hpx = (8 + k.kh - 1) * (32 + k.kw - 1);
+            const int st_ = image ? 2 : 1;
+            const int hpx = (7 * st_ + 3) * (31 * st_ + 3);
             const int hbytes = (hpx * g.cpt * 16 + 1023) / 1024 * 1024;
-            const int nbuf = g.cpt == 4 ? 2 : 1;
-            const size_t lds = (size_t)taps * bnS * g.cpt * 16 + (size_t)nbuf * hbytes;
-            const bool fits = lds <= 80 * 1024 && !(g.cpt == 8 && bnS == 64);
-            if (fits) {
-                dim3 grid(512);
-                auto launch = [&](auto kern) {
-                    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, k);
-                };
-                if (g.cpt == 4 && bnS == 32) launch(conv_small_kernel<4, 32, 2, 3, 3>);
-                else if (g.cpt == 4) launch(conv_small_kernel<4, 64, 2, 3, 3>);
-                else launch(conv_small_kernel<8, 32, 1, 3, 3>);
-                DIN_CHECK_LAUNCH(what);
-                return DIN_OK;
-            }
+            const int nbuf = g.cpt == 8 ? 1 : 2;
+            const size_t lds = (size_t)(image ? 3 * bnS * 64 : 9 * bnS * g.cpt * 16) + (size_t)nbuf * hbytes;
+            dim3 grid(512);
+            auto launch = [&](auto kern) {
+                if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, k);
+            };
+            if (image) launch(conv_small_kernel<1, 32, 2, 3, 3, 2>);
+            else if (g.cpt == 4 && bnS == 32) launch(conv_small_kernel<4, 32, 2, 3, 3, 1>);
+            else if (g.cpt == 4) launch(conv_small_kernel<4, 64, 2, 3, 3, 1>);
+            else launch(conv_small_kernel<8, 32, 1, 3, 3, 1>);
+            DIN_CHECK_LAUNCH(what);
+            return DIN_OK;
         }
     }
     if (dtype == DIN_F32) launch_gather<float>(k, g.n_px_tiles, g.bm, g.bn, st);
@@ -1750,7 +1989,7 @@ int din_conv_pack_weights(const din_conv_desc* d, const float* w, const float* s
 
 int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t* bn) {
     DIN_REQUIRE(d && bm && bn && which >= 0 && which <= 2, "conv_kernel_tile: bad argument");
-    if (which == 2) { WgradPlan wp = plan_wgrad(d); *bm = wp.bco; *bn = WG_TILE; return DIN_OK; }
+    if (which == 2) { WgradPlan wp = plan_wgrad(d); *bm = wp.small ? 0 : wp.bco; *bn = wp.small ? wp.bco : WG_TILE; return DIN_OK; }
     const bool strided = which == 1 && (d->sh > 1 || d->sw > 1);
     GatherPlan g = which == 0 ? plan_gather(d->nb * d->oh * d->ow, d->cin, d->cout, d->kh * d->kw, d->dtype)
                               : plan_gather(d->nb * (strided ? (d->h + d->sh - 1) / d->sh * ((d->w + d->sw - 1) / d->sw) : d->h * d->w),
@@ -1764,6 +2003,8 @@ int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t
         if ((sv ? atoi(sv) != 0 : true) && d->dtype == DIN_BF16 && d->kh == 3 && d->kw == 3 && d->sh == 1 && d->sw == 1 && d->dh == 1 &&
             d->dw == 1 && (cred == 32 || cred == 64) && cprod <= 64 && cprod % 8 == 0 && !(cred == 64 && cprod > 32) && g.splitk == 1 &&
             M >= 256 * 1024) { *bm = 0; *bn = cprod <= 32 ? 32 : 64; }
+        if ((sv ? atoi(sv) != 0 : true) && which == 0 && d->dtype == DIN_BF16 && d->kh == 3 && d->kw == 3 && d->sh == 2 && d->sw == 2 &&
+            d->dh == 1 && d->dw == 1 && d->cin <= 8 && d->cout <= 32 && d->cout % 8 == 0 && g.splitk == 1 && M >= 256 * 1024) { *bm = 0; *bn = 32; }
     }
     return DIN_OK;
 }
@@ -1933,7 +2174,23 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
     } else {
         int epc = 8;
         DIN_REQUIRE(d->ldo % epc == 0 && d->cooff % epc == 0, "conv_wgrad: bf16 dout stride/offset must be multiples of 8");
-        if (wp.v2) {
+        if (wp.small) {
+            if (dbias) {
+                if (hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
+                k.dbias = dbias;
+                bias_fused = true;
+            }
+            const int st_ = wp.small == 3 ? 2 : 1, cpp = wp.small == 3 ? 1 : 4;
+            const int hbytes = ((7 * st_ + 3) * (31 * st_ + 3) * cpp * 16 + 1023) / 1024 * 1024;
+            const size_t lds = 2 * ((size_t)hbytes + 256 * (size_t)wp.bco * 2);
+            auto launch = [&](auto kern) {
+                if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(kern, dim3(WGRAD_SMALL_GRID), dim3(NTHREADS), lds, st, k);
+            };
+            if (wp.small == 1) launch(conv_wgrad_small_kernel<4, 32, 1>);
+            else if (wp.small == 2) launch(conv_wgrad_small_kernel<4, 64, 1>);
+            else launch(conv_wgrad_small_kernel<1, 32, 2>);
+        } else if (wp.v2) {
             if (dbias) {
                 if (hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
                 k.dbias = dbias;

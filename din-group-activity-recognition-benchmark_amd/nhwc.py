@@ -83,7 +83,10 @@ class _timed:
             L.load().din_conv_kernel_tile(C.byref(d), which, C.byref(bm), C.byref(bn))
             tn = "unsigned short" if d.dtype == L.DIN_BF16 else "float"
             if self.kind == "wgrad":
-                variant = f"conv_wgrad_bf16_kernel<{bm.value}>" if d.dtype == L.DIN_BF16 else "conv_wgrad_f32_kernel"
+                if bm.value == 0:
+                    variant = f"conv_wgrad_small_kernel<..., {bn.value}, ...>"
+                else:
+                    variant = f"conv_wgrad_bf16_kernel<{bm.value}>" if d.dtype == L.DIN_BF16 else "conv_wgrad_f32_kernel"
             elif bm.value == 0:
                 variant = f"conv_small_kernel<..., {bn.value}, ...>"
             else:

@@ -55,6 +55,7 @@ CONV_CASES = [
     # stem shapes (>= 256K pixels): bf16 runs the stationary-filter halo kernel (fwd cpt4, dgrad cpt4 / cpt8), ragged tile edges
     ("stem_32_32_p0", 1, 32, 515, 517, 32, (3, 3), (1, 1), (0, 0), 1),
     ("stem_32_64_p1", 2, 32, 363, 365, 64, (3, 3), (1, 1), (1, 1), 1),
+    ("image_3_32_s2", 1, 3, 1031, 1029, 32, (3, 3), (2, 2), (0, 0), 1),     # Inception Conv2d_1a: image layer of the halo kernel
 ]
 
 
