@@ -884,6 +884,7 @@ struct WgradK {
     int kh, kw, sh, sw, ph, pw, dh, dw;
     int cin_pad, kcols, kcols_pad, cout_pad;   // kcols = kh*kw*cin_pad
     int M, n_co_tiles, n_k_tiles, slices, m_per_slice;
+    int probe;      // diagnostics (env DIN_WGRAD_PROBE): 1 = stream only (no transpose reads / MFMA), 2 = compute only (one DMA stage)
 };
 
 constexpr int WG_TILE = 128;
@@ -1189,8 +1190,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) 
         int it = 0;
         for (int m0 = m_begin; m0 < m_end; m0 += PK, ++it) {
             const int cur = it & 1;
-            if (m0 + PK < m_end) issue_dma(cur ^ 1, m0 + PK);
-            compute(cur);
+            if (m0 + PK < m_end && p.probe != 2) issue_dma(cur ^ 1, m0 + PK);
+            if (p.probe != 1) compute(cur);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -1203,6 +1204,211 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) 
         for (int j = 0; j < 4; ++j) {
             int co = co_tile * BCO + wm * (BCO / 2) + i * 16 + (lane >> 4) * 4;
             int kc = k_tile * WG_TILE + wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(int64_t)(co + e) * p.kcols_pad + kc] = acc[i][j][e];
+        }
+    if (do_bias && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            int co = co_tile * BCO + wm * (BCO / 2) + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (co + e < p.Cout) atomicAdd(p.dbias + co + e, accb[i][e]);
+        }
+    }
+#endif
+}
+
+// v4 ("ring"): the v3 kernel is bound by the global->LDS stream (DIN_WGRAD_PROBE=1: streaming alone takes 75-87 % of its time, at
+// ~9-10 TB/s of LDS-DMA traffic), so the lever is bytes per FLOP: BCO x BK = {128,192,256} x 256 tiles (per-wave (BCO/2) x 128) move
+// 1.3-2.3x fewer bytes than BCO x 128.  One workgroup per CU (accumulators fill the register file), so latency is hidden inside
+// the wave: a 4-stage ring of 32-pixel stages with the LDS-DMA issued THREE stages ahead (hand-counted vmcnt), and the transpose
+// reads of stage s in flight while the MFMAs of stage s-1 run (register double buffer).  One s_barrier per stage.
+template <int BCO, int BK>
+__global__ __launch_bounds__(NTHREADS, 1) void conv_wgrad_ring_kernel(WgradK p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int PK = 32, NS = 4;
+    constexpr int CG = BCO / 8, CX = BK / 8;                      // 16-byte chunks per G / X row
+    constexpr int RBG = BCO * 2, RBX = BK * 2;                    // row bytes (unpadded)
+    constexpr int TI = BCO / 32, XJ = BK / 32;                    // 16-row / 16-column MFMA tiles per wave (wave tile = BCO/2 x BK/2)
+    constexpr int GP = (PK * CG + NTHREADS - 1) / NTHREADS, XP = PK * CX / NTHREADS;
+    static_assert(PK * CX % NTHREADS == 0, "whole X DMA transfers per thread");
+    // every wave issues the same number of transfers (the vmcnt bookkeeping is a compile-time constant): when the G tile is not a
+    // whole number of 4-KiB rounds (BCO = 160) the surplus transfers fetch nothing and land in a pad behind the G tile
+    constexpr int OPG = GP * 4096, OPX = PK * RBX, STAGE = OPG + OPX;
+    static_assert(OPG >= PK * RBG, "G region");
+    constexpr int RPT = 64 / CX;                                  // X rows per wave-level transfer
+    constexpr int NDMA = GP + XP;                                 // DMA instructions per stage per wave
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    int bx_, by_;
+    xcd_block(bx_, by_);
+    const int k_tile = bx_ % p.n_k_tiles, co_tile = bx_ / p.n_k_tiles;
+    const int slice = by_;
+    const int m_begin = slice * p.m_per_slice;                   // multiple of PK
+    int m_end = m_begin + p.m_per_slice;
+    if (m_end > p.M) m_end = p.M;
+
+    const int ohw = p.OH * p.OW;
+    const int n_first = m_begin / ohw;
+    const long long img_bytes = (long long)p.H * p.W * p.ldi * 2ll;
+    const long long x_off = (long long)n_first * img_bytes;
+    long long x_rem = (long long)p.NB * img_bytes - x_off;
+    if (x_rem > 0x7fffffffll) x_rem = 0x7fffffffll;
+    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.in)) + x_off, 0, (int)x_rem, 0x00020000);
+    const long long g_off = (long long)m_begin * p.ldo * 2ll;
+    long long g_rem = (long long)p.M * p.ldo * 2ll - g_off;
+    if (g_rem > 0x7fffffffll) g_rem = 0x7fffffffll;
+    __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.g)) + g_off, 0, (int)g_rem, 0x00020000);
+
+    // ---- G DMA plan: transfer t covers chunk ids [(wid + 4 t) * 64, +64): id -> (row id / CG, slot id % CG); the lane fetches the
+    //      logical chunk (slot - 2*(row & 7)) mod CG of that row (rotation against transpose-read bank conflicts) --------------
+    unsigned voffG[GP];
+#pragma unroll
+    for (int t = 0; t < GP; ++t) {
+        const int id = (wid + 4 * t) * 64 + lane;
+        const int grow = id / CG, slot = id - grow * CG;
+        int gc = slot - 2 * (grow & 7);
+        gc += gc < 0 ? CG : 0;
+        const int gco = co_tile * BCO + gc * 8;
+        voffG[t] = (grow < PK && gco + 7 < p.Cout) ? (unsigned)((grow * p.ldo + p.cooff + gco) * 2) : OOB;   // Cout % 8 == 0 enforced
+    }
+    // ---- X DMA plan: transfer t covers rows (wid + 4 t) * RPT + lane / CX; (row & 7) is the same for all t -----------------------
+    const int xrow0 = wid * RPT + lane / CX;                       // rows xrow0 + 4 RPT t
+    int xc = (lane % CX) - 2 * (xrow0 & 7);
+    xc += xc < 0 ? CX : 0;
+    const int kcol = k_tile * BK + xc * 8;
+    const bool kok = kcol < p.kcols;
+    const int tap = kok ? kcol / p.cin_pad : 0;
+    const int ci = kcol - tap * p.cin_pad;
+    const int tr_ = tap / p.kw, ts_ = tap - tr_ * p.kw;
+    const bool ci_ok = kok && ci + 7 < p.Cin;
+    const int dy0 = -p.ph + tr_ * p.dh, dx0 = -p.pw + ts_ * p.dw;   // iy = oy*sh + dy0, ix = ox*sw + dx0
+    const int step_bytes = p.sw * p.ldi * 2;
+    int px[XP], py[XP], rowoff[XP];
+#pragma unroll
+    for (int t = 0; t < XP; ++t) {
+        int m = m_begin + xrow0 + 4 * RPT * t;
+        int n = m / ohw;
+        int rem = m - n * ohw;
+        py[t] = rem / p.OW; px[t] = rem - py[t] * p.OW;
+        rowoff[t] = (((n - n_first) * p.H + py[t] * p.sh + dy0) * p.W + dx0) * p.ldi * 2 + (p.cioff + ci) * 2;
+    }
+    const int row_jump = p.sh * p.W * p.ldi * 2;
+    const int img_jump = (p.H - p.OH * p.sh) * p.W * p.ldi * 2;
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw;
+    const uint32_t ldsW = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(wid * 1024));
+    auto issue_dma = [&](int buf, int m0) {                         // called with consecutive m0 (the X cursors advance by PK)
+        const uint32_t Gd = ldsW + (uint32_t)(buf * STAGE), Xd = Gd + (uint32_t)OPG;
+        const int soffG = (m0 - m_begin) * p.ldo * 2;
+#pragma unroll
+        for (int t = 0; t < GP; ++t) lds_dma16(Gd + (uint32_t)(t * 4096), rsG, (int)voffG[t], soffG);   // rows past M: out of range -> zeros
+#pragma unroll
+        for (int t = 0; t < XP; ++t) {
+            const int iy = py[t] * p.sh + dy0, ix = px[t] * p.sw + dx0;
+            const bool ok = ci_ok && (m0 + xrow0 + 4 * RPT * t < m_end) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            lds_dma16(Xd + (uint32_t)(t * 4096), rsX, ok ? rowoff[t] + px[t] * step_bytes : (int)OOB, 0);
+            px[t] += PK;
+            while (px[t] >= p.OW) {
+                px[t] -= p.OW; rowoff[t] += row_jump;
+                if (++py[t] == p.OH) { py[t] = 0; rowoff[t] += img_jump; }
+            }
+        }
+    };
+
+    f32x4 acc[TI][XJ], accb[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = p.dbias != nullptr && k_tile == 0 && wn == 0;       // wave-uniform
+    const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+
+    const int li = lane & 15, lg = lane >> 4;
+    const int prow = 4 * lg + (li >> 2);
+    const int rot = 2 * (prow & 7);
+    uint32_t colG[TI], colX[XJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        int ch = (wm * (BCO / 2) + i * 16) / 8 + rot;                         // even
+        ch -= ch >= CG ? CG : 0;
+        colG[i] = (uint32_t)(prow * RBG + (ch + ((li & 3) >> 1)) * 16 + (li & 1) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+        int ch = (wn * (BK / 2) + j * 16) / 8 + rot;
+        ch -= ch >= CX ? CX : 0;
+        colX[j] = (uint32_t)(prow * RBX + (ch + ((li & 3) >> 1)) * 16 + (li & 1) * 8);
+    }
+    u32x4 gf[2][TI], xf[2][XJ];
+    auto load_frags = [&](int buf, u32x4 (&gfr)[TI], u32x4 (&xfr)[XJ]) {
+        const uint32_t Gb = lds_base + (uint32_t)(buf * STAGE), Xb = Gb + (uint32_t)OPG;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            u32x2 lo = lds_tr_read(Gb + colG[i]), hi = lds_tr_read(Gb + colG[i] + 16 * RBG);
+            gfr[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            u32x2 lo = lds_tr_read(Xb + colX[j]), hi = lds_tr_read(Xb + colX[j] + 16 * RBX);
+            xfr[j] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+    };
+    auto mma = [&](const u32x4 (&gfr)[TI], const u32x4 (&xfr)[XJ]) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < XJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gfr[i]), __builtin_bit_cast(bf16x8, xfr[j]), acc[i][j], 0, 0, 0);
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+                accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gfr[i]), __builtin_bit_cast(bf16x8, ones), accb[i], 0, 0, 0);
+        }
+    };
+
+    const int nst = (m_end - m_begin + PK - 1) / PK;                          // stages of this slice (>= 0)
+    if (nst > 0) {
+        // prologue: stages 0..2 in flight
+#pragma unroll
+        for (int s0 = 0; s0 < NS - 1; ++s0)
+            if (s0 < nst) issue_dma(s0, m_begin + s0 * PK);
+        // iteration s: [stage s landed] barrier, DMA stage s+3, transpose reads of stage s || MFMAs of stage s-1
+        for (int sb = 0; sb < nst; sb += 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int s2 = sb + h;
+                if (s2 < nst) {
+                    // stages s2+1, s2+2 may stay in flight (issued after stage s2); near the end fewer are outstanding -> drain
+                    if (s2 + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NDMA) : "memory");
+                    else if (s2 + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (s2 + NS - 1 < nst) issue_dma((s2 + NS - 1) & (NS - 1), m_begin + (s2 + NS - 1) * PK);
+                    load_frags(s2 & (NS - 1), gf[h], xf[h]);
+                    if (s2 > 0) mma(gf[h ^ 1], xf[h ^ 1]);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if ((nst - 1) & 1) mma(gf[1], xf[1]);
+        else mma(gf[0], xf[0]);
+    }
+    float* dst = p.partial + (int64_t)slice * p.cout_pad * p.kcols_pad;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            int co = co_tile * BCO + wm * (BCO / 2) + i * 16 + (lane >> 4) * 4;
+            int kc = k_tile * BK + wn * (BK / 2) + j * 16 + (lane & 15);
 #pragma unroll
             for (int e = 0; e < 4; ++e) dst[(int64_t)(co + e) * p.kcols_pad + kc] = acc[i][j][e];
         }
@@ -1331,9 +1537,9 @@ __global__ __launch_bounds__(NTHREADS, (CPP == 4 && BN == 64) ? 1 : 2) void conv
         asm volatile("" ::: "memory");
         if (tile + (int)gridDim.x < ntiles) issue(cur ^ 1, tile + gridDim.x);
         const uint32_t Hb = lds_base + (uint32_t)(cur * STAGE), Gb = Hb + (uint32_t)HBYTES;
-#pragma unroll 2
-        for (int ks = 0; ks < TH; ++ks) {
-            u32x4 gf[TI], xf[TJ];
+        // software pipeline: the transpose reads of k-step ks+1 are in flight while the MFMAs of k-step ks run
+        u32x4 gf[2][TI], xf[2][TJ];
+        auto load_frags = [&](int ks, u32x4 (&gfr)[TI], u32x4 (&xfr)[TJ]) {
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 u32x2 rr[2];
@@ -1343,7 +1549,7 @@ __global__ __launch_bounds__(NTHREADS, (CPP == 4 && BN == 64) ? 1 : 2) void conv
                     const int ch = (i * 2) ^ swzG(t);
                     rr[rd] = lds_tr_read(Gb + (uint32_t)((t * CG + ch + csel) * 16 + chalf));
                 }
-                gf[i] = u32x4{rr[0][0], rr[0][1], rr[1][0], rr[1][1]};
+                gfr[i] = u32x4{rr[0][0], rr[0][1], rr[1][0], rr[1][1]};
             }
 #pragma unroll
             for (int jj = 0; jj < TJ; ++jj) {
@@ -1356,21 +1562,28 @@ __global__ __launch_bounds__(NTHREADS, (CPP == 4 && BN == 64) ? 1 : 2) void conv
                     else a = (uint32_t)(hp * 16 + chalf);
                     rr[rd] = lds_tr_read(Hb + a);
                 }
-                xf[jj] = u32x4{rr[0][0], rr[0][1], rr[1][0], rr[1][1]};
+                xfr[jj] = u32x4{rr[0][0], rr[0][1], rr[1][0], rr[1][1]};
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        load_frags(0, gf[0], xf[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < TH; ++ks) {
+            if (ks + 1 < TH) load_frags(ks + 1, gf[(ks + 1) & 1], xf[(ks + 1) & 1]);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int jj = 0; jj < TJ; ++jj)
-                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gf[i]), __builtin_bit_cast(bf16x8, xf[jj]),
-                                                                         acc[i][jj], 0, 0, 0);
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gf[ks & 1][i]),
+                                                                         __builtin_bit_cast(bf16x8, xf[ks & 1][jj]), acc[i][jj], 0, 0, 0);
             if (do_bias) {
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
-                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gf[i]), __builtin_bit_cast(bf16x8, ones), accb[i], 0, 0, 0);
+                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gf[ks & 1][i]), __builtin_bit_cast(bf16x8, ones), accb[i], 0, 0, 0);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
         }
         cur ^= 1;
     }
@@ -1721,7 +1934,7 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype) {
     return g;
 }
 
-struct WgradPlan { int cin_pad, kcols, kcols_pad, cout_pad, n_co_tiles, n_k_tiles, slices, m_per_slice, bco, v2, small; int64_t ws_bytes; };
+struct WgradPlan { int cin_pad, kcols, kcols_pad, cout_pad, n_co_tiles, n_k_tiles, slices, m_per_slice, bco, v2, small, ring; int64_t ws_bytes; };
 constexpr int WGRAD_SMALL_GRID = 512;
 WgradPlan plan_wgrad(const din_conv_desc* d) {
     WgradPlan w;
@@ -1766,16 +1979,41 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
         w.ws_bytes = (int64_t)w.slices * w.cout_pad * w.kcols_pad * 4;
         return w;
     }
-    int pk = d->dtype == DIN_F32 ? 16 : (w.v2 ? 64 : 32);
     w.cin_pad = pad_to(d->cin, epc);
     w.kcols = d->kh * d->kw * w.cin_pad;
-    w.kcols_pad = pad_to(w.kcols, WG_TILE);
+    // ring kernel (BCO x 256 tiles, one workgroup per CU): wide filter banks with enough k columns -- fewest filter tiles, then least padding
+    w.ring = 0;
+    {
+        const char* rv = getenv("DIN_WGRAD_RING");
+        const int mode = rv ? atoi(rv) : 1;
+        if (w.v2 && mode && d->cout >= (mode == 2 ? 64 : 112) && w.kcols >= 256) {
+            w.ring = 1;
+            int best = 128, best_tiles = (d->cout + 127) / 128, best_pad = best_tiles * 128;
+            const int cands[2] = {160, 192};
+            for (int ci = 0; ci < 2; ++ci) {
+                int bc = cands[ci], tl = (d->cout + bc - 1) / bc, pad = tl * bc;
+                if (tl < best_tiles || (tl == best_tiles && pad < best_pad)) { best = bc; best_tiles = tl; best_pad = pad; }
+            }
+            // measured (profiles/r01_wgrad_ring.txt): the ring wins where the 128-row tiles pad badly (cout 192 -> 2 x 128 wastes a
+            // quarter of the MFMAs); at equal tile height the two-workgroups-per-CU v3 kernel is faster
+            if (best == 192 || mode == 2) w.bco = best;
+            else w.ring = 0;
+        }
+    }
+    const int bk = w.ring ? 256 : WG_TILE;
+    int pk = d->dtype == DIN_F32 ? 16 : (w.ring ? 32 : (w.v2 ? 64 : 32));
+    w.kcols_pad = pad_to(w.kcols, bk);
     w.n_co_tiles = (d->cout + w.bco - 1) / w.bco;
     w.cout_pad = pad_to(w.n_co_tiles * w.bco, WG_TILE);            // partial-sum rows cover every filter tile
-    w.n_k_tiles = w.kcols_pad / WG_TILE;
+    w.n_k_tiles = w.kcols_pad / bk;
     int M = d->nb * d->oh * d->ow;
     int tiles = w.n_co_tiles * w.n_k_tiles;
     int want = (1024 + tiles - 1) / tiles;             // ~4 workgroups per CU
+    if (w.ring) {                                      // one resident workgroup per CU: a single full round (or two for long slices)
+        const int rounds = (int64_t)M * tiles >= (int64_t)256 * 64 * 1024 ? 2 : 1;
+        want = 256 * rounds / tiles;
+        if (want < 1) want = 1;
+    }
     int64_t max_by_ws = ((int64_t)1 << 30) / ((int64_t)w.cout_pad * w.kcols_pad * 4);   // keep workspace <= 1 GiB
     if (max_by_ws < 1) max_by_ws = 1;
     if (want > max_by_ws) want = (int)max_by_ws;
@@ -1989,7 +2227,7 @@ int din_conv_pack_weights(const din_conv_desc* d, const float* w, const float* s
 
 int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t* bn) {
     DIN_REQUIRE(d && bm && bn && which >= 0 && which <= 2, "conv_kernel_tile: bad argument");
-    if (which == 2) { WgradPlan wp = plan_wgrad(d); *bm = wp.small ? 0 : wp.bco; *bn = wp.small ? wp.bco : WG_TILE; return DIN_OK; }
+    if (which == 2) { WgradPlan wp = plan_wgrad(d); *bm = wp.small ? 0 : wp.bco; *bn = wp.small ? wp.bco : (wp.ring ? 256 : WG_TILE); return DIN_OK; }
     const bool strided = which == 1 && (d->sh > 1 || d->sw > 1);
     GatherPlan g = which == 0 ? plan_gather(d->nb * d->oh * d->ow, d->cin, d->cout, d->kh * d->kw, d->dtype)
                               : plan_gather(d->nb * (strided ? (d->h + d->sh - 1) / d->sh * ((d->w + d->sw - 1) / d->sw) : d->h * d->w),
@@ -2167,6 +2405,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
     k.cin_pad = wp.cin_pad; k.kcols = wp.kcols; k.kcols_pad = wp.kcols_pad; k.cout_pad = wp.cout_pad;
     k.M = d->nb * d->oh * d->ow; k.n_co_tiles = wp.n_co_tiles; k.n_k_tiles = wp.n_k_tiles;
     k.slices = wp.slices; k.m_per_slice = wp.m_per_slice;
+    { const char* pv = getenv("DIN_WGRAD_PROBE"); k.probe = pv ? atoi(pv) : 0; }
     dim3 grid(wp.n_co_tiles * wp.n_k_tiles, wp.slices);
     bool bias_fused = false;
     if (d->dtype == DIN_F32) {
@@ -2190,6 +2429,20 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
             if (wp.small == 1) launch(conv_wgrad_small_kernel<4, 32, 1>);
             else if (wp.small == 2) launch(conv_wgrad_small_kernel<4, 64, 1>);
             else launch(conv_wgrad_small_kernel<1, 32, 2>);
+        } else if (wp.ring) {
+            if (dbias) {
+                if (hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
+                k.dbias = dbias;
+                bias_fused = true;
+            }
+            const size_t lds = 4 * ((size_t)((32 * wp.bco / 8 + 255) / 256) * 4096 + 32 * 256 * 2);   // four 32-pixel stages (G tile in 4-KiB rounds)
+            auto launch = [&](auto kern) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, k);
+            };
+            if (wp.bco == 128) launch(conv_wgrad_ring_kernel<128, 256>);
+            else if (wp.bco == 160) launch(conv_wgrad_ring_kernel<160, 256>);
+            else launch(conv_wgrad_ring_kernel<192, 256>);
         } else if (wp.v2) {
             if (dbias) {
                 if (hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
