@@ -85,6 +85,7 @@ SIGNATURES: Dict[str, tuple] = {
     "din_nhwc_to_nchw_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "din_nchw_f32_to_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
     "din_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
+    "din_adam_step_multi": (_I, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _I, _F, _P]),
 }
 
 _lib = None

@@ -149,6 +149,33 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// multi-tensor form: one launch for the whole parameter list.  ptrs[t] = {p, g, m, v} of tensor t; workgroup b updates elements
+// [chunk_index[b] * chunk, +chunk) of tensor chunk_tensor[b]
+__global__ __launch_bounds__(256) void adam_multi_kernel(const uint64_t* __restrict__ ptrs, const int64_t* __restrict__ sizes,
+                                                         const int32_t* __restrict__ chunk_tensor, const int32_t* __restrict__ chunk_index,
+                                                         int chunk, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                         float bc2_sqrt, float gscale) {
+    const int t = chunk_tensor[blockIdx.x];
+    float* __restrict__ p = reinterpret_cast<float*>(ptrs[4 * t + 0]);
+    const float* __restrict__ g = reinterpret_cast<const float*>(ptrs[4 * t + 1]);
+    float* __restrict__ m = reinterpret_cast<float*>(ptrs[4 * t + 2]);
+    float* __restrict__ v = reinterpret_cast<float*>(ptrs[4 * t + 3]);
+    const int64_t n = sizes[t];
+    const int64_t i0 = (int64_t)chunk_index[blockIdx.x] * chunk;
+    int64_t i1 = i0 + chunk;
+    if (i1 > n) i1 = n;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        float gi = g[i] * gscale;
+        float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        float mi = b1 * m[i] + (1.f - b1) * gi;
+        float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -237,6 +264,18 @@ int din_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
     hipLaunchKernelGGL(adam_kernel, dim3(grid_1d(n, 256, 4096)), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2, eps,
                        weight_decay, bc1, bc2, grad_scale);
     DIN_CHECK_LAUNCH("adam_step");
+    return DIN_OK;
+}
+
+int din_adam_step_multi(const uint64_t* ptrs, const int64_t* sizes, const int32_t* chunk_tensor, const int32_t* chunk_index, int nchunks,
+                        int chunk_elems, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                        void* stream) {
+    DIN_REQUIRE(ptrs && sizes && chunk_tensor && chunk_index && nchunks >= 0 && chunk_elems > 0 && step >= 1, "adam_step_multi: bad argument");
+    if (nchunks == 0) return DIN_OK;
+    float bc1 = 1.f - powf(beta1, (float)step), bc2 = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(nchunks), dim3(256), 0, as_stream(stream), ptrs, sizes, chunk_tensor, chunk_index, chunk_elems,
+                       lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+    DIN_CHECK_LAUNCH("adam_step_multi");
     return DIN_OK;
 }
 

@@ -247,6 +247,12 @@ int din_nchw_f32_to_nhwc(const float* in, int nb, int h, int w, int c, void* out
 /* fused Adam step over a flat fp32 parameter/gradient buffer (train_net_dynamic.py:104,224) */
 int din_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* The same update for a whole parameter list in ONE launch.  Device tables: ptrs [nt][4] = {p, g, m, v} addresses, sizes [nt]
+ * element counts, and one (tensor, chunk index) pair per workgroup: workgroup b updates elements
+ * [chunk_index[b]*chunk_elems, +chunk_elems) of tensor chunk_tensor[b]. */
+int din_adam_step_multi(const uint64_t* ptrs, const int64_t* sizes, const int32_t* chunk_tensor, const int32_t* chunk_index,
+                        int nchunks, int chunk_elems, float lr, float beta1, float beta2, float eps, float weight_decay,
+                        int step, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

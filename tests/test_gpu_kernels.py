@@ -385,6 +385,21 @@ def test_head_and_adam(env):
         opt.step()
         ops.adam_step(pd, gr.cuda(), m, v, 1e-2, 0.9, 0.999, 1e-8, 0.01, step)
     assert rel(pd, pr) <= 1e-5
+    # FusedAdam: the whole parameter list in one multi-tensor launch (ragged sizes around the 8192-element chunk)
+    from din_amd.optim import FusedAdam
+    shapes = [(3,), (8192,), (8193,), (70, 300), (1,)]
+    ps = [torch.randn(sh, generator=g) for sh in shapes]
+    refs = [t.clone().requires_grad_(True) for t in ps]
+    devs = [t.cuda().requires_grad_(True) for t in ps]
+    ropt = torch.optim.Adam(refs, lr=3e-3, weight_decay=1e-4)
+    fopt = FusedAdam(devs, lr=3e-3, weight_decay=1e-4)
+    for step in range(3):
+        for r_, d_ in zip(refs, devs):
+            gr = torch.randn(r_.shape, generator=g)
+            r_.grad, d_.grad = gr.clone(), gr.cuda()
+        ropt.step(); fopt.step()
+    for r_, d_ in zip(refs, devs):
+        assert rel(d_.detach(), r_.detach()) <= 1e-5
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
