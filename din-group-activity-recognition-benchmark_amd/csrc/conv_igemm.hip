@@ -1996,7 +1996,7 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
             }
             // measured (profiles/r01_wgrad_ring.txt): the ring wins where the 128-row tiles pad badly (cout 192 -> 2 x 128 wastes a
             // quarter of the MFMAs); at equal tile height the two-workgroups-per-CU v3 kernel is faster
-            if (best == 192 || mode == 2) w.bco = best;
+            if ((best == 192 && best_pad * 100 <= d->cout * 105) || mode == 2) w.bco = best;
             else w.ring = 0;
         }
     }
