@@ -18,6 +18,7 @@
 // Replaces the arithmetic of torch.nn.Conv2d / nn.Linear reached from the reference at
 // backbone/backbone.py:44-99, infer_model.py:184,190,226 and infer_module/dynamic_infer_module.py:149,191,195.
 #include "din_common.h"
+#include <unordered_map>
 #include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -820,6 +821,258 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_small_kernel(ConvK p) {
             __syncthreads();                                                            // staging buffer free again
             if (tile + (int)gridDim.x < ntiles) issue_halo(0, tile + gridDim.x);
         }
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Halo-tiled convolution for the mid-network multi-tap layers (3x3, 1x7, 7x1; stride 1; bf16; fwd and dgrad).
+// The implicit-GEMM kernel streams every input pixel once per tap and the filter slab once per 128 pixels; measured, it runs at
+// (FLOP per streamed byte) x ~9.6 TB/s.  Here a workgroup owns a TH x TW = 256-pixel output tile: per 64-channel block the input
+// HALO is brought into LDS once (all taps are formed from it) and only the filter slab of one (tap, channel block) moves through
+// a small LDS-DMA ring: 2-3x fewer streamed bytes per FLOP.  Both LDS images use a 160-byte row pitch (8 data chunks + 2 pad
+// chunks the DMA leaves empty): 16 consecutive rows x one chunk are then conflict-free for ds_read_b128 at ANY row offset, so a
+// tap is nothing but an immediate offset on the fragment reads -- no per-tap address arithmetic (the first version of this kernel
+// spent 46 % of its wave cycles issuing address / bookkeeping instructions; SQ counters in profiles/r01_halo_probe.txt).
+// Persistent workgroups (one per CU) walk the (tile, filter tile) items; the next block's halo (also across items) is in flight
+// during the current block's taps, the slab ring runs NSW-1 tap steps ahead, one s_barrier per tap step, vmcnt counted by hand
+// (every wave issues the same number of transfers; surplus ones fetch nothing into pad space).  Epilogue straight from the
+// accumulators as always-issued buffer stores (bias / ReLU / ReLU-backward mask / accumulate).
+// ------------------------------------------------------------------------------------------------
+template <int BN, int KH, int KW, int TH, int TW, int NSW>
+__global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvK p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef bf16_t T;
+    // 8 waves: wave = (pixel group wp of 64 pixels, filter half wc): two waves per SIMD, so one wave's waits (barrier, vmcnt, LDS
+    // latency) hide behind the other's MFMAs -- with 4 waves (one per SIMD) the kernel ran at 20 % MFMA utilisation
+    constexpr int NWV = 8, NTAPS = KH * KW, TI = BN / 32, TJ = 4;
+    constexpr int HWW = TW + KW - 1, HWH = TH + KH - 1, HPX = HWW * HWH;
+    constexpr int PCH = 10, PB = PCH * 16;                            // row pitch: 10 chunks = 160 bytes
+    constexpr int NTR_H = (HPX * PCH + 64 * NWV - 1) / (64 * NWV), HBYTES = NTR_H * 1024 * NWV;
+    constexpr int NTR_W = (BN * PCH + 64 * NWV - 1) / (64 * NWV), WBYTES = NTR_W * 1024 * NWV;
+    static_assert(TH * TW == 256 && TW % 16 == 0 && NTAPS > NSW && BN % 32 == 0, "tile shape");
+    constexpr int NST = TI * TJ;                                       // epilogue stores per wave per item
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int frow = lane & 15, g4 = lane >> 4;
+    const int wp = wid & 3, wc = wid >> 2;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw;
+    const uint32_t ldsWv = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(wid * 1024));
+
+    // ---- DMA plans ------------------------------------------------------------------------------------------------------------
+    // (the halo plan is recomputed per transfer at issue time -- once per 64-channel block; as per-lane arrays it cost ~60 VGPRs and
+    //  pushed the tap loop into AGPR spills)
+    int relW[NTR_W]; signed char wcc[NTR_W];
+#pragma unroll
+    for (int i = 0; i < NTR_W; ++i) {
+        const int id = (wid + NWV * i) * 64 + lane;
+        const int co = id / PCH, cc = id - co * PCH;
+        relW[i] = (co < BN && cc < 8) ? co * p.wld * 16 + cc * 16 : -1;  // + filter-tile row offset + (tap * cpt + 8 b) * 16
+        wcc[i] = (signed char)cc;
+    }
+    const int hy0 = p.by + (p.cy < 0 ? (KH - 1) * p.cy : 0), hx0 = p.bx + (p.cx < 0 ? (KW - 1) * p.cx : 0);
+    const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + TH - 1) / TH;
+    const int tiles_img = tiles_x * tiles_y, nitems = tiles_img * p.NB * p.n_co_tiles;
+    const long long img_bytes = (long long)p.H * p.W * p.ldi * 2ll;
+    const long long oimg_bytes = (long long)p.OH * p.OW * p.ldo * 2ll, mimg_bytes = (long long)p.OH * p.OW * p.ldm * 2ll;
+    const int nblk = (p.cpt + 7) >> 3;                                  // 64-channel blocks
+    __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+
+    struct Item { int n, ty, tx, co_tile; };
+    auto decode_item = [&](int item) {
+        Item it;
+        it.co_tile = item % p.n_co_tiles;
+        const int tile = item / p.n_co_tiles;
+        it.n = tile / tiles_img;
+        const int tr = tile - it.n * tiles_img;
+        it.ty = tr / tiles_x; it.tx = tr - it.ty * tiles_x;
+        return it;
+    };
+    auto issue_halo = [&](int buf, const Item& it, int b) {
+        const int gy0 = it.ty * TH + hy0, gx0 = it.tx * TW + hx0;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(p.in)) + (long long)it.n * img_bytes, 0, (int)img_bytes, 0x00020000);
+        const int base = (gy0 * p.W + gx0) * p.ldi * 2 + (p.cioff + b * 64) * 2;
+        const int nch = p.cpt - b * 8;                                  // chunks of this block that exist (>= 8: all)
+        const uint32_t dst = ldsWv + (uint32_t)(buf * HBYTES);
+#pragma unroll 2
+        for (int i = 0; i < NTR_H; ++i) {
+            const int id = (wid + NWV * i) * 64 + lane;
+            const int hp = (int)(((unsigned)id * 52429u) >> 19);         // id / 10 for id < 81920
+            const int cc = id - hp * PCH;
+            const int hy = (int)(((unsigned)hp * (65536u / HWW + 1u)) >> 16), hx = hp - hy * HWW;   // hp / HWW (hp < 1024)
+            const int gy = gy0 + hy, gx = gx0 + hx;
+            const bool ok = hp < HPX && cc < 8 && cc < nch && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            lds_dma16(dst + (uint32_t)(i * 1024 * NWV), rs, ok ? base + (hy * p.W + hx) * p.ldi * 2 + cc * 16 : (int)OOB, 0);
+        }
+    };
+    auto issue_w = [&](int slot, int co_tile, int b, int tap) {
+        const int nch = p.cpt - b * 8;
+        const int soff = (co_tile * BN * p.wld + tap * p.cpt + b * 8) * 16;
+        const uint32_t dst = ldsWv + (uint32_t)(2 * HBYTES + slot * WBYTES);
+#pragma unroll
+        for (int i = 0; i < NTR_W; ++i) lds_dma16(dst + (uint32_t)(i * 1024 * NWV), rsW, (relW[i] >= 0 && wcc[i] < nch) ? relW[i] : (int)OOB, soff);
+    };
+
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragment read bases (bytes): pixel segment j of this wave at tap (0,0) of the gather direction, chunk g4; filter row frow, chunk g4
+    const int yb = p.cy > 0 ? 0 : KH - 1, xb = p.cx > 0 ? 0 : KW - 1;
+    const int tstep_y = (p.cy > 0 ? 1 : -1) * HWW * PB, tstep_x = (p.cx > 0 ? 1 : -1) * PB;     // byte step of one tap row / column
+    uint32_t xbase[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int q = wp * 4 + j;
+        const int qy = TW == 32 ? (q >> 1) : q, qx = TW == 32 ? (q & 1) * 16 : 0;
+        xbase[j] = (uint32_t)(((qy + yb) * HWW + qx + frow + xb) * PB + g4 * 16);
+    }
+    const uint32_t wbase = (uint32_t)(2 * HBYTES + (wc * (BN / 2) + frow) * PB + g4 * 16);
+
+    // ---- (item, channel block) pair walk ----------------------------------------------------------------------------------------
+    const int G = (int)gridDim.x;
+    int item = xcd_remap((int)blockIdx.x, G);
+    if (item >= nitems) return;
+    Item cur = decode_item(item);
+    int b = 0, hb = 0;
+    int item_w = item, b_w = 0, tap_w = 0;                              // (item, block, tap) of the next filter slab to issue
+    int co_w = cur.co_tile;
+    bool w_live = true;
+    auto advance_w = [&]() {
+        if (++tap_w == NTAPS) {
+            tap_w = 0;
+            if (++b_w == nblk) { b_w = 0; item_w += G; w_live = item_w < nitems; if (w_live) co_w = item_w % p.n_co_tiles; }
+        }
+    };
+    issue_halo(0, cur, 0);
+    int wslot_issue = 0;
+#pragma unroll
+    for (int s0 = 0; s0 < NSW - 1; ++s0) {
+        if (w_live) { issue_w(wslot_issue, co_w, b_w, tap_w); advance_w(); }
+        wslot_issue = wslot_issue + 1 == NSW ? 0 : wslot_issue + 1;
+    }
+    int wslot = 0;                                                      // ring slot of the current step
+    bool fresh_item = false;                                            // an epilogue's stores were issued since the last tap step
+    for (;;) {
+        int item_n = item, b_n = b + 1;
+        if (b_n == nblk) { b_n = 0; item_n = item + G; }
+        const bool has_next = item_n < nitems;
+        const Item nxt = (b_n == 0 && has_next) ? decode_item(item_n) : cur;
+        const uint32_t hoff = (uint32_t)(hb * HBYTES);
+        const bool two = p.cpt - b * 8 > 4;                             // second 32-channel slice present
+#pragma unroll
+        for (int tap = 0; tap < NTAPS; ++tap) {
+            // ---- slab of this step landed?  Younger transfers that may stay in flight (in-order completion): the NSW-2 slabs issued
+            //      after it, the halo issued at this pair's tap-0 step (taps 1 .. NSW-1), the stores of an epilogue issued since ----
+            {
+                constexpr int base_allow = (NSW - 2) * NTR_W;
+                const bool halo_tap = tap >= 1 && tap <= NSW - 1;
+                const bool store_tap = tap <= NSW - 2;
+                constexpr int a_hs = base_allow + NTR_H + NST > 63 ? 63 : base_allow + NTR_H + NST;
+                constexpr int a_s = base_allow + NST > 63 ? 63 : base_allow + NST;
+                const bool hy_ = halo_tap && has_next, st_ = store_tap && fresh_item;
+                if (!w_live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // tail of the walk: drain
+                else if (hy_ && st_) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(a_hs) : "memory");
+                else if (hy_) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(base_allow + NTR_H) : "memory");
+                else if (st_) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(a_s) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(base_allow) : "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (w_live) { issue_w(wslot_issue, co_w, b_w, tap_w); advance_w(); }
+            wslot_issue = wslot_issue + 1 == NSW ? 0 : wslot_issue + 1;
+            if (tap == 0 && has_next) issue_halo(hb ^ 1, nxt, b_n);
+            // ---- MFMAs of (block b, tap): every fragment address = lane base + compile-time offset ------------------------------------
+            const int r = tap / KW, s2 = tap - r * KW;
+            const uint32_t xoff = hoff + (uint32_t)(r * tstep_y + s2 * tstep_x);
+            const uint32_t woff = (uint32_t)(wslot * WBYTES);
+            u32x4 wf[2][TI], xf[2][TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) wf[0][i] = *reinterpret_cast<const u32x4*>(smem_raw + wbase + woff + i * 16 * PB);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) xf[0][j] = *reinterpret_cast<const u32x4*>(smem_raw + xbase[j] + xoff);
+            __builtin_amdgcn_sched_barrier(0);
+            if (two) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i) wf[1][i] = *reinterpret_cast<const u32x4*>(smem_raw + wbase + woff + i * 16 * PB + 64);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) xf[1][j] = *reinterpret_cast<const u32x4*>(smem_raw + xbase[j] + xoff + 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) Mma<T>::run(wf[0][i], xf[0][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (two) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) Mma<T>::run(wf[1][i], xf[1][j], acc[i][j]);
+            }
+            wslot = wslot + 1 == NSW ? 0 : wslot + 1;
+            if (tap == NSW - 2) fresh_item = false;
+        }
+        // ---- end of the item: epilogue straight from the accumulators ----------------------------------------------------------------
+        if (b == nblk - 1) {
+            __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + (long long)cur.n * oimg_bytes, 0, (int)oimg_bytes, 0x00020000);
+            __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(reinterpret_cast<const char*>((p.flags & DIN_CONV_MASK) ? p.mask : p.out)) + (long long)cur.n * mimg_bytes, 0,
+                (p.flags & DIN_CONV_MASK) ? (int)mimg_bytes : 0, 0x00020000);
+            // bias first (one batch of loads; a load between the stores would wait for every store before it: vmcnt is in-order)
+            f32x4 bv[TI];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const int co = cur.co_tile * BN + wc * (BN / 2) + i * 16 + g4 * 4;
+                bv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if ((p.flags & DIN_CONV_BIAS) && co < p.Cout) bv[i] = *reinterpret_cast<const f32x4*>(p.bias + co);
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int q = wp * 4 + j;
+                const int qy = TW == 32 ? (q >> 1) : q, qx = TW == 32 ? (q & 1) * 16 : 0;
+                const int gy = cur.ty * TH + qy, gx = cur.tx * TW + qx + frow;
+                const bool pok = gy < p.OH && gx < p.OW;
+                const int opx = gy * p.OW + gx;
+                u32x2 mk[TI], old[TI];
+                int off[TI];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {                                 // all loads of this pixel segment, then all its stores
+                    const int co = cur.co_tile * BN + wc * (BN / 2) + i * 16 + g4 * 4;
+                    const bool ok = pok && co < p.Cout;                      // Cout % 4 == 0 (host)
+                    off[i] = ok ? (opx * p.ldo + p.cooff + co) * 2 : (int)OOB;
+                    if (p.flags & DIN_CONV_MASK) mk[i] = __builtin_amdgcn_raw_buffer_load_b64(rsM, ok ? (opx * p.ldm + p.moff + co) * 2 : (int)OOB, 0, 0);
+                    if (p.flags & DIN_CONV_ACCUM) old[i] = __builtin_amdgcn_raw_buffer_load_b64(rsO, off[i], 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    f32x4 v = acc[i][j] + bv[i];
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (p.flags & DIN_CONV_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (p.flags & DIN_CONV_MASK) {
+                        if (!(__uint_as_float(mk[i][0] << 16) > 0.f)) v[0] = 0.f;
+                        if (!(__uint_as_float(mk[i][0] & 0xffff0000u) > 0.f)) v[1] = 0.f;
+                        if (!(__uint_as_float(mk[i][1] << 16) > 0.f)) v[2] = 0.f;
+                        if (!(__uint_as_float(mk[i][1] & 0xffff0000u) > 0.f)) v[3] = 0.f;
+                    }
+                    if (p.flags & DIN_CONV_ACCUM) {
+                        v[0] += __uint_as_float(old[i][0] << 16); v[1] += __uint_as_float(old[i][0] & 0xffff0000u);
+                        v[2] += __uint_as_float(old[i][1] << 16); v[3] += __uint_as_float(old[i][1] & 0xffff0000u);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, rsO, off[i], 0, 0);
+                }
+            }
+            fresh_item = true;
+        }
+        if (!has_next) break;
+        item = item_n; b = b_n; hb ^= 1;
+        if (b == 0) cur = nxt;
     }
 #endif
 }
@@ -1913,6 +2166,7 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype) {
     } else if (!(force && atoi(force) == 128)) {
         const int nco256 = (cprod + 255) / 256;
         if (dtype == DIN_BF16 && cprod >= 224 && nco256 * 256 * 100 <= cprod * 115 && g.nk >= 24 && tiles256 * nco256 >= 768) { g.bm = 256; g.bn = 256; }
+        else if (dtype == DIN_BF16 && force && atoi(force) == 256 && tiles256 >= 512) g.bm = 256;      // experiment: 256 x {96..192}
     }
     g.cout_pad = pad_to(cprod, 128);
     g.n_co_tiles = (cprod + g.bn - 1) / g.bn;
@@ -2043,13 +2297,52 @@ int check_desc(const din_conv_desc* d) {
     return DIN_OK;
 }
 
+
+// halo kernel eligibility / shape (shared by run_gather and din_conv_kernel_tile).  Returns the filter-tile width (0: not eligible).
+// hipFuncSetAttribute is a slow host call: raise a kernel's dynamic-LDS limit once per (thread, kernel), not per launch
+template <typename K>
+static void raise_lds_limit(K kern, size_t lds) {
+    static thread_local std::unordered_map<const void*, size_t> granted;
+    const void* fn = reinterpret_cast<const void*>(kern);
+    auto it = granted.find(fn);
+    if (it != granted.end() && lds <= it->second) return;
+    hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    granted[fn] = lds;
+}
+
+struct HaloPlan { int bn, th, tw, nsw, n_co_tiles; size_t lds; };
+static bool plan_halo(int dtype, int kh, int kw, int cred, int cprod, int oh, int ow, int64_t M, HaloPlan& hp) {
+    const char* hv = getenv("DIN_CONV_HALO");
+    if (hv && atoi(hv) == 0) return false;
+    if (dtype != DIN_BF16 || cred < 32 || cred % 8 != 0 || cprod % 8 != 0 || cprod < 40 || M < 64 * 1024) return false;
+    const bool k33 = kh == 3 && kw == 3, k17 = kh == 1 && kw == 7, k71 = kh == 7 && kw == 1;
+    if (!(k33 || k17 || k71)) return false;
+    // filter tiles of 64 or 96 rows: fewest tiles, then least padding
+    const int t96 = (cprod + 95) / 96, t64 = (cprod + 63) / 64;
+    hp.bn = (t96 < t64 || (t96 == t64 && t96 * 96 <= t64 * 64)) ? 96 : 64;
+    hp.n_co_tiles = hp.bn == 96 ? t96 : t64;
+    if (hp.n_co_tiles * hp.bn * 100 > cprod * 125) return false;
+    // measured (profiles/r01_halo_probe.txt): wins 15-22 % on 3x3 layers whose filters fit ONE tile (no halo re-read per filter tile);
+    // loses against the 128x192 / 128x160 gather tiles on the wide 192-filter and 7-tap layers.  DIN_CONV_HALO=2 forces it everywhere.
+    if (!(hv && atoi(hv) == 2) && !(k33 && hp.n_co_tiles == 1)) return false;
+    hp.th = k33 ? 8 : 16; hp.tw = k33 ? 32 : 16;
+    // padded-area waste of the tile grid must stay moderate
+    const int64_t padded = (int64_t)((oh + hp.th - 1) / hp.th * hp.th) * ((ow + hp.tw - 1) / hp.tw * hp.tw);
+    if (padded * 100 > (int64_t)oh * ow * 118) return false;
+    const int hpx = (hp.th + kh - 1) * (hp.tw + kw - 1);
+    const size_t hbytes = (size_t)((hpx * 10 + 511) / 512) * 8192, wbytes = (size_t)((hp.bn * 10 + 511) / 512) * 8192;
+    hp.nsw = 3;
+    hp.lds = 2 * hbytes + 3 * wbytes;
+    return hp.lds <= 160 * 1024;
+}
+
 template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS>
 void launch_fast(const ConvK& k, dim3 grid, hipStream_t st) {
     size_t stage = (size_t)NS * (BMT + BN) * KCS * 16 + (k.remap ? 128 : 0);     // stage ring (+ remap table)
     size_t epi = (size_t)BMT * (BN * sizeof(T) + 16);
     size_t lds = stage > epi ? stage : epi;
     auto kern = conv_gather_fast_kernel<T, BMT, BN, WM, WN, KCS, NS>;
-    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 65536) raise_lds_limit(kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, st, k);
 }
 
@@ -2059,7 +2352,7 @@ void launch_fast_multi(const ConvK& k, dim3 grid, hipStream_t st) {
     size_t epi = (size_t)128 * (BN * sizeof(T) + 16);
     size_t lds = stage > epi ? stage : epi;
     auto kern = conv_gather_fast_kernel<T, 128, BN, 2, 2, 8, 2, true>;
-    if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 65536) raise_lds_limit(kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k);
 }
 
@@ -2091,6 +2384,14 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
     else if (bm == 256 && bn == 256) {
         if constexpr (sizeof(T) == 2) { if (pipe == 1) launch_fast<T, 256, 256, 4, 2, 4, 4>(k, grid, st); else launch_fast<T, 256, 256, 4, 2, 8, 2>(k, grid, st); }
     }
+    else if (bm == 256) {
+        if constexpr (sizeof(T) == 2) {
+            if (bn == 96) launch_fast<T, 256, 96, 2, 2, 8, 2>(k, grid, st);
+            else if (bn == 160) launch_fast<T, 256, 160, 2, 2, 8, 2>(k, grid, st);
+            else if (bn == 192) launch_fast<T, 256, 192, 4, 2, 8, 2>(k, grid, st);
+            else { if (pipe == 1) launch_fast<T, 256, 128, 4, 2, 4, 4>(k, grid, st); else launch_fast<T, 256, 128, 4, 2, 8, 2>(k, grid, st); }
+        }
+    }
     else if (bn == 64) { if (pipe == 1) launch_fast<T, 128, 64, 2, 2, 8, 3>(k, grid, st); else launch_fast<T, 128, 64, 2, 2, 8, 2>(k, grid, st); }
     else if (bn == 96) launch_fast<T, 128, 96, 2, 2, 8, 2>(k, grid, st);
     else if (bn == 160) launch_fast<T, 128, 160, 2, 2, 8, 2>(k, grid, st);
@@ -2119,6 +2420,32 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
         k.partial = reinterpret_cast<float*>(workspace);
     }
     {
+        // mid-network multi-tap layers: halo tiles + filter-slab ring (conv_halo_kernel); the stem shapes keep their own kernel below
+        HaloPlan hp;
+        const bool stem_shape = k.kh == 3 && k.kw == 3 && (k.Cin == 32 || k.Cin == 64) && k.Cout <= 64 && !(k.Cin == 64 && k.Cout > 32) &&
+                                (int64_t)k.M >= 256 * 1024;
+        if (fast && !k.remap && k.nsrc == 0 && g.splitk == 1 && !stem_shape && k.ay == 1 && k.ax == 1 && (k.cy == 1 || k.cy == -1) &&
+            (k.cx == 1 || k.cx == -1) && k.cy == k.cx && k.out_sy == 0 && k.ldi % 8 == 0 && k.cioff % 8 == 0 && k.ldo % 4 == 0 && k.cooff % 4 == 0 &&
+            (!(k.flags & DIN_CONV_MASK) || (k.ldm % 4 == 0 && k.moff % 4 == 0)) &&
+            (long long)k.H * k.W * k.ldi * 2 < 0x7fffffffll && (long long)k.OH * k.OW * k.ldo * 2 < 0x7fffffffll &&
+            (long long)k.OH * k.OW * (k.ldm > 0 ? k.ldm : 1) * 2 < 0x7fffffffll &&
+            plan_halo(dtype, k.kh, k.kw, k.Cin, k.Cout, k.OH, k.OW, k.M, hp)) {
+            k.n_co_tiles = hp.n_co_tiles;
+            const int tiles = ((k.OH + hp.th - 1) / hp.th) * ((k.OW + hp.tw - 1) / hp.tw) * k.NB * hp.n_co_tiles;
+            dim3 grid(tiles < 256 ? tiles : 256);
+            auto launch = [&](auto kern) {
+                raise_lds_limit(kern, hp.lds);
+                hipLaunchKernelGGL(kern, grid, dim3(512), hp.lds, st, k);
+            };
+            bool done = true;
+            if (k.kh == 3 && k.kw == 3) { if (hp.bn == 64) launch(conv_halo_kernel<64, 3, 3, 8, 32, 3>); else launch(conv_halo_kernel<96, 3, 3, 8, 32, 3>); }
+            else if (k.kh == 1 && k.kw == 7) { if (hp.bn == 64) launch(conv_halo_kernel<64, 1, 7, 16, 16, 3>); else launch(conv_halo_kernel<96, 1, 7, 16, 16, 3>); }
+            else if (k.kh == 7 && k.kw == 1) { if (hp.bn == 64) launch(conv_halo_kernel<64, 7, 1, 16, 16, 3>); else launch(conv_halo_kernel<96, 7, 1, 16, 16, 3>); }
+            else done = false;
+            if (done) { DIN_CHECK_LAUNCH(what); return DIN_OK; }
+        }
+    }
+    {
         // stem layers: stationary filters + halo tiles (conv_small_kernel)
         const char* sv = getenv("DIN_CONV_SMALL");
         const bool want = sv ? atoi(sv) != 0 : true;
@@ -2142,7 +2469,7 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
             const size_t lds = (size_t)(image ? 3 * bnS * 64 : 9 * bnS * g.cpt * 16) + (size_t)nbuf * hbytes;
             dim3 grid(512);
             auto launch = [&](auto kern) {
-                if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (lds > 65536) raise_lds_limit(kern, lds);
                 hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, k);
             };
             if (image) launch(conv_small_kernel<1, 32, 2, 3, 3, 2>);
@@ -2234,6 +2561,13 @@ int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t
                                             d->cout, d->cin, d->kh * d->kw, d->dtype);
     if (g.bm == 256 && (strided || g.splitk > 1)) { g.bm = 128; if (g.bn == 256) g.bn = 128; }
     *bm = g.bm; *bn = g.bn;
+    {   // mid-network multi-tap layers run conv_halo_kernel: bm = 1
+        HaloPlan hp;
+        const int cred = which == 0 ? d->cin : d->cout, cprod = which == 0 ? d->cout : d->cin;
+        const int64_t M = which == 0 ? (int64_t)d->nb * d->oh * d->ow : (int64_t)d->nb * d->h * d->w;
+        const int oh_ = which == 0 ? d->oh : d->h, ow_ = which == 0 ? d->ow : d->w;
+        if (d->sh == 1 && d->sw == 1 && d->dh == 1 && d->dw == 1 && g.splitk == 1 && plan_halo(d->dtype, d->kh, d->kw, cred, cprod, oh_, ow_, M, hp)) { *bm = 1; *bn = hp.bn; }
+    }
     {   // stem layers run conv_small_kernel (same conditions as run_gather, for tensors with 16-byte aligned channel offsets): bm = 0
         const int cred = which == 0 ? d->cin : d->cout, cprod = which == 0 ? d->cout : d->cin;
         const int64_t M = which == 0 ? (int64_t)d->nb * d->oh * d->ow : (int64_t)d->nb * d->h * d->w;
@@ -2423,7 +2757,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
             const int hbytes = ((7 * st_ + 3) * (31 * st_ + 3) * cpp * 16 + 1023) / 1024 * 1024;
             const size_t lds = 2 * ((size_t)hbytes + 256 * (size_t)wp.bco * 2);
             auto launch = [&](auto kern) {
-                if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (lds > 65536) raise_lds_limit(kern, lds);
                 hipLaunchKernelGGL(kern, dim3(WGRAD_SMALL_GRID), dim3(NTHREADS), lds, st, k);
             };
             if (wp.small == 1) launch(conv_wgrad_small_kernel<4, 32, 1>);
@@ -2437,7 +2771,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
             }
             const size_t lds = 4 * ((size_t)((32 * wp.bco / 8 + 255) / 256) * 4096 + 32 * 256 * 2);   // four 32-pixel stages (G tile in 4-KiB rounds)
             auto launch = [&](auto kern) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                raise_lds_limit(kern, lds);
                 hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, k);
             };
             if (wp.bco == 128) launch(conv_wgrad_ring_kernel<128, 256>);
@@ -2451,7 +2785,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
             }
             size_t lds = 2 * 64 * ((size_t)(wp.bco * 2) + (WG_TILE * 2));        // two unpadded stages
             auto launch = [&](auto kern) {
-                if (lds > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (lds > 65536) raise_lds_limit(kern, lds);
                 hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, k);
             };
             if (wp.bco == 64) launch(conv_wgrad_bf16_kernel<64>);

@@ -91,6 +91,8 @@ class _timed:
                     variant = f"conv_wgrad_bf16_kernel<{bm.value}>" if d.dtype == L.DIN_BF16 else "conv_wgrad_f32_kernel"
             elif bm.value == 0:
                 variant = f"conv_small_kernel<..., {bn.value}, ...>"
+            elif bm.value == 1:
+                variant = f"conv_halo_kernel<{bn.value}, ...>"
             else:
                 variant = f"conv_gather_fast_kernel<{tn}, {bm.value}, {bn.value}, ...>"
             PROFILE.append((self.kind, variant, _conv_flops(d), int(d.dtype), self.e0, self.e1, self.name))

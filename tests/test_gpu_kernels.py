@@ -56,14 +56,23 @@ CONV_CASES = [
     ("stem_32_32_p0", 1, 32, 515, 517, 32, (3, 3), (1, 1), (0, 0), 1),
     ("stem_32_64_p1", 2, 32, 363, 365, 64, (3, 3), (1, 1), (1, 1), 1),
     ("image_3_32_s2", 1, 3, 1031, 1029, 32, (3, 3), (2, 2), (0, 0), 1),     # Inception Conv2d_1a: image layer of the halo kernel
+    # mid-network multi-tap shapes (>= 64K pixels): bf16 runs conv_halo_kernel for fwd and dgrad (partial 64-channel blocks,
+    # ragged tiles, every tap geometry it is instantiated for)
+    ("halo_3x3_64_96", 6, 64, 87, 157, 96, (3, 3), (1, 1), (1, 1), 1),
+    ("halo_3x3_80_192_p0", 2, 80, 181, 321, 192, (3, 3), (1, 1), (0, 0), 1),
+    ("halo_5x5_48_64", 6, 48, 87, 157, 64, (5, 5), (1, 1), (2, 2), 1),
+    ("halo_1x7_128_160", 20, 128, 43, 78, 160, (1, 7), (1, 1), (0, 3), 1),
+    ("halo_7x1_160_192", 20, 160, 43, 78, 192, (7, 1), (1, 1), (3, 0), 1),
 ]
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv_fwd_dgrad_wgrad(env, case, dtype):
+def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
     lib, L, nhwc, ops = env
     name, nb, cin, h, w, cout, k, s, p, dil = case
+    if name.startswith("halo_"):
+        monkeypatch.setenv("DIN_CONV_HALO", "2")        # the planner only picks the halo kernel where it wins; cover every instantiation
     dt = L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
     tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
     epc = 4 if dtype == "fp32" else 8

@@ -1,2 +1,1 @@
-timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "stem or image or conv1" 2>&1 | tail -3
-timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --per-layer gpurun_out/per_layer.txt 2>&1 | tail -1 | cut -c1-200
+timeout 1200 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "halo and bf16" 2>&1 | tail -15
