@@ -1477,24 +1477,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) 
 // the wave: a 4-stage ring of 32-pixel stages with the LDS-DMA issued THREE stages ahead (hand-counted vmcnt), and the transpose
 // reads of stage s in flight while the MFMAs of stage s-1 run (register double buffer).  One s_barrier per stage.
 template <int BCO, int BK>
-__global__ __launch_bounds__(NTHREADS, 1) void conv_wgrad_ring_kernel(WgradK p) {
+__global__ __launch_bounds__(512, 1) void conv_wgrad_ring_kernel(WgradK p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int PK = 32, NS = 4;
+    // 8 waves (2 x 4: filter half wm, k-column quarter wn), two per SIMD: one wave's barrier / vmcnt / transpose-read waits hide
+    // behind the other's MFMAs (with one wave per SIMD they are all serial; cf. profiles/r01_halo_probe.txt)
+    constexpr int PK = 32, NS = 4, NWV = 8, NTH = 64 * NWV;
     constexpr int CG = BCO / 8, CX = BK / 8;                      // 16-byte chunks per G / X row
     constexpr int RBG = BCO * 2, RBX = BK * 2;                    // row bytes (unpadded)
-    constexpr int TI = BCO / 32, XJ = BK / 32;                    // 16-row / 16-column MFMA tiles per wave (wave tile = BCO/2 x BK/2)
-    constexpr int GP = (PK * CG + NTHREADS - 1) / NTHREADS, XP = PK * CX / NTHREADS;
-    static_assert(PK * CX % NTHREADS == 0, "whole X DMA transfers per thread");
+    constexpr int TI = BCO / 32, XJ = BK / 64;                    // 16-row / 16-column MFMA tiles per wave (wave tile = BCO/2 x BK/4)
+    constexpr int GP = (PK * CG + NTH - 1) / NTH, XP = PK * CX / NTH;
+    static_assert(PK * CX % NTH == 0, "whole X DMA transfers per thread");
     // every wave issues the same number of transfers (the vmcnt bookkeeping is a compile-time constant): when the G tile is not a
     // whole number of 4-KiB rounds (BCO = 160) the surplus transfers fetch nothing and land in a pad behind the G tile
-    constexpr int OPG = GP * 4096, OPX = PK * RBX, STAGE = OPG + OPX;
+    constexpr int OPG = GP * 1024 * NWV, OPX = PK * RBX, STAGE = OPG + OPX;
     static_assert(OPG >= PK * RBG, "G region");
     constexpr int RPT = 64 / CX;                                  // X rows per wave-level transfer
     constexpr int NDMA = GP + XP;                                 // DMA instructions per stage per wave
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid >> 2, wn = wid & 3;
     int bx_, by_;
     xcd_block(bx_, by_);
     const int k_tile = bx_ % p.n_k_tiles, co_tile = bx_ / p.n_k_tiles;
@@ -1522,7 +1524,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_wgrad_ring_kernel(WgradK p) 
     unsigned voffG[GP];
 #pragma unroll
     for (int t = 0; t < GP; ++t) {
-        const int id = (wid + 4 * t) * 64 + lane;
+        const int id = (wid + NWV * t) * 64 + lane;
         const int grow = id / CG, slot = id - grow * CG;
         int gc = slot - 2 * (grow & 7);
         gc += gc < 0 ? CG : 0;
@@ -1530,7 +1532,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_wgrad_ring_kernel(WgradK p) 
         voffG[t] = (grow < PK && gco + 7 < p.Cout) ? (unsigned)((grow * p.ldo + p.cooff + gco) * 2) : OOB;   // Cout % 8 == 0 enforced
     }
     // ---- X DMA plan: transfer t covers rows (wid + 4 t) * RPT + lane / CX; (row & 7) is the same for all t -----------------------
-    const int xrow0 = wid * RPT + lane / CX;                       // rows xrow0 + 4 RPT t
+    const int xrow0 = wid * RPT + lane / CX;                       // rows xrow0 + NWV RPT t
     int xc = (lane % CX) - 2 * (xrow0 & 7);
     xc += xc < 0 ? CX : 0;
     const int kcol = k_tile * BK + xc * 8;
@@ -1544,7 +1546,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_wgrad_ring_kernel(WgradK p) 
     int px[XP], py[XP], rowoff[XP];
 #pragma unroll
     for (int t = 0; t < XP; ++t) {
-        int m = m_begin + xrow0 + 4 * RPT * t;
+        int m = m_begin + xrow0 + NWV * RPT * t;
         int n = m / ohw;
         int rem = m - n * ohw;
         py[t] = rem / p.OW; px[t] = rem - py[t] * p.OW;
@@ -1559,12 +1561,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_wgrad_ring_kernel(WgradK p) 
         const uint32_t Gd = ldsW + (uint32_t)(buf * STAGE), Xd = Gd + (uint32_t)OPG;
         const int soffG = (m0 - m_begin) * p.ldo * 2;
 #pragma unroll
-        for (int t = 0; t < GP; ++t) lds_dma16(Gd + (uint32_t)(t * 4096), rsG, (int)voffG[t], soffG);   // rows past M: out of range -> zeros
+        for (int t = 0; t < GP; ++t) lds_dma16(Gd + (uint32_t)(t * 1024 * NWV), rsG, (int)voffG[t], soffG);   // rows past M: out of range -> zeros
 #pragma unroll
         for (int t = 0; t < XP; ++t) {
             const int iy = py[t] * p.sh + dy0, ix = px[t] * p.sw + dx0;
-            const bool ok = ci_ok && (m0 + xrow0 + 4 * RPT * t < m_end) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            lds_dma16(Xd + (uint32_t)(t * 4096), rsX, ok ? rowoff[t] + px[t] * step_bytes : (int)OOB, 0);
+            const bool ok = ci_ok && (m0 + xrow0 + NWV * RPT * t < m_end) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            lds_dma16(Xd + (uint32_t)(t * 1024 * NWV), rsX, ok ? rowoff[t] + px[t] * step_bytes : (int)OOB, 0);
             px[t] += PK;
             while (px[t] >= p.OW) {
                 px[t] -= p.OW; rowoff[t] += row_jump;
@@ -1595,34 +1597,22 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_wgrad_ring_kernel(WgradK p) 
     }
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
-        int ch = (wn * (BK / 2) + j * 16) / 8 + rot;
+        int ch = (wn * (BK / 4) + j * 16) / 8 + rot;
         ch -= ch >= CX ? CX : 0;
         colX[j] = (uint32_t)(prow * RBX + (ch + ((li & 3) >> 1)) * 16 + (li & 1) * 8);
     }
-    u32x4 gf[2][TI], xf[2][XJ];
-    auto load_frags = [&](int buf, u32x4 (&gfr)[TI], u32x4 (&xfr)[XJ]) {
+    u32x4 gf[TI], xf[XJ];
+    auto load_frags = [&](int buf) {
         const uint32_t Gb = lds_base + (uint32_t)(buf * STAGE), Xb = Gb + (uint32_t)OPG;
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             u32x2 lo = lds_tr_read(Gb + colG[i]), hi = lds_tr_read(Gb + colG[i] + 16 * RBG);
-            gfr[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            gf[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
 #pragma unroll
         for (int j = 0; j < XJ; ++j) {
             u32x2 lo = lds_tr_read(Xb + colX[j]), hi = lds_tr_read(Xb + colX[j] + 16 * RBX);
-            xfr[j] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-        }
-    };
-    auto mma = [&](const u32x4 (&gfr)[TI], const u32x4 (&xfr)[XJ]) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < XJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gfr[i]), __builtin_bit_cast(bf16x8, xfr[j]), acc[i][j], 0, 0, 0);
-        if (do_bias) {
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-                accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gfr[i]), __builtin_bit_cast(bf16x8, ones), accb[i], 0, 0, 0);
+            xf[j] = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
     };
 
@@ -1632,28 +1622,30 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_wgrad_ring_kernel(WgradK p) 
 #pragma unroll
         for (int s0 = 0; s0 < NS - 1; ++s0)
             if (s0 < nst) issue_dma(s0, m_begin + s0 * PK);
-        // iteration s: [stage s landed] barrier, DMA stage s+3, transpose reads of stage s || MFMAs of stage s-1
-        for (int sb = 0; sb < nst; sb += 2) {
+        // iteration s: [stage s landed] barrier, DMA stage s+3, transpose reads + MFMAs of stage s (the SIMD's other wave overlaps)
+        for (int s2 = 0; s2 < nst; ++s2) {
+            // stages s2+1, s2+2 may stay in flight (issued after stage s2); near the end fewer are outstanding -> drain
+            if (s2 + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NDMA) : "memory");
+            else if (s2 + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (s2 + NS - 1 < nst) issue_dma((s2 + NS - 1) & (NS - 1), m_begin + (s2 + NS - 1) * PK);
+            load_frags(s2 & (NS - 1));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int s2 = sb + h;
-                if (s2 < nst) {
-                    // stages s2+1, s2+2 may stay in flight (issued after stage s2); near the end fewer are outstanding -> drain
-                    if (s2 + 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NDMA) : "memory");
-                    else if (s2 + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    if (s2 + NS - 1 < nst) issue_dma((s2 + NS - 1) & (NS - 1), m_begin + (s2 + NS - 1) * PK);
-                    load_frags(s2 & (NS - 1), gf[h], xf[h]);
-                    if (s2 > 0) mma(gf[h ^ 1], xf[h ^ 1]);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < XJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gf[i]), __builtin_bit_cast(bf16x8, xf[j]), acc[i][j], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gf[i]), __builtin_bit_cast(bf16x8, ones), accb[i], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if ((nst - 1) & 1) mma(gf[1], xf[1]);
-        else mma(gf[0], xf[0]);
     }
     float* dst = p.partial + (int64_t)slice * p.cout_pad * p.kcols_pad;
 #pragma unroll
@@ -1661,7 +1653,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv_wgrad_ring_kernel(WgradK p) 
 #pragma unroll
         for (int j = 0; j < XJ; ++j) {
             int co = co_tile * BCO + wm * (BCO / 2) + i * 16 + (lane >> 4) * 4;
-            int kc = k_tile * BK + wn * (BK / 2) + j * 16 + (lane & 15);
+            int kc = k_tile * BK + wn * (BK / 4) + j * 16 + (lane & 15);
 #pragma unroll
             for (int e = 0; e < 4; ++e) dst[(int64_t)(co + e) * p.kcols_pad + kc] = acc[i][j][e];
         }
@@ -2250,7 +2242,9 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
             }
             // measured (profiles/r01_wgrad_ring.txt): the ring wins where the 128-row tiles pad badly (cout 192 -> 2 x 128 wastes a
             // quarter of the MFMAs); at equal tile height the two-workgroups-per-CU v3 kernel is faster
-            if ((best == 192 && best_pad * 100 <= d->cout * 105) || mode == 2) w.bco = best;
+            // (8-wave ring: +25..40 % on 192-row banks, +5..11 % on exact 128 / 256-row banks, behind v3 when rows or k columns pad)
+            const int kpad = pad_to(w.kcols, 256);
+            if ((best_pad * 100 <= d->cout * 105 && (best == 192 || kpad * 100 <= w.kcols * 112)) || mode == 2) w.bco = best;
             else w.ring = 0;
         }
     }
@@ -2769,10 +2763,10 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
                 k.dbias = dbias;
                 bias_fused = true;
             }
-            const size_t lds = 4 * ((size_t)((32 * wp.bco / 8 + 255) / 256) * 4096 + 32 * 256 * 2);   // four 32-pixel stages (G tile in 4-KiB rounds)
+            const size_t lds = 4 * ((size_t)((32 * wp.bco / 8 + 511) / 512) * 8192 + 32 * 256 * 2);   // four 32-pixel stages (G tile in 8-KiB rounds)
             auto launch = [&](auto kern) {
                 raise_lds_limit(kern, lds);
-                hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, k);
+                hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, k);
             };
             if (wp.bco == 128) launch(conv_wgrad_ring_kernel<128, 256>);
             else if (wp.bco == 160) launch(conv_wgrad_ring_kernel<160, 256>);
