@@ -209,6 +209,57 @@ __global__ __launch_bounds__(256) void maxpool_bwd_amax_kernel(din_pool_desc d, 
     }
 }
 
+
+// k = 3, stride 2, pad 0 (the backbones' only overlapping max-pool): one thread owns a 2x2 block of input pixels.  Its four pixels
+// lie in the same (up to) four windows (oy in {a-1, a}, ox in {b-1, b}), so the arg-max bytes and gradients of those windows are
+// loaded once and serve four outputs -- a quarter of the L2 traffic of the one-pixel-per-thread form.
+template <int V>
+__global__ __launch_bounds__(256) void maxpool_bwd_amax_k3s2_kernel(din_pool_desc d, Dec3 dd, const uint8_t* __restrict__ amax,
+                                                                    const void* __restrict__ dout, void* __restrict__ din_, int accumulate) {
+    const int hb = (d.h + 1) >> 1, wb = (d.w + 1) >> 1;
+    const int64_t total = (int64_t)d.nb * hb * wb * (d.c / V);
+    DIN_GRID_STRIDE(i, total) {
+        int cg, bx, by, n; int64_t pblk;
+        decode(dd, i, cg, bx, by, n, pblk);
+        uint32_t pk[4][V / 4]; Vec<V> go[4]; bool wok[4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int oy = by - 1 + a, ox = bx - 1 + b;
+                wok[a * 2 + b] = oy >= 0 && oy < d.oh && ox >= 0 && ox < d.ow;
+                const int oyc = min(max(oy, 0), d.oh - 1), oxc = min(max(ox, 0), d.ow - 1);
+                const int64_t po = ((int64_t)n * d.oh + oyc) * d.ow + oxc;
+                amax_load<V>(amax + po * d.c + cg * V, pk[a * 2 + b]);
+                go[a * 2 + b] = vload<V>(dout, d.dtype, po * d.ldo + d.cooff + cg * V);
+            }
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int iy = 2 * by + dy, ix = 2 * bx + dx;
+                if (iy >= d.h || ix >= d.w) continue;
+                Vec<V> g = vzero<V>();
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        // window (by-1+a, bx-1+b) starts at input (2(by-1+a), 2(bx-1+b)): this pixel is its tap (dy + 2(1-a), dx + 2(1-b))
+                        const int ty = dy + 2 * (1 - a), tx = dx + 2 * (1 - b);
+                        if (ty > 2 || tx > 2) continue;                       // compile-time: pixel outside that window
+                        const uint32_t tap = wok[a * 2 + b] ? (uint32_t)(ty * 3 + tx) : 254u;
+#pragma unroll
+                        for (int e = 0; e < V; ++e) g.v[e] += ((pk[a * 2 + b][e / 4] >> (8 * (e & 3))) & 0xff) == tap ? go[a * 2 + b].v[e] : 0.f;
+                    }
+                const int64_t self_off = (((int64_t)n * d.h + iy) * d.w + ix) * d.ldi + d.cioff + cg * V;
+                if (accumulate) { Vec<V> o = vload<V>(din_, d.dtype, self_off);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) g.v[e] += o.v[e]; }
+                vstore<V>(din_, d.dtype, self_off, g);
+            }
+    }
+}
+
 // Map-free backward (recomputes each window's arg-max): for callers that did not save the map.
 __global__ void maxpool_bwd_kernel(din_pool_desc d, Dec3 dd, const void* __restrict__ in, const void* __restrict__ dout,
                                    void* __restrict__ din_, int relu_mask, int accumulate) {
@@ -499,6 +550,15 @@ int din_maxpool_bwd(const din_pool_desc* d, const void* in, const uint8_t* argma
     if (argmax) {
         DIN_REQUIRE(relu_mask, "maxpool_bwd: the arg-max map encodes the fused ReLU mask; relu_mask must be set");
         const int v = wide8(d) ? 8 : 4;
+        if (d->k == 3 && d->stride == 2 && d->pad == 0) {
+            const int hb = (d->h + 1) / 2, wb = (d->w + 1) / 2;
+            const int64_t totalb = (int64_t)d->nb * hb * wb * (d->c / v);
+            const Dec3 ddb = make_dec(d->c / v, wb, hb, totalb);
+            if (v == 8) POOL_LAUNCH((maxpool_bwd_amax_k3s2_kernel<8>), totalb, *d, ddb, argmax, dout, din_, accumulate);
+            else POOL_LAUNCH((maxpool_bwd_amax_k3s2_kernel<4>), totalb, *d, ddb, argmax, dout, din_, accumulate);
+            DIN_CHECK_LAUNCH("maxpool_bwd");
+            return DIN_OK;
+        }
         const int64_t total = (int64_t)d->nb * d->h * d->w * (d->c / v);
         const Dec3 dd = make_dec(d->c / v, d->w, d->h, total);
         const int nw = (d->k + d->stride - 1) / d->stride;       // windows per axis that can contain one input element
