@@ -2345,6 +2345,13 @@ void launch_fast_multi(const ConvK& k, dim3 grid, hipStream_t st) {
     size_t stage = (size_t)2 * (128 + BN) * 8 * 16;
     size_t epi = (size_t)128 * (BN * sizeof(T) + 16);
     size_t lds = stage > epi ? stage : epi;
+    const char* pv = getenv("DIN_CONV_PIPE");
+    if (BN % 64 == 0 && sizeof(T) == 2 && !(pv && atoi(pv) == 4)) {   // 8 waves (bf16) where the filter tile splits over the 512-thread loader
+        auto kern = conv_gather_fast_kernel<T, 128, (BN % 64 == 0 ? BN : 128), 4, 2, 8, 2, true>;
+        if (lds > 65536) raise_lds_limit(kern, lds);
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, k);
+        return;
+    }
     auto kern = conv_gather_fast_kernel<T, 128, BN, 2, 2, 8, 2, true>;
     if (lds > 65536) raise_lds_limit(kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k);
@@ -2388,9 +2395,11 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
     }
     else if (bn == 64) { if (pipe == 1) launch_fast<T, 128, 64, 2, 2, 8, 3>(k, grid, st); else launch_fast<T, 128, 64, 2, 2, 8, 2>(k, grid, st); }
     else if (bn == 96) launch_fast<T, 128, 96, 2, 2, 8, 2>(k, grid, st);
-    else if (bn == 160) launch_fast<T, 128, 160, 2, 2, 8, 2>(k, grid, st);
-    else if (bn == 192) launch_fast<T, 128, 192, 2, 2, 8, 2>(k, grid, st);
-    else { if (pipe == 1) launch_fast<T, 128, 128, 2, 2, 4, 4>(k, grid, st); else launch_fast<T, 128, 128, 2, 2, 8, 2>(k, grid, st); }
+    else if (bn == 160) { if (pipe != 4 && sizeof(T) == 2) launch_fast<T, 128, 160, 4, 2, 8, 2>(k, grid, st); else launch_fast<T, 128, 160, 2, 2, 8, 2>(k, grid, st); }
+    // 128 x {128,160,192}: 8 waves (4 x 2, four per SIMD at two workgroups per CU) -- same LDS ring, more waves to hide the stage waits:
+    // +8..12 % on the 7-tap layers, +24 % on thin-K dgrads (bf16 only; DIN_CONV_PIPE=4 restores the 4-wave form)
+    else if (bn == 192) { if (pipe != 4 && sizeof(T) == 2) launch_fast<T, 128, 192, 4, 2, 8, 2>(k, grid, st); else launch_fast<T, 128, 192, 2, 2, 8, 2>(k, grid, st); }
+    else { if (pipe == 1) launch_fast<T, 128, 128, 2, 2, 4, 4>(k, grid, st); else if (pipe != 4 && sizeof(T) == 2) launch_fast<T, 128, 128, 4, 2, 8, 2>(k, grid, st); else launch_fast<T, 128, 128, 2, 2, 8, 2>(k, grid, st); }
 }
 
 int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_bytes, hipStream_t st, const char* what) {
