@@ -2154,7 +2154,7 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype) {
     const int64_t tiles256 = ((int64_t)M + 255) / 256;
     const char* force = getenv("DIN_CONV_TILE");
     if (g.bn == 64) {
-        if (M >= 256 * 1024) g.bm = 256;
+        if (M >= 256 * 1024 && !(force && atoi(force) == 128)) g.bm = 256;
     } else if (!(force && atoi(force) == 128)) {
         const int nco256 = (cprod + 255) / 256;
         if (dtype == DIN_BF16 && cprod >= 224 && nco256 * 256 * 100 <= cprod * 115 && g.nk >= 24 && tiles256 * nco256 >= 768) { g.bm = 256; g.bn = 256; }
@@ -2393,7 +2393,11 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
             else { if (pipe == 1) launch_fast<T, 256, 128, 4, 2, 4, 4>(k, grid, st); else launch_fast<T, 256, 128, 4, 2, 8, 2>(k, grid, st); }
         }
     }
-    else if (bn == 64) { if (pipe == 1) launch_fast<T, 128, 64, 2, 2, 8, 3>(k, grid, st); else launch_fast<T, 128, 64, 2, 2, 8, 2>(k, grid, st); }
+    else if (bn == 64) {
+        if (pipe == 1) launch_fast<T, 128, 64, 2, 2, 8, 3>(k, grid, st);
+        else if (pipe != 4 && sizeof(T) == 2) launch_fast<T, 128, 64, 4, 2, 8, 2>(k, grid, st);
+        else launch_fast<T, 128, 64, 2, 2, 8, 2>(k, grid, st);
+    }
     else if (bn == 96) launch_fast<T, 128, 96, 2, 2, 8, 2>(k, grid, st);
     else if (bn == 160) { if (pipe != 4 && sizeof(T) == 2) launch_fast<T, 128, 160, 4, 2, 8, 2>(k, grid, st); else launch_fast<T, 128, 160, 2, 2, 8, 2>(k, grid, st); }
     // 128 x {128,160,192}: 8 waves (4 x 2, four per SIMD at two workgroups per CU) -- same LDS ring, more waves to hide the stage waits:

@@ -102,13 +102,27 @@ class _timed:
 # ------------------------------------------------------------------------------------------------
 # shared split-K / wgrad workspace (per device; ops on one stream are serialised, so one buffer is safe)
 # ------------------------------------------------------------------------------------------------
-_WS: Dict[int, torch.Tensor] = {}
+_WS: Dict[Tuple[int, str], torch.Tensor] = {}
 
 
-def workspace(nbytes: int, device) -> Tuple[Optional[torch.Tensor], int]:
+_SIDE: Dict[int, "torch.cuda.Stream"] = {}
+WGRAD_SIDE_STREAM = _os.environ.get("DIN_WGRAD_STREAM", "0") != "0"     # opt-in: measured 472 -> 351 clips/s (the LDS-heavy kernels of the two streams evict each other)
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """Second HIP stream per device: wgrad (+ slice reduce, BN parameter gradients) of layer l runs here while the main stream goes
+    on with the dgrad chain -- both only depend on the gradient at the layer's output, and each kernel's last partial round of
+    workgroups leaves CUs idle that the other stream's kernel can fill."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
+def workspace(nbytes: int, device, tag: str = "") -> Tuple[Optional[torch.Tensor], int]:
     if nbytes <= 0:
         return None, 0
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
@@ -344,7 +358,19 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
     dev = bufs[g.input_tid].device
     tdt = torch_dtype(dt)
     st = _stream()
+    main = torch.cuda.current_stream()
+    side = side_stream(dev) if (WGRAD_SIDE_STREAM and PROFILE is None) else None
     gbufs: Dict[int, torch.Tensor] = dict(out_grads)
+
+    def on_side(tensors):
+        """the main stream's work so far is visible to the side stream; the listed tensors stay alive for it"""
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        for t_ in tensors:
+            if t_ is not None:
+                t_.record_stream(side)
+        return C.c_void_p(side.cuda_stream)
 
     def grad_target(view: View) -> Tuple[torch.Tensor, bool]:
         """gradient buffer of view.tid and whether to accumulate into it"""
@@ -433,28 +459,41 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 gtmp = torch.empty((nb, pd.h, pd.w, pd.c), dtype=tdt, device=dev)
                 L.check(lib.din_avgpool_bwd(C.byref(pd), _ptr(gout), _ptr(gtmp), None, 0, st), "avgpool_bwd(epilogue)")
                 gout, g_ld, g_coff = gtmp, pd.c, 0
-            # ---- wgrad (+ bias / BN parameter gradients)
+            # ---- wgrad (+ bias / BN parameter gradients): on the side stream when enabled
             dw = torch.empty_like(w)
+            wsbytes = lib.din_conv_workspace_bytes(C.byref(d), 2)
             if op.bn:
                 gamma, beta, mean, var = params[po + 1:po + 5]
                 dshift = dshift_pre if dshift_pre is not None else torch.empty_like(gamma)
                 wdot = torch.empty_like(gamma)
-                ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 2), dev)
+                dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+                if side is not None:
+                    stw = on_side([bufs[op.src.tid], gout, dw, dshift, wdot, dgamma, dbeta, scale])
+                    with torch.cuda.stream(side):
+                        ws, wsb = workspace(wsbytes, dev, "side")
+                else:
+                    stw = st
+                    ws, wsb = workspace(wsbytes, dev)
                 with _timed("wgrad", d, op.name):
                     L.check(lib.din_conv_wgrad(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dw),
                                                None if dshift_pre is not None else _ptr(dshift), _ptr(scale),
-                                               _ptr(w), _ptr(wdot), 0, _ptr(ws), wsb, st), "conv_wgrad " + op.name)
-                dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+                                               _ptr(w), _ptr(wdot), 0, _ptr(ws), wsb, stw), "conv_wgrad " + op.name)
                 L.check(lib.din_bn_fold_bwd(_ptr(wdot), _ptr(dshift), _ptr(mean), _ptr(var), BN_EPS, _ptr(dgamma), _ptr(dbeta),
-                                            gamma.numel(), st), "bn_fold_bwd")
+                                            gamma.numel(), stw), "bn_fold_bwd")
                 grads[po], grads[po + 1], grads[po + 2] = dw, dgamma, dbeta
             else:
                 db = (dshift_pre if dshift_pre is not None else torch.empty_like(params[po + 1])) if op.bias else None
-                ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 2), dev)
+                if side is not None:
+                    stw = on_side([bufs[op.src.tid], gout, dw, db])
+                    with torch.cuda.stream(side):
+                        ws, wsb = workspace(wsbytes, dev, "side")
+                else:
+                    stw = st
+                    ws, wsb = workspace(wsbytes, dev)
                 with _timed("wgrad", d, op.name):
                     L.check(lib.din_conv_wgrad(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dw),
                                                None if dshift_pre is not None else _ptr(db), None, None, None, 0,
-                                               _ptr(ws), wsb, st), "conv_wgrad " + op.name)
+                                               _ptr(ws), wsb, stw), "conv_wgrad " + op.name)
                 grads[po] = dw
                 if op.bias:
                     grads[po + 1] = db
@@ -491,6 +530,8 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
         # order for our graphs only per view, so free conservatively when no earlier op writes this tensor
         if not any(o.dst.tid == op.dst.tid for o in g.ops[:oi]):
             gbufs.pop(op.dst.tid, None)
+    if side is not None:
+        main.wait_stream(side)                        # parameter gradients are complete for whoever runs next on the main stream
     return grads
 
 
