@@ -1477,7 +1477,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_kernel(WgradK p) 
 // the wave: a 4-stage ring of 32-pixel stages with the LDS-DMA issued THREE stages ahead (hand-counted vmcnt), and the transpose
 // reads of stage s in flight while the MFMAs of stage s-1 run (register double buffer).  One s_barrier per stage.
 template <int BCO, int BK>
-__global__ __launch_bounds__(512, 1) void conv_wgrad_ring_kernel(WgradK p) {
+__global__ __launch_bounds__(512, (4 * (((32 * (BCO / 8) + 511) / 512) * 8192 + 32 * BK * 2) <= 80 * 1024) ? 2 : 1) void conv_wgrad_ring_kernel(WgradK p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // 8 waves (2 x 4: filter half wm, k-column quarter wn), two per SIMD: one wave's barrier / vmcnt / transpose-read waits hide
     // behind the other's MFMAs (with one wave per SIMD they are all serial; cf. profiles/r01_halo_probe.txt)
@@ -1528,6 +1528,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_ring_kernel(WgradK p) {
         const int grow = id / CG, slot = id - grow * CG;
         int gc = slot - 2 * (grow & 7);
         gc += gc < 0 ? CG : 0;
+        gc += gc < 0 ? CG : 0;                                      // 2*(row&7) <= 14 exceeds CG = 8 / 12 once more
         const int gco = co_tile * BCO + gc * 8;
         voffG[t] = (grow < PK && gco + 7 < p.Cout) ? (unsigned)((grow * p.ldo + p.cooff + gco) * 2) : OOB;   // Cout % 8 == 0 enforced
     }
@@ -1592,6 +1593,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_ring_kernel(WgradK p) {
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
         int ch = (wm * (BCO / 2) + i * 16) / 8 + rot;                         // even
+        ch -= ch >= CG ? CG : 0;
         ch -= ch >= CG ? CG : 0;
         colG[i] = (uint32_t)(prow * RBG + (ch + ((li & 3) >> 1)) * 16 + (li & 1) * 8);
     }
@@ -2180,7 +2182,7 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype) {
     return g;
 }
 
-struct WgradPlan { int cin_pad, kcols, kcols_pad, cout_pad, n_co_tiles, n_k_tiles, slices, m_per_slice, bco, v2, small, ring; int64_t ws_bytes; };
+struct WgradPlan { int cin_pad, kcols, kcols_pad, cout_pad, n_co_tiles, n_k_tiles, slices, m_per_slice, bco, v2, small, ring, bk; int64_t ws_bytes; };
 constexpr int WGRAD_SMALL_GRID = 512;
 WgradPlan plan_wgrad(const din_conv_desc* d) {
     WgradPlan w;
@@ -2248,8 +2250,16 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
             else w.ring = 0;
         }
     }
-    const int bk = w.ring ? 256 : WG_TILE;
+    int ring_bk = 256;
+    {
+        const char* rv = getenv("DIN_WGRAD_RING");
+        const int mode = rv ? atoi(rv) : 1;
+        // 64 / 96-row banks: the 8-wave ring with 128 k columns (two workgroups per CU) beats v3 by ~20 %; 128 rows: equal, 160: behind
+        if (!w.ring && w.v2 && mode != 0 && (mode == 3 || w.bco == 64 || w.bco == 96)) { w.ring = 1; ring_bk = 128; }
+    }
+    const int bk = w.ring ? ring_bk : WG_TILE;
     int pk = d->dtype == DIN_F32 ? 16 : (w.ring ? 32 : (w.v2 ? 64 : 32));
+    w.bk = bk;
     w.kcols_pad = pad_to(w.kcols, bk);
     w.n_co_tiles = (d->cout + w.bco - 1) / w.bco;
     w.cout_pad = pad_to(w.n_co_tiles * w.bco, WG_TILE);            // partial-sum rows cover every filter tile
@@ -2259,7 +2269,7 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
     int want = (1024 + tiles - 1) / tiles;             // ~4 workgroups per CU
     if (w.ring) {                                      // one resident workgroup per CU: a single full round (or two for long slices)
         const int rounds = (int64_t)M * tiles >= (int64_t)256 * 64 * 1024 ? 2 : 1;
-        want = 256 * rounds / tiles;
+        want = 256 * rounds * (ring_bk == 128 ? 2 : 1) / tiles;
         if (want < 1) want = 1;
     }
     int64_t max_by_ws = ((int64_t)1 << 30) / ((int64_t)w.cout_pad * w.kcols_pad * 4);   // keep workspace <= 1 GiB
@@ -2561,7 +2571,7 @@ int din_conv_pack_weights(const din_conv_desc* d, const float* w, const float* s
 
 int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t* bn) {
     DIN_REQUIRE(d && bm && bn && which >= 0 && which <= 2, "conv_kernel_tile: bad argument");
-    if (which == 2) { WgradPlan wp = plan_wgrad(d); *bm = wp.small ? 0 : wp.bco; *bn = wp.small ? wp.bco : (wp.ring ? 256 : WG_TILE); return DIN_OK; }
+    if (which == 2) { WgradPlan wp = plan_wgrad(d); *bm = wp.small ? 0 : wp.bco; *bn = wp.small ? wp.bco : (wp.ring ? 1000 + wp.bk : WG_TILE); return DIN_OK; }
     const bool strided = which == 1 && (d->sh > 1 || d->sw > 1);
     GatherPlan g = which == 0 ? plan_gather(d->nb * d->oh * d->ow, d->cin, d->cout, d->kh * d->kw, d->dtype)
                               : plan_gather(d->nb * (strided ? (d->h + d->sh - 1) / d->sh * ((d->w + d->sw - 1) / d->sw) : d->h * d->w),
@@ -2776,12 +2786,18 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
                 k.dbias = dbias;
                 bias_fused = true;
             }
-            const size_t lds = 4 * ((size_t)((32 * wp.bco / 8 + 511) / 512) * 8192 + 32 * 256 * 2);   // four 32-pixel stages (G tile in 8-KiB rounds)
+            const size_t lds = 4 * ((size_t)((32 * wp.bco / 8 + 511) / 512) * 8192 + 32 * (size_t)wp.bk * 2);   // four 32-pixel stages (G tile in 8-KiB rounds)
             auto launch = [&](auto kern) {
                 raise_lds_limit(kern, lds);
                 hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, k);
             };
-            if (wp.bco == 128) launch(conv_wgrad_ring_kernel<128, 256>);
+            if (wp.bk == 128) {
+                if (wp.bco == 64) launch(conv_wgrad_ring_kernel<64, 128>);
+                else if (wp.bco == 96) launch(conv_wgrad_ring_kernel<96, 128>);
+                else if (wp.bco == 160) launch(conv_wgrad_ring_kernel<160, 128>);
+                else launch(conv_wgrad_ring_kernel<128, 128>);
+            }
+            else if (wp.bco == 128) launch(conv_wgrad_ring_kernel<128, 256>);
             else if (wp.bco == 160) launch(conv_wgrad_ring_kernel<160, 256>);
             else launch(conv_wgrad_ring_kernel<192, 256>);
         } else if (wp.v2) {

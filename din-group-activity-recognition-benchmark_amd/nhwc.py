@@ -85,8 +85,8 @@ class _timed:
             if self.kind == "wgrad":
                 if bm.value == 0:
                     variant = f"conv_wgrad_small_kernel<..., {bn.value}, ...>"
-                elif bn.value == 256:
-                    variant = f"conv_wgrad_ring_kernel<{bm.value}, 256>"
+                elif bn.value >= 1000:
+                    variant = f"conv_wgrad_ring_kernel<{bm.value}, {bn.value - 1000}>"
                 else:
                     variant = f"conv_wgrad_bf16_kernel<{bm.value}>" if d.dtype == L.DIN_BF16 else "conv_wgrad_f32_kernel"
             elif bm.value == 0:

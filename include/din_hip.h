@@ -86,7 +86,8 @@ int64_t din_conv_packed_elems(const din_conv_desc* d, int transposed);
 int din_conv_pack_weights(const din_conv_desc* d, const float* w, const float* scale, void* wpk,
                           int transposed, void* stream);
 /* which tile variant the planner picks (which: 0 fwd, 1 dgrad -> pixels x filters of conv_gather_*_kernel; 2 wgrad -> filter rows x
- * k columns of conv_wgrad_*_kernel; bm = 0 -> the stationary-filter stem kernel conv_small_kernel with bn filters): lets a
+ * k columns of conv_wgrad_*_kernel, bn = 1000 + k columns for conv_wgrad_ring_kernel; bm = 0 -> the stationary-filter stem kernels
+ * conv_small_kernel / conv_wgrad_small_kernel with bn filters; bm = 1 -> conv_halo_kernel): lets a
  * profiler-side caller name the kernel a launch resolves to */
 int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t* bn);
 /* workspace bytes needed by fwd / dgrad / wgrad for this descriptor (split-K partial sums) */
