@@ -2156,7 +2156,9 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype) {
     const int64_t tiles256 = ((int64_t)M + 255) / 256;
     const char* force = getenv("DIN_CONV_TILE");
     if (g.bn == 64) {
-        if (M >= 256 * 1024 && !(force && atoi(force) == 128)) g.bm = 256;
+        // fp32: 256x64 (4 waves, 2 workgroups / CU).  bf16: 128x64 on 8 waves measured +6..14 % on the 1x1 / dgrad launches, -2.5 % on the
+        // 5x5 forward (DIN_CONV_TILE=256 restores 256x64)
+        if (M >= 256 * 1024 && (dtype == DIN_F32 || (force && atoi(force) == 256))) g.bm = 256;
     } else if (!(force && atoi(force) == 128)) {
         const int nco256 = (cprod + 255) / 256;
         if (dtype == DIN_BF16 && cprod >= 224 && nco256 * 256 * 100 <= cprod * 115 && g.nk >= 24 && tiles256 * nco256 >= 768) { g.bm = 256; g.bn = 256; }

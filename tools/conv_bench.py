@@ -17,6 +17,8 @@ LAYERS = {  # name: (nb, h, w, cin, cout, k, s, p)
     "inc_6c_1x7": (96, 43, 78, 160, 160, (1, 7), 1, (0, 3)),
     "inc_2b_3x3": (96, 357, 637, 32, 64, 3, 1, 1),
     "inc_2a_3x3": (96, 359, 639, 32, 32, 3, 1, 0),
+    "inc_5b_5x5": (96, 87, 157, 48, 64, 5, 1, 2),
+    "inc_3b_1x1": (96, 178, 318, 64, 80, 1, 1, 0),
     "inc_5d_1x1_288": (96, 87, 157, 288, 64, 1, 1, 0),
     "inc_6a_3x3dbl1": (96, 87, 157, 288, 64, 1, 1, 0),
     "inc_6e_1x1_768": (96, 43, 78, 768, 192, 1, 1, 0),
