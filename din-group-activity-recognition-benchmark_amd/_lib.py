@@ -61,6 +61,8 @@ SIGNATURES: Dict[str, tuple] = {
     "din_colsum": (_I, [_P, _I, _L, _I, _I, _I, _P, _P]),
     "din_bn_fold": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "din_bn_fold_bwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
+    "din_bn_fold_multi": (_I, [_P, _P, _I, _I, _F, _P, _P, _P]),
+    "din_bn_fold_bwd_multi": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P, _P]),
     "din_maxpool_fwd": (_I, [_PD, _P, _P, _P, _P]),
     "din_maxpool_bwd": (_I, [_PD, _P, _P, _P, _P, _I, _I, _P]),
     "din_avgpool_fwd": (_I, [_PD, _P, _P, _P, _I, _P]),

@@ -2119,6 +2119,38 @@ __global__ void bn_fold_bwd_kernel(const float* wdot, const float* dshift, const
     }
 }
 
+// all BatchNorm layers of a backbone in one launch: ptrs[l] = {gamma, beta, mean, var}, channel l-range = [offs[l], offs[l+1])
+__device__ __forceinline__ int bn_layer_of(const int32_t* __restrict__ offs, int n, int i) {
+    int lo = 0, hi = n;                                       // offs[lo] <= i < offs[hi]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= i) lo = mid; else hi = mid; }
+    return lo;
+}
+__global__ void bn_fold_multi_kernel(const uint64_t* __restrict__ ptrs, const int32_t* __restrict__ offs, int n, int total, float eps,
+                                     float* __restrict__ scale, float* __restrict__ shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int l = bn_layer_of(offs, n, i), c = i - offs[l];
+    const float* gamma = reinterpret_cast<const float*>(ptrs[4 * l + 0]);
+    const float* beta = reinterpret_cast<const float*>(ptrs[4 * l + 1]);
+    const float* mean = reinterpret_cast<const float*>(ptrs[4 * l + 2]);
+    const float* var = reinterpret_cast<const float*>(ptrs[4 * l + 3]);
+    const float s = gamma[c] / sqrtf(var[c] + eps);
+    scale[i] = s;
+    shift[i] = beta[c] - mean[c] * s;
+}
+__global__ void bn_fold_bwd_multi_kernel(const uint64_t* __restrict__ ptrs, const int32_t* __restrict__ offs, int n, int total, float eps,
+                                         const float* __restrict__ wdot, const float* __restrict__ dshift, float* __restrict__ dgamma,
+                                         float* __restrict__ dbeta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int l = bn_layer_of(offs, n, i), c = i - offs[l];
+    const float* mean = reinterpret_cast<const float*>(ptrs[4 * l + 2]);
+    const float* var = reinterpret_cast<const float*>(ptrs[4 * l + 3]);
+    const float rstd = 1.f / sqrtf(var[c] + eps);
+    dgamma[i] = (wdot[i] - dshift[i] * mean[c]) * rstd;
+    dbeta[i] = dshift[i];
+}
+
 // ---- host-side planning ----------------------------------------------------------------------------
 inline int epc_of(int dtype) { return dtype == DIN_F32 ? 4 : 8; }
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
@@ -2747,6 +2779,8 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
     DIN_REQUIRE(in && dout && dw, "conv_wgrad: null pointer");
     DIN_REQUIRE(!wdot || w, "conv_wgrad: wdot needs w");
     hipStream_t st = as_stream(stream);
+    const bool prezeroed = (accumulate & 2) != 0;            // dbias / wdot were zeroed by the caller (one memset for a whole backbone)
+    accumulate &= 1;
     WgradPlan wp = plan_wgrad(d);
     if (workspace_bytes < wp.ws_bytes || !workspace)
         DIN_FAIL(DIN_E_WORKSPACE, "conv_wgrad: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)wp.ws_bytes);
@@ -2768,7 +2802,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
         DIN_REQUIRE(d->ldo % epc == 0 && d->cooff % epc == 0, "conv_wgrad: bf16 dout stride/offset must be multiples of 8");
         if (wp.small) {
             if (dbias) {
-                if (hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
+                if (!prezeroed && hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
                 k.dbias = dbias;
                 bias_fused = true;
             }
@@ -2784,7 +2818,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
             else launch(conv_wgrad_small_kernel<1, 32, 2>);
         } else if (wp.ring) {
             if (dbias) {
-                if (hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
+                if (!prezeroed && hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
                 k.dbias = dbias;
                 bias_fused = true;
             }
@@ -2804,7 +2838,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
             else launch(conv_wgrad_ring_kernel<192, 256>);
         } else if (wp.v2) {
             if (dbias) {
-                if (hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
+                if (!prezeroed && hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
                 k.dbias = dbias;
                 bias_fused = true;
             }
@@ -2823,7 +2857,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
         }
     }
     DIN_CHECK_LAUNCH("conv_wgrad");
-    if (wdot && hipMemsetAsync(wdot, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
+    if (wdot && !prezeroed && hipMemsetAsync(wdot, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
     {
         int kc_total = d->kh * d->kw * wp.cin_pad;
         dim3 rgrid(d->cout, (kc_total + 63) / 64);
@@ -2856,6 +2890,21 @@ int din_bn_fold_bwd(const float* wdot, const float* dshift, const float* mean, c
     DIN_REQUIRE(wdot && dshift && mean && var && dgamma && dbeta && c > 0, "bn_fold_bwd: bad argument");
     hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), wdot, dshift, mean, var, eps, dgamma, dbeta, c);
     DIN_CHECK_LAUNCH("bn_fold_bwd");
+    return DIN_OK;
+}
+
+int din_bn_fold_multi(const uint64_t* ptrs, const int32_t* offs, int n, int total, float eps, float* scale, float* shift, void* stream) {
+    DIN_REQUIRE(ptrs && offs && scale && shift && n > 0 && total > 0, "bn_fold_multi: bad argument");
+    hipLaunchKernelGGL(bn_fold_multi_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), ptrs, offs, n, total, eps, scale, shift);
+    DIN_CHECK_LAUNCH("bn_fold_multi");
+    return DIN_OK;
+}
+int din_bn_fold_bwd_multi(const uint64_t* ptrs, const int32_t* offs, int n, int total, float eps, const float* wdot, const float* dshift,
+                          float* dgamma, float* dbeta, void* stream) {
+    DIN_REQUIRE(ptrs && offs && wdot && dshift && dgamma && dbeta && n > 0 && total > 0, "bn_fold_bwd_multi: bad argument");
+    hipLaunchKernelGGL(bn_fold_bwd_multi_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), ptrs, offs, n, total, eps, wdot,
+                       dshift, dgamma, dbeta);
+    DIN_CHECK_LAUNCH("bn_fold_bwd_multi");
     return DIN_OK;
 }
 

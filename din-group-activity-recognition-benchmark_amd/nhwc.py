@@ -283,6 +283,36 @@ def _pooled_descs(g: Graph, op: Op, nb: int, dt: int) -> Tuple[L.ConvDesc, L.Poo
 BN_EPS = 1e-3      # torchvision BasicConv2d
 
 
+class _BnTables:
+    """device-side pointer / offset tables of a graph's BatchNorm layers (parameters keep their addresses across steps)"""
+    def __init__(self, key, ptrs, offs, off_list):
+        self.key, self.ptrs, self.offs, self.off_list = key, ptrs, offs, off_list
+        self.n, self.total = len(off_list) - 1, off_list[-1]
+
+
+def _bn_tables(g: "Graph", params: Sequence[torch.Tensor], dev) -> Optional[_BnTables]:
+    rows, off_list, pos = [], [0], 0
+    for op in g.ops:
+        if op.kind != "conv":
+            continue
+        if op.bn:
+            gamma, beta, mean, var = params[pos + 1:pos + 5]
+            rows.append([gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), var.data_ptr()])
+            off_list.append(off_list[-1] + gamma.numel())
+            pos += 5
+        else:
+            pos += 2 if op.bias else 1
+    if not rows:
+        return None
+    key = tuple(r[0] for r in rows)
+    cached = getattr(g, "_bn_tables", None)
+    if cached is not None and cached.key == key and cached.ptrs.device == dev:
+        return cached
+    tb = _BnTables(key, torch.tensor(rows, dtype=torch.int64).to(dev), torch.tensor(off_list, dtype=torch.int32).to(dev), off_list)
+    g._bn_tables = tb
+    return tb
+
+
 def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tensor], dt: int, save_for_backward: bool = True):
     """Run the graph.  image_buf: NHWC [nb,h,w,cpad] of dtype dt.  Returns (bufs, aux) for backward."""
     lib = L.load()
@@ -294,6 +324,13 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
     it = iter(params)
     aux = []
     st = _stream()
+    bn = _bn_tables(g, params, dev)
+    if bn is not None:
+        # every BatchNorm layer of the graph folded in ONE launch into flat scale / shift arrays (views per layer below)
+        bn_scale = torch.empty(bn.total, dtype=torch.float32, device=dev)
+        bn_shift = torch.empty(bn.total, dtype=torch.float32, device=dev)
+        L.check(lib.din_bn_fold_multi(_ptr(bn.ptrs), _ptr(bn.offs), bn.n, bn.total, BN_EPS, _ptr(bn_scale), _ptr(bn_shift), st), "bn_fold_multi")
+    bn_i = 0
     for op in g.ops:
         td = g.tensors[op.dst.tid]
         if bufs[op.dst.tid] is None:
@@ -306,10 +343,9 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
             scale = shift = None
             if op.bn:
                 gamma, beta, mean, var = next(it), next(it), next(it), next(it)
-                scale = torch.empty_like(gamma)
-                shift = torch.empty_like(gamma)
-                L.check(lib.din_bn_fold(_ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), BN_EPS, _ptr(scale), _ptr(shift),
-                                        gamma.numel(), st), "bn_fold")
+                o0, o1 = bn.off_list[bn_i], bn.off_list[bn_i + 1]
+                bn_i += 1
+                scale, shift = bn_scale[o0:o1], bn_shift[o0:o1]
                 bias = shift
             else:
                 bias = next(it) if op.bias else None
@@ -391,6 +427,18 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
         else:
             offsets.append(-1)
     grads: List[Optional[torch.Tensor]] = [None] * len(params)
+    bn = _bn_tables(g, params, dev)
+    if bn is not None:
+        # flat, pre-zeroed accumulators for every layer's shift gradient and <W, dW> dot (one memset instead of two per layer)
+        bn_acc = torch.zeros(2 * bn.total, dtype=torch.float32, device=dev)
+        bn_dshift, bn_wdot = bn_acc[:bn.total], bn_acc[bn.total:]
+        bn_index = {}
+        k_ = 0
+        for oi_, op_ in enumerate(g.ops):
+            if op_.kind == "conv" and op_.bn:
+                bn_index[oi_] = k_
+                k_ += 1
+        bn_touched = False
 
     # 1x1 / stride-1 convs that read the same view (branch-entry convs of the Inception blocks): their dgrads are fused into ONE
     # multi-source launch, issued when the last member (first in program order) has been visited
@@ -454,7 +502,10 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 d, pd = _pooled_descs(g, op, nb, dt)
                 td_ = g.tensors[op.dst.tid]
                 if op.bn or op.bias:
-                    dshift_pre = torch.empty(op.dst.c, dtype=torch.float32, device=dev)
+                    if op.bn:                                   # straight into this layer's slice of the flat accumulator
+                        dshift_pre = bn_dshift[bn.off_list[bn_index[oi]]:bn.off_list[bn_index[oi] + 1]]
+                    else:
+                        dshift_pre = torch.empty(op.dst.c, dtype=torch.float32, device=dev)
                     L.check(lib.din_colsum(_ptr(gout), dt, nb * td_.h * td_.w, op.dst.c, td_.c, op.dst.coff, _ptr(dshift_pre), st), "colsum")
                 gtmp = torch.empty((nb, pd.h, pd.w, pd.c), dtype=tdt, device=dev)
                 L.check(lib.din_avgpool_bwd(C.byref(pd), _ptr(gout), _ptr(gtmp), None, 0, st), "avgpool_bwd(epilogue)")
@@ -463,12 +514,11 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
             dw = torch.empty_like(w)
             wsbytes = lib.din_conv_workspace_bytes(C.byref(d), 2)
             if op.bn:
-                gamma, beta, mean, var = params[po + 1:po + 5]
-                dshift = dshift_pre if dshift_pre is not None else torch.empty_like(gamma)
-                wdot = torch.empty_like(gamma)
-                dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+                o0, o1 = bn.off_list[bn_index[oi]], bn.off_list[bn_index[oi] + 1]
+                dshift, wdot = bn_dshift[o0:o1], bn_wdot[o0:o1]          # views of the pre-zeroed flat accumulators
+                bn_touched = True
                 if side is not None:
-                    stw = on_side([bufs[op.src.tid], gout, dw, dshift, wdot, dgamma, dbeta, scale])
+                    stw = on_side([bufs[op.src.tid], gout, dw, bn_acc, scale])
                     with torch.cuda.stream(side):
                         ws, wsb = workspace(wsbytes, dev, "side")
                 else:
@@ -477,10 +527,8 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 with _timed("wgrad", d, op.name):
                     L.check(lib.din_conv_wgrad(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dw),
                                                None if dshift_pre is not None else _ptr(dshift), _ptr(scale),
-                                               _ptr(w), _ptr(wdot), 0, _ptr(ws), wsb, stw), "conv_wgrad " + op.name)
-                L.check(lib.din_bn_fold_bwd(_ptr(wdot), _ptr(dshift), _ptr(mean), _ptr(var), BN_EPS, _ptr(dgamma), _ptr(dbeta),
-                                            gamma.numel(), stw), "bn_fold_bwd")
-                grads[po], grads[po + 1], grads[po + 2] = dw, dgamma, dbeta
+                                               _ptr(w), _ptr(wdot), 2, _ptr(ws), wsb, stw), "conv_wgrad " + op.name)
+                grads[po] = dw
             else:
                 db = (dshift_pre if dshift_pre is not None else torch.empty_like(params[po + 1])) if op.bias else None
                 if side is not None:
@@ -532,6 +580,15 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
             gbufs.pop(op.dst.tid, None)
     if side is not None:
         main.wait_stream(side)                        # parameter gradients are complete for whoever runs next on the main stream
+    if bn is not None and bn_touched:
+        # BatchNorm parameter gradients of every layer in one launch: dgamma = (wdot - dshift * mean) * rstd, dbeta = dshift
+        bn_out = torch.empty(2 * bn.total, dtype=torch.float32, device=dev)
+        L.check(lib.din_bn_fold_bwd_multi(_ptr(bn.ptrs), _ptr(bn.offs), bn.n, bn.total, BN_EPS, _ptr(bn_wdot), _ptr(bn_dshift),
+                                          _ptr(bn_out), _ptr(bn_out[bn.total:]), st), "bn_fold_bwd_multi")
+        for oi_, k_ in bn_index.items():
+            if grads[offsets[oi_]] is not None:       # the layer took part in this backward
+                o0, o1 = bn.off_list[k_], bn.off_list[k_ + 1]
+                grads[offsets[oi_] + 1], grads[offsets[oi_] + 2] = bn_out[o0:o1], bn_out[bn.total + o0:bn.total + o1]
     return grads
 
 

@@ -112,7 +112,9 @@ int din_conv1x1_dgrad_multi(int nsrc, const din_conv_src* srcs, int dtype, int n
                             int cioff, void* din, const void* mask, int ldm, int moff, int flags, void* stream);
 /* dw: [cout][cin][kh][kw] fp32, overwritten (or += when accumulate!=0), multiplied by scale[cout] when scale
  * is given.  dbias (nullable) [cout] fp32 = column sums of dout.  wdot (nullable) [cout] fp32 =
- * <w[co,:], dw_raw[co,:]> (needs w) -- the BatchNorm-eval scale gradient.                                */
+ * <w[co,:], dw_raw[co,:]> (needs w) -- the BatchNorm-eval scale gradient.  accumulate bit 1 (value 2): dbias / wdot were zeroed by
+ * the caller (they are accumulated into with atomics; a backbone zeroes one flat buffer for all its layers instead of 2 memsets per
+ * layer).                                                                                                   */
 int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, float* dw, float* dbias,
                    const float* scale, const float* w, float* wdot, int accumulate,
                    void* workspace, int64_t workspace_bytes, void* stream);
@@ -127,6 +129,13 @@ int din_bn_fold(const float* gamma, const float* beta, const float* mean, const 
 /* dgamma = (wdot - dshift*mean)*rsqrt(var+eps); dbeta = dshift                                            */
 int din_bn_fold_bwd(const float* wdot, const float* dshift, const float* mean, const float* var, float eps,
                     float* dgamma, float* dbeta, int c, void* stream);
+/* The same two maps for ALL BatchNorm layers of a backbone in one launch each.  Device tables: ptrs [n][4] = addresses of
+ * {gamma, beta, running_mean, running_var} per layer; offs [n+1] = prefix sums of the channel counts (offs[n] = total).  scale / shift /
+ * wdot / dshift / dgamma / dbeta are flat [total] fp32 arrays, layer l owning [offs[l], offs[l+1]). */
+int din_bn_fold_multi(const uint64_t* ptrs, const int32_t* offs, int n, int total, float eps, float* scale, float* shift,
+                      void* stream);
+int din_bn_fold_bwd_multi(const uint64_t* ptrs, const int32_t* offs, int n, int total, float eps, const float* wdot,
+                          const float* dshift, float* dgamma, float* dbeta, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pools / resize (backbone.py:51,57 max_pool2d; torchvision InceptionA/C avg_pool2d(3,1,1), InceptionB
