@@ -239,6 +239,22 @@ def main():
                                       "time_s": round(sum(v[1] for v in agg.values()), 4)},
                 "other_kernels": {kname: {"TFLOP/s": round(v[0] / max(v[1], 1e-9) / 1e12, 2), "launches": v[2],
                                           "time_s": round(v[1], 4)} for kname, v in sorted(agg.items(), key=lambda kv: -kv[1][1]) if kname != dom}}
+    # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process; they come from the separate rocprofv3
+    # --pmc passes over this same command whose per-kernel result is committed under profiles/ (tools/pmc_traffic.py)
+    try:
+        tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
+        if tr.get("workload") == a.workload and tr.get("global_batch") == a.global_batch and world == 1:
+            prefix = dom.split(", ...>")[0]
+            hits = [v for k, v in tr["kernels"].items() if k.startswith(prefix)]
+            n = sum(h["launches"] for h in hits)
+            if n:
+                rd = sum(h["fetch_bytes_per_launch"] * h["launches"] for h in hits) / n
+                wr = sum((h["write_bytes_per_launch"] or 0.0) * h["launches"] for h in hits) / n
+                roofline["traffic"] = round(rd + wr)
+                roofline["traffic_detail"] = {"unit": "HBM bytes per launch", "read": round(rd), "write": round(wr),
+                                              "source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"}
+    except (OSError, ValueError, KeyError):
+        pass
     conv_time = sum(v[1] for v in agg.values())
 
     if rank == 0:

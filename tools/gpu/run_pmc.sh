@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-rm -rf gpurun_out/pmc; mkdir -p gpurun_out/pmc
-for H in 1; do
-DIN_CONV_HALO=$H timeout 150 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d gpurun_out/pmc/sq_$H -o x -- python tools/conv_bench.py --layer inc_5d_3x3 --which fwd --iters 3 > gpurun_out/pmc/sq_$H.log 2>&1; echo "rc=$?"
-DIN_CONV_HALO=$H timeout 150 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/pmc/sq2_$H -o x -- python tools/conv_bench.py --layer inc_5d_3x3 --which fwd --iters 3 > gpurun_out/pmc/sq2_$H.log 2>&1; echo "rc=$?"
-done
+rm -rf gpurun_out/pmcb; mkdir -p gpurun_out/pmcb
+timeout 700 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcb/fetch -o x -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmcb/fetch.log 2>&1; echo "rc=$?"
+timeout 700 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmcb/write -o x -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmcb/write.log 2>&1; echo "rc=$?"
+ls -la gpurun_out/pmcb/*/ | head
