@@ -1,1 +1,2 @@
-timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], r['kernel'], r['achieved'], r['traffic'], r.get('traffic_detail'))"
+timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "roi" 2>&1 | tail -3
+timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
