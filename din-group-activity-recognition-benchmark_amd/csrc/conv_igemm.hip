@@ -273,8 +273,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
     constexpr int NT = 64 * WM * WN;                         // threads per workgroup
     constexpr int LR = NT / KC;                              // tile rows covered by one loader pass (KC chunk lanes per row)
     constexpr int RW = 64 / KC;                              // rows written by one wave-level DMA (1 KiB)
-    constexpr int TI = BN / WN / 16, TJ = BM / WM / 16, PA = BM / LR, PB = BN / LR;
-    constexpr int BUF = (BM + BN) * KC;                      // 16-byte units per stage
+    // the loader covers LR rows per pass: a filter tile that is not a multiple (160 or 96 rows on 8 waves) is loaded as PB whole passes
+    // into a padded LDS region; the surplus rows (next tile's filters or zeros) are never read
+    constexpr int TI = BN / WN / 16, TJ = BM / WM / 16, PA = BM / LR, PB = (BN + LR - 1) / LR, BNP = PB * LR;
+    static_assert(BM % LR == 0, "pixel tile must be whole loader passes");
+    constexpr int BUF = (BM + BNP) * KC;                     // 16-byte units per stage
     auto lds_slot = [](int row, int chunk) { return row * KCS + (chunk ^ ((row >> 1) & (KCS - 1))); };   // conflict-free for 4 and 8
     constexpr int CPITCH = BN * (int)sizeof(T) + 16;         // epilogue tile row pitch (bytes): +16 B kills bank conflicts
     constexpr unsigned OOB = 0x80000000u;
@@ -2376,7 +2379,8 @@ static bool plan_halo(int dtype, int kh, int kw, int cred, int cprod, int oh, in
 
 template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS>
 void launch_fast(const ConvK& k, dim3 grid, hipStream_t st) {
-    size_t stage = (size_t)NS * (BMT + BN) * KCS * 16 + (k.remap ? 128 : 0);     // stage ring (+ remap table)
+    constexpr int LR_ = 64 * WM * WN / KCS, BNP_ = (BN + LR_ - 1) / LR_ * LR_;       // filter rows padded to whole loader passes
+    size_t stage = (size_t)NS * (BMT + BNP_) * KCS * 16 + (k.remap ? 128 : 0);   // stage ring (+ remap table)
     size_t epi = (size_t)BMT * (BN * sizeof(T) + 16);
     size_t lds = stage > epi ? stage : epi;
     auto kern = conv_gather_fast_kernel<T, BMT, BN, WM, WN, KCS, NS>;
@@ -2386,16 +2390,18 @@ void launch_fast(const ConvK& k, dim3 grid, hipStream_t st) {
 
 template <typename T, int BN>
 void launch_fast_multi(const ConvK& k, dim3 grid, hipStream_t st) {
-    size_t stage = (size_t)2 * (128 + BN) * 8 * 16;
     size_t epi = (size_t)128 * (BN * sizeof(T) + 16);
-    size_t lds = stage > epi ? stage : epi;
     const char* pv = getenv("DIN_CONV_PIPE");
-    if (BN % 64 == 0 && sizeof(T) == 2 && !(pv && atoi(pv) == 4)) {   // 8 waves (bf16) where the filter tile splits over the 512-thread loader
-        auto kern = conv_gather_fast_kernel<T, 128, (BN % 64 == 0 ? BN : 128), 4, 2, 8, 2, true>;
-        if (lds > 65536) raise_lds_limit(kern, lds);
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, k);
+    if (sizeof(T) == 2 && (BN % 64 == 0 || (pv && atoi(pv) == 8)) && !(pv && atoi(pv) == 4)) {   // 8 waves (bf16) where the filter tile is whole 64-row loader passes
+        size_t stage8 = (size_t)2 * (128 + (BN + 63) / 64 * 64) * 8 * 16;
+        size_t lds8 = stage8 > epi ? stage8 : epi;
+        auto kern = conv_gather_fast_kernel<T, 128, BN, 4, 2, 8, 2, true>;
+        if (lds8 > 65536) raise_lds_limit(kern, lds8);
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds8, st, k);
         return;
     }
+    size_t stage = (size_t)2 * (128 + BN) * 8 * 16;
+    size_t lds = stage > epi ? stage : epi;
     auto kern = conv_gather_fast_kernel<T, 128, BN, 2, 2, 8, 2, true>;
     if (lds > 65536) raise_lds_limit(kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k);
@@ -2442,7 +2448,7 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
         else if (pipe != 4 && sizeof(T) == 2) launch_fast<T, 128, 64, 4, 2, 8, 2>(k, grid, st);
         else launch_fast<T, 128, 64, 2, 2, 8, 2>(k, grid, st);
     }
-    else if (bn == 96) launch_fast<T, 128, 96, 2, 2, 8, 2>(k, grid, st);
+    else if (bn == 96) { if (pipe == 8 && sizeof(T) == 2) launch_fast<T, 128, 96, 4, 2, 8, 2>(k, grid, st); else launch_fast<T, 128, 96, 2, 2, 8, 2>(k, grid, st); }   // 8 waves measured 5 % slower here
     else if (bn == 160) { if (pipe != 4 && sizeof(T) == 2) launch_fast<T, 128, 160, 4, 2, 8, 2>(k, grid, st); else launch_fast<T, 128, 160, 2, 2, 8, 2>(k, grid, st); }
     // 128 x {128,160,192}: 8 waves (4 x 2, four per SIMD at two workgroups per CU) -- same LDS ring, more waves to hide the stage waits:
     // +8..12 % on the 7-tap layers, +24 % on thin-K dgrads (bf16 only; DIN_CONV_PIPE=4 restores the 4-wave form)

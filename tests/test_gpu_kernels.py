@@ -51,6 +51,9 @@ CONV_CASES = [
     ("7x1", 1, 32, 14, 9, 192, (7, 1), (1, 1), (3, 0), 1),
     ("dil3_grid", 2, 32, 10, 12, 27, (3, 3), (1, 1), (3, 3), 3),
     ("big_tile", 1, 128, 40, 48, 256, (3, 3), (1, 1), (1, 1), 1),
+    ("tile160_1x7", 1, 64, 24, 40, 160, (1, 7), (1, 1), (0, 3), 1),      # 160-filter tile: padded loader passes on the 8-wave variant
+    ("tile96_3x3", 1, 64, 24, 40, 96, (3, 3), (1, 1), (1, 1), 1),         # 96-filter tile, likewise
+    ("tile192_1x1", 1, 96, 24, 40, 192, (1, 1), (1, 1), (0, 0), 1),
     ("linear_splitk", 1, 1600, 1, 72, 128, (1, 1), (1, 1), (0, 0), 1),
     # stem shapes (>= 256K pixels): bf16 runs the stationary-filter halo kernel (fwd cpt4, dgrad cpt4 / cpt8), ragged tile edges
     ("stem_32_32_p0", 1, 32, 515, 517, 32, (3, 3), (1, 1), (0, 0), 1),
