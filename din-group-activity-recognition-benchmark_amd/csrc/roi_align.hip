@@ -190,28 +190,62 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
         // prezeroed (the host cleared the whole view with one memset, ~90 % of it stays zero): only the columns the row's active boxes
         // span are visited, and pixels without a contribution are left alone
         const int x_begin = prezeroed ? max(rx0_s, 0) : 0, x_end = prezeroed ? min(rx1_s, wf - 1) : wf - 1;
+        // per pixel the (wave-uniform) scan over boxes x samples runs ONCE and leaves the contributing samples in a small per-wave LDS
+        // list (source offset, weight); the channel passes then only walk that list
+        constexpr int CL = 48;
+        __shared__ int cl_off[4][CL];
+        __shared__ float cl_w[4][CL];
         for (int x = x_begin + wave; x <= x_end; x += 4) {
             const int64_t pix = ((int64_t)n * hf + y) * wf + x;
+            int ncl = 0;
+            bool overflow = false;
+            for (int a = 0; a < nact; ++a) {
+                const int j = act[a];
+                if (x < xmin[j] || x > xmax[j]) continue;
+                const int b = boxid[j];
+                for (int qy = 0; qy < k; ++qy) {
+                    const float wy = wyv[j * k + qy];
+                    if (wy == 0.f) continue;
+                    for (int qx = 0; qx < k; ++qx) {
+                        const int lo = xlo[j * k + qx], hi = xhi[j * k + qx];
+                        const float l = xl[j * k + qx];
+                        const float wx = (lo == x ? 1.f - l : 0.f) + (hi == x ? l : 0.f);
+                        if (wx == 0.f) continue;
+                        if (ncl < CL) { cl_off[wave][ncl] = b * kk + qy * k + qx; cl_w[wave][ncl] = wy * wx; }   // same value from every lane
+                        else overflow = true;
+                        ++ncl;
+                    }
+                }
+            }
+            const bool any = ncl > 0;
+            if (prezeroed && !any) continue;
             for (int ch0 = lane; ch0 - lane < nchunk; ch0 += 64) {
                 const bool lane_ok = ch0 < nchunk;
                 float acc[V];
 #pragma unroll
                 for (int e = 0; e < V; ++e) acc[e] = 0.f;
-                bool any = false;
-                for (int a = 0; a < nact; ++a) {
-                    const int j = act[a];
-                    if (x < xmin[j] || x > xmax[j]) continue;
-                    const int b = boxid[j];
-                    for (int qy = 0; qy < k; ++qy) {
-                        const float wy = wyv[j * k + qy];
-                        if (wy == 0.f) continue;
-                        for (int qx = 0; qx < k; ++qx) {
-                            const int lo = xlo[j * k + qx], hi = xhi[j * k + qx];
-                            const float l = xl[j * k + qx];
-                            const float wx = (lo == x ? 1.f - l : 0.f) + (hi == x ? l : 0.f);
-                            if (wx == 0.f) continue;
-                            any = true;
-                            if (lane_ok) {
+                if (lane_ok && !overflow) {
+                    for (int t = 0; t < ncl; ++t) {
+                        const int off = cl_off[wave][t];
+                        const float w = cl_w[wave][t];
+                        const int bq = off / kk;                            // box * kk + sample -> ((box * c + ch) * kk + sample)
+                        const float* src = dout + ((int64_t)bq * c + ch0 * V) * kk + (off - bq * kk);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) acc[e] += w * src[(int64_t)e * kk];
+                    }
+                } else if (lane_ok) {                                       // more than CL samples touch this pixel: rescan (rare)
+                    for (int a = 0; a < nact; ++a) {
+                        const int j = act[a];
+                        if (x < xmin[j] || x > xmax[j]) continue;
+                        const int b = boxid[j];
+                        for (int qy = 0; qy < k; ++qy) {
+                            const float wy = wyv[j * k + qy];
+                            if (wy == 0.f) continue;
+                            for (int qx = 0; qx < k; ++qx) {
+                                const int lo = xlo[j * k + qx], hi = xhi[j * k + qx];
+                                const float l = xl[j * k + qx];
+                                const float wx = (lo == x ? 1.f - l : 0.f) + (hi == x ? l : 0.f);
+                                if (wx == 0.f) continue;
                                 const float w = wy * wx;
                                 const float* src = dout + ((int64_t)b * c + ch0 * V) * kk + qy * k + qx;
 #pragma unroll
