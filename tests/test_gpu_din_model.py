@@ -161,6 +161,54 @@ def test_bf16_backbone_tracks_fp32(gpu):
             assert cos >= 0.85, (k, cos)
 
 
+def test_inception_bf16_features_and_grads_track_fp32(gpu):
+    """Inception-v3 backbone alone, bf16 vs fp32 on the same weights: every tile variant of the conv kernels the backbone picks
+    (64/96/128/160/192-filter tiles, multi-source dgrad, strided dgrad, commuted pool) must reproduce the fp32 feature maps to bf16
+    accuracy -- a wrong filter tile shows up as O(1) error in a block of channels.  Tolerances: features 3e-2 rel-L2, every block of
+    16 channels within 0.15 relative L2; parameter gradients cosine >= 0.9 (bf16 rounding amplified through ~45 layers)."""
+    from din_amd.backbone.backbone import MyInception_v3
+    g = torch.Generator().manual_seed(33)
+    images = torch.randint(0, 256, (3, 3, 235, 331), generator=g, dtype=torch.uint8)
+    ref = MyInception_v3(compute_dtype="fp32")
+    sd = {}
+    for k, v in ref.state_dict().items():
+        if v.dtype.is_floating_point:
+            if k.endswith("running_var"):
+                sd[k] = torch.rand(v.shape, generator=g) + 0.5
+            elif k.endswith("bn.weight"):
+                sd[k] = torch.rand(v.shape, generator=g) * 0.5 + 0.75
+            elif k.endswith("conv.weight"):
+                fan = v.shape[1] * v.shape[2] * v.shape[3]
+                sd[k] = torch.randn(v.shape, generator=g) * (2.0 / fan) ** 0.5
+            else:
+                sd[k] = torch.randn(v.shape, generator=g) * 0.1
+        else:
+            sd[k] = v
+    outs = {}
+    for dt in ("fp32", "bf16"):
+        m = MyInception_v3(compute_dtype=dt)
+        m.load_state_dict(sd)
+        m = m.to(gpu).eval()
+        feats = m(images.to(gpu))
+        loss = sum((f.float() ** 2).mean() for f in feats)
+        loss.backward()
+        outs[dt] = ([f.detach().float() for f in feats], {k: p.grad.detach().double() for k, p in m.named_parameters() if p.grad is not None})
+    for fa, fb in zip(outs["fp32"][0], outs["bf16"][0]):
+        assert fa.shape == fb.shape
+        assert rel(fb, fa) <= 3e-2
+        ea, eb = (fa ** 2).sum(dim=(0, 2, 3)), ((fb - fa) ** 2).sum(dim=(0, 2, 3))
+        c16 = ea.numel() // 16 * 16                                      # blocks of 16 channels (single near-dead channels are noisy)
+        ea16, eb16 = ea[:c16].view(-1, 16).sum(1), eb[:c16].view(-1, 16).sum(1)
+        live = ea16 > 1e-6 * ea16.max()
+        assert float((eb16[live] / ea16[live]).sqrt().max()) <= 0.15, "a block of channels is off: wrong filter tile?"
+    for k, ref_g in outs["fp32"][1].items():
+        got = outs["bf16"][1][k]
+        if ref_g.norm() == 0:
+            continue
+        cos = float((got.flatten() @ ref_g.flatten()) / (got.norm() * ref_g.norm() + 1e-30))
+        assert cos >= 0.9, (k, cos)
+
+
 def test_hierarchical_din_matches_reference_golden(gpu, golden_dir):
     """row D7: DPI_1 -> LN -> ReLU -> (dropout off) -> DPI_2 at the only shape the reference allows (T=10, N=12, C=1024)"""
     from din_amd.infer_module.dynamic_infer_module import Hierarchical_Dynamic_Inference
