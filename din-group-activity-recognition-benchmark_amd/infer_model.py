@@ -81,7 +81,8 @@ class _DynamicBase(nn.Module):
         crops = self.roi_align(fm, boxes_flat, boxes_idx, nhwc=True, channels=D,
                                relu_masked=graph.tensors[tid].relu_masked)          # [BTN, D, K, K]  (:178-180)
         feats = crops.reshape(B, T, N, D * K * K)
-        x = ops.linear(feats, self.fc_emb_1.weight, self.fc_emb_1.bias)              # :184
+        x = ops.linear(feats, self.fc_emb_1.weight, self.fc_emb_1.bias,
+                       lowp=getattr(self.cfg, "backbone_dtype", "fp32") == "bf16")              # :184
         x = ops.layer_norm(x, self.nl_emb_1.weight, self.nl_emb_1.bias, relu=True)   # :185-186
         return x
 

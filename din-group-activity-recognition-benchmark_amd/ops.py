@@ -97,32 +97,40 @@ class GridConvFunction(torch.autograd.Function):
     the fused p_conv/scale_conv (dynamic_infer_module.py:191,195)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, dil: int):
+    def forward(ctx, x, weight, bias, dil: int, lowp: bool = False):
+        """lowp: bf16 operands / fp32 MFMA accumulation (throughput mode, used for the 26400-wide embedding GEMM when the backbone
+        already runs in bf16); x, y and all gradients stay fp32 tensors at the interface."""
         lib = L.load()
         x = x.contiguous()
         weight = weight.contiguous()
         require_gpu(x, weight, bias)
         nb, h, w, cin = x.shape
         cout, _, kh, kw = weight.shape
-        ldo = (cout + 3) // 4 * 4
+        lowp = bool(lowp) and cin % 8 == 0 and cout % 8 == 0
+        tdt = torch.bfloat16 if lowp else torch.float32
+        ldo = cout if lowp else (cout + 3) // 4 * 4
         d = _desc(nb, h, w, cin, cout, kh, kw, (kh - 1) // 2 * dil, (kw - 1) // 2 * dil, dil, cin, ldo)
+        if lowp:
+            d.dtype = L.DIN_BF16
+            x = x.to(torch.bfloat16)
         st = _stream()
-        y = (torch.zeros if ldo != cout else torch.empty)((nb, h, w, ldo), dtype=torch.float32, device=x.device)
-        wpk = torch.empty(lib.din_conv_packed_elems(C.byref(d), 0), dtype=torch.float32, device=x.device)
+        y = (torch.zeros if ldo != cout else torch.empty)((nb, h, w, ldo), dtype=tdt, device=x.device)
+        wpk = torch.empty(lib.din_conv_packed_elems(C.byref(d), 0), dtype=tdt, device=x.device)
         L.check(lib.din_conv_pack_weights(C.byref(d), _ptr(weight), None, _ptr(wpk), 0, st), "conv_pack")
         ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 0), x.device)
         L.check(lib.din_conv_fwd(C.byref(d), _ptr(x), _ptr(wpk), _ptr(bias), _ptr(y), L.CONV_BIAS if bias is not None else 0,
                                  _ptr(ws), wsb, st), "grid_conv_fwd")
         ctx.save_for_backward(x, weight)
-        ctx.d, ctx.has_bias = d, bias is not None
-        return y
+        ctx.d, ctx.has_bias, ctx.lowp = d, bias is not None, lowp
+        return y.float() if lowp else y
 
     @staticmethod
     def backward(ctx, gy):
         lib = L.load()
         x, weight = ctx.saved_tensors
         d = ctx.d
-        gy = gy.contiguous()
+        tdt = torch.bfloat16 if ctx.lowp else torch.float32
+        gy = gy.contiguous().to(tdt)
         st = _stream()
         dx = dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
@@ -133,18 +141,20 @@ class GridConvFunction(torch.autograd.Function):
                     "grid_conv_wgrad")
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            wpt = torch.empty(lib.din_conv_packed_elems(C.byref(d), 1), dtype=torch.float32, device=x.device)
+            wpt = torch.empty(lib.din_conv_packed_elems(C.byref(d), 1), dtype=tdt, device=x.device)
             L.check(lib.din_conv_pack_weights(C.byref(d), _ptr(weight), None, _ptr(wpt), 1, st), "conv_pack_t")
             ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 1), x.device)
             L.check(lib.din_conv_dgrad(C.byref(d), _ptr(gy), _ptr(wpt), _ptr(dx), None, 0, 0, 0, _ptr(ws), wsb, st), "grid_conv_dgrad")
-        return dx, dw, db, None
+            if ctx.lowp:
+                dx = dx.float()
+        return dx, dw, db, None, None
 
 
-def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], lowp: bool = False) -> torch.Tensor:
     """y = x @ weight.T + bias over the last dim, on the MFMA contraction kernel (cout must be a multiple of 4)."""
     shp = x.shape
     rows = x.numel() // shp[-1]
-    y = GridConvFunction.apply(x.reshape(1, 1, rows, shp[-1]), weight.reshape(weight.shape[0], weight.shape[1], 1, 1), bias, 1)
+    y = GridConvFunction.apply(x.reshape(1, 1, rows, shp[-1]), weight.reshape(weight.shape[0], weight.shape[1], 1, 1), bias, 1, lowp)
     cout = weight.shape[0]
     if y.shape[-1] != cout:
         y = y[..., :cout]
