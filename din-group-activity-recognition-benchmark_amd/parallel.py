@@ -64,6 +64,9 @@ class GradBuckets:
         self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
 
     def allreduce(self, world: Optional[int] = None, async_op: bool = True) -> None:
+        """Average the gradients across ranks.  Per bucket: ONE concatenation into the flat buffer (not one copy per tensor: a
+        backbone has ~220 parameter tensors, most of them BatchNorm vectors), one asynchronous all-reduce, one scale; afterwards
+        every `p.grad` IS a view of the flat buffer (no copy back) -- the optimizer reads the views."""
         if not dist.is_initialized() or dist.get_world_size() == 1:
             return
         world = world or dist.get_world_size()
@@ -74,14 +77,23 @@ class GradBuckets:
             flat = self._flat[bi]
             if flat is None or flat.numel() != total or flat.device != dev:
                 flat = self._flat[bi] = torch.empty(total, dtype=torch.float32, device=dev)
-            off = 0
+            pieces, off, already = [], 0, True
             for p in bucket:
                 n = p.numel()
-                if p.grad is None:
-                    flat[off:off + n].zero_()
-                else:
-                    flat[off:off + n].copy_(p.grad.reshape(-1))
+                g = p.grad
+                if g is None:
+                    g = torch.zeros(n, dtype=torch.float32, device=dev)
+                # a gradient that already lives at its slot (previous step's view, accumulated into in place) needs no packing
+                if not (g.dtype == torch.float32 and g.is_contiguous() and g.data_ptr() == flat.data_ptr() + 4 * off):
+                    already = False
+                pieces.append(g.reshape(-1).float())
                 off += n
+            if not already:
+                lo, hi = flat.data_ptr(), flat.data_ptr() + 4 * total
+                if any(lo <= g.data_ptr() < hi for g in pieces):
+                    flat.copy_(torch.cat(pieces))              # some pieces are views of `flat` itself (kept from the last step)
+                else:
+                    torch.cat(pieces, out=flat)
             handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op), bi))
         for h, bi in handles:
             if h is not None and async_op:
@@ -90,10 +102,7 @@ class GradBuckets:
             flat.div_(world)
             for p in self.buckets[bi]:
                 n = p.numel()
-                if p.grad is None:
-                    p.grad = flat[off:off + n].reshape(p.shape).clone()
-                else:
-                    p.grad.copy_(flat[off:off + n].reshape(p.shape))
+                p.grad = flat[off:off + n].view(p.shape)
                 off += n
 
 
