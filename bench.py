@@ -163,6 +163,14 @@ def main():
         loss.backward()
         if buckets is not None:
             buckets.allreduce()
+            if os.environ.get("DIN_CHECK_ALLREDUCE") == "1":     # debugging aid: every rank must hold the same averaged gradients
+                chk = torch.stack([p.grad.double().sum() for p in params if p.grad is not None]).sum().reshape(1)
+                lo, hi = chk.clone(), chk.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+                assert float((hi - lo).abs()) <= 1e-9 * max(1.0, float(hi.abs())), (float(lo), float(hi))
+                if rank == 0:
+                    print(f"allreduce check ok: grad checksum {float(chk):.6e}", file=sys.stderr, flush=True)
         if not a.no_adam:
             opt.step()
         return loss

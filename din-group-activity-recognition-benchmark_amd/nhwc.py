@@ -55,6 +55,9 @@ def require_gpu(*tensors: torch.Tensor) -> None:
 # (kind, flops, start_event, end_event) recorded on the stream the kernel is launched on.
 # ------------------------------------------------------------------------------------------------
 PROFILE = None
+# Called as GRAD_HOOK(weight, dweight) right after a conv layer's weight gradient has been enqueued (backward order: last layer
+# first).  parallel.GradBuckets uses it to start a bucket's all-reduce while the rest of the backward pass is still running.
+GRAD_HOOK = None
 import os as _os
 FUSE_1X1_DGRAD = _os.environ.get("DIN_FUSE_1X1", "1") != "0"     # fuse the dgrads of 1x1 convs that read the same tensor
 
@@ -545,6 +548,8 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 grads[po] = dw
                 if op.bias:
                     grads[po + 1] = db
+            if GRAD_HOOK is not None and side is None:
+                GRAD_HOOK(w, dw)
             # ---- dgrad
             if src_needs_grad and oi in member_of:
                 key = member_of[oi]

@@ -45,23 +45,100 @@ def shard_range(total: int, rank: int, world: int) -> range:
 
 
 class GradBuckets:
-    """Flat fp32 gradient buckets over a parameter list; `allreduce()` averages them across ranks in place."""
+    """Flat fp32 gradient buckets over a parameter list; `allreduce()` averages them across ranks in place.
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20):
+    Overlap with the backward pass: the conv stack is one autograd node, so autograd hooks would only fire at its end.  Instead
+    `nhwc.GRAD_HOOK` reports every conv weight gradient the moment its kernel is enqueued (last layer first).  The first step
+    learns that order; from then on the hooked weights are laid out in buckets in exactly that order ("early" buckets), each
+    packed with one concatenation and sent off with an asynchronous all-reduce as soon as its last gradient was reported --
+    RCCL then runs over xGMI while the remaining layers are still computing.  Everything else (BatchNorm vectors, which one
+    kernel produces at the very end, and the head) goes into the final bucket, reduced in `allreduce()`."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, overlap: bool = True):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
-        order = list(reversed(self.params))                    # backward produces the last layers first
+        self.bucket_bytes = bucket_bytes
+        self._by_ptr = {p.data_ptr(): p for p in self.params}
+        self._hook_order: List[torch.nn.Parameter] = []         # order in which hooked gradients arrived this step
+        self._learned: Optional[List[int]] = None               # data_ptrs of the hooked params, in arrival order
+        self._early = 0                                          # number of leading buckets driven by the hook
+        self._got: dict = {}                                     # data_ptr -> gradient tensor reported this step
+        self._inflight: dict = {}                                # bucket index -> async work handle
+        self._build(list(reversed(self.params)), 0)             # backward produces the last layers first
+        if overlap and dist.is_initialized() and dist.get_world_size() > 1:
+            try:
+                from . import nhwc
+                nhwc.GRAD_HOOK = self._on_grad
+            except Exception:                                    # host-only use (CPU tests): no conv executor
+                pass
+
+    def _build(self, order: List[torch.nn.Parameter], early_params: int) -> None:
+        """buckets over `order`; the first `early_params` parameters (hook-driven) never share a bucket with the rest"""
         self.buckets: List[List[torch.nn.Parameter]] = []
         cur, cur_bytes = [], 0
-        for p in order:
+        for i, p in enumerate(order):
             nb = p.numel() * 4
-            if cur and cur_bytes + nb > bucket_bytes:
+            if cur and (cur_bytes + nb > self.bucket_bytes or i == early_params):
                 self.buckets.append(cur)
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nb
         if cur:
             self.buckets.append(cur)
+        self._early = 0
+        seen = 0
+        for bkt in self.buckets:
+            if seen + len(bkt) <= early_params:
+                self._early += 1
+                seen += len(bkt)
         self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+        self._slot = {}
+        for bi, bkt in enumerate(self.buckets):
+            off = 0
+            for p in bkt:
+                self._slot[p.data_ptr()] = (bi, off)
+                off += p.numel()
+
+    def _flat_of(self, bi: int) -> torch.Tensor:
+        bucket = self.buckets[bi]
+        total = sum(p.numel() for p in bucket)
+        dev = bucket[0].device
+        flat = self._flat[bi]
+        if flat is None or flat.numel() != total or flat.device != dev:
+            flat = self._flat[bi] = torch.empty(total, dtype=torch.float32, device=dev)
+        return flat
+
+    def _pack(self, bi: int, grads: List[Optional[torch.Tensor]]) -> torch.Tensor:
+        flat = self._flat_of(bi)
+        pieces, off, already = [], 0, True
+        for p, g in zip(self.buckets[bi], grads):
+            n = p.numel()
+            if g is None:
+                g = torch.zeros(n, dtype=torch.float32, device=flat.device)
+            # a gradient that already lives at its slot (previous step's view, accumulated into in place) needs no packing
+            if not (g.dtype == torch.float32 and g.is_contiguous() and g.data_ptr() == flat.data_ptr() + 4 * off):
+                already = False
+            pieces.append(g.reshape(-1).float())
+            off += n
+        if not already:
+            lo, hi = flat.data_ptr(), flat.data_ptr() + 4 * off
+            if any(lo <= g.data_ptr() < hi for g in pieces):
+                flat.copy_(torch.cat(pieces))                  # some pieces are views of `flat` itself (kept from the last step)
+            else:
+                torch.cat(pieces, out=flat)
+        return flat
+
+    def _on_grad(self, param: torch.Tensor, grad: torch.Tensor) -> None:
+        key = param.data_ptr()
+        if key not in self._by_ptr:
+            return
+        self._hook_order.append(key)
+        if self._learned is None:
+            return                                               # first step: only learn the order
+        self._got[key] = grad
+        bi, _ = self._slot[key]
+        if bi < self._early and bi not in self._inflight and all(q.data_ptr() in self._got for q in self.buckets[bi]):
+            flat = self._pack(bi, [self._got[q.data_ptr()] for q in self.buckets[bi]])
+            self._inflight[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def allreduce(self, world: Optional[int] = None, async_op: bool = True) -> None:
         """Average the gradients across ranks.  Per bucket: ONE concatenation into the flat buffer (not one copy per tensor: a
@@ -72,31 +149,13 @@ class GradBuckets:
         world = world or dist.get_world_size()
         handles = []
         for bi, bucket in enumerate(self.buckets):
-            total = sum(p.numel() for p in bucket)
-            dev = bucket[0].device
-            flat = self._flat[bi]
-            if flat is None or flat.numel() != total or flat.device != dev:
-                flat = self._flat[bi] = torch.empty(total, dtype=torch.float32, device=dev)
-            pieces, off, already = [], 0, True
-            for p in bucket:
-                n = p.numel()
-                g = p.grad
-                if g is None:
-                    g = torch.zeros(n, dtype=torch.float32, device=dev)
-                # a gradient that already lives at its slot (previous step's view, accumulated into in place) needs no packing
-                if not (g.dtype == torch.float32 and g.is_contiguous() and g.data_ptr() == flat.data_ptr() + 4 * off):
-                    already = False
-                pieces.append(g.reshape(-1).float())
-                off += n
-            if not already:
-                lo, hi = flat.data_ptr(), flat.data_ptr() + 4 * total
-                if any(lo <= g.data_ptr() < hi for g in pieces):
-                    flat.copy_(torch.cat(pieces))              # some pieces are views of `flat` itself (kept from the last step)
-                else:
-                    torch.cat(pieces, out=flat)
+            if bi in self._inflight:                             # started from the hook while backward was still running
+                handles.append((self._inflight[bi], bi))
+                continue
+            flat = self._pack(bi, [p.grad for p in bucket])
             handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op), bi))
         for h, bi in handles:
-            if h is not None and async_op:
+            if h is not None and (async_op or bi in self._inflight):
                 h.wait()
             flat, off = self._flat[bi], 0
             flat.div_(world)
@@ -104,6 +163,17 @@ class GradBuckets:
                 n = p.numel()
                 p.grad = flat[off:off + n].view(p.shape)
                 off += n
+        # ---- bookkeeping for the next step
+        self._inflight.clear()
+        self._got.clear()
+        if self._learned is None and self._hook_order:
+            # every rank saw the same order (same graph): hooked weights first, in arrival order, then everything else
+            self._learned = list(dict.fromkeys(self._hook_order))
+            hooked = [self._by_ptr[k] for k in self._learned]
+            hooked_set = set(self._learned)
+            rest = [p for p in reversed(self.params) if p.data_ptr() not in hooked_set]
+            self._build(hooked + rest, len(hooked))
+        self._hook_order.clear()
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:

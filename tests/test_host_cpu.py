@@ -136,6 +136,20 @@ ref.load_state_dict(lin.state_dict())
 ref(clips).pow(2).mean().backward()
 for p, q in zip(lin.parameters(), ref.parameters()):
     assert torch.allclose(p.grad, q.grad, atol=1e-6), (p.grad - q.grad).abs().max()
+# overlap path: the conv executor reports weight gradients through the hook while backward is still running.  Step 1 teaches the
+# order, from step 2 on the hooked weights form the leading buckets and are reduced from inside the hook.
+weights = [lin[1].weight, lin[0].weight]                       # backward order
+for step in range(3):
+    for p in lin.parameters():
+        p.grad = None
+    lin(clips[mine]).pow(2).mean().backward()
+    for w in weights:
+        b._on_grad(w, w.grad)
+    if step >= 1:
+        assert b._early >= 1 and len(b._inflight) >= 1, (b._early, len(b._inflight))
+    b.allreduce()
+    for p, q in zip(lin.parameters(), ref.parameters()):
+        assert torch.allclose(p.grad, q.grad, atol=1e-6), (step, (p.grad - q.grad).abs().max())
 dist.barrier()
 sys.stdout.write(f"RANK_OK_{rank}\n"); sys.stdout.flush()
 """
