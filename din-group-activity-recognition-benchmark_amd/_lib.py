@@ -36,6 +36,11 @@ class PoolDesc(C.Structure):
         "nb", "h", "w", "c", "oh", "ow", "k", "stride", "pad", "ldi", "cioff", "ldo", "cooff", "dtype")]
 
 
+class PackDesc(C.Structure):
+    _fields_ = [("w", C.c_uint64), ("scale", C.c_uint64), ("out", C.c_uint64)] + [(n, C.c_int32) for n in (
+        "cout", "cin", "kh", "kw", "rows", "rows_pad", "inner", "inner_pad", "kelems", "transposed", "dtype", "reserved")]
+
+
 class ConvSrc(C.Structure):
     _fields_ = [("dout", C.c_void_p), ("wpk_t", C.c_void_p), ("cout", C.c_int32), ("ldo", C.c_int32), ("cooff", C.c_int32)]
 
@@ -52,6 +57,8 @@ SIGNATURES: Dict[str, tuple] = {
     "din_prep_images_nhwc": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "din_conv_packed_elems": (_L, [_CD, _I]),
     "din_conv_pack_weights": (_I, [_CD, _P, _P, _P, _I, _P]),
+    "din_conv_pack_desc": (_I, [_CD, _P, _P, _P, _I, C.POINTER(PackDesc)]),
+    "din_conv_pack_multi": (_I, [_P, _P, _P, _I, _I, _P]),
     "din_conv_kernel_tile": (_I, [_CD, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "din_conv_workspace_bytes": (_L, [_CD, _I]),
     "din_conv_fwd": (_I, [_CD, _P, _P, _P, _P, _I, _P, _L, _P]),

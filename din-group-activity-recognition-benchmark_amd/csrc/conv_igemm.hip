@@ -1128,6 +1128,33 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, const float* __res
     }
 }
 
+// every filter bank of a backbone (both orientations) in one launch: workgroup b packs elements [chunk_index[b] * chunk, +chunk) of
+// bank layer_of[b]; the table lives on the device and is built once (weights, scales and packed buffers keep their addresses)
+__global__ __launch_bounds__(256) void conv_pack_multi_kernel(const din_pack_desc* __restrict__ table, const int32_t* __restrict__ layer_of,
+                                                              const int32_t* __restrict__ chunk_index, int chunk) {
+    const din_pack_desc d = table[layer_of[blockIdx.x]];
+    const float* __restrict__ w = reinterpret_cast<const float*>(d.w);
+    const float* __restrict__ scale = reinterpret_cast<const float*>(d.scale);
+    const int64_t total = (int64_t)d.rows_pad * d.kelems;
+    const int64_t i0 = (int64_t)chunk_index[blockIdx.x] * chunk;
+    int64_t i1 = i0 + chunk;
+    if (i1 > total) i1 = total;
+    const int taps = d.kh * d.kw;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const int row = (int)(i / d.kelems), k = (int)(i - (int64_t)row * d.kelems);
+        const int tap = k / d.inner_pad, c = k - tap * d.inner_pad;
+        float v = 0.f;
+        if (row < d.rows && tap < taps && c < d.inner) {
+            const int r = tap / d.kw, s2 = tap - r * d.kw;
+            const int co = d.transposed ? c : row, ci = d.transposed ? row : c;
+            v = w[(((int64_t)co * d.cin + ci) * d.kh + r) * d.kw + s2];
+            if (scale) v *= scale[co];
+        }
+        if (d.dtype == DIN_F32) reinterpret_cast<float*>(d.out)[i] = v;
+        else reinterpret_cast<bf16_t*>(d.out)[i] = f32_to_bf16(v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // wgrad:  dW[co][(r,s,ci)] = sum_pix G[pix][co] * im2col(X)[pix][(r,s,ci)]
 // 128 (co) x 128 (k columns) tile per workgroup, reduction over a slice of the pixels; partials to a
@@ -2606,6 +2633,28 @@ int din_conv_pack_weights(const din_conv_desc* d, const float* w, const float* s
         hipLaunchKernelGGL(conv_pack_kernel<bf16_t>, dim3(grid_1d(total, 256)), dim3(256), 0, st, w, scale, (bf16_t*)wpk,
                            d->cout, d->cin, d->kh, d->kw, cprod, rows_pad, cred, inner_pad, kelems, transposed);
     DIN_CHECK_LAUNCH("conv_pack");
+    return DIN_OK;
+}
+
+int din_conv_pack_desc(const din_conv_desc* d, const float* w, const float* scale, void* wpk, int transposed, din_pack_desc* out) {
+    DIN_REQUIRE(d && w && wpk && out, "conv_pack_desc: null pointer");
+    const int epc = epc_of(d->dtype);
+    const int cred = transposed ? d->cout : d->cin, cprod = transposed ? d->cin : d->cout;
+    const int inner_pad = pad_to(cred, epc), cpt = inner_pad / epc;
+    const int nk = (d->kh * d->kw * cpt + KC - 1) / KC;
+    out->w = (uint64_t)(uintptr_t)w; out->scale = (uint64_t)(uintptr_t)scale; out->out = (uint64_t)(uintptr_t)wpk;
+    out->cout = d->cout; out->cin = d->cin; out->kh = d->kh; out->kw = d->kw;
+    out->rows = cprod; out->rows_pad = pad_to(cprod, 256); out->inner = cred; out->inner_pad = inner_pad; out->kelems = nk * KC * epc;
+    out->transposed = transposed; out->dtype = d->dtype;
+    return DIN_OK;
+}
+
+int din_conv_pack_multi(const din_pack_desc* table, const int32_t* layer_of, const int32_t* chunk_index, int nblocks, int chunk_elems,
+                        void* stream) {
+    DIN_REQUIRE(table && layer_of && chunk_index && nblocks >= 0 && chunk_elems > 0, "conv_pack_multi: bad argument");
+    if (nblocks == 0) return DIN_OK;
+    hipLaunchKernelGGL(conv_pack_multi_kernel, dim3(nblocks), dim3(256), 0, as_stream(stream), table, layer_of, chunk_index, chunk_elems);
+    DIN_CHECK_LAUNCH("conv_pack_multi");
     return DIN_OK;
 }
 

@@ -316,6 +316,63 @@ def _bn_tables(g: "Graph", params: Sequence[torch.Tensor], dev) -> Optional[_BnT
     return tb
 
 
+PACK_CHUNK = 16384
+
+
+class _PackCache:
+    """persistent packed filter banks of a graph (+ the device table that lets ONE launch repack all of them every step)"""
+    pass
+
+
+def _pack_cache(g: Graph, params: Sequence[torch.Tensor], dt: int, dev, with_transposed: bool, bn: Optional[_BnTables]) -> _PackCache:
+    lib = L.load()
+    key = (tuple(p.data_ptr() for p in params), dt, bool(with_transposed), str(dev))
+    pc = getattr(g, "_pack_cache", None)
+    if pc is not None and pc.key == key:
+        return pc
+    pc = _PackCache()
+    pc.key = key
+    tdt = torch_dtype(dt)
+    pc.bn_scale = torch.empty(bn.total, dtype=torch.float32, device=dev) if bn is not None else None
+    pc.bn_shift = torch.empty(bn.total, dtype=torch.float32, device=dev) if bn is not None else None
+    pc.wpk, pc.wpt = {}, {}
+    descs, layer_of, chunk_index = [], [], []
+    pos, bn_i = 0, 0
+    for oi, op in enumerate(g.ops):
+        if op.kind != "conv":
+            continue
+        cin = g.cin_image if op.src.tid == g.input_tid else op.src.c
+        d = _conv_desc(g, op, 1, dt, cin)
+        w = params[pos]
+        scale_ptr = None
+        if op.bn:
+            o0 = bn.off_list[bn_i]
+            scale_ptr = C.c_void_p(pc.bn_scale.data_ptr() + 4 * o0)
+            bn_i += 1
+            pos += 5
+        else:
+            pos += 2 if op.bias else 1
+        for transposed in ((0, 1) if (with_transposed and op.src.tid != g.input_tid) else (0,)):
+            n_el = lib.din_conv_packed_elems(C.byref(d), transposed)
+            buf = torch.empty(n_el, dtype=tdt, device=dev)
+            (pc.wpt if transposed else pc.wpk)[oi] = buf
+            pd = L.PackDesc()
+            L.check(lib.din_conv_pack_desc(C.byref(d), _ptr(w), scale_ptr, _ptr(buf), transposed, C.byref(pd)), "conv_pack_desc")
+            li = len(descs)
+            descs.append(pd)
+            nchunk = (n_el + PACK_CHUNK - 1) // PACK_CHUNK
+            layer_of += [li] * nchunk
+            chunk_index += list(range(nchunk))
+    raw = (L.PackDesc * len(descs))(*descs)
+    host = torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8).clone()
+    pc.table = host.to(dev)
+    pc.layer_of = torch.tensor(layer_of, dtype=torch.int32).to(dev)
+    pc.chunk_index = torch.tensor(chunk_index, dtype=torch.int32).to(dev)
+    pc.nblocks = len(layer_of)
+    g._pack_cache = pc
+    return pc
+
+
 def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tensor], dt: int, save_for_backward: bool = True):
     """Run the graph.  image_buf: NHWC [nb,h,w,cpad] of dtype dt.  Returns (bufs, aux) for backward."""
     lib = L.load()
@@ -328,13 +385,15 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
     aux = []
     st = _stream()
     bn = _bn_tables(g, params, dev)
+    pc = _pack_cache(g, params, dt, dev, save_for_backward, bn)
     if bn is not None:
         # every BatchNorm layer of the graph folded in ONE launch into flat scale / shift arrays (views per layer below)
-        bn_scale = torch.empty(bn.total, dtype=torch.float32, device=dev)
-        bn_shift = torch.empty(bn.total, dtype=torch.float32, device=dev)
+        bn_scale, bn_shift = pc.bn_scale, pc.bn_shift
         L.check(lib.din_bn_fold_multi(_ptr(bn.ptrs), _ptr(bn.offs), bn.n, bn.total, BN_EPS, _ptr(bn_scale), _ptr(bn_shift), st), "bn_fold_multi")
+    # ... and every filter bank (forward and, when training, dgrad orientation) repacked with the folded scale in ONE launch
+    L.check(lib.din_conv_pack_multi(_ptr(pc.table), _ptr(pc.layer_of), _ptr(pc.chunk_index), pc.nblocks, PACK_CHUNK, st), "conv_pack_multi")
     bn_i = 0
-    for op in g.ops:
+    for oi, op in enumerate(g.ops):
         td = g.tensors[op.dst.tid]
         if bufs[op.dst.tid] is None:
             bufs[op.dst.tid] = torch.empty((nb, td.h, td.w, td.c), dtype=tdt, device=dev)
@@ -352,8 +411,7 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
                 bias = shift
             else:
                 bias = next(it) if op.bias else None
-            wpk = torch.empty(lib.din_conv_packed_elems(C.byref(d), 0), dtype=tdt, device=dev)
-            L.check(lib.din_conv_pack_weights(C.byref(d), _ptr(w), _ptr(scale), _ptr(wpk), 0, st), "conv_pack")
+            wpk = pc.wpk[oi]
             flags = (L.CONV_BIAS if bias is not None else 0) | (L.CONV_RELU if op.relu else 0)
             if op.pooled is not None:
                 d, pd = _pooled_descs(g, op, nb, dt)
@@ -431,6 +489,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
             offsets.append(-1)
     grads: List[Optional[torch.Tensor]] = [None] * len(params)
     bn = _bn_tables(g, params, dev)
+    pcache = _pack_cache(g, params, dt, dev, True, bn)          # the forward pass of this step packed both orientations
     if bn is not None:
         # flat, pre-zeroed accumulators for every layer's shift gradient and <W, dW> dot (one memset instead of two per layer)
         bn_acc = torch.zeros(2 * bn.total, dtype=torch.float32, device=dev)
@@ -467,8 +526,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
         for j, (oi_, gout_, w_, scale_, ldj, coffj) in enumerate(items):
             opj = g.ops[oi_]
             dj = _conv_desc(g, opj, nb, dt)
-            wpt = torch.empty(lib.din_conv_packed_elems(C.byref(dj), 1), dtype=tdt, device=dev)
-            L.check(lib.din_conv_pack_weights(C.byref(dj), _ptr(w_), _ptr(scale_), _ptr(wpt), 1, st), "conv_pack_t")
+            wpt = pcache.wpt[oi_]
             keep.append(wpt)
             srcs[j].dout, srcs[j].wpk_t = gout_.data_ptr(), wpt.data_ptr()
             srcs[j].cout, srcs[j].ldo, srcs[j].cooff = opj.dst.c, ldj, coffj
@@ -559,8 +617,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                     flush_group(key)
             elif src_needs_grad:
                 gsrc, acc = grad_target(op.src)
-                wpt = torch.empty(lib.din_conv_packed_elems(C.byref(d), 1), dtype=tdt, device=dev)
-                L.check(lib.din_conv_pack_weights(C.byref(d), _ptr(w), _ptr(scale), _ptr(wpt), 1, st), "conv_pack_t")
+                wpt = pcache.wpt[oi]
                 flags = (L.CONV_ACCUM if acc else 0) | (L.CONV_MASK if ts.relu_masked else 0)
                 ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 1), dev)
                 with _timed("dgrad", d, op.name):

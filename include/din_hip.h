@@ -85,6 +85,18 @@ int64_t din_conv_packed_elems(const din_conv_desc* d, int transposed);
  * (BatchNorm-eval: backbone.py BasicConv2d).  transposed=0 -> [cout_pad][(r,s,ci)], =1 -> [cin_pad][(r,s,co)] */
 int din_conv_pack_weights(const din_conv_desc* d, const float* w, const float* scale, void* wpk,
                           int transposed, void* stream);
+/* All filter banks of a backbone in ONE launch.  din_conv_pack_desc fills one table entry on the host (same layout rules as
+ * din_conv_pack_weights); the caller uploads the table once and then calls din_conv_pack_multi every step with, per workgroup, the
+ * bank it packs (layer_of) and which chunk_elems-sized chunk of it (chunk_index).  All three arrays live on the device. */
+typedef struct din_pack_desc {
+    uint64_t w, scale, out;          /* device addresses: fp32 [cout][cin][kh][kw] filters, fp32 [cout] scale (0: none), packed bank */
+    int32_t cout, cin, kh, kw;
+    int32_t rows, rows_pad, inner, inner_pad, kelems, transposed, dtype;
+    int32_t reserved;
+} din_pack_desc;
+int din_conv_pack_desc(const din_conv_desc* d, const float* w, const float* scale, void* wpk, int transposed, din_pack_desc* out);
+int din_conv_pack_multi(const din_pack_desc* table, const int32_t* layer_of, const int32_t* chunk_index, int nblocks,
+                        int chunk_elems, void* stream);
 /* which tile variant the planner picks (which: 0 fwd, 1 dgrad -> pixels x filters of conv_gather_*_kernel; 2 wgrad -> filter rows x
  * k columns of conv_wgrad_*_kernel, bn = 1000 + k columns for conv_wgrad_ring_kernel; bm = 0 -> the stationary-filter stem kernels
  * conv_small_kernel / conv_wgrad_small_kernel with bn filters; bm = 1 -> conv_halo_kernel): lets a
