@@ -2498,6 +2498,9 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
         k.korder = (want && fast && !k.remap && g.splitk == 1 && (g.cpt % KC) == 0 && k.kh * k.kw > 1) ? 1 : 0;
     }
     k.splitk = g.splitk; k.ks_per_split = g.ks_per_split; k.n_co_tiles = g.n_co_tiles;
+    if (getenv("DIN_DEBUG_PLAN"))
+        fprintf(stderr, "[din] %s M=%d NB=%d HxW=%dx%d Cin=%d Cout=%d k=%dx%d ay=%d cy=%d tile=%dx%d splitk=%d korder=%d remap=%d flags=%d dtype=%d\n", what,
+                k.M, k.NB, k.H, k.W, k.Cin, k.Cout, k.kh, k.kw, k.ay, k.cy, g.bm, g.bn, g.splitk, k.korder, k.remap, k.flags, dtype);
     if (g.splitk > 1) {
         if (ws_bytes < g.ws_bytes || workspace == nullptr)
             DIN_FAIL(DIN_E_WORKSPACE, "%s: workspace %lld < %lld bytes", what, (long long)ws_bytes, (long long)g.ws_bytes);

@@ -55,6 +55,8 @@ CONV_CASES = [
     ("tile96_3x3", 1, 64, 24, 40, 96, (3, 3), (1, 1), (1, 1), 1),         # 96-filter tile, likewise
     ("tile192_1x1", 1, 96, 24, 40, 192, (1, 1), (1, 1), (0, 0), 1),
     ("linear_splitk", 1, 1600, 1, 72, 128, (1, 1), (1, 1), (0, 0), 1),
+    ("splitk_3x3_multi_image", 6, 256, 8, 12, 512, (3, 3), (1, 1), (1, 1), 1),   # VGG conv4_1 on a small frame: split-K, tiles span images
+    ("korder_rows_w96", 6, 64, 64, 96, 64, (3, 3), (1, 1), (1, 1), 1),            # VGG conv1_2 on the smoke frame: tap-inner k order, tiles span rows
     # stem shapes (>= 256K pixels): bf16 runs the stationary-filter halo kernel (fwd cpt4, dgrad cpt4 / cpt8), ragged tile edges
     ("stem_32_32_p0", 1, 32, 515, 517, 32, (3, 3), (1, 1), (0, 0), 1),
     ("stem_32_64_p1", 2, 32, 363, 365, 64, (3, 3), (1, 1), (1, 1), 1),

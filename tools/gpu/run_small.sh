@@ -1,1 +1,2 @@
-for B in 4 8 16 32; do timeout 600 python bench.py --steps 5 --warmup 2 --global-batch $B --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('batch',d['config']['global_batch'], d['value'],'clips/s', d['ms_per_step'],'ms', 'conv frac', d['conv_time_frac_sampled_step'])"; done
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v "amdgpu.ids\|Inference\|Deactivate"
+DIN_CONV_KORDER=0 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v "amdgpu.ids\|Inference\|Deactivate"
