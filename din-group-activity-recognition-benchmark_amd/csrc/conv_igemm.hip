@@ -93,6 +93,32 @@ __device__ __forceinline__ void lds_dma16(uint32_t lds_addr, __amdgpu_buffer_rsr
                  : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 
+// One k-step of the FASTK loop: NA pixel-tile + NB filter-tile wave-level DMAs into consecutive STRIDE-byte slots of a ring stage, as
+// ONE asm statement: M0 is written once and then advanced (declared clobbered instead of saved/restored around every transfer),
+// 3 instructions per transfer instead of 5 -- the scalar unit is shared by the CU's 16 waves and was 40 % busy (SQ_ACTIVE_INST_SCA).
+template <int NA, int NB, int STRIDE>
+__device__ __forceinline__ void lds_dma_stage(uint32_t lds_addr, __amdgpu_buffer_rsrc_t rsA, const unsigned (&va)[NA], int soffA,
+                                              __amdgpu_buffer_rsrc_t rsB, const int (&vb)[NB], int soffB) {
+#define DIN_DMA_FIRST(V, R, S) "s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 " V ", " R ", " S " offen lds\n\t"
+#define DIN_DMA_NEXT(V, R, S) "s_add_u32 m0, m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 " V ", " R ", " S " offen lds\n\t"
+    static_assert(NA == 2 && NB >= 1 && NB <= 3, "instantiated for the 8-wave 128-pixel tiles");
+    if constexpr (NB == 1)
+        asm volatile(DIN_DMA_FIRST("%6", "%1", "%3") DIN_DMA_NEXT("%7", "%1", "%3") DIN_DMA_NEXT("%8", "%2", "%4")
+                     :: "s"(lds_addr), "s"(rsA), "s"(rsB), "s"(soffA), "s"(soffB), "n"(STRIDE), "v"(va[0]), "v"(va[1]), "v"(vb[0])
+                     : "memory", "m0", "scc");
+    else if constexpr (NB == 2)
+        asm volatile(DIN_DMA_FIRST("%6", "%1", "%3") DIN_DMA_NEXT("%7", "%1", "%3") DIN_DMA_NEXT("%8", "%2", "%4") DIN_DMA_NEXT("%9", "%2", "%4")
+                     :: "s"(lds_addr), "s"(rsA), "s"(rsB), "s"(soffA), "s"(soffB), "n"(STRIDE), "v"(va[0]), "v"(va[1]), "v"(vb[0]), "v"(vb[1])
+                     : "memory", "m0", "scc");
+    else
+        asm volatile(DIN_DMA_FIRST("%6", "%1", "%3") DIN_DMA_NEXT("%7", "%1", "%3") DIN_DMA_NEXT("%8", "%2", "%4") DIN_DMA_NEXT("%9", "%2", "%4")
+                     DIN_DMA_NEXT("%10", "%2", "%4")
+                     :: "s"(lds_addr), "s"(rsA), "s"(rsB), "s"(soffA), "s"(soffB), "n"(STRIDE), "v"(va[0]), "v"(va[1]), "v"(vb[0]), "v"(vb[1]), "v"(vb[2])
+                     : "memory", "m0", "scc");
+#undef DIN_DMA_FIRST
+#undef DIN_DMA_NEXT
+}
+
 // direct (un-staged) epilogue shared by both kernels: lane holds D[co0 + i*16 + (lane>>4)*4 + e][pix0 + j*16 + (lane&15)]
 template <typename T, int TI, int TJ, int BN, int BMT = BM, int WM = 2, int WN = 2>
 __device__ __forceinline__ void epilogue_direct(const ConvK& p, f32x4 (&acc)[TI][TJ], int co_tile, int px_tile, int wm, int wn, int lane, int split) {
@@ -264,7 +290,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_generic_kernel(ConvK 
 // this kernel (Little: ~2 us loaded latency), so the ring keeps NS-1 stages in flight: per stage ONE counted s_waitcnt vmcnt(N)
 // (VMEM completes in order: N = DMAs of the younger stages) + ONE raw s_barrier (every wave's share of the stage landed, and
 // every wave is done reading the stage about to be refilled).
-template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS, bool MULTI = false>
+// FASTK (bf16 8-wave tiles; host: whole k-steps per tap, no tap remap, k-order = taps inside channel chunks): every piece of per-step
+// loader state is scalar except one validity select per tile row, the offsets of the NEXT transfer are prepared while the current
+// stage is multiplied (so only the transfers themselves sit between the barrier and the MFMAs), and no other mode is compiled in.
+template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS, bool MULTI = false, bool FASTK = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the host pass only needs the launch stub (the LDS-DMA builtin is device-only)
     constexpr int EPC = Elem<T>::EPC;
@@ -494,6 +523,44 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
 
     constexpr int NDMA = PA + PB;                                  // wave-level DMAs per stage per wave (issued unconditionally)
     static_assert((NS - 2) * NDMA <= 63, "vmcnt field");
+    if constexpr (FASTK) {
+        static_assert(!MULTI && NS == 2 && PA == 2, "FASTK: 8-wave 128-pixel tiles, double-buffered");
+        // scalar walk over k-steps: ks -> (channel chunk ks / ntaps, tap ks % ntaps); td = byte delta of the tap, fa / fb = scalar byte
+        // offsets of the step inside a pixel's channels / inside a packed filter row
+        int tap = ks_begin % ntaps, tr = (tap * inv_kw) >> 16, tc = tap - tr * p.kw;
+        int td = tr * dA + tc * dB;
+        int fa = (ks_begin / ntaps) * KC * 16, fb = (tap * p.cpt) * 16 + fa;
+        const int tap_row_wrap = dA - p.kw * dB, cpt16 = p.cpt * 16;
+        unsigned pixq[PA];
+#pragma unroll
+        for (int i = 0; i < PA; ++i) pixq[i] = (unsigned)(pixoff[i] + cq * 16);
+        unsigned va[PA];
+        int soffA = 0, soffB = 0;
+        auto prepare = [&]() {                                     // offsets of the transfer for the walk's current step, then advance it
+            const unsigned bit = 1u << tap;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) va[i] = (vmask[i] & bit) ? pixq[i] + (unsigned)td : OOB;
+            soffA = fa; soffB = fb;
+            ++tap; ++tc; td += dB; fb += cpt16;
+            if (tc == p.kw) { tc = 0; td += tap_row_wrap; }
+            if (tap == ntaps) { tap = 0; td = 0; fa += KC * 16; fb = fa; }
+        };
+        if (ks_begin < ks_end) {
+            prepare();
+            lds_dma_stage<PA, PB, LR * KC * 16>(ldsA0, rsA, va, soffA, rsB, voffB, soffB);
+            prepare();
+            int cur = 0;
+            for (int ks = ks_begin; ks < ks_end; ++ks) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (ks + 1 < ks_end) lds_dma_stage<PA, PB, LR * KC * 16>(ldsA0 + (uint32_t)((cur ^ 1) * BUF * 16), rsA, va, soffA, rsB, voffB, soffB);
+                compute(cur);
+                prepare();
+                cur ^= 1;
+            }
+        }
+    } else
     if (ks_begin < ks_end) {
 #pragma unroll
         for (int s0 = 0; s0 < NS - 1; ++s0)
@@ -2404,15 +2471,30 @@ static bool plan_halo(int dtype, int kh, int kw, int cred, int cprod, int oh, in
     return hp.lds <= 160 * 1024;
 }
 
-template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS>
+template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS, bool FASTK = false>
 void launch_fast(const ConvK& k, dim3 grid, hipStream_t st) {
     constexpr int LR_ = 64 * WM * WN / KCS, BNP_ = (BN + LR_ - 1) / LR_ * LR_;       // filter rows padded to whole loader passes
     size_t stage = (size_t)NS * (BMT + BNP_) * KCS * 16 + (k.remap ? 128 : 0);   // stage ring (+ remap table)
     size_t epi = (size_t)BMT * (BN * sizeof(T) + 16);
     size_t lds = stage > epi ? stage : epi;
-    auto kern = conv_gather_fast_kernel<T, BMT, BN, WM, WN, KCS, NS>;
+    auto kern = conv_gather_fast_kernel<T, BMT, BN, WM, WN, KCS, NS, false, FASTK>;
     if (lds > 65536) raise_lds_limit(kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, st, k);
+}
+
+// 8-wave 128 x BN tile: the scalar-walk specialisation (FASTK) whenever the launch qualifies (bf16, whole k-steps per tap, no tap remap,
+// taps-inside-chunks k-order or a single tap); DIN_CONV_FASTK=0 keeps the general loop
+template <typename T, int BN>
+void launch_wave8(const ConvK& k, dim3 grid, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        const char* fv = getenv("DIN_CONV_FASTK");
+        const bool want = fv ? atoi(fv) != 0 : true;
+        if (want && !k.remap && k.nsrc == 0 && (k.cpt % 8) == 0 && (k.korder || k.kh * k.kw == 1)) {
+            launch_fast<T, 128, BN, 4, 2, 8, 2, true>(k, grid, st);
+            return;
+        }
+    }
+    launch_fast<T, 128, BN, 4, 2, 8, 2>(k, grid, st);
 }
 
 template <typename T, int BN>
@@ -2472,15 +2554,15 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
     }
     else if (bn == 64) {
         if (pipe == 1) launch_fast<T, 128, 64, 2, 2, 8, 3>(k, grid, st);
-        else if (pipe != 4 && sizeof(T) == 2) launch_fast<T, 128, 64, 4, 2, 8, 2>(k, grid, st);
+        else if (pipe != 4 && sizeof(T) == 2) launch_wave8<T, 64>(k, grid, st);
         else launch_fast<T, 128, 64, 2, 2, 8, 2>(k, grid, st);
     }
     else if (bn == 96) { if (pipe == 8 && sizeof(T) == 2) launch_fast<T, 128, 96, 4, 2, 8, 2>(k, grid, st); else launch_fast<T, 128, 96, 2, 2, 8, 2>(k, grid, st); }   // 8 waves measured 5 % slower here
-    else if (bn == 160) { if (pipe != 4 && sizeof(T) == 2) launch_fast<T, 128, 160, 4, 2, 8, 2>(k, grid, st); else launch_fast<T, 128, 160, 2, 2, 8, 2>(k, grid, st); }
+    else if (bn == 160) { if (pipe != 4 && sizeof(T) == 2) launch_wave8<T, 160>(k, grid, st); else launch_fast<T, 128, 160, 2, 2, 8, 2>(k, grid, st); }
     // 128 x {128,160,192}: 8 waves (4 x 2, four per SIMD at two workgroups per CU) -- same LDS ring, more waves to hide the stage waits:
     // +8..12 % on the 7-tap layers, +24 % on thin-K dgrads (bf16 only; DIN_CONV_PIPE=4 restores the 4-wave form)
-    else if (bn == 192) { if (pipe != 4 && sizeof(T) == 2) launch_fast<T, 128, 192, 4, 2, 8, 2>(k, grid, st); else launch_fast<T, 128, 192, 2, 2, 8, 2>(k, grid, st); }
-    else { if (pipe == 1) launch_fast<T, 128, 128, 2, 2, 4, 4>(k, grid, st); else if (pipe != 4 && sizeof(T) == 2) launch_fast<T, 128, 128, 4, 2, 8, 2>(k, grid, st); else launch_fast<T, 128, 128, 2, 2, 8, 2>(k, grid, st); }
+    else if (bn == 192) { if (pipe != 4 && sizeof(T) == 2) launch_wave8<T, 192>(k, grid, st); else launch_fast<T, 128, 192, 2, 2, 8, 2>(k, grid, st); }
+    else { if (pipe == 1) launch_fast<T, 128, 128, 2, 2, 4, 4>(k, grid, st); else if (pipe != 4 && sizeof(T) == 2) launch_wave8<T, 128>(k, grid, st); else launch_fast<T, 128, 128, 2, 2, 8, 2>(k, grid, st); }
 }
 
 int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_bytes, hipStream_t st, const char* what) {

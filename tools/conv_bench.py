@@ -23,6 +23,13 @@ LAYERS = {  # name: (nb, h, w, cin, cout, k, s, p)
     "inc_6a_3x3dbl1": (96, 87, 157, 288, 64, 1, 1, 0),
     "inc_6e_1x1_768": (96, 43, 78, 768, 192, 1, 1, 0),
     "inc_4a_3x3": (96, 178, 318, 80, 192, 3, 1, 0),
+    "inc_6e_7x1": (96, 43, 78, 192, 192, (7, 1), 1, (3, 0)),
+    "k_7x1_64": (96, 43, 78, 64, 192, (7, 1), 1, (3, 0)),
+    "k_7x1_384": (96, 43, 78, 384, 192, (7, 1), 1, (3, 0)),
+    "k_7x1_768": (96, 43, 78, 768, 192, (7, 1), 1, (3, 0)),
+    "k_1x1_192": (96, 43, 78, 192, 192, 1, 1, 0),
+    "k_1x1_1536": (96, 43, 78, 1536, 192, 1, 1, 0),
+    "inc_6e_1x7": (96, 43, 78, 192, 192, (1, 7), 1, (0, 3)),
 }
 
 def main():
@@ -31,6 +38,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--which", default="fwd", choices=["fwd", "dgrad", "wgrad"])
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--const", action="store_true", help="constant operands (low toggle rate): shows how much the clock sags on random data")
     a = ap.parse_args()
     lib = L.load()
     nb, h, w, cin, cout, k, s, p = LAYERS[a.layer]
@@ -48,6 +56,8 @@ def main():
     gy = torch.randn(nb, oh, ow, cout, device="cuda").to(tdt)
     wt = torch.randn(cout, cin, k[0], k[1], device="cuda") * 0.05
     bias = torch.zeros(cout, device="cuda")
+    if a.const:
+        x.fill_(1.0); gy.fill_(1.0); wt.fill_(0.03125)
     y = torch.empty(nb, oh, ow, cout, device="cuda", dtype=tdt)
     dx = torch.empty_like(x)
     dw = torch.empty_like(wt)
