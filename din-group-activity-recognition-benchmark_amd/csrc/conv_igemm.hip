@@ -611,48 +611,62 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
             }
         }
     }
-    __syncthreads();
     {
         constexpr int CPR = BN * (int)sizeof(T) / 16;                // 16-byte chunks per tile row
         constexpr int RPP = NT / CPR;                                // rows per pass (threads beyond RPP*CPR idle when CPR !| NT)
+        constexpr int NROW = (BM + RPP - 1) / RPP;                   // rows per thread
         const int c = tid % CPR, rr = tid / CPR;
         const int co = co_tile * BN + c * EPC;
-        if (co < p.Cout && rr < RPP) {
-            T* __restrict__ outp = reinterpret_cast<T*>(p.out);
-            const T* __restrict__ maskp = reinterpret_cast<const T*>(p.mask);
-            for (int row = rr; row < BM; row += RPP) {
-                const int m = m_first + row;
-                if (m >= p.M) break;
-                u32x4 v = *reinterpret_cast<const u32x4*>(smem_raw + row * CPITCH + c * 16);
-                const int64_t opx = out_pixel(p, m);
-                const int64_t o = opx * p.ldo + p.cooff + co;
-                if (p.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM)) {
-                    u32x4 mk = {0u, 0u, 0u, 0u}, old = {0u, 0u, 0u, 0u};
-                    if (p.flags & DIN_CONV_MASK) mk = *reinterpret_cast<const u32x4*>(maskp + opx * p.ldm + p.moff + co);
-                    if (p.flags & DIN_CONV_ACCUM) old = *reinterpret_cast<const u32x4*>(outp + o);
-                    if constexpr (sizeof(T) == 4) {
+        const bool act = co < p.Cout && rr < RPP;
+        T* __restrict__ outp = reinterpret_cast<T*>(p.out);
+        const T* __restrict__ maskp = reinterpret_cast<const T*>(p.mask);
+        // ReLU-backward mask / accumulate inputs of ALL this thread's rows are requested before the staged tile is read back: one
+        // memory latency per tile instead of one per row (the per-row load -> wait -> store chain cost 60-80 us per launch on the
+        // 288-channel dgrads; profiles/r01_stream_probe.txt)
+        u32x4 mkv[NROW], oldv[NROW];
+        int opx[NROW];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float x = __uint_as_float(v[e]);
-                            if ((p.flags & DIN_CONV_MASK) && !(__uint_as_float(mk[e]) > 0.f)) x = 0.f;
-                            if (p.flags & DIN_CONV_ACCUM) x += __uint_as_float(old[e]);
-                            v[e] = __float_as_uint(x);
-                        }
-                    } else {
+        for (int q = 0; q < NROW; ++q) {
+            mkv[q] = u32x4{0u, 0u, 0u, 0u}; oldv[q] = u32x4{0u, 0u, 0u, 0u}; opx[q] = -1;
+            const int row = rr + q * RPP, m = m_first + row;
+            if (act && row < BM && m < p.M) {
+                const int64_t px = out_pixel(p, m);
+                opx[q] = (int)px;
+                if (p.flags & DIN_CONV_MASK) mkv[q] = *reinterpret_cast<const u32x4*>(maskp + px * p.ldm + p.moff + co);
+                if (p.flags & DIN_CONV_ACCUM) oldv[q] = *reinterpret_cast<const u32x4*>(outp + px * p.ldo + p.cooff + co);
+            }
+        }
+        __syncthreads();
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
-                            if (p.flags & DIN_CONV_MASK) {
-                                if (!(__uint_as_float(mk[e] << 16) > 0.f)) lo = 0.f;
-                                if (!(__uint_as_float(mk[e] & 0xffff0000u) > 0.f)) hi = 0.f;
-                            }
-                            if (p.flags & DIN_CONV_ACCUM) { lo += __uint_as_float(old[e] << 16); hi += __uint_as_float(old[e] & 0xffff0000u); }
-                            v[e] = pack_bf16x2(lo, hi);
+        for (int q = 0; q < NROW; ++q) {
+            if (opx[q] < 0) continue;
+            const int row = rr + q * RPP;
+            u32x4 v = *reinterpret_cast<const u32x4*>(smem_raw + row * CPITCH + c * 16);
+            const int64_t o = (int64_t)opx[q] * p.ldo + p.cooff + co;
+            if (p.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM)) {
+                const u32x4 mk = mkv[q], old = oldv[q];
+                if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = __uint_as_float(v[e]);
+                        if ((p.flags & DIN_CONV_MASK) && !(__uint_as_float(mk[e]) > 0.f)) x = 0.f;
+                        if (p.flags & DIN_CONV_ACCUM) x += __uint_as_float(old[e]);
+                        v[e] = __float_as_uint(x);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+                        if (p.flags & DIN_CONV_MASK) {
+                            if (!(__uint_as_float(mk[e] << 16) > 0.f)) lo = 0.f;
+                            if (!(__uint_as_float(mk[e] & 0xffff0000u) > 0.f)) hi = 0.f;
                         }
+                        if (p.flags & DIN_CONV_ACCUM) { lo += __uint_as_float(old[e] << 16); hi += __uint_as_float(old[e] & 0xffff0000u); }
+                        v[e] = pack_bf16x2(lo, hi);
                     }
                 }
-                *reinterpret_cast<u32x4*>(outp + o) = v;
             }
+            *reinterpret_cast<u32x4*>(outp + o) = v;
         }
     }
 #endif
@@ -2274,6 +2288,7 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype) {
             if (tl < best_tiles || (tl == best_tiles && pad < best_pad)) { best = bnc; best_tiles = tl; best_pad = pad; }
         }
         g.bn = best;
+        if (const char* fb = getenv("DIN_CONV_BN")) { const int v = atoi(fb); if (v == 96 || v == 160 || v == 192) g.bn = v; }   // tuning override
     }
     // Tile choice (measured on MI355X, tools/conv_bench.py).  The L2->CU operand stream limits the 128x128
     // tile to ~770 TFLOP/s (64 FLOP per byte pulled from L2):

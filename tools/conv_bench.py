@@ -24,6 +24,12 @@ LAYERS = {  # name: (nb, h, w, cin, cout, k, s, p)
     "inc_6e_1x1_768": (96, 43, 78, 768, 192, 1, 1, 0),
     "inc_4a_3x3": (96, 178, 318, 80, 192, 3, 1, 0),
     "inc_6e_7x1": (96, 43, 78, 192, 192, (7, 1), 1, (3, 0)),
+    "inc_6a_3x3": (96, 87, 157, 288, 384, 3, 2, 0),
+    "k_1x1_384_288": (96, 43, 78, 384, 288, 1, 1, 0),
+    "k_1x1_288_384": (96, 43, 78, 288, 384, 1, 1, 0),
+    "k_1x1_288_384_s2": (96, 87, 157, 288, 384, 1, 2, 0),
+    "inc_6a_dbl3": (96, 87, 157, 96, 96, 3, 2, 0),
+    "inc_3b_1x1_80": (96, 178, 318, 64, 80, 1, 1, 0),
     "k_7x1_64": (96, 43, 78, 64, 192, (7, 1), 1, (3, 0)),
     "k_7x1_384": (96, 43, 78, 384, 192, (7, 1), 1, (3, 0)),
     "k_7x1_768": (96, 43, 78, 768, 192, (7, 1), 1, (3, 0)),
@@ -38,6 +44,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--which", default="fwd", choices=["fwd", "dgrad", "wgrad"])
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--flags", type=int, default=8, help="dgrad epilogue flags (8 = ReLU mask, 4 = accumulate)")
     ap.add_argument("--const", action="store_true", help="constant operands (low toggle rate): shows how much the clock sags on random data")
     a = ap.parse_args()
     lib = L.load()
@@ -72,7 +79,7 @@ def main():
         if a.which == "fwd":
             L.check(lib.din_conv_fwd(C.byref(d), x.data_ptr(), wpk.data_ptr(), bias.data_ptr(), y.data_ptr(), 3, ws.data_ptr(), wsb, None))
         elif a.which == "dgrad":
-            L.check(lib.din_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), dx.data_ptr(), x.data_ptr(), cin, 0, 8, ws.data_ptr(), wsb, None))
+            L.check(lib.din_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), dx.data_ptr(), x.data_ptr(), cin, 0, a.flags, ws.data_ptr(), wsb, None))
         else:
             L.check(lib.din_conv_wgrad(C.byref(d), x.data_ptr(), gy.data_ptr(), dw.data_ptr(), bias.data_ptr(), None, None, None, 0, ws.data_ptr(), wsb, None))
     for _ in range(3):

@@ -1,6 +1,7 @@
-for l in inc_6e_7x1 k_7x1_768 inc_6e_1x1_768; do
-python tools/conv_bench.py --layer $l --which fwd --iters 20 2>&1 | grep -v amdgpu.ids
-python tools/conv_bench.py --layer $l --which fwd --iters 20 --const 2>&1 | grep -v amdgpu.ids
-done
-echo constant payload; timeout 300 tools/probes/probe_stream 2>&1 | grep "^tile" | head -12
-echo random payload; PROBE_RANDOM=1 timeout 300 tools/probes/probe_stream 2>&1 | grep "^tile" | head -12
+python bench.py --steps 300 --warmup 2 --no-cpu-baseline > /tmp/b.json 2>/dev/null &
+BP=$!
+while kill -0 $BP 2>/dev/null; do
+  rocm-smi --showclocks --showpower 2>/dev/null | grep -i "sclk\|Package Power" | sed 's/.*: //' | tr '\n' ' '; echo
+  sleep 2
+done | sort | uniq -c | sort -k1,1n | tail -12
+tail -c 4000 /tmp/b.json | grep -o '"value": [0-9.]*' | head -1
