@@ -14,7 +14,8 @@
 namespace {
 
 constexpr int CH = 64;            // channels per workgroup (one lane each)
-constexpr int WALK_THREADS = 256;
+constexpr int WALK_THREADS = 1024;   // 16 waves: the T x N positions of a clip are walked 16 at a time (the kernel is latency-bound: one
+                                     // workgroup per (clip, 64-channel chunk), a few dozen positions, k2 dependent steps each)
 constexpr int MAXK2 = 49;         // up to 7x7 ST kernels
 
 struct WalkK {
@@ -75,22 +76,33 @@ __device__ __forceinline__ void stage_relation(const WalkK& p, int b, float* a_s
     }
 }
 
+// offsets (2*k2 per position) of clip b -> LDS off_s[pos*2*k2 + j]: the walk loops then touch global memory only for gz / z
+__device__ __forceinline__ void stage_offsets(const WalkK& p, int b, float* off_s) {
+    const int per = 2 * p.k2;
+    for (int i = threadIdx.x; i < p.t * p.n * per; i += WALK_THREADS) {
+        const int pos = i / per, j = i - pos * per;
+        off_s[i] = p.pred[((int64_t)b * p.t * p.n + pos) * p.cp + j];
+    }
+}
+
 __global__ __launch_bounds__(WALK_THREADS) void din_walk_fwd_kernel(WalkK p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tile = smem;                                   // hp*wp*CH
     float* a_s = tile + p.hp * p.wp * CH;                 // t*n*k2
+    float* off_s = a_s + p.t * p.n * p.k2;                // t*n*2*k2
     const int nchunks = (p.c + CH - 1) / CH;
     const int b = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks, c0 = chunk * CH;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     stage_tile(p, p.x, b, c0, tile);
     stage_relation(p, b, a_s);
+    stage_offsets(p, b, off_s);
     __syncthreads();
     if (chunk == 0) {
         // saved relation weights and the (bit-exact) integer corners
         for (int i = threadIdx.x; i < p.t * p.n * p.k2; i += WALK_THREADS) {
             int pos = i / p.k2, k = i - pos * p.k2;
             int tt = pos / p.n, nn = pos - tt * p.n;
-            const float* pr = p.pred + ((int64_t)b * p.t * p.n + pos) * p.cp;
+            const float* pr = off_s + pos * 2 * p.k2;
             Corner c = corners(p, tt, nn, k, pr[k], pr[p.k2 + k]);
             int64_t o = ((int64_t)b * p.t * p.n + pos) * p.k2 + k;
             p.a[o] = a_s[i];
@@ -100,7 +112,7 @@ __global__ __launch_bounds__(WALK_THREADS) void din_walk_fwd_kernel(WalkK p) {
     const bool cok = c0 + lane < p.c;
     for (int pos = w; pos < p.t * p.n; pos += WALK_THREADS / 64) {
         int tt = pos / p.n, nn = pos - tt * p.n;
-        const float* pr = p.pred + ((int64_t)b * p.t * p.n + pos) * p.cp;
+        const float* pr = off_s + pos * 2 * p.k2;
         float zacc = 0.f;
         for (int k = 0; k < p.k2; ++k) {
             Corner c = corners(p, tt, nn, k, pr[k], pr[p.k2 + k]);
@@ -125,10 +137,14 @@ __global__ __launch_bounds__(WALK_THREADS) void din_walk_bwd_kernel(WalkK p) {
     const int cells = p.hp * p.wp;
     float* tile = smem;                       // P
     float* dtile = tile + cells * CH;         // dP
+    float* off_s = dtile + cells * CH;        // t*n*2*k2 offsets
+    float* a_s = off_s + p.t * p.n * 2 * p.k2; // t*n*k2 saved relation weights
     const int nchunks = (p.c + CH - 1) / CH;
     const int b = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks, c0 = chunk * CH;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     stage_tile(p, p.x, b, c0, tile);
+    stage_offsets(p, b, off_s);
+    for (int i = threadIdx.x; i < p.t * p.n * p.k2; i += WALK_THREADS) a_s[i] = p.a[(int64_t)b * p.t * p.n * p.k2 + i];
     for (int i = threadIdx.x; i < cells * CH; i += WALK_THREADS) dtile[i] = 0.f;
     __syncthreads();
     const bool cok = c0 + lane < p.c;
@@ -137,11 +153,11 @@ __global__ __launch_bounds__(WALK_THREADS) void din_walk_bwd_kernel(WalkK p) {
     for (int pos = w; pos < p.t * p.n; pos += WALK_THREADS / 64) {
         int tt = pos / p.n, nn = pos - tt * p.n;
         const int64_t gpos = (int64_t)b * p.t * p.n + pos;
-        const float* pr = p.pred + gpos * p.cp;
+        const float* pr = off_s + pos * 2 * p.k2;
         const float g = cok ? p.gz[gpos * p.c + c0 + lane] : 0.f;
         for (int k = 0; k < p.k2; ++k) {
             Corner c = corners(p, tt, nn, k, pr[k], pr[p.k2 + k]);
-            const float ak = p.a[gpos * p.k2 + k];
+            const float ak = a_s[pos * p.k2 + k];
             float wy_l = coef(c.py, c.ly), wy_r = coef(c.py, c.ry), wx_l = coef(c.px, c.lx), wx_r = coef(c.px, c.rx);
             const int i_lt = (c.ly * p.wp + c.lx) * CH + lane, i_rb = (c.ry * p.wp + c.rx) * CH + lane;
             const int i_lb = (c.ry * p.wp + c.lx) * CH + lane, i_rt = (c.ly * p.wp + c.rx) * CH + lane;
@@ -217,7 +233,7 @@ int din_walk_fwd(const float* x, const float* pred, int cp, int b, int t, int n,
     WalkK p{};
     if (int e = fill(p, cp, b, t, n, c, kh, kw, ratio, scale_factor)) return e;
     p.x = x; p.pred = pred; p.z = z; p.a = a; p.idx = idx; p.mad = mad;
-    size_t lds = ((size_t)p.hp * p.wp * CH + (size_t)t * n * p.k2) * sizeof(float);
+    size_t lds = ((size_t)p.hp * p.wp * CH + (size_t)t * n * 3 * p.k2) * sizeof(float);
     DIN_REQUIRE(lds <= 160 * 1024, "din_walk_fwd: T x N grid too large for one LDS tile (%zu bytes)", lds);
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(din_walk_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int nchunks = (c + CH - 1) / CH;
@@ -236,7 +252,7 @@ int din_walk_bwd(const float* x, const float* pred, int cp, const float* a, cons
     int64_t positions = (int64_t)b * t * n;
     hipError_t me = hipMemsetAsync(scratch, 0, sizeof(float) * positions * 3 * p.k2, st);
     if (me != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "din_walk_bwd: memset: %s", hipGetErrorString(me));
-    size_t lds = (size_t)2 * p.hp * p.wp * CH * sizeof(float);
+    size_t lds = ((size_t)2 * p.hp * p.wp * CH + (size_t)t * n * 3 * p.k2) * sizeof(float);
     DIN_REQUIRE(lds <= 160 * 1024, "din_walk_bwd: T x N grid too large for the LDS tiles (%zu bytes)", lds);
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(din_walk_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int nchunks = (c + CH - 1) / CH;

@@ -46,23 +46,66 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
     const int64_t row = blockIdx.x;
     const float* xr = x + row * len;
     const float* rr = res ? res + row * len : nullptr;
+    // rows are streamed as float4 when len % 4 == 0 (every DIN shape); element order inside the sums differs from the scalar loop only
+    // by fp32 rounding
+    const bool vec = (len & 3) == 0;
+    const int64_t n4 = len >> 2;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(xr);
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(rr);
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < len; i += LN_THREADS) s += xr[i] + (rr ? rr[i] : 0.f);
+    if (vec) {
+        for (int64_t i = threadIdx.x; i < n4; i += LN_THREADS) {
+            f32x4 a = x4[i];
+            if (rr) a += r4[i];
+            s += (a[0] + a[1]) + (a[2] + a[3]);
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < len; i += LN_THREADS) s += xr[i] + (rr ? rr[i] : 0.f);
+    }
     const float mean = block_sum<LN_WAVES>(s, red) / (float)len;
     float q = 0.f;
-    for (int64_t i = threadIdx.x; i < len; i += LN_THREADS) {
-        float d = xr[i] + (rr ? rr[i] : 0.f) - mean;
-        q += d * d;
+    if (vec) {
+        for (int64_t i = threadIdx.x; i < n4; i += LN_THREADS) {
+            f32x4 a = x4[i];
+            if (rr) a += r4[i];
+            a -= mean;
+            q += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < len; i += LN_THREADS) {
+            float d = xr[i] + (rr ? rr[i] : 0.f) - mean;
+            q += d * d;
+        }
     }
     const float var = block_sum<LN_WAVES>(q, red) / (float)len;
     const float rstd = 1.f / sqrtf(var + eps);
     if (threadIdx.x == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
     float* yr = y + row * len;
-    for (int64_t i = threadIdx.x; i < len; i += LN_THREADS) {
-        float v = (xr[i] + (rr ? rr[i] : 0.f) - mean) * rstd * gamma[i] + beta[i];
-        if (relu) v = fmaxf(v, 0.f);
-        v *= keep_scale(seed, row * len + i, drop_p);
-        yr[i] = v;
+    if (vec) {
+        const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
+        const f32x4* b4 = reinterpret_cast<const f32x4*>(beta);
+        f32x4* y4 = reinterpret_cast<f32x4*>(yr);
+        for (int64_t i = threadIdx.x; i < n4; i += LN_THREADS) {
+            f32x4 a = x4[i];
+            if (rr) a += r4[i];
+            const f32x4 g = g4[i], bb = b4[i];
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = (a[e] - mean) * rstd * g[e] + bb[e];
+                if (relu) t = fmaxf(t, 0.f);
+                t *= keep_scale(seed, row * len + i * 4 + e, drop_p);
+                v[e] = t;
+            }
+            y4[i] = v;
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < len; i += LN_THREADS) {
+            float v = (xr[i] + (rr ? rr[i] : 0.f) - mean) * rstd * gamma[i] + beta[i];
+            if (relu) v = fmaxf(v, 0.f);
+            v *= keep_scale(seed, row * len + i, drop_p);
+            yr[i] = v;
+        }
     }
 }
 
@@ -78,28 +121,71 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
     const float* rr = res ? res + row * len : nullptr;
     const float* dyr = dy + row * len;
     const float* yr = y + row * len;
+    const bool vec = (len & 3) == 0;
+    const int64_t n4 = len >> 2;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(xr);
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(rr);
+    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dyr);
+    const f32x4* y4 = reinterpret_cast<const f32x4*>(yr);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
     float s1 = 0.f, s2 = 0.f;
-    for (int64_t i = threadIdx.x; i < len; i += LN_THREADS) {
-        float xh = (xr[i] + (rr ? rr[i] : 0.f) - mean) * rstd;
-        float g = dyr[i] * keep_scale(seed, row * len + i, drop_p);
-        if (relu && !(yr[i] > 0.f)) {
-            // y == 0 either because ReLU clipped or because dropout zeroed a positive value; in the latter case the
-            // keep-scale is already 0, so masking by (y > 0) is exact for both
-            g = 0.f;
+    if (vec) {
+        for (int64_t i = threadIdx.x; i < n4; i += LN_THREADS) {
+            f32x4 a = x4[i];
+            if (rr) a += r4[i];
+            const f32x4 d = dy4[i], yv = y4[i], gm = g4[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (a[e] - mean) * rstd;
+                float g = d[e] * keep_scale(seed, row * len + i * 4 + e, drop_p);
+                if (relu && !(yv[e] > 0.f)) g = 0.f;
+                const float gg = g * gm[e];
+                s1 += gg;
+                s2 += gg * xh;
+                if (atomic_params) { atomicAdd(dgamma + i * 4 + e, g * xh); atomicAdd(dbeta + i * 4 + e, g); }
+            }
         }
-        float gg = g * gamma[i];
-        s1 += gg;
-        s2 += gg * xh;
-        if (atomic_params) { atomicAdd(dgamma + i, g * xh); atomicAdd(dbeta + i, g); }
+    } else {
+        for (int64_t i = threadIdx.x; i < len; i += LN_THREADS) {
+            float xh = (xr[i] + (rr ? rr[i] : 0.f) - mean) * rstd;
+            float g = dyr[i] * keep_scale(seed, row * len + i, drop_p);
+            if (relu && !(yr[i] > 0.f)) {
+                // y == 0 either because ReLU clipped or because dropout zeroed a positive value; in the latter case the
+                // keep-scale is already 0, so masking by (y > 0) is exact for both
+                g = 0.f;
+            }
+            float gg = g * gamma[i];
+            s1 += gg;
+            s2 += gg * xh;
+            if (atomic_params) { atomicAdd(dgamma + i, g * xh); atomicAdd(dbeta + i, g); }
+        }
     }
     const float m1 = block_sum<LN_WAVES>(s1, red) / (float)len;
     const float m2 = block_sum<LN_WAVES>(s2, red) / (float)len;
     float* dxr = dx + row * len;
-    for (int64_t i = threadIdx.x; i < len; i += LN_THREADS) {
-        float xh = (xr[i] + (rr ? rr[i] : 0.f) - mean) * rstd;
-        float g = dyr[i] * keep_scale(seed, row * len + i, drop_p);
-        if (relu && !(yr[i] > 0.f)) g = 0.f;
-        dxr[i] = rstd * (g * gamma[i] - m1 - xh * m2);
+    if (vec) {
+        f32x4* dx4 = reinterpret_cast<f32x4*>(dxr);
+        for (int64_t i = threadIdx.x; i < n4; i += LN_THREADS) {
+            f32x4 a = x4[i];
+            if (rr) a += r4[i];
+            const f32x4 d = dy4[i], yv = y4[i], gm = g4[i];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (a[e] - mean) * rstd;
+                float g = d[e] * keep_scale(seed, row * len + i * 4 + e, drop_p);
+                if (relu && !(yv[e] > 0.f)) g = 0.f;
+                o[e] = rstd * (g * gm[e] - m1 - xh * m2);
+            }
+            dx4[i] = o;
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < len; i += LN_THREADS) {
+            float xh = (xr[i] + (rr ? rr[i] : 0.f) - mean) * rstd;
+            float g = dyr[i] * keep_scale(seed, row * len + i, drop_p);
+            if (relu && !(yr[i] > 0.f)) g = 0.f;
+            dxr[i] = rstd * (g * gamma[i] - m1 - xh * m2);
+        }
     }
 }
 
