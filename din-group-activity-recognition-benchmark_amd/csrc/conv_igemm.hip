@@ -2105,20 +2105,21 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ partial, floa
                                          const float* __restrict__ scale, const float* __restrict__ w,
                                          float* __restrict__ wdot, int cout, int cin, int kh, int kw, int cin_pad,
                                          int cout_pad, int kcols_pad, int slices, int accumulate) {
-    // grid (co, 64-column chunk), block (64 columns, SG slice groups): every wave reads 256 contiguous bytes of one slice per step
-    // (partials keep their own column order), the SG partial sums meet in LDS in a fixed order (deterministic result)
-    __shared__ float red[16][64];
+    // grid (co, 256-column chunk), block (64 lanes x 4 columns, SG slice groups): every wave reads 1 KiB contiguous of one slice per
+    // step as float4 (partials keep their own column order; cin_pad % 4 == 0, so a float4 never straddles a tap), the SG partial sums
+    // meet in LDS in a fixed order (deterministic result).  50 MB of partials per layer: 16-byte lanes run this 14 -> ~8 us.
+    __shared__ f32x4 red[16][64];
     const int co = blockIdx.x;
     const int taps = kh * kw;
     const int per = cin * taps;
-    const int kc = blockIdx.y * 64 + threadIdx.x;
+    const int kc = (blockIdx.y * 64 + threadIdx.x) * 4;
     const int sg = threadIdx.y, nsg = blockDim.y;
     const bool col_ok = kc < taps * cin_pad;
-    float v = 0.f;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (col_ok) {
-        const float* __restrict__ pp = partial + (int64_t)co * kcols_pad + kc;
-        const int64_t sstride = (int64_t)cout_pad * kcols_pad;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        const f32x4* __restrict__ pp = reinterpret_cast<const f32x4*>(partial + (int64_t)co * kcols_pad + kc);
+        const int64_t sstride = (int64_t)cout_pad * kcols_pad / 4;
+        f32x4 v0 = v, v1 = v, v2 = v, v3 = v;
         int s = sg;
         for (; s + 3 * nsg < slices; s += 4 * nsg) {
             v0 += pp[(int64_t)s * sstride];
@@ -2135,12 +2136,17 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ partial, floa
     for (int g = 1; g < nsg; ++g) v += red[g][threadIdx.x];
     float dot = 0.f;
     if (col_ok) {
-        int t = kc / cin_pad, ci = kc - t * cin_pad;            // t = r*kw + s
-        if (ci < cin) {
-            int64_t o = (int64_t)co * per + (int64_t)ci * taps + t;
-            if (wdot) dot = v * w[o];
-            if (scale) v *= scale[co];
-            dw[o] = accumulate ? dw[o] + v : v;
+        const int t = kc / cin_pad, ci0 = kc - t * cin_pad;    // t = r*kw + s
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ci = ci0 + e;
+            if (ci < cin) {
+                const int64_t o = (int64_t)co * per + (int64_t)ci * taps + t;
+                float x = v[e];
+                if (wdot) dot += x * w[o];
+                if (scale) x *= scale[co];
+                dw[o] = accumulate ? dw[o] + x : x;
+            }
         }
     }
     if (wdot) {
@@ -2412,7 +2418,11 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
     w.n_k_tiles = w.kcols_pad / bk;
     int M = d->nb * d->oh * d->ow;
     int tiles = w.n_co_tiles * w.n_k_tiles;
-    int want = (1024 + tiles - 1) / tiles;             // ~4 workgroups per CU
+    // v2/v3 kernels: ~4 workgroups per CU; short reductions (small per-GPU batch) take 2 -- every workgroup writes a full partial tile, so
+    // halving them halves the partial traffic (4-clip step 12.47 -> 12.14 ms).  The ring kernel sets its own count below.
+    static const int want_env = getenv("DIN_WGRAD_BLOCKS") ? atoi(getenv("DIN_WGRAD_BLOCKS")) : 0;
+    const int want_total = want_env > 0 ? want_env : (M < 128 * 1024 ? 512 : 1024);
+    int want = (want_total + tiles - 1) / tiles;
     if (w.ring) {                                      // one resident workgroup per CU: a single full round (or two for long slices)
         const int rounds = (int64_t)M * tiles >= (int64_t)256 * 64 * 1024 ? 2 : 1;
         want = 256 * rounds * (ring_bk == 128 ? 2 : 1) / tiles;
@@ -3015,7 +3025,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
     if (wdot && !prezeroed && hipMemsetAsync(wdot, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
     {
         int kc_total = d->kh * d->kw * wp.cin_pad;
-        dim3 rgrid(d->cout, (kc_total + 63) / 64);
+        dim3 rgrid(d->cout, (kc_total + 255) / 256);
         const int nsg = wp.slices >= 64 ? 16 : wp.slices >= 8 ? 4 : 1;
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel, rgrid, dim3(64, nsg), 0, st, k.partial, dw, scale, w, wdot,
                            d->cout, d->cin, d->kh, d->kw, wp.cin_pad, wp.cout_pad, wp.kcols_pad, wp.slices, accumulate);
