@@ -148,8 +148,11 @@ __global__ __launch_bounds__(WALK_THREADS) void din_walk_bwd_kernel(WalkK p) {
     for (int i = threadIdx.x; i < cells * CH; i += WALK_THREADS) dtile[i] = 0.f;
     __syncthreads();
     const bool cok = c0 + lane < p.c;
-    float* d_off = p.scratch;                                     // [b,t,n,2k2]
-    float* d_a = p.scratch + (int64_t)p.b * p.t * p.n * 2 * p.k2;  // [b,t,n,k2]
+    // per-chunk partial sums, plain stores (each (chunk, position, k) is written exactly once): scratch[chunk][ d_off [b,t,n,2k2] | d_a [b,t,n,k2] ].
+    // A float atomicAdd to global memory compiles to a compare-and-swap loop here; three of them per (position, k) from one lane
+    // made this kernel 120 us of serialized round trips.  din_walk_bwd_finish_kernel adds the chunks in a fixed order.
+    float* d_off = p.scratch + (int64_t)chunk * p.b * p.t * p.n * 3 * p.k2;
+    float* d_a = d_off + (int64_t)p.b * p.t * p.n * 2 * p.k2;
     for (int pos = w; pos < p.t * p.n; pos += WALK_THREADS / 64) {
         int tt = pos / p.n, nn = pos - tt * p.n;
         const int64_t gpos = (int64_t)b * p.t * p.n + pos;
@@ -180,9 +183,9 @@ __global__ __launch_bounds__(WALK_THREADS) void din_walk_bwd_kernel(WalkK p) {
                 const float sx_l = -sgn(c.px - (float)c.lx), sx_r = -sgn(c.px - (float)c.rx);
                 float doy = d_lt * sy_l * wx_l + d_rb * sy_r * wx_r + d_lb * sy_r * wx_l + d_rt * sy_l * wx_r;
                 float dox = d_lt * wy_l * sx_l + d_rb * wy_r * sx_r + d_lb * wy_r * sx_l + d_rt * wy_l * sx_r;
-                atomicAdd(d_off + gpos * 2 * p.k2 + k, my * ak * doy);
-                atomicAdd(d_off + gpos * 2 * p.k2 + p.k2 + k, mx * ak * dox);
-                if (p.scale_factor) atomicAdd(d_a + gpos * p.k2 + k, d_s);
+                d_off[gpos * 2 * p.k2 + k] = my * ak * doy;
+                d_off[gpos * 2 * p.k2 + p.k2 + k] = mx * ak * dox;
+                d_a[gpos * p.k2 + k] = d_s;
             }
         }
     }
@@ -196,17 +199,26 @@ __global__ __launch_bounds__(WALK_THREADS) void din_walk_bwd_kernel(WalkK p) {
 
 // dpred[.., 0:2k2] = d offset ; dpred[.., 2k2:3k2] = a_k (dA_k - sum_j a_j dA_j)
 __global__ void din_walk_bwd_finish_kernel(const float* __restrict__ scratch, const float* __restrict__ a, float* __restrict__ dpred,
-                                           int64_t positions, int k2, int cp, int scale_factor) {
+                                           int64_t positions, int k2, int cp, int scale_factor, int nchunks) {
     int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= positions) return;
-    const float* d_off = scratch + pos * 2 * k2;
-    const float* d_a = scratch + positions * 2 * k2 + pos * k2;
+    const int64_t cstride = positions * 3 * k2;
     float* o = dpred + pos * cp;
-    for (int k = 0; k < 2 * k2; ++k) o[k] = d_off[k];
+    for (int k = 0; k < 2 * k2; ++k) {
+        float v = 0.f;
+        for (int c = 0; c < nchunks; ++c) v += scratch[c * cstride + pos * 2 * k2 + k];
+        o[k] = v;
+    }
     if (scale_factor) {
+        float da[MAXK2];
         float dot = 0.f;
-        for (int k = 0; k < k2; ++k) dot += a[pos * k2 + k] * d_a[k];
-        for (int k = 0; k < k2; ++k) o[2 * k2 + k] = a[pos * k2 + k] * (d_a[k] - dot);
+        for (int k = 0; k < k2; ++k) {
+            float v = 0.f;
+            for (int c = 0; c < nchunks; ++c) v += scratch[c * cstride + positions * 2 * k2 + pos * k2 + k];
+            da[k] = v;
+            dot += a[pos * k2 + k] * v;
+        }
+        for (int k = 0; k < k2; ++k) o[2 * k2 + k] = a[pos * k2 + k] * (da[k] - dot);
     }
 }
 
@@ -250,8 +262,6 @@ int din_walk_bwd(const float* x, const float* pred, int cp, const float* a, cons
     p.x = x; p.pred = pred; p.a = const_cast<float*>(a); p.gz = gz; p.dx = dx; p.scratch = scratch;
     hipStream_t st = as_stream(stream);
     int64_t positions = (int64_t)b * t * n;
-    hipError_t me = hipMemsetAsync(scratch, 0, sizeof(float) * positions * 3 * p.k2, st);
-    if (me != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "din_walk_bwd: memset: %s", hipGetErrorString(me));
     size_t lds = ((size_t)2 * p.hp * p.wp * CH + (size_t)t * n * 3 * p.k2) * sizeof(float);
     DIN_REQUIRE(lds <= 160 * 1024, "din_walk_bwd: T x N grid too large for the LDS tiles (%zu bytes)", lds);
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(din_walk_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -259,7 +269,7 @@ int din_walk_bwd(const float* x, const float* pred, int cp, const float* a, cons
     hipLaunchKernelGGL(din_walk_bwd_kernel, dim3(b * nchunks), dim3(WALK_THREADS), lds, st, p);
     DIN_CHECK_LAUNCH("din_walk_bwd");
     hipLaunchKernelGGL(din_walk_bwd_finish_kernel, dim3((unsigned)ceil_div64(positions, 128)), dim3(128), 0, st, scratch, a, dpred,
-                       positions, p.k2, cp, scale_factor);
+                       positions, p.k2, cp, scale_factor, nchunks);
     DIN_CHECK_LAUNCH("din_walk_bwd_finish");
     return DIN_OK;
 }

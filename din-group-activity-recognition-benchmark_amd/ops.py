@@ -238,7 +238,7 @@ class DynamicWalkFunction(torch.autograd.Function):
         gz = gz.contiguous()
         dx = torch.empty_like(x)
         dpred = torch.zeros_like(pred)
-        scratch = torch.empty(b * t * n * 3 * kh * kw, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(((c + 63) // 64) * b * t * n * 3 * kh * kw, dtype=torch.float32, device=x.device)
         L.check(lib.din_walk_bwd(_ptr(x), _ptr(pred), cp, _ptr(a), _ptr(gz), b, t, n, c, kh, kw, ratio, int(scale_factor), _ptr(dx),
                                  _ptr(dpred), _ptr(scratch), _stream()), "din_walk_bwd")
         return dx, dpred, None, None, None, None, None

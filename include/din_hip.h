@@ -234,7 +234,7 @@ int din_walk_fwd(const float* x, const float* pred, int cp, int b, int t, int n,
                  float* z, float* a, int32_t* idx, float* mad, void* stream);
 /* gz [b,t,n,c] -> dx_walk [b,t,n,c] (overwritten), dpred [b,t,n,cp] (first 3*k2 channels written):
  * d offset through the |.| coefficients with detached floor (Q4), inclusive clamp pass-through (Q9),
- * sign(0)=0 (Q8); d logits through the softmax.  scratch: fp32 [b,t,n,3*k2] zeroed by the call.     */
+ * sign(0)=0 (Q8); d logits through the softmax.  scratch: fp32 [ceil(c/64)][b,t,n,3*k2] (per-channel-chunk partial sums, written by the call).     */
 int din_walk_bwd(const float* x, const float* pred, int cp, const float* a, const float* gz,
                  int b, int t, int n, int c, int kh, int kw, int ratio, int scale_factor,
                  float* dx, float* dpred, float* scratch, void* stream);
