@@ -50,7 +50,7 @@ __device__ __forceinline__ float coef(float p, int c) { return __fsub_rn(1.f, fa
 __device__ __forceinline__ void stage_tile(const WalkK& p, const float* __restrict__ src, int b, int c0, float* tile) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool cok = c0 + lane < p.c;
-    for (int cell = w; cell < p.hp * p.wp; cell += WALK_THREADS / 64) {
+    for (int cell = w; cell < p.hp * p.wp; cell += (int)blockDim.x / 64) {
         int y = cell / p.wp, xx = cell - y * p.wp;
         int tt = y - p.pt, nn = xx - p.pl;
         float v = 0.f;
@@ -79,7 +79,7 @@ __device__ __forceinline__ void stage_relation(const WalkK& p, int b, float* a_s
 // offsets (2*k2 per position) of clip b -> LDS off_s[pos*2*k2 + j]: the walk loops then touch global memory only for gz / z
 __device__ __forceinline__ void stage_offsets(const WalkK& p, int b, float* off_s) {
     const int per = 2 * p.k2;
-    for (int i = threadIdx.x; i < p.t * p.n * per; i += WALK_THREADS) {
+    for (int i = threadIdx.x; i < p.t * p.n * per; i += (int)blockDim.x) {
         const int pos = i / per, j = i - pos * per;
         off_s[i] = p.pred[((int64_t)b * p.t * p.n + pos) * p.cp + j];
     }
@@ -132,7 +132,12 @@ __global__ __launch_bounds__(WALK_THREADS) void din_walk_fwd_kernel(WalkK p) {
 
 __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 
-__global__ __launch_bounds__(WALK_THREADS) void din_walk_bwd_kernel(WalkK p) {
+// Backward: one workgroup of WALK_BWD_WAVES waves per (clip, 64-channel chunk, group of WALK_BWD_WAVES positions) -- one position per
+// wave, so the k2 dependent steps of a position are the whole critical path and a 4-clip batch still fills the chip (the first version ran
+// all T*N positions of a clip chunk in one workgroup: 64 workgroups, 139 us).  Feature gradients of the groups meet in dx through native
+// fp32 atomics (dx is zeroed by the call); offset / relation gradients are per-(chunk) partial sums, plain stores.
+constexpr int WALK_BWD_WAVES = 4;
+__global__ __launch_bounds__(WALK_BWD_WAVES * 64) void din_walk_bwd_kernel(WalkK p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int cells = p.hp * p.wp;
     float* tile = smem;                       // P
@@ -140,20 +145,22 @@ __global__ __launch_bounds__(WALK_THREADS) void din_walk_bwd_kernel(WalkK p) {
     float* off_s = dtile + cells * CH;        // t*n*2*k2 offsets
     float* a_s = off_s + p.t * p.n * 2 * p.k2; // t*n*k2 saved relation weights
     const int nchunks = (p.c + CH - 1) / CH;
-    const int b = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks, c0 = chunk * CH;
+    const int ngroups = (p.t * p.n + WALK_BWD_WAVES - 1) / WALK_BWD_WAVES;
+    const int grp = blockIdx.x % ngroups, bc = blockIdx.x / ngroups;
+    const int b = bc / nchunks, chunk = bc % nchunks, c0 = chunk * CH;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     stage_tile(p, p.x, b, c0, tile);
     stage_offsets(p, b, off_s);
-    for (int i = threadIdx.x; i < p.t * p.n * p.k2; i += WALK_THREADS) a_s[i] = p.a[(int64_t)b * p.t * p.n * p.k2 + i];
-    for (int i = threadIdx.x; i < cells * CH; i += WALK_THREADS) dtile[i] = 0.f;
+    for (int i = threadIdx.x; i < p.t * p.n * p.k2; i += (int)blockDim.x) a_s[i] = p.a[(int64_t)b * p.t * p.n * p.k2 + i];
+    for (int i = threadIdx.x; i < cells * CH; i += (int)blockDim.x) dtile[i] = 0.f;
     __syncthreads();
     const bool cok = c0 + lane < p.c;
-    // per-chunk partial sums, plain stores (each (chunk, position, k) is written exactly once): scratch[chunk][ d_off [b,t,n,2k2] | d_a [b,t,n,k2] ].
-    // A float atomicAdd to global memory compiles to a compare-and-swap loop here; three of them per (position, k) from one lane
-    // made this kernel 120 us of serialized round trips.  din_walk_bwd_finish_kernel adds the chunks in a fixed order.
+    // per-chunk partial sums, plain stores (each (chunk, position, k) is written exactly once): scratch[chunk][ d_off [b,t,n,2k2] | d_a [b,t,n,k2] ];
+    // din_walk_bwd_finish_kernel adds the chunks in a fixed order
     float* d_off = p.scratch + (int64_t)chunk * p.b * p.t * p.n * 3 * p.k2;
     float* d_a = d_off + (int64_t)p.b * p.t * p.n * 2 * p.k2;
-    for (int pos = w; pos < p.t * p.n; pos += WALK_THREADS / 64) {
+    const int pos = grp * WALK_BWD_WAVES + w;
+    if (pos < p.t * p.n) {
         int tt = pos / p.n, nn = pos - tt * p.n;
         const int64_t gpos = (int64_t)b * p.t * p.n + pos;
         const float* pr = off_s + pos * 2 * p.k2;
@@ -190,35 +197,39 @@ __global__ __launch_bounds__(WALK_THREADS) void din_walk_bwd_kernel(WalkK p) {
         }
     }
     __syncthreads();
-    // un-pad: dx[b,t,n,c] = dP[pt+t][pl+n][c]
-    for (int pos = w; pos < p.t * p.n; pos += WALK_THREADS / 64) {
-        int tt = pos / p.n, nn = pos - tt * p.n;
-        if (cok) p.dx[((int64_t)b * p.t * p.n + pos) * p.c + c0 + lane] = dtile[((p.pt + tt) * p.wp + p.pl + nn) * CH + lane];
+    // un-pad and add this group's share: dx[b,t,n,c] += dP[pt+t][pl+n][c]
+    for (int q = w; q < p.t * p.n; q += WALK_BWD_WAVES) {
+        int tt = q / p.n, nn = q - tt * p.n;
+        const float v = dtile[((p.pt + tt) * p.wp + p.pl + nn) * CH + lane];
+        if (cok && v != 0.f) atomicAdd(&p.dx[((int64_t)b * p.t * p.n + q) * p.c + c0 + lane], v);
     }
 }
 
 // dpred[.., 0:2k2] = d offset ; dpred[.., 2k2:3k2] = a_k (dA_k - sum_j a_j dA_j)
 __global__ void din_walk_bwd_finish_kernel(const float* __restrict__ scratch, const float* __restrict__ a, float* __restrict__ dpred,
                                            int64_t positions, int k2, int cp, int scale_factor, int nchunks) {
-    int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= positions) return;
+    // one wave per position: lane j < 3*k2 adds the chunks of its value (fixed order), the softmax backward needs the dot over k
+    const int64_t pos = blockIdx.x;
+    const int j = threadIdx.x;
     const int64_t cstride = positions * 3 * k2;
-    float* o = dpred + pos * cp;
-    for (int k = 0; k < 2 * k2; ++k) {
-        float v = 0.f;
-        for (int c = 0; c < nchunks; ++c) v += scratch[c * cstride + pos * 2 * k2 + k];
-        o[k] = v;
+    float v = 0.f;
+    if (j < 2 * k2) {
+        for (int c = 0; c < nchunks; ++c) v += scratch[c * cstride + pos * 2 * k2 + j];
+        dpred[pos * cp + j] = v;
+    } else if (j < 3 * k2) {
+        for (int c = 0; c < nchunks; ++c) v += scratch[c * cstride + positions * 2 * k2 + pos * k2 + (j - 2 * k2)];
     }
     if (scale_factor) {
-        float da[MAXK2];
-        float dot = 0.f;
-        for (int k = 0; k < k2; ++k) {
-            float v = 0.f;
-            for (int c = 0; c < nchunks; ++c) v += scratch[c * cstride + positions * 2 * k2 + pos * k2 + k];
-            da[k] = v;
-            dot += a[pos * k2 + k] * v;
-        }
-        for (int k = 0; k < k2; ++k) o[2 * k2 + k] = a[pos * k2 + k] * (da[k] - dot);
+        const bool is_a = j >= 2 * k2 && j < 3 * k2;
+        const float ak = is_a ? a[pos * k2 + (j - 2 * k2)] : 0.f;
+        float dot = is_a ? ak * v : 0.f;
+        __shared__ float part[4];
+        dot = wave_sum(dot);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = dot;
+        __syncthreads();
+        float tot = 0.f;
+        for (int q = 0; q < (int)blockDim.x / 64; ++q) tot += part[q];
+        if (is_a) dpred[pos * cp + j] = ak * (v - tot);
     }
 }
 
@@ -265,10 +276,13 @@ int din_walk_bwd(const float* x, const float* pred, int cp, const float* a, cons
     size_t lds = ((size_t)2 * p.hp * p.wp * CH + (size_t)t * n * 3 * p.k2) * sizeof(float);
     DIN_REQUIRE(lds <= 160 * 1024, "din_walk_bwd: T x N grid too large for the LDS tiles (%zu bytes)", lds);
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(din_walk_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipMemsetAsync(dx, 0, sizeof(float) * positions * c, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "din_walk_bwd: memset");
     int nchunks = (c + CH - 1) / CH;
-    hipLaunchKernelGGL(din_walk_bwd_kernel, dim3(b * nchunks), dim3(WALK_THREADS), lds, st, p);
+    const int ngroups = (t * n + WALK_BWD_WAVES - 1) / WALK_BWD_WAVES;
+    hipLaunchKernelGGL(din_walk_bwd_kernel, dim3(b * nchunks * ngroups), dim3(WALK_BWD_WAVES * 64), lds, st, p);
     DIN_CHECK_LAUNCH("din_walk_bwd");
-    hipLaunchKernelGGL(din_walk_bwd_finish_kernel, dim3((unsigned)ceil_div64(positions, 128)), dim3(128), 0, st, scratch, a, dpred,
+    const int fin_threads = (3 * p.k2 + 63) / 64 * 64;
+    hipLaunchKernelGGL(din_walk_bwd_finish_kernel, dim3((unsigned)positions), dim3(fin_threads), 0, st, scratch, a, dpred,
                        positions, p.k2, cp, scale_factor, nchunks);
     DIN_CHECK_LAUNCH("din_walk_bwd_finish");
     return DIN_OK;
