@@ -2797,6 +2797,29 @@ int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t
     return DIN_OK;
 }
 
+int din_conv_kernel_variant(const din_conv_desc* d, int which, int32_t* flags) {
+    DIN_REQUIRE(d && flags && which >= 0 && which <= 1, "conv_kernel_variant: bad argument");
+    int32_t bm = 0, bn = 0;
+    if (int e = din_conv_kernel_tile(d, which, &bm, &bn)) return e;
+    *flags = 0;
+    if (bm != 128 || d->dtype != DIN_BF16) return DIN_OK;          // the 8-wave / FASTK instantiations exist for bf16 128 x BN tiles only
+    const char* pv = getenv("DIN_CONV_PIPE");
+    const int pipe = pv ? atoi(pv) : -1;
+    const bool wave8 = (bn == 64 || bn == 128 || bn == 160 || bn == 192) && pipe != 4 && pipe != 1;
+    if (wave8) *flags |= 2;
+    const bool strided = which == 1 && (d->sh > 1 || d->sw > 1);
+    const int ntaps = d->kh * d->kw, cred = which == 0 ? d->cin : d->cout;
+    const int cpt = pad_to(cred, 8) / 8;
+    GatherPlan g = which == 0 ? plan_gather(d->nb * d->oh * d->ow, d->cin, d->cout, ntaps, d->dtype)
+                              : plan_gather(d->nb * (strided ? (d->h + d->sh - 1) / d->sh * ((d->w + d->sw - 1) / d->sw) : d->h * d->w), d->cout, d->cin, ntaps, d->dtype);
+    const char* ko = getenv("DIN_CONV_KORDER");
+    const char* fv = getenv("DIN_CONV_FASTK");
+    const bool fast = ntaps <= 32 && (which == 0 || (d->sh == 1 && d->sw == 1));      // stride-1 gather: divy == divx == 1, no tap remap
+    const bool korder = (ko ? atoi(ko) != 0 : true) && fast && g.splitk == 1 && cpt % KC == 0 && ntaps > 1;
+    if (wave8 && fast && cpt % KC == 0 && (korder || ntaps == 1) && (fv ? atoi(fv) != 0 : true)) *flags |= 1;
+    return DIN_OK;
+}
+
 int64_t din_conv_workspace_bytes(const din_conv_desc* d, int which) {
     if (!d) return 0;
     if (which == 0) return plan_gather(d->nb * d->oh * d->ow, d->cin, d->cout, d->kh * d->kw, d->dtype).ws_bytes;

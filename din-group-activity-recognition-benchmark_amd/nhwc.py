@@ -97,7 +97,20 @@ class _timed:
             elif bm.value == 1:
                 variant = f"conv_halo_kernel<{bn.value}, ...>"
             else:
-                variant = f"conv_gather_fast_kernel<{tn}, {bm.value}, {bn.value}, ...>"
+                # the exact instantiation, spelled as rocprofv3 prints it: <T, BM, BN, WM, WN, KCS, NS, MULTI, FASTK>
+                fl = C.c_int32(0)
+                multi = self.kind == "dgrad" and "+" in self.name
+                if not multi:
+                    L.load().din_conv_kernel_variant(C.byref(d), which, C.byref(fl))
+                BM, BN = bm.value, bn.value
+                if BM == 256:
+                    geo = "4, 1, 4, 4" if BN == 64 else ("2, 2, 8, 2" if BN in (96, 160) else "4, 2, 8, 2")
+                elif multi:
+                    geo = "4, 2, 8, 2" if (BN % 64 == 0 and d.dtype == L.DIN_BF16) else "2, 2, 8, 2"
+                else:
+                    geo = "4, 2, 8, 2" if fl.value & 2 else "2, 2, 8, 2"
+                variant = (f"conv_gather_fast_kernel<{tn}, {BM}, {BN}, {geo}, {'true' if multi else 'false'}, "
+                           f"{'true' if fl.value & 1 else 'false'}>")
             PROFILE.append((self.kind, variant, _conv_flops(d), int(d.dtype), self.e0, self.e1, self.name))
         return False
 

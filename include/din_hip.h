@@ -102,6 +102,9 @@ int din_conv_pack_multi(const din_pack_desc* table, const int32_t* layer_of, con
  * conv_small_kernel / conv_wgrad_small_kernel with bn filters; bm = 1 -> conv_halo_kernel): lets a
  * profiler-side caller name the kernel a launch resolves to */
 int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t* bn);
+/* which instantiation of conv_gather_fast_kernel a fwd (0) / dgrad (1) launch resolves to: flags bit 0 = FASTK (scalar k-walk), bit 1 = 8 waves
+ * (4 x 2) instead of 4 (2 x 2) -- so that a profiler-side caller can spell the exact kernel name rocprofv3 prints */
+int din_conv_kernel_variant(const din_conv_desc* d, int which, int32_t* flags);
 /* workspace bytes needed by fwd / dgrad / wgrad for this descriptor (split-K partial sums) */
 int64_t din_conv_workspace_bytes(const din_conv_desc* d, int which /*0 fwd,1 dgrad,2 wgrad*/);
 

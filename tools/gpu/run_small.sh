@@ -1,1 +1,6 @@
-DIN_BENCH_TORCH_PROFILE=gpurun_out/torch_prof_b4.txt timeout 600 python bench.py --steps 2 --warmup 2 --global-batch 4 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-120
+timeout 600 python bench.py --steps 5 --warmup 2 2>&1 | tail -1 > gpurun_out/bench_last.json
+cut -c1-700 gpurun_out/bench_last.json
+rm -rf gpurun_out/prof
+export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r01 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1
+rm -f gpurun_out/prof/*kernel_trace.csv

@@ -34,7 +34,9 @@ def main():
         wv = w.get(k, [])
         res[k] = dict(launches=len(v), fetch_bytes_per_launch=2.0 * 1e3 * sum(v) / len(v),
                       write_bytes_per_launch=1e3 * sum(wv) / len(wv) if wv else None)
-    json.dump(dict(source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 1 --no-cpu-baseline`; "
+    workload = sys.argv[4] if len(sys.argv) > 4 else "inv3_bf16"
+    global_batch = int(sys.argv[5]) if len(sys.argv) > 5 else 32
+    json.dump(dict(workload=workload, global_batch=global_batch, n_gpus=1, source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 1 --no-cpu-baseline`; "
                           "FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as counted", kernels=res), open(out, "w"), indent=1)
     print("wrote", out, len(res), "kernels")
 
