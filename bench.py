@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--frames", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adam", action="store_true")
+    ap.add_argument("--forward-only", action="store_true", help="evaluation path (SURVEY 8f-3): model.eval(), torch.no_grad(), forward + loss only")
     ap.add_argument("--per-layer", default="", help="write the per-layer conv launch table of the sampled step to this file")
     a = ap.parse_args()
 
@@ -156,7 +157,13 @@ def main():
     _, boxes, labels = synth_inputs(a.global_batch, T, N, 8, 8, OH, OW, 8, seed=0)
     boxes, labels = boxes[mine.start:mine.stop].to(dev), labels[mine.start:mine.stop].to(dev)
 
+    if a.forward_only:
+        model.eval()
+
     def step():
+        if a.forward_only:
+            with torch.no_grad():
+                return F.cross_entropy(model((images, boxes))["activities"], labels)
         opt.zero_grad()
         ret = model((images, boxes))
         loss = F.cross_entropy(ret["activities"], labels)
@@ -275,13 +282,14 @@ def main():
     if rank == 0:
         clips = a.global_batch * a.steps if world > 1 else B * a.steps
         out = {
-            "metric": "clips/sec (fwd+bwd), Volleyball DIN stage-2, BxTx12 actors",
+            "metric": "clips/sec (fwd only, eval), Volleyball DIN stage-2, BxTx12 actors" if a.forward_only else "clips/sec (fwd+bwd), Volleyball DIN stage-2, BxTx12 actors",
             "value": round(clips / elapsed, 3), "unit": "clips/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"Volleyball stage-2 DIN, {backbone}, T={T}, ST_kernel=(3,3), N=12, 720x1280, {dtype}",
                        "global_batch": a.global_batch, "clips_per_gpu": B, "frames": T, "parallelism": f"dp{world}",
-                       "includes": "fwd + cross-entropy + bwd" + (" + RCCL grad all-reduce" if world > 1 else "")
+                       "includes": "fwd + cross-entropy (eval mode, no_grad)" if a.forward_only else
+                                   "fwd + cross-entropy + bwd" + (" + RCCL grad all-reduce" if world > 1 else "")
                                    + ("" if a.no_adam else " + fused Adam"),
                        "bn_mode": "running statistics (set_bn_eval)" if backbone == "inv3" else "n/a"},
             "roofline": roofline,
