@@ -61,6 +61,8 @@ SIGNATURES: Dict[str, tuple] = {
     "din_conv_pack_multi": (_I, [_P, _P, _P, _I, _I, _P]),
     "din_conv_kernel_tile": (_I, [_CD, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "din_conv_kernel_variant": (_I, [_CD, _I, C.POINTER(C.c_int32)]),
+    "din_wgrad_set_reduce_stream": (_I, [_P]),
+    "din_wgrad_reduce_join": (_I, [_P]),
     "din_conv_workspace_bytes": (_L, [_CD, _I]),
     "din_conv_fwd": (_I, [_CD, _P, _P, _P, _P, _I, _P, _L, _P]),
     "din_conv_dgrad": (_I, [_CD, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P]),

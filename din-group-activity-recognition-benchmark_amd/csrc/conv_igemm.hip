@@ -19,6 +19,7 @@
 // backbone/backbone.py:44-99, infer_model.py:184,190,226 and infer_module/dynamic_infer_module.py:149,191,195.
 #include "din_common.h"
 #include <unordered_map>
+#include <mutex>
 #include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -2961,6 +2962,37 @@ int din_conv1x1_dgrad_multi(int nsrc, const din_conv_src* srcs, int dtype, int n
     return DIN_OK;
 }
 
+// ---- slice reduce on a second stream ------------------------------------------------------------------------------------------
+// The slice reduce of layer l only feeds the parameter gradient, which nobody needs before the end of backward (or the next gradient
+// bucket); it is a short memory-bound kernel, the dgrad that follows it on the main stream is MFMA-bound.  With a reduce stream set
+// (din_wgrad_set_reduce_stream) the reduce is enqueued there, ordered after the wgrad kernel by an event; the NEXT wgrad kernel waits
+// for it (it overwrites the partial-sum workspace), and din_wgrad_reduce_join makes any consumer stream wait for the last one.
+// The caller must give wgrad a workspace that no other kernel writes in between (split-K forward / dgrad launches use their own).
+static std::mutex g_reduce_mu;
+static hipStream_t g_reduce_stream = nullptr;
+static hipEvent_t g_ev_kernel = nullptr, g_ev_reduce = nullptr;
+static bool g_reduce_pending = false;
+
+int din_wgrad_set_reduce_stream(void* stream) {
+    std::lock_guard<std::mutex> lk(g_reduce_mu);
+    if (stream && !g_ev_kernel) {
+        if (hipEventCreateWithFlags(&g_ev_kernel, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g_ev_reduce, hipEventDisableTiming) != hipSuccess)
+            DIN_FAIL(DIN_E_LAUNCH, "wgrad_set_reduce_stream: event creation failed");
+    }
+    g_reduce_stream = as_stream(stream);
+    if (!stream) g_reduce_pending = false;
+    return DIN_OK;
+}
+
+int din_wgrad_reduce_join(void* stream) {
+    std::lock_guard<std::mutex> lk(g_reduce_mu);
+    if (g_reduce_stream && g_reduce_pending) {
+        if (hipStreamWaitEvent(as_stream(stream), g_ev_reduce, 0) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "wgrad_reduce_join: wait failed");
+    }
+    return DIN_OK;
+}
+
 int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, float* dw, float* dbias, const float* scale,
                    const float* w, float* wdot, int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
     if (int e = check_desc(d)) return e;
@@ -2972,6 +3004,11 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
     WgradPlan wp = plan_wgrad(d);
     if (workspace_bytes < wp.ws_bytes || !workspace)
         DIN_FAIL(DIN_E_WORKSPACE, "conv_wgrad: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)wp.ws_bytes);
+    {   // the previous layer's reduce may still be reading the workspace this launch overwrites
+        std::lock_guard<std::mutex> lk(g_reduce_mu);
+        if (g_reduce_stream && g_reduce_stream != st && g_reduce_pending && hipStreamWaitEvent(st, g_ev_reduce, 0) != hipSuccess)
+            DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: wait for the previous reduce failed");
+    }
     WgradK k{};
     k.in = in; k.g = dout; k.partial = reinterpret_cast<float*>(workspace); k.dbias = nullptr;
     k.NB = d->nb; k.H = d->h; k.W = d->w; k.Cin = d->cin; k.ldi = d->ldi; k.cioff = d->cioff;
@@ -3050,9 +3087,23 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
         int kc_total = d->kh * d->kw * wp.cin_pad;
         dim3 rgrid(d->cout, (kc_total + 255) / 256);
         const int nsg = wp.slices >= 64 ? 16 : wp.slices >= 8 ? 4 : 1;
-        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, rgrid, dim3(64, nsg), 0, st, k.partial, dw, scale, w, wdot,
+        hipStream_t rst = st;
+        {
+            std::lock_guard<std::mutex> lk(g_reduce_mu);
+            if (g_reduce_stream && g_reduce_stream != st) {
+                if (hipEventRecord(g_ev_kernel, st) != hipSuccess || hipStreamWaitEvent(g_reduce_stream, g_ev_kernel, 0) != hipSuccess)
+                    DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: reduce-stream hand-over failed");
+                rst = g_reduce_stream;
+            }
+        }
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, rgrid, dim3(64, nsg), 0, rst, k.partial, dw, scale, w, wdot,
                            d->cout, d->cin, d->kh, d->kw, wp.cin_pad, wp.cout_pad, wp.kcols_pad, wp.slices, accumulate);
         DIN_CHECK_LAUNCH("conv_wgrad_reduce");
+        if (rst != st) {
+            std::lock_guard<std::mutex> lk(g_reduce_mu);
+            if (hipEventRecord(g_ev_reduce, rst) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: reduce event");
+            g_reduce_pending = true;
+        }
     }
     if (dbias && !bias_fused) {
         if (int e = launch_colsum(d->dtype, dout, dbias, k.M, d->cout, d->ldo, d->cooff, st)) return e;

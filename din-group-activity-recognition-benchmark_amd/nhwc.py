@@ -125,6 +125,29 @@ _SIDE: Dict[int, "torch.cuda.Stream"] = {}
 WGRAD_SIDE_STREAM = _os.environ.get("DIN_WGRAD_STREAM", "0") != "0"     # opt-in: measured 472 -> 351 clips/s (the LDS-heavy kernels of the two streams evict each other)
 
 
+REDUCE_SIDE_STREAM = _os.environ.get("DIN_REDUCE_STREAM", "0") != "0"   # opt-in: wgrad slice reduces on a second stream.  Measured SLOWER
+# (4-clip step 11.94 -> 12.79 ms, 32 clips 493 -> 486 clips/s): two event hand-overs per layer cost more than the 10 us reduce they hide
+_REDUCE_SET: Dict[int, bool] = {}
+
+
+def reduce_stream_setup(device) -> bool:
+    """Register this device's side stream with the library as the stream of the wgrad slice reduces (once per process)."""
+    if not REDUCE_SIDE_STREAM or WGRAD_SIDE_STREAM:
+        return False
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _REDUCE_SET:
+        L.check(L.load().din_wgrad_set_reduce_stream(side_stream(device).cuda_stream), "wgrad_set_reduce_stream")
+        _REDUCE_SET[key] = True
+    return True
+
+
+def reduce_join(stream=None) -> None:
+    """Make `stream` (default: the current one) wait for the last enqueued slice reduce: call before reading a conv weight gradient."""
+    if _REDUCE_SET:
+        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        L.check(L.load().din_wgrad_reduce_join(st), "wgrad_reduce_join")
+
+
 def side_stream(device) -> "torch.cuda.Stream":
     """Second HIP stream per device: wgrad (+ slice reduce, BN parameter gradients) of layer l runs here while the main stream goes
     on with the dgrad chain -- both only depend on the gradient at the layer's output, and each kernel's last partial round of
@@ -470,6 +493,8 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
     st = _stream()
     main = torch.cuda.current_stream()
     side = side_stream(dev) if (WGRAD_SIDE_STREAM and PROFILE is None) else None
+    rs = reduce_stream_setup(dev)                      # slice reduces run on the side stream; wgrad then owns its own workspace
+    wtag = "wgrad" if rs else ""
     gbufs: Dict[int, torch.Tensor] = dict(out_grads)
 
     def on_side(tensors):
@@ -597,7 +622,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                         ws, wsb = workspace(wsbytes, dev, "side")
                 else:
                     stw = st
-                    ws, wsb = workspace(wsbytes, dev)
+                    ws, wsb = workspace(wsbytes, dev, wtag)
                 with _timed("wgrad", d, op.name):
                     L.check(lib.din_conv_wgrad(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dw),
                                                None if dshift_pre is not None else _ptr(dshift), _ptr(scale),
@@ -611,7 +636,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                         ws, wsb = workspace(wsbytes, dev, "side")
                 else:
                     stw = st
-                    ws, wsb = workspace(wsbytes, dev)
+                    ws, wsb = workspace(wsbytes, dev, wtag)
                 with _timed("wgrad", d, op.name):
                     L.check(lib.din_conv_wgrad(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dw),
                                                None if dshift_pre is not None else _ptr(db), None, None, None, 0,
@@ -655,6 +680,8 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
             gbufs.pop(op.dst.tid, None)
     if side is not None:
         main.wait_stream(side)                        # parameter gradients are complete for whoever runs next on the main stream
+    if rs:
+        reduce_join(st)                               # ... and so are the slice reduces of the last layers
     if bn is not None and bn_touched:
         # BatchNorm parameter gradients of every layer in one launch: dgamma = (wdot - dshift * mean) * rstd, dbeta = dshift
         bn_out = torch.empty(2 * bn.total, dtype=torch.float32, device=dev)

@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib as L
-from .nhwc import _ptr, _stream, din_dtype, require_gpu, workspace
+from .nhwc import _ptr, _stream, din_dtype, reduce_join, require_gpu, workspace
 
 
 # ------------------------------------------------------------------------------------------------
@@ -136,7 +136,7 @@ class GridConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(weight)
             db = torch.empty(weight.shape[0], dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 2), x.device)
+            ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 2), x.device, "wgrad")   # not shared with split-K launches
             L.check(lib.din_conv_wgrad(C.byref(d), _ptr(x), _ptr(gy), _ptr(dw), _ptr(db), None, None, None, 0, _ptr(ws), wsb, st),
                     "grid_conv_wgrad")
         if ctx.needs_input_grad[0]:
@@ -147,6 +147,7 @@ class GridConvFunction(torch.autograd.Function):
             L.check(lib.din_conv_dgrad(C.byref(d), _ptr(gy), _ptr(wpt), _ptr(dx), None, 0, 0, 0, _ptr(ws), wsb, st), "grid_conv_dgrad")
             if ctx.lowp:
                 dx = dx.float()
+        reduce_join(st)                                 # dw is handed to autograd right away: wait for its slice reduce (if on the side stream)
         return dx, dw, db, None, None
 
 

@@ -137,6 +137,8 @@ class GradBuckets:
         self._got[key] = grad
         bi, _ = self._slot[key]
         if bi < self._early and bi not in self._inflight and all(q.data_ptr() in self._got for q in self.buckets[bi]):
+            from . import nhwc as _nhwc
+            _nhwc.reduce_join()                                  # the bucket's last slice reduces may still be running on the side stream
             flat = self._pack(bi, [self._got[q.data_ptr()] for q in self.buckets[bi]])
             self._inflight[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 

@@ -105,6 +105,12 @@ int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t
 /* which instantiation of conv_gather_fast_kernel a fwd (0) / dgrad (1) launch resolves to: flags bit 0 = FASTK (scalar k-walk), bit 1 = 8 waves
  * (4 x 2) instead of 4 (2 x 2) -- so that a profiler-side caller can spell the exact kernel name rocprofv3 prints */
 int din_conv_kernel_variant(const din_conv_desc* d, int which, int32_t* flags);
+/* Optional: run the slice-reduce kernel of din_conv_wgrad on `stream` (NULL: back on the caller's stream).  The reduce is ordered after its
+ * wgrad kernel by an event and the next din_conv_wgrad waits for it before it overwrites the workspace, so wgrad must then own a workspace
+ * that no other launch writes in between.  din_wgrad_reduce_join(stream) makes `stream` wait for the last enqueued reduce: call it before
+ * anything reads a weight gradient (end of backward, gradient bucket hand-over).  Process-wide setting (one process per GPU). */
+int din_wgrad_set_reduce_stream(void* stream);
+int din_wgrad_reduce_join(void* stream);
 /* workspace bytes needed by fwd / dgrad / wgrad for this descriptor (split-K partial sums) */
 int64_t din_conv_workspace_bytes(const din_conv_desc* d, int which /*0 fwd,1 dgrad,2 wgrad*/);
 
