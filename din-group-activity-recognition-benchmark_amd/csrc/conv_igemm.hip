@@ -285,12 +285,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_generic_kernel(ConvK 
 //    stores with vector loads for the ReLU-backward mask and the accumulate input.
 // Tile variants <BMT, BN, WM x WN waves, DEEP>: 128x128 (2x2), 128x64 (2x2) and 256x64 (4x1; twice the work per barrier for the
 // short-K, latency-bound 64-filter layers; single register set to stay under 256 VGPRs, no LDS tables so two workgroups fit a CU).
-// 512-thread variants 256x128 (4x2 waves) and 256x256 (4x2 waves, 64x128 wave tiles) raise the FLOPs per byte pulled from L2
-// from 64 to 85 / 128 -- the 128x128 tile saturates the L2->CU path at ~770 TFLOP/s.
-// Pipeline: an NS-stage ring of LDS stages of KCS 16-byte chunks per row, filled by LDS-DMA.  Bytes in flight (not MFMA rate) bound
-// this kernel (Little: ~2 us loaded latency), so the ring keeps NS-1 stages in flight: per stage ONE counted s_waitcnt vmcnt(N)
-// (VMEM completes in order: N = DMAs of the younger stages) + ONE raw s_barrier (every wave's share of the stage landed, and
-// every wave is done reading the stage about to be refilled).
+// 512-thread variants 256x128 (4x2 waves) and 256x256 (4x2 waves, 64x128 wave tiles) raise the FLOPs per byte streamed into LDS
+// from 64 to 85 / 128; measured throughput follows that ratio (128x128 ~770, 256x256 ~1150 TFLOP/s) although the L2->LDS path itself
+// is not the limiter (profiles/r01_stream_probe.txt: 37 TB/s raw; the k-loop structure tops out at ~68 % of MFMA peak, and the MFMA
+// rate drops a further ~27 % on real, toggling operands).
+// Pipeline: an NS-stage ring of LDS stages of KCS 16-byte chunks per row, filled by LDS-DMA, NS-1 stages in flight: per stage ONE
+// counted s_waitcnt vmcnt(N) (VMEM completes in order: N = DMAs of the younger stages) + ONE raw s_barrier (every wave's share of
+// the stage landed, and every wave is done reading the stage about to be refilled).
 // FASTK (bf16 8-wave tiles; host: whole k-steps per tap, no tap remap, k-order = taps inside channel chunks): every piece of per-step
 // loader state is scalar except one validity select per tile row, the offsets of the NEXT transfer are prepared while the current
 // stage is multiplied (so only the transfers themselves sit between the barrier and the MFMAs), and no other mode is compiled in.

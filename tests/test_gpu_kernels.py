@@ -150,6 +150,65 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
         assert rel(from_nhwc(dx, cin), want) <= 2 * tolg
 
 
+def test_wgrad_reduce_on_second_stream_matches(env):
+    """din_wgrad_set_reduce_stream / din_wgrad_reduce_join: the slice reduce enqueued on a second stream gives the same dW bit for bit,
+    back-to-back launches that share the workspace stay ordered, and NULL restores the single-stream behaviour."""
+    lib, L, nhwc, ops = env
+    g = torch.Generator().manual_seed(11)
+    nb, h, w, cin, cout = 3, 40, 56, 64, 96
+    d = L.ConvDesc()
+    d.nb, d.h, d.w, d.cin, d.oh, d.ow, d.cout = nb, h, w, cin, h, w, cout
+    d.kh = d.kw = 3
+    d.sh = d.sw = d.ph = d.pw = d.dh = d.dw = 1
+    d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = cin, 0, cout, 0, L.DIN_BF16
+    xs = [torch.randn(nb, h, w, cin, generator=g).bfloat16().cuda() for _ in range(3)]
+    gs = [torch.randn(nb, h, w, cout, generator=g).bfloat16().cuda() for _ in range(3)]
+    wsb = lib.din_conv_workspace_bytes(C.byref(d), 2)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device="cuda")
+
+    def run():
+        outs = [torch.empty(cout, cin, 3, 3, device="cuda") for _ in range(3)]
+        dbs = [torch.empty(cout, device="cuda") for _ in range(3)]
+        for x, gy, dw, db in zip(xs, gs, outs, dbs):          # three launches through ONE workspace
+            L.check(lib.din_conv_wgrad(C.byref(d), x.data_ptr(), gy.data_ptr(), dw.data_ptr(), db.data_ptr(), None, None, None, 0,
+                                       ws.data_ptr(), wsb, None))
+        L.check(lib.din_wgrad_reduce_join(None))
+        torch.cuda.synchronize()
+        return outs
+
+    base = run()
+    side = torch.cuda.Stream()
+    L.check(lib.din_wgrad_set_reduce_stream(side.cuda_stream))
+    try:
+        other = run()
+    finally:
+        L.check(lib.din_wgrad_set_reduce_stream(None))
+    for a, b in zip(base, other):
+        assert torch.equal(a, b)
+    ref = torch.nn.grad.conv2d_weight(xs[0].float().permute(0, 3, 1, 2), (cout, cin, 3, 3), gs[0].float().permute(0, 3, 1, 2), padding=1)
+    assert rel(base[0], ref) <= 2e-2
+
+
+def test_conv_kernel_variant_names_the_instantiation(env):
+    """din_conv_kernel_variant: bit 0 = FASTK, bit 1 = 8 waves -- the flags bench.py spells the rocprofv3 kernel name from."""
+    lib, L, nhwc, ops = env
+    def flags(cin, cout, k, which=0, dtype=None, s=1):
+        d = L.ConvDesc()
+        d.nb, d.h, d.w, d.cin, d.cout = 96, 43, 78, cin, cout
+        d.kh, d.kw = k
+        d.sh = d.sw = s
+        d.ph, d.pw, d.dh, d.dw = k[0] // 2, k[1] // 2, 1, 1
+        d.oh, d.ow = (43 + 2 * d.ph - k[0]) // s + 1, (78 + 2 * d.pw - k[1]) // s + 1
+        d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = cin, 0, cout, 0, (L.DIN_BF16 if dtype is None else dtype)
+        f = C.c_int32(-1)
+        L.check(lib.din_conv_kernel_variant(C.byref(d), which, C.byref(f)))
+        return f.value
+    assert flags(192, 192, (7, 1)) == 3                 # whole k-steps per tap, 8-wave 128x192 tile
+    assert flags(768, 192, (1, 1)) == 3                 # single tap
+    assert flags(80, 192, (3, 3)) == 2                  # 80 channels: k-steps straddle taps -> general loop, still 8 waves
+    assert flags(192, 192, (7, 1), dtype=L.DIN_F32) == 0
+
+
 def test_bn_fold_and_wdot(env):
     lib, L, nhwc, ops = env
     c = 24
