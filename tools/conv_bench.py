@@ -93,7 +93,8 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
     fl = 2.0 * nb * oh * ow * cout * cin * k[0] * k[1]
-    print(f"{a.layer:14s} {a.dtype} {a.which:5s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s  (M={nb*oh*ow}, K={cin*k[0]*k[1]}, N={cout})", flush=True)
+    chk = {"fwd": y, "dgrad": dx, "wgrad": dw}[a.which].float().abs().sum().item()
+    print(f"{a.layer:14s} {a.dtype} {a.which:5s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s  (M={nb*oh*ow}, K={cin*k[0]*k[1]}, N={cout})  |out|_1 = {chk:.6e}", flush=True)
 
 if __name__ == "__main__":
     main()
