@@ -1,5 +1,3 @@
-for l in inc_6e_7x1 k_7x1_768 inc_6e_1x1_768 inc_4a_3x3; do
-python tools/conv_bench.py --layer $l --which fwd --iters 20 2>&1 | grep -v amdgpu.ids
-DIN_CONV_TILE=256 DIN_CONV_PIPE=16 python tools/conv_bench.py --layer $l --which fwd --iters 20 2>&1 | grep -v amdgpu.ids
-DIN_CONV_TILE=256 python tools/conv_bench.py --layer $l --which fwd --iters 20 2>&1 | grep -v amdgpu.ids
-done
+timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "conv" 2>&1 | tail -2
+python tools/conv_bench.py --layer inc_6a_3x3 --which dgrad --iters 10 2>&1 | grep -v amdgpu.ids
+timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-180
