@@ -46,6 +46,7 @@ CONV_CASES = [
     ("3x3_s2_p0", 2, 32, 15, 19, 48, (3, 3), (2, 2), (0, 0), 1),
     ("3x3_s2_p1", 2, 32, 14, 18, 48, (3, 3), (2, 2), (1, 1), 1),
     ("1x1_s2", 1, 32, 9, 11, 32, (1, 1), (2, 2), (0, 0), 1),
+    ("3x3_s2_cin288", 1, 288, 21, 25, 64, (3, 3), (2, 2), (0, 0), 1),           # Mixed_6a.branch3x3 dgrad: parity classes on 3 x 96-wide tiles
     ("5x5_p2", 1, 48, 10, 12, 64, (5, 5), (1, 1), (2, 2), 1),
     ("1x7", 1, 32, 9, 14, 32, (1, 7), (1, 1), (0, 3), 1),
     ("7x1", 1, 32, 14, 9, 192, (7, 1), (1, 1), (3, 0), 1),
