@@ -186,11 +186,11 @@ def main():
         step()
     if os.environ.get("DIN_BENCH_TORCH_PROFILE"):          # tuning aid: which host-side torch ops launch the small fill / copy kernels
         from torch.profiler import profile, ProfilerActivity
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
             step()
             torch.cuda.synchronize()
         with open(os.environ["DIN_BENCH_TORCH_PROFILE"], "w") as f:
-            f.write(prof.key_averages(group_by_stack_n=8).table(sort_by="self_cuda_time_total", row_limit=80, max_src_column_width=120))
+            f.write(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=200, max_shapes_column_width=90))
 
     # calibrate what a HIP event pair adds around ONE launch (two marker packets; kernels otherwise run back to back):
     # per-launch cost of a trivial kernel bracketed individually minus its cost inside one long bracket

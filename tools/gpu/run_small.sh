@@ -1,1 +1,3 @@
-timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "cin288" 2>&1 | tail -2
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 600 python bench.py 2>&1 | tail -1 | cut -c1-300
