@@ -210,11 +210,15 @@ class MyInception_v3(_GraphBackbone):
                 out_tid, base = fused_tid, 0
             else:
                 out_tid, base = gb.tensor(h5, w5, ctot), 0
+            # the three 1x1 convs that read the block input are laid out for ONE forward launch (nhwc.Graph.fwd_groups): consecutive ops,
+            # the two temporaries adjacent views of one tensor.  Separately they are three 64-wide launches bound by re-reading the input.
+            tmp_tid = gb.tensor(h5, w5, 48 + 64)
             bc(blk + "branch1x1", v, View(out_tid, base, 64))
-            t = bc(blk + "branch5x5_1", v)
-            bc(blk + "branch5x5_2", t, View(out_tid, base + 64, 64))
-            t = bc(blk + "branch3x3dbl_1", v)
-            t = bc(blk + "branch3x3dbl_2", t)
+            t5 = bc(blk + "branch5x5_1", v, View(tmp_tid, 0, 48))
+            t3 = bc(blk + "branch3x3dbl_1", v, View(tmp_tid, 48, 64))
+            gb.fuse_forward(3)
+            bc(blk + "branch5x5_2", t5, View(out_tid, base + 64, 64))
+            t = bc(blk + "branch3x3dbl_2", t3)
             bc(blk + "branch3x3dbl_3", t, View(out_tid, base + 128, 96))
             branch_pool(blk + "branch_pool", v, View(out_tid, base + 224, pf))
             v = View(out_tid, base, ctot)

@@ -54,6 +54,9 @@ struct ConvK {
     // concatenation of the sources' channels; source b = its own tensor (pixel stride, channel offset) + its own filter bank
     int nsrc;
     struct Src { const void* in; const void* w; long long in_bytes, w_bytes; int cpt, ld, coff, wld; } src[4];
+    // second destination (fused sibling convs that read one tensor): produced channels >= csplit go to out2 (pixel stride ldo2, channel
+    // offset cooff2 + (channel - csplit)); csplit == 0: single destination.  Staged (aligned) epilogue only, no mask / accumulate.
+    void* out2; int ldo2, cooff2, csplit;
 };
 
 __device__ __forceinline__ int64_t out_pixel(const ConvK& p, int m) {
@@ -644,7 +647,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
             if (opx[q] < 0) continue;
             const int row = rr + q * RPP;
             u32x4 v = *reinterpret_cast<const u32x4*>(smem_raw + row * CPITCH + c * 16);
-            const int64_t o = (int64_t)opx[q] * p.ldo + p.cooff + co;
+            const bool second = p.csplit > 0 && co >= p.csplit;
+            if (second) outp = reinterpret_cast<T*>(p.out2);
+            const int64_t o = second ? (int64_t)opx[q] * p.ldo2 + p.cooff2 + (co - p.csplit) : (int64_t)opx[q] * p.ldo + p.cooff + co;
             if (p.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM)) {
                 const u32x4 mk = mkv[q], old = oldv[q];
                 if constexpr (sizeof(T) == 4) {
@@ -2613,6 +2618,7 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
     if (getenv("DIN_DEBUG_PLAN"))
         fprintf(stderr, "[din] %s M=%d NB=%d HxW=%dx%d Cin=%d Cout=%d k=%dx%d ay=%d cy=%d tile=%dx%d splitk=%d korder=%d remap=%d flags=%d dtype=%d\n", what,
                 k.M, k.NB, k.H, k.W, k.Cin, k.Cout, k.kh, k.kw, k.ay, k.cy, g.bm, g.bn, g.splitk, k.korder, k.remap, k.flags, dtype);
+    if (k.csplit > 0 && (!fast || g.splitk > 1)) DIN_FAIL(DIN_E_ARG, "%s: two destinations need the staged epilogue of the buffer-addressed kernel", what);
     if (g.splitk > 1) {
         if (ws_bytes < g.ws_bytes || workspace == nullptr)
             DIN_FAIL(DIN_E_WORKSPACE, "%s: workspace %lld < %lld bytes", what, (long long)ws_bytes, (long long)g.ws_bytes);
@@ -2623,7 +2629,7 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
         HaloPlan hp;
         const bool stem_shape = k.kh == 3 && k.kw == 3 && (k.Cin == 32 || k.Cin == 64) && k.Cout <= 64 && !(k.Cin == 64 && k.Cout > 32) &&
                                 (int64_t)k.M >= 256 * 1024;
-        if (fast && !k.remap && k.nsrc == 0 && g.splitk == 1 && !stem_shape && k.ay == 1 && k.ax == 1 && (k.cy == 1 || k.cy == -1) &&
+        if (fast && !k.remap && k.nsrc == 0 && k.csplit == 0 && g.splitk == 1 && !stem_shape && k.ay == 1 && k.ax == 1 && (k.cy == 1 || k.cy == -1) &&
             (k.cx == 1 || k.cx == -1) && k.cy == k.cx && k.out_sy == 0 && k.ldi % 8 == 0 && k.cioff % 8 == 0 && k.ldo % 4 == 0 && k.cooff % 4 == 0 &&
             (!(k.flags & DIN_CONV_MASK) || (k.ldm % 4 == 0 && k.moff % 4 == 0)) &&
             (long long)k.H * k.W * k.ldi * 2 < 0x7fffffffll && (long long)k.OH * k.OW * k.ldo * 2 < 0x7fffffffll &&
@@ -2648,7 +2654,7 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
         // stem layers: stationary filters + halo tiles (conv_small_kernel)
         const char* sv = getenv("DIN_CONV_SMALL");
         const bool want = sv ? atoi(sv) != 0 : true;
-        const bool common = want && dtype == DIN_BF16 && fast && !k.remap && k.nsrc == 0 && g.splitk == 1 && k.kh == 3 && k.kw == 3 &&
+        const bool common = want && dtype == DIN_BF16 && fast && !k.remap && k.nsrc == 0 && k.csplit == 0 && g.splitk == 1 && k.kh == 3 && k.kw == 3 &&
                             k.Cout <= 64 && k.Cout % 8 == 0 && k.cooff % 8 == 0 && k.ldo % 8 == 0 && k.ldi % 8 == 0 && k.cioff % 8 == 0 &&
                             (!(k.flags & DIN_CONV_MASK) || (k.ldm % 8 == 0 && k.moff % 8 == 0)) &&
                             (long long)k.H * k.W * k.ldi * 2 < 0x7fffffffll && (long long)k.OH * k.OW * k.ldo * 2 < 0x7fffffffll &&
@@ -2866,6 +2872,33 @@ int din_conv_fwd(const din_conv_desc* d, const void* in, const void* wpk, const 
     k.w_bytes = din_conv_packed_elems(d, 0) * (d->dtype == DIN_F32 ? 4 : 2);
     GatherPlan g = plan_gather(k.M, d->cin, d->cout, d->kh * d->kw, d->dtype);
     return run_gather(k, g, d->dtype, workspace, workspace_bytes, as_stream(stream), "conv_fwd");
+}
+
+int din_conv_fwd2(const din_conv_desc* d, const void* in, const void* wpk, const float* bias, void* out, void* out2, int ldo2, int cooff2,
+                  int csplit, int flags, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    DIN_REQUIRE(in && wpk && out && out2, "conv_fwd2: null pointer");
+    DIN_REQUIRE(!(flags & DIN_CONV_BIAS) || bias, "conv_fwd2: BIAS flag without bias");
+    DIN_REQUIRE(!(flags & (DIN_CONV_ACCUM | DIN_CONV_MASK)), "conv_fwd2: ACCUM/MASK are dgrad-only flags");
+    const int epc = epc_of(d->dtype);
+    DIN_REQUIRE(d->kh * d->kw <= 32 && d->dh == 1 && d->dw == 1, "conv_fwd2: needs the buffer-addressed gather kernel (<= 32 taps)");
+    DIN_REQUIRE(csplit > 0 && csplit < d->cout && csplit % epc == 0 && d->cout % epc == 0 && d->ldo % epc == 0 && d->cooff % epc == 0 &&
+                ldo2 % epc == 0 && cooff2 % epc == 0 && ldo2 >= cooff2 + (d->cout - csplit) && d->ldo >= d->cooff + csplit,
+                "conv_fwd2: split / strides / offsets must be multiples of %d and the destinations must hold their channel ranges", epc);
+    ConvK k{};
+    k.in = in; k.w = wpk; k.out = out; k.bias = bias; k.mask = nullptr; k.partial = nullptr;
+    k.out2 = out2; k.ldo2 = ldo2; k.cooff2 = cooff2; k.csplit = csplit;
+    k.NB = d->nb; k.H = d->h; k.W = d->w; k.Cin = d->cin; k.ldi = d->ldi; k.cioff = d->cioff;
+    k.OH = d->oh; k.OW = d->ow; k.Cout = d->cout; k.ldo = d->ldo; k.cooff = d->cooff;
+    k.kh = d->kh; k.kw = d->kw;
+    k.ay = d->sh; k.by = -d->ph; k.cy = d->dh; k.divy = 1;
+    k.ax = d->sw; k.bx = -d->pw; k.cx = d->dw; k.divx = 1;
+    k.M = d->nb * d->oh * d->ow; k.flags = flags; k.ldm = 0; k.moff = 0;
+    k.in_bytes = (long long)d->nb * d->h * d->w * d->ldi * (d->dtype == DIN_F32 ? 4 : 2);
+    k.w_bytes = din_conv_packed_elems(d, 0) * (d->dtype == DIN_F32 ? 4 : 2);
+    GatherPlan g = plan_gather(k.M, d->cin, d->cout, d->kh * d->kw, d->dtype);
+    if (g.splitk > 1) DIN_FAIL(DIN_E_ARG, "conv_fwd2: this shape runs split-K (%d pixels): launch the sibling convs separately", k.M);
+    return run_gather(k, g, d->dtype, workspace, workspace_bytes, as_stream(stream), "conv_fwd2");
 }
 
 int din_conv_dgrad(const din_conv_desc* d, const void* dout, const void* wpk_t, void* din_, const void* mask, int ldm,

@@ -60,6 +60,7 @@ PROFILE = None
 GRAD_HOOK = None
 import os as _os
 FUSE_1X1_DGRAD = _os.environ.get("DIN_FUSE_1X1", "1") != "0"     # fuse the dgrads of 1x1 convs that read the same tensor
+FUSE_FWD_SIBLINGS = _os.environ.get("DIN_FUSE_FWD", "1") != "0"   # run Graph.fwd_groups (sibling 1x1 convs) as one two-destination launch
 
 
 def _conv_flops(d) -> float:
@@ -210,6 +211,8 @@ class Graph:
     input_tid: int = 0
     output_tids: List[int] = field(default_factory=list)
     cin_image: int = 3
+    fwd_groups: List[Tuple[int, ...]] = field(default_factory=list)   # consecutive sibling conv ops (same source view, same 1x1 geometry) whose
+                                                                      # forward runs as ONE launch: first member -> its own view, the rest -> adjacent views of one tensor
 
     def add_tensor(self, h, w, c) -> int:
         self.tensors.append(TensorSpec(h, w, c))
@@ -262,6 +265,19 @@ class GraphBuilder:
         td.relu_masked = td.relu_masked or relu
         self.g.ops.append(Op("conv", src, dst, name, tuple(k), tuple(s), tuple(p), relu, bias, bn, pooled))
         return dst
+
+    def fuse_forward(self, n_last: int) -> None:
+        """Declare the last n_last conv ops a forward group (see Graph.fwd_groups); checks the layout the fused launch needs."""
+        idx = tuple(range(len(self.g.ops) - n_last, len(self.g.ops)))
+        ops = [self.g.ops[i] for i in idx]
+        a = ops[0]
+        assert all(o.kind == "conv" and o.src == a.src and o.k == a.k and o.s == a.s and o.p == a.p and o.bn == a.bn and o.bias == a.bias
+                   and o.relu == a.relu and o.pooled is None for o in ops), "fused siblings must share source and geometry"
+        rest = ops[1:]
+        assert all(o.dst.tid == rest[0].dst.tid for o in rest) and rest[0].dst.tid != a.dst.tid
+        for x, y in zip(rest, rest[1:]):
+            assert y.dst.coff == x.dst.coff + x.dst.c, "second-destination views must be adjacent"
+        self.g.fwd_groups.append(idx)
 
     def pool(self, kind, src: View, k, s, p, dst: Optional[View] = None) -> View:
         ts = self.g.tensors[src.tid]
@@ -374,6 +390,8 @@ def _pack_cache(g: Graph, params: Sequence[torch.Tensor], dt: int, dev, with_tra
     pc.wpk, pc.wpt = {}, {}
     descs, layer_of, chunk_index = [], [], []
     pos, bn_i = 0, 0
+    src_of: Dict[int, tuple] = {}
+    pc.wfused = {}
     for oi, op in enumerate(g.ops):
         if op.kind != "conv":
             continue
@@ -388,6 +406,7 @@ def _pack_cache(g: Graph, params: Sequence[torch.Tensor], dt: int, dev, with_tra
             pos += 5
         else:
             pos += 2 if op.bias else 1
+        src_of[oi] = (w, scale_ptr)
         for transposed in ((0, 1) if (with_transposed and op.src.tid != g.input_tid) else (0,)):
             n_el = lib.din_conv_packed_elems(C.byref(d), transposed)
             buf = torch.empty(n_el, dtype=tdt, device=dev)
@@ -399,6 +418,30 @@ def _pack_cache(g: Graph, params: Sequence[torch.Tensor], dt: int, dev, with_tra
             nchunk = (n_el + PACK_CHUNK - 1) // PACK_CHUNK
             layer_of += [li] * nchunk
             chunk_index += list(range(nchunk))
+    # forward groups: the siblings' banks packed row after row into ONE bank (each member writes exactly its own rows; the tail rows of
+    # the zero-initialised buffer stay zero), so the fused launch sees a single conv with cout = sum of the members
+    esz = 4 if dt == L.DIN_F32 else 2
+    for grp in g.fwd_groups:
+        a = g.ops[grp[0]]
+        dF = _conv_desc(g, a, 1, dt, a.src.c)
+        dF.cout = sum(g.ops[i].dst.c for i in grp)
+        fused = torch.zeros(lib.din_conv_packed_elems(C.byref(dF), 0), dtype=tdt, device=dev)
+        pc.wfused[grp[0]] = fused
+        row0 = 0
+        for oi in grp:
+            op = g.ops[oi]
+            d = _conv_desc(g, op, 1, dt, op.src.c)
+            w, scale_ptr = src_of[oi]
+            pd = L.PackDesc()
+            L.check(lib.din_conv_pack_desc(C.byref(d), _ptr(w), scale_ptr, _ptr(fused), 0, C.byref(pd)), "conv_pack_desc(fused)")
+            pd.out = fused.data_ptr() + row0 * pd.kelems * esz
+            pd.rows_pad = pd.rows
+            li = len(descs)
+            descs.append(pd)
+            nchunk = (pd.rows * pd.kelems + PACK_CHUNK - 1) // PACK_CHUNK
+            layer_of += [li] * nchunk
+            chunk_index += list(range(nchunk))
+            row0 += op.dst.c
     raw = (L.PackDesc * len(descs))(*descs)
     host = torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8).clone()
     pc.table = host.to(dev)
@@ -429,6 +472,8 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
     # ... and every filter bank (forward and, when training, dgrad orientation) repacked with the folded scale in ONE launch
     L.check(lib.din_conv_pack_multi(_ptr(pc.table), _ptr(pc.layer_of), _ptr(pc.chunk_index), pc.nblocks, PACK_CHUNK, st), "conv_pack_multi")
     bn_i = 0
+    group_of = {grp[0]: grp for grp in g.fwd_groups} if FUSE_FWD_SIBLINGS else {}
+    fused_done = set()                                     # members whose output the group launch already produced
     for oi, op in enumerate(g.ops):
         td = g.tensors[op.dst.tid]
         if bufs[op.dst.tid] is None:
@@ -447,6 +492,29 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
                 bias = shift
             else:
                 bias = next(it) if op.bias else None
+            if oi in fused_done:
+                aux.append((scale,))
+                continue
+            if oi in group_of and op.bn:
+                # sibling convs of one source: ONE launch over the concatenated filter bank, first member into its own view, the others into
+                # the adjacent views of their shared tensor (din_conv_fwd2).  Shapes that would run split-K fall through to separate launches.
+                grp = group_of[oi]
+                rest = [g.ops[i] for i in grp[1:]]
+                ctot = op.dst.c + sum(o.dst.c for o in rest)
+                dF = _conv_desc(g, op, nb, dt, cin)
+                dF.cout = ctot
+                t2 = rest[0].dst.tid
+                td2 = g.tensors[t2]
+                if lib.din_conv_workspace_bytes(C.byref(dF), 0) == 0 and bn.off_list[bn_i - 1 + len(grp)] - o0 == ctot:
+                    if bufs[t2] is None:
+                        bufs[t2] = torch.empty((nb, td2.h, td2.w, td2.c), dtype=tdt, device=dev)
+                    flags = L.CONV_BIAS | (L.CONV_RELU if op.relu else 0)
+                    with _timed("fwd", dF, "+".join(g.ops[i].name for i in grp)):
+                        L.check(lib.din_conv_fwd2(C.byref(dF), _ptr(src), _ptr(pc.wfused[oi]), _ptr(bn_shift[o0:o0 + ctot]), _ptr(dst),
+                                                  _ptr(bufs[t2]), td2.c, rest[0].dst.coff, op.dst.c, flags, None, 0, st), "conv_fwd2 " + op.name)
+                    fused_done.update(grp[1:])
+                    aux.append((scale,))
+                    continue
             wpk = pc.wpk[oi]
             flags = (L.CONV_BIAS if bias is not None else 0) | (L.CONV_RELU if op.relu else 0)
             if op.pooled is not None:
@@ -507,15 +575,46 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 t_.record_stream(side)
         return C.c_void_p(side.cuda_stream)
 
+    gwritten: Dict[int, List[Tuple[int, int]]] = {}          # tid -> channel ranges already written (buffers this pass allocated un-zeroed)
+
+    def partitioned(tid: int) -> bool:
+        """True when the readers of tensor tid use pairwise identical-or-disjoint channel views that together cover every producer's view:
+        then each channel range of the gradient is first WRITTEN by its first reader (no zero fill, no accumulate), and nothing is read
+        before it was written (temporaries of sibling convs that share one tensor)."""
+        cons = sorted({(o.src.coff, o.src.c) for o in g.ops if o.src.tid == tid})
+        for (a0, ac), (b0, bc_) in zip(cons, cons[1:]):
+            if b0 < a0 + ac:
+                return False
+        for o in g.ops:
+            if o.dst.tid == tid:
+                lo, hi = o.dst.coff, o.dst.coff + o.dst.c
+                for c0, cc in cons:
+                    if c0 <= lo < c0 + cc:
+                        lo = min(hi, c0 + cc)
+                if lo < hi:
+                    return False
+        return True
+
     def grad_target(view: View) -> Tuple[torch.Tensor, bool]:
         """gradient buffer of view.tid and whether to accumulate into it"""
         ts = g.tensors[view.tid]
+        rng = (view.coff, view.c)
         if view.tid in gbufs:
-            return gbufs[view.tid], True
+            wr = gwritten.get(view.tid)
+            if wr is None:                                  # handed in by the caller or zero-filled: always add
+                return gbufs[view.tid], True
+            acc = any(rng[0] < r0 + rc and r0 < rng[0] + rng[1] for r0, rc in wr)
+            wr.append(rng)
+            return gbufs[view.tid], acc
         full = view.coff == 0 and view.c == ts.c
-        buf = (torch.empty if full else torch.zeros)((nb, ts.h, ts.w, ts.c), dtype=tdt, device=dev)
+        if full or partitioned(view.tid):
+            buf = torch.empty((nb, ts.h, ts.w, ts.c), dtype=tdt, device=dev)
+            gwritten[view.tid] = [rng]
+            gbufs[view.tid] = buf
+            return buf, False
+        buf = torch.zeros((nb, ts.h, ts.w, ts.c), dtype=tdt, device=dev)
         gbufs[view.tid] = buf
-        return buf, (not full)
+        return buf, True
 
     # index params per conv op
     offsets, pos = [], 0

@@ -151,6 +151,70 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
         assert rel(from_nhwc(dx, cin), want) <= 2 * tolg
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_conv_fwd_two_destinations(env, dtype):
+    """din_conv_fwd2: sibling 1x1 convs of one input as ONE launch -- channels [0, csplit) into the first tensor's view, the rest into a second
+    tensor; equals the separate convs, and nothing outside the two channel ranges is touched."""
+    lib, L, nhwc, ops = env
+    dt = L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
+    tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    g = torch.Generator().manual_seed(21)
+    nb, h, w, cin = 2, 40, 48, 192
+    couts = (64, 48, 64)
+    ctot = sum(couts)
+    x = torch.randn(nb, cin, h, w, generator=g)
+    ws_ = [torch.randn(c, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5 for c in couts]
+    bias = torch.randn(ctot, generator=g) * 0.1
+    if dtype == "bf16":
+        x, ws_ = x.bfloat16().float(), [t.bfloat16().float() for t in ws_]
+    ref = F.relu(F.conv2d(x, torch.cat(ws_), bias))
+    ldi, ld1, off1, ld2, off2 = cin, 256, 8, 128, 8
+    d = L.ConvDesc()
+    d.nb, d.h, d.w, d.cin, d.oh, d.ow, d.cout = nb, h, w, cin, h, w, ctot
+    d.kh = d.kw = d.sh = d.sw = d.dh = d.dw = 1
+    d.ph = d.pw = 0
+    d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = ldi, 0, ld1, off1, dt
+    xin = to_nhwc(x, tdt, ldi)
+    # the fused bank: every sibling packed at its row offset (what nhwc._pack_cache does with din_conv_pack_desc / din_conv_pack_multi)
+    bank = torch.zeros(lib.din_conv_packed_elems(C.byref(d), 0), dtype=tdt, device="cuda")
+    esz = 4 if dtype == "fp32" else 2
+    keep, descs, row0 = [], [], 0
+    for wt in ws_:
+        dm = L.ConvDesc()
+        for f, _ in L.ConvDesc._fields_:
+            setattr(dm, f, getattr(d, f))
+        dm.cout = wt.shape[0]
+        wd = wt.cuda()
+        keep.append(wd)
+        pd = L.PackDesc()
+        L.check(lib.din_conv_pack_desc(C.byref(dm), wd.data_ptr(), None, bank.data_ptr(), 0, C.byref(pd)))
+        pd.out = bank.data_ptr() + row0 * pd.kelems * esz
+        pd.rows_pad = pd.rows
+        descs.append(pd)
+        row0 += wt.shape[0]
+    chunk = 4096
+    layer_of, chunk_index = [], []
+    for li, pd in enumerate(descs):
+        n = (pd.rows * pd.kelems + chunk - 1) // chunk
+        layer_of += [li] * n
+        chunk_index += list(range(n))
+    raw = (L.PackDesc * len(descs))(*descs)
+    table = torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8).clone().cuda()
+    lo, ci = torch.tensor(layer_of, dtype=torch.int32).cuda(), torch.tensor(chunk_index, dtype=torch.int32).cuda()
+    L.check(lib.din_conv_pack_multi(table.data_ptr(), lo.data_ptr(), ci.data_ptr(), len(layer_of), chunk, None))
+    out1 = torch.full((nb, h, w, ld1), 7.0, dtype=tdt, device="cuda")
+    out2 = torch.full((nb, h, w, ld2), 7.0, dtype=tdt, device="cuda")
+    bdev = bias.cuda()
+    L.check(lib.din_conv_fwd2(C.byref(d), xin.data_ptr(), bank.data_ptr(), bdev.data_ptr(), out1.data_ptr(), out2.data_ptr(), ld2, off2,
+                              couts[0], L.CONV_BIAS | L.CONV_RELU, None, 0, None))
+    torch.cuda.synchronize()
+    tol = 2e-5 if dtype == "fp32" else 1.5e-2
+    assert rel(from_nhwc(out1, couts[0], off1), ref[:, :couts[0]]) <= tol
+    assert rel(from_nhwc(out2, ctot - couts[0], off2), ref[:, couts[0]:]) <= tol
+    assert float(out1[..., :off1].float().min()) == 7.0 and float(out1[..., off1 + couts[0]:].float().min()) == 7.0
+    assert float(out2[..., :off2].float().min()) == 7.0 and float(out2[..., off2 + ctot - couts[0]:].float().min()) == 7.0
+
+
 def test_wgrad_reduce_on_second_stream_matches(env):
     """din_wgrad_set_reduce_stream / din_wgrad_reduce_join: the slice reduce enqueued on a second stream gives the same dW bit for bit,
     back-to-back launches that share the workspace stay ordered, and NULL restores the single-stream behaviour."""

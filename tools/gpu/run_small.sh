@@ -1,3 +1,5 @@
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 600 python bench.py 2>&1 | tail -1 | cut -c1-300
+for f in 1 0; do
+echo fuse_fwd=$f
+DIN_FUSE_FWD=$f timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-180
+DIN_FUSE_FWD=$f timeout 600 python bench.py --steps 10 --warmup 2 --global-batch 4 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-180
+done
