@@ -235,12 +235,19 @@ class MyInception_v3(_GraphBackbone):
         v = View(out_tid, 0, 768)
         for blk in ("Mixed_6b.", "Mixed_6c.", "Mixed_6d.", "Mixed_6e."):
             out_tid = gb.tensor(h6, w6, 768)
+            c7 = spec[blk + "branch7x7_1"][2]
             bc(blk + "branch1x1", v, View(out_tid, 0, 192))
-            t = bc(blk + "branch7x7_1", v)
-            t = bc(blk + "branch7x7_2", t)
+            if os.environ.get("DIN_FUSE_FWD6", "1") != "0":
+                tmp_tid = gb.tensor(h6, w6, 2 * c7)
+                t7 = bc(blk + "branch7x7_1", v, View(tmp_tid, 0, c7))
+                td = bc(blk + "branch7x7dbl_1", v, View(tmp_tid, c7, c7))
+                gb.fuse_forward(3)
+            else:
+                t7 = bc(blk + "branch7x7_1", v)
+                td = bc(blk + "branch7x7dbl_1", v)
+            t = bc(blk + "branch7x7_2", t7)
             bc(blk + "branch7x7_3", t, View(out_tid, 192, 192))
-            t = bc(blk + "branch7x7dbl_1", v)
-            t = bc(blk + "branch7x7dbl_2", t)
+            t = bc(blk + "branch7x7dbl_2", td)
             t = bc(blk + "branch7x7dbl_3", t)
             t = bc(blk + "branch7x7dbl_4", t)
             bc(blk + "branch7x7dbl_5", t, View(out_tid, 384, 192))
