@@ -61,6 +61,7 @@ GRAD_HOOK = None
 import os as _os
 FUSE_1X1_DGRAD = _os.environ.get("DIN_FUSE_1X1", "1") != "0"     # fuse the dgrads of 1x1 convs that read the same tensor
 FUSE_FWD_SIBLINGS = _os.environ.get("DIN_FUSE_FWD", "1") != "0"   # run Graph.fwd_groups (sibling 1x1 convs) as one two-destination launch
+FUSE_WGRAD_SIBLINGS = _os.environ.get("DIN_FUSE_WGRAD", "1") != "0"  # ... and the wgrads of the members that share the second tensor as one launch
 
 
 def _conv_flops(d) -> float:
@@ -676,6 +677,10 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                     "conv1x1_dgrad_multi")
         pending[key] = []
 
+    # sibling groups: the members behind the first one share a tensor -> one wgrad launch, issued when the LAST of them comes up (the
+    # reverse pass reaches it first; by then the consumers of every member have written their slice of the shared gradient buffer)
+    wgrad_group = {grp[-1]: tuple(grp[1:]) for grp in g.fwd_groups if len(grp) >= 3} if FUSE_WGRAD_SIBLINGS else {}
+    wgrad_done = set()
     for oi in range(len(g.ops) - 1, -1, -1):
         op = g.ops[oi]
         if op.dst.tid not in gbufs:
@@ -709,9 +714,39 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 L.check(lib.din_avgpool_bwd(C.byref(pd), _ptr(gout), _ptr(gtmp), None, 0, st), "avgpool_bwd(epilogue)")
                 gout, g_ld, g_coff = gtmp, pd.c, 0
             # ---- wgrad (+ bias / BN parameter gradients): on the side stream when enabled
-            dw = torch.empty_like(w)
-            wsbytes = lib.din_conv_workspace_bytes(C.byref(d), 2)
-            if op.bn:
+            if oi in wgrad_done:
+                pass                                              # produced by the group launch of a sibling (below)
+            elif oi in wgrad_group and op.bn and side is None:
+                # the members of a forward group that share the second tensor: their output gradients are adjacent channel views of ONE
+                # buffer, their BatchNorm slots adjacent -> one wgrad over the concatenated filter rows; dW lands in one buffer whose
+                # row ranges are the members' gradients
+                mem = wgrad_group[oi]
+                mops = [g.ops[i] for i in mem]
+                ctot = sum(o.dst.c for o in mops)
+                dF = _conv_desc(g, mops[0], nb, dt, cin)
+                dF.cout = ctot
+                o0, o1 = bn.off_list[bn_index[mem[0]]], bn.off_list[bn_index[mem[-1]] + 1]
+                assert o1 - o0 == ctot
+                wcat = torch.cat([params[offsets[i]] for i in mem])
+                dwf = torch.empty_like(wcat)
+                bn_touched = True
+                ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(dF), 2), dev, wtag)
+                with _timed("wgrad", dF, "+".join(o.name for o in mops)):
+                    L.check(lib.din_conv_wgrad(C.byref(dF), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dwf), _ptr(bn_dshift[o0:o1]),
+                                               _ptr(pcache.bn_scale[o0:o1]), _ptr(wcat), _ptr(bn_wdot[o0:o1]), 2, _ptr(ws), wsb, st),
+                            "conv_wgrad " + mops[0].name + "+")
+                r0 = 0
+                for i, o in zip(mem, mops):
+                    grads[offsets[i]] = dwf[r0:r0 + o.dst.c]
+                    r0 += o.dst.c
+                    if GRAD_HOOK is not None:
+                        GRAD_HOOK(params[offsets[i]], grads[offsets[i]])
+                wgrad_done.update(mem)
+            if oi in wgrad_done:
+                dw = grads[po]
+            elif op.bn:
+                dw = torch.empty_like(w)
+                wsbytes = lib.din_conv_workspace_bytes(C.byref(d), 2)
                 o0, o1 = bn.off_list[bn_index[oi]], bn.off_list[bn_index[oi] + 1]
                 dshift, wdot = bn_dshift[o0:o1], bn_wdot[o0:o1]          # views of the pre-zeroed flat accumulators
                 bn_touched = True
@@ -728,6 +763,8 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                                                _ptr(w), _ptr(wdot), 2, _ptr(ws), wsb, stw), "conv_wgrad " + op.name)
                 grads[po] = dw
             else:
+                dw = torch.empty_like(w)
+                wsbytes = lib.din_conv_workspace_bytes(C.byref(d), 2)
                 db = (dshift_pre if dshift_pre is not None else torch.empty_like(params[po + 1])) if op.bias else None
                 if side is not None:
                     stw = on_side([bufs[op.src.tid], gout, dw, db])
@@ -743,7 +780,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 grads[po] = dw
                 if op.bias:
                     grads[po + 1] = db
-            if GRAD_HOOK is not None and side is None:
+            if GRAD_HOOK is not None and side is None and oi not in wgrad_done:
                 GRAD_HOOK(w, dw)
             # ---- dgrad
             if src_needs_grad and oi in member_of:
