@@ -1,6 +1,6 @@
-timeout 1500 python -m pytest tests/test_gpu_din_model.py -x -q 2>&1 | tail -4
-for f in 1 0; do
-echo fuse_wgrad=$f
-DIN_FUSE_WGRAD=$f timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-180
-DIN_FUSE_WGRAD=$f timeout 600 python bench.py --steps 10 --warmup 2 --global-batch 4 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-180
-done
+bash tools/gpu/run_profiles.sh > /dev/null 2>&1
+bash tools/gpu/run_layers.sh > /dev/null 2>&1
+bash tools/gpu/run_pmc.sh > /dev/null 2>&1
+bash tools/gpu/run_prof4.sh > /dev/null 2>&1
+timeout 600 python bench.py --steps 5 --warmup 2 --forward-only --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_fwd_only.json
+ls gpurun_out/p gpurun_out/prof gpurun_out/pmcb/fetch | head -30
