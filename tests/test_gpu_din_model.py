@@ -218,6 +218,42 @@ def test_inception_bf16_features_and_grads_track_fp32(gpu):
         assert cos >= 0.9, (k, cos)
 
 
+def test_inception_sibling_fusion_matches_separate_launches(gpu, monkeypatch):
+    """The fused sibling launches (one two-destination forward conv + one wgrad for the convs that share a tensor, nhwc.Graph.fwd_groups)
+    against the same backbone with every conv launched on its own: fp32, features equal to 1e-6 rel (same k order per output), parameter
+    gradients to 1e-5 rel (the wgrad slices differ)."""
+    from din_amd import nhwc
+    from din_amd.backbone.backbone import MyInception_v3
+    g = torch.Generator().manual_seed(41)
+    images = torch.randint(0, 256, (2, 3, 203, 267), generator=g, dtype=torch.uint8)
+    ref = MyInception_v3(compute_dtype="fp32")
+    sd = {}
+    for k, v in ref.state_dict().items():
+        if not v.dtype.is_floating_point:
+            sd[k] = v
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(v.shape, generator=g) + 0.5
+        elif k.endswith("conv.weight"):
+            sd[k] = torch.randn(v.shape, generator=g) * (2.0 / (v.shape[1] * v.shape[2] * v.shape[3])) ** 0.5
+        else:
+            sd[k] = torch.randn(v.shape, generator=g) * 0.1 + (1.0 if k.endswith("bn.weight") else 0.0)
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(nhwc, "FUSE_FWD_SIBLINGS", fused)
+        monkeypatch.setattr(nhwc, "FUSE_WGRAD_SIBLINGS", fused)
+        m = MyInception_v3(compute_dtype="fp32")
+        m.load_state_dict(sd)
+        m = m.to(gpu).eval()
+        feats = m(images.to(gpu))
+        sum((f.float() ** 2).mean() for f in feats).backward()
+        outs.append(([f.detach() for f in feats], {k: p.grad.detach() for k, p in m.named_parameters() if p.grad is not None}))
+    for fa, fb in zip(outs[0][0], outs[1][0]):
+        assert rel(fa, fb) <= 1e-6
+    assert outs[0][1].keys() == outs[1][1].keys()
+    for k, gb_ in outs[1][1].items():
+        assert rel(outs[0][1][k], gb_) <= 1e-5, k
+
+
 def test_hierarchical_din_matches_reference_golden(gpu, golden_dir):
     """row D7: DPI_1 -> LN -> ReLU -> (dropout off) -> DPI_2 at the only shape the reference allows (T=10, N=12, C=1024)"""
     from din_amd.infer_module.dynamic_infer_module import Hierarchical_Dynamic_Inference
