@@ -65,7 +65,7 @@ SIGNATURES: Dict[str, tuple] = {
     "din_wgrad_reduce_join": (_I, [_P]),
     "din_conv_workspace_bytes": (_L, [_CD, _I]),
     "din_conv_fwd": (_I, [_CD, _P, _P, _P, _P, _I, _P, _L, _P]),
-    "din_conv_fwd2": (_I, [_CD, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P]),
+    "din_conv_fwd2": (_I, [_CD, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "din_conv_dgrad": (_I, [_CD, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P]),
     "din_conv1x1_dgrad_multi": (_I, [_I, C.POINTER(ConvSrc), _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
     "din_conv_wgrad": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P]),

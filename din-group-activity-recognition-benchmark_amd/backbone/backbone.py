@@ -186,9 +186,10 @@ class MyInception_v3(_GraphBackbone):
         # pool moves cout (32..192) instead of cin (192..768) channels.  DIN_POOL_COMMUTE=0 keeps the reference's op order.
         commute = os.environ.get("DIN_POOL_COMMUTE", "1") != "0"
 
-        def branch_pool(name, src: View, dst: View):
+        def branch_pool(name, src: View, dst: View, mid=None):
             if commute:
-                return bc(name, src, dst, pooled=(3, 1, 1))
+                _, _cin, cout, k, s, p = spec[name]
+                return gb.conv(name, src, cout, k, s, p, relu=True, bn=True, dst=dst, pooled=(3, 1, 1), mid=mid)
             return bc(name, gb.pool("avgpool", src, 3, 1, 1), dst)
 
         v = gb.full(gb.g.input_tid)
@@ -212,15 +213,21 @@ class MyInception_v3(_GraphBackbone):
                 out_tid, base = gb.tensor(h5, w5, ctot), 0
             # the three 1x1 convs that read the block input are laid out for ONE forward launch (nhwc.Graph.fwd_groups): consecutive ops,
             # the two temporaries adjacent views of one tensor.  Separately they are three 64-wide launches bound by re-reading the input.
-            tmp_tid = gb.tensor(h5, w5, 48 + 64)
+            # opt-in: the branch_pool conv as a fourth, raw-stored sibling (din_conv_fwd2 craw).  Measured no gain (64.55 vs 64.49 ms/step): 208 / 240
+            # filters need two 128-wide tiles instead of one 192-wide tile for the three-way group
+            pool4 = commute and os.environ.get("DIN_FUSE_POOL", "0") != "0"
+            tmp_tid = gb.tensor(h5, w5, 48 + 64 + (pf if pool4 else 0))
             bc(blk + "branch1x1", v, View(out_tid, base, 64))
             t5 = bc(blk + "branch5x5_1", v, View(tmp_tid, 0, 48))
             t3 = bc(blk + "branch3x3dbl_1", v, View(tmp_tid, 48, 64))
-            gb.fuse_forward(3)
+            if pool4:
+                branch_pool(blk + "branch_pool", v, View(out_tid, base + 224, pf), mid=View(tmp_tid, 112, pf))
+            gb.fuse_forward(4 if pool4 else 3)
             bc(blk + "branch5x5_2", t5, View(out_tid, base + 64, 64))
             t = bc(blk + "branch3x3dbl_2", t3)
             bc(blk + "branch3x3dbl_3", t, View(out_tid, base + 128, 96))
-            branch_pool(blk + "branch_pool", v, View(out_tid, base + 224, pf))
+            if not pool4:
+                branch_pool(blk + "branch_pool", v, View(out_tid, base + 224, pf))
             v = View(out_tid, base, ctot)
         v5d = v
         # Mixed_6a (InceptionB)

@@ -57,6 +57,7 @@ struct ConvK {
     // second destination (fused sibling convs that read one tensor): produced channels >= csplit go to out2 (pixel stride ldo2, channel
     // offset cooff2 + (channel - csplit)); csplit == 0: single destination.  Staged (aligned) epilogue only, no mask / accumulate.
     void* out2; int ldo2, cooff2, csplit;
+    int craw;                       // > 0: produced channels >= craw get neither bias nor ReLU (a sibling whose epilogue runs later, after its pool)
 };
 
 __device__ __forceinline__ int64_t out_pixel(const ConvK& p, int m) {
@@ -602,11 +603,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
         for (int i = 0; i < TI; ++i) {
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
             const int co = co_tile * BN + co_l + i * 16;
-            if ((p.flags & DIN_CONV_BIAS) && co < p.Cout) bv = *reinterpret_cast<const f32x4*>(p.bias + co);   // Cout % 4 == 0 here
+            const bool cooked = p.craw <= 0 || co < p.craw;             // (craw is a multiple of 4: uniform over the lane's 4 channels)
+            if ((p.flags & DIN_CONV_BIAS) && co < p.Cout && cooked) bv = *reinterpret_cast<const f32x4*>(p.bias + co);   // Cout % 4 == 0 here
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 f32x4 v = acc[i][j] + bv;
-                if (p.flags & DIN_CONV_RELU) {
+                if ((p.flags & DIN_CONV_RELU) && cooked) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
@@ -2875,7 +2877,7 @@ int din_conv_fwd(const din_conv_desc* d, const void* in, const void* wpk, const 
 }
 
 int din_conv_fwd2(const din_conv_desc* d, const void* in, const void* wpk, const float* bias, void* out, void* out2, int ldo2, int cooff2,
-                  int csplit, int flags, void* workspace, int64_t workspace_bytes, void* stream) {
+                  int csplit, int craw, int flags, void* workspace, int64_t workspace_bytes, void* stream) {
     if (int e = check_desc(d)) return e;
     DIN_REQUIRE(in && wpk && out && out2, "conv_fwd2: null pointer");
     DIN_REQUIRE(!(flags & DIN_CONV_BIAS) || bias, "conv_fwd2: BIAS flag without bias");
@@ -2887,7 +2889,8 @@ int din_conv_fwd2(const din_conv_desc* d, const void* in, const void* wpk, const
                 "conv_fwd2: split / strides / offsets must be multiples of %d and the destinations must hold their channel ranges", epc);
     ConvK k{};
     k.in = in; k.w = wpk; k.out = out; k.bias = bias; k.mask = nullptr; k.partial = nullptr;
-    k.out2 = out2; k.ldo2 = ldo2; k.cooff2 = cooff2; k.csplit = csplit;
+    DIN_REQUIRE(craw == 0 || (craw >= csplit && craw < d->cout && craw % epc == 0), "conv_fwd2: craw must be 0 or a multiple of %d in [csplit, cout)", epc);
+    k.out2 = out2; k.ldo2 = ldo2; k.cooff2 = cooff2; k.csplit = csplit; k.craw = craw;
     k.NB = d->nb; k.H = d->h; k.W = d->w; k.Cin = d->cin; k.ldi = d->ldi; k.cioff = d->cioff;
     k.OH = d->oh; k.OW = d->ow; k.Cout = d->cout; k.ldo = d->ldo; k.cooff = d->cooff;
     k.kh = d->kh; k.kw = d->kw;

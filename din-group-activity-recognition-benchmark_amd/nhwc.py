@@ -203,6 +203,7 @@ class Op:
     bn: bool = False        # conv followed by BatchNorm (Inception BasicConv2d)
     pooled: Optional[Tuple[int, int, int]] = None   # (k, s, p): the reference runs avg_pool2d(k, s, p) on src BEFORE this 1x1 conv
                                                     # (InceptionA/C branch_pool); executed as conv1x1 -> avgpool(+shift, ReLU) on cout channels
+    mid: Optional[View] = None                      # pooled convs only: where the raw conv output goes when the conv runs inside a forward group
 
 
 @dataclass
@@ -239,6 +240,11 @@ def conv_out(h, k, s, p, d=1):
     return (h + 2 * p - d * (k - 1) - 1) // s + 1
 
 
+def group_view(op: Op) -> Optional[View]:
+    """where a forward-group member's conv output lands: its dst, or `mid` for a conv whose pool was commuted behind it"""
+    return op.mid if op.pooled is not None else op.dst
+
+
 class GraphBuilder:
     """Tiny helper used by backbone/backbone.py to lay out the layer tables."""
 
@@ -253,7 +259,7 @@ class GraphBuilder:
         return View(tid, 0, self.g.tensors[tid].c)
 
     def conv(self, name, src: View, cout, k, s=(1, 1), p=(0, 0), relu=True, bias=False, bn=False,
-             dst: Optional[View] = None, pooled: Optional[Tuple[int, int, int]] = None) -> View:
+             dst: Optional[View] = None, pooled: Optional[Tuple[int, int, int]] = None, mid: Optional[View] = None) -> View:
         ts = self.g.tensors[src.tid]
         oh, ow = conv_out(ts.h, k[0], s[0], p[0]), conv_out(ts.w, k[1], s[1], p[1])
         if pooled is not None:
@@ -264,20 +270,25 @@ class GraphBuilder:
         td = self.g.tensors[dst.tid]
         assert (td.h, td.w) == (oh, ow) and dst.c == cout, (name, td, oh, ow)
         td.relu_masked = td.relu_masked or relu
-        self.g.ops.append(Op("conv", src, dst, name, tuple(k), tuple(s), tuple(p), relu, bias, bn, pooled))
+        assert mid is None or pooled is not None
+        self.g.ops.append(Op("conv", src, dst, name, tuple(k), tuple(s), tuple(p), relu, bias, bn, pooled, mid))
         return dst
 
     def fuse_forward(self, n_last: int) -> None:
-        """Declare the last n_last conv ops a forward group (see Graph.fwd_groups); checks the layout the fused launch needs."""
+        """Declare the last n_last conv ops a forward group (see Graph.fwd_groups); checks the layout the fused launch needs.  Members
+        with a commuted pool (raw conv output into `mid`, bias + ReLU after the pool) must come last."""
         idx = tuple(range(len(self.g.ops) - n_last, len(self.g.ops)))
         ops = [self.g.ops[i] for i in idx]
         a = ops[0]
+        assert a.pooled is None
         assert all(o.kind == "conv" and o.src == a.src and o.k == a.k and o.s == a.s and o.p == a.p and o.bn == a.bn and o.bias == a.bias
-                   and o.relu == a.relu and o.pooled is None for o in ops), "fused siblings must share source and geometry"
-        rest = ops[1:]
-        assert all(o.dst.tid == rest[0].dst.tid for o in rest) and rest[0].dst.tid != a.dst.tid
-        for x, y in zip(rest, rest[1:]):
-            assert y.dst.coff == x.dst.coff + x.dst.c, "second-destination views must be adjacent"
+                   and o.relu == a.relu for o in ops), "fused siblings must share source and geometry"
+        second = [group_view(o) for o in ops[1:]]
+        assert all(v is not None and v.tid == second[0].tid for v in second) and second[0].tid != a.dst.tid
+        for x, y in zip(second, second[1:]):
+            assert y.coff == x.coff + x.c, "second-destination views must be adjacent"
+        pooled = [o.pooled is not None for o in ops]
+        assert pooled == sorted(pooled), "pooled members last"
         self.g.fwd_groups.append(idx)
 
     def pool(self, kind, src: View, k, s, p, dst: Optional[View] = None) -> View:
@@ -494,6 +505,11 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
             else:
                 bias = next(it) if op.bias else None
             if oi in fused_done:
+                if op.pooled is not None:                   # the group launch left the raw conv output in `mid`: pool + shift + ReLU into dst
+                    _, pd = _pooled_descs(g, op, nb, dt)
+                    pd.ldi, pd.cioff = g.tensors[op.mid.tid].c, op.mid.coff
+                    L.check(lib.din_avgpool_fwd(C.byref(pd), _ptr(bufs[op.mid.tid]), _ptr(dst), _ptr(bias),
+                                                L.CONV_BIAS | (L.CONV_RELU if op.relu else 0), st), "avgpool_fwd(epilogue)")
                 aux.append((scale,))
                 continue
             if oi in group_of and op.bn:
@@ -502,9 +518,11 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
                 grp = group_of[oi]
                 rest = [g.ops[i] for i in grp[1:]]
                 ctot = op.dst.c + sum(o.dst.c for o in rest)
+                craw = ctot - sum(o.dst.c for o in rest if o.pooled is not None)
                 dF = _conv_desc(g, op, nb, dt, cin)
                 dF.cout = ctot
-                t2 = rest[0].dst.tid
+                v2 = group_view(rest[0])
+                t2 = v2.tid
                 td2 = g.tensors[t2]
                 if lib.din_conv_workspace_bytes(C.byref(dF), 0) == 0 and bn.off_list[bn_i - 1 + len(grp)] - o0 == ctot:
                     if bufs[t2] is None:
@@ -512,7 +530,8 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
                     flags = L.CONV_BIAS | (L.CONV_RELU if op.relu else 0)
                     with _timed("fwd", dF, "+".join(g.ops[i].name for i in grp)):
                         L.check(lib.din_conv_fwd2(C.byref(dF), _ptr(src), _ptr(pc.wfused[oi]), _ptr(bn_shift[o0:o0 + ctot]), _ptr(dst),
-                                                  _ptr(bufs[t2]), td2.c, rest[0].dst.coff, op.dst.c, flags, None, 0, st), "conv_fwd2 " + op.name)
+                                                  _ptr(bufs[t2]), td2.c, v2.coff, op.dst.c, craw if craw < ctot else 0, flags, None, 0, st),
+                                "conv_fwd2 " + op.name)
                     fused_done.update(grp[1:])
                     aux.append((scale,))
                     continue
@@ -679,7 +698,12 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
 
     # sibling groups: the members behind the first one share a tensor -> one wgrad launch, issued when the LAST of them comes up (the
     # reverse pass reaches it first; by then the consumers of every member have written their slice of the shared gradient buffer)
-    wgrad_group = {grp[-1]: tuple(grp[1:]) for grp in g.fwd_groups if len(grp) >= 3} if FUSE_WGRAD_SIBLINGS else {}
+    wgrad_group = {}
+    if FUSE_WGRAD_SIBLINGS:
+        for grp in g.fwd_groups:
+            mem = tuple(i for i in grp[1:] if g.ops[i].pooled is None)      # (a commuted-pool member keeps its own wgrad: its gradient
+            if len(mem) >= 2:                                               #  operand is the un-pooled map, a separate buffer)
+                wgrad_group[mem[-1]] = mem
     wgrad_done = set()
     for oi in range(len(g.ops) - 1, -1, -1):
         op = g.ops[oi]

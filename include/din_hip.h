@@ -101,9 +101,10 @@ int din_conv_pack_multi(const din_pack_desc* table, const int32_t* layer_of, con
  * `out2` (pixel stride ldo2, channel offset cooff2).  For sibling convs that read the same tensor (torchvision InceptionA: branch1x1,
  * branch5x5_1, branch3x3dbl_1 -- backbone.py MyInception_v3 via torchvision inception.py InceptionA.forward): one launch over the
  * concatenated filter bank reads the input once and runs on a wide tile.  wpk = the banks of the siblings packed row after row (same cin,
- * kh, kw); bias = their shifts concatenated.  Not available for shapes that need split-K (returns DIN_E_ARG: launch them separately). */
+ * kh, kw); bias = their shifts concatenated.  craw > 0: channels >= craw are stored raw (no bias, no ReLU) -- the branch_pool conv whose
+ * bias + ReLU follow its average pool.  Not available for shapes that need split-K (returns DIN_E_ARG: launch them separately). */
 int din_conv_fwd2(const din_conv_desc* d, const void* in, const void* wpk, const float* bias, void* out, void* out2, int ldo2, int cooff2,
-                  int csplit, int flags, void* workspace, int64_t workspace_bytes, void* stream);
+                  int csplit, int craw, int flags, void* workspace, int64_t workspace_bytes, void* stream);
 /* which tile variant the planner picks (which: 0 fwd, 1 dgrad -> pixels x filters of conv_gather_*_kernel; 2 wgrad -> filter rows x
  * k columns of conv_wgrad_*_kernel, bn = 1000 + k columns for conv_wgrad_ring_kernel; bm = 0 -> the stationary-filter stem kernels
  * conv_small_kernel / conv_wgrad_small_kernel with bn filters; bm = 1 -> conv_halo_kernel): lets a

@@ -205,10 +205,12 @@ def test_conv_fwd_two_destinations(env, dtype):
     out1 = torch.full((nb, h, w, ld1), 7.0, dtype=tdt, device="cuda")
     out2 = torch.full((nb, h, w, ld2), 7.0, dtype=tdt, device="cuda")
     bdev = bias.cuda()
+    craw = couts[0] + couts[1]                               # the last sibling stored raw: no bias, no ReLU (branch_pool conv)
     L.check(lib.din_conv_fwd2(C.byref(d), xin.data_ptr(), bank.data_ptr(), bdev.data_ptr(), out1.data_ptr(), out2.data_ptr(), ld2, off2,
-                              couts[0], L.CONV_BIAS | L.CONV_RELU, None, 0, None))
+                              couts[0], craw, L.CONV_BIAS | L.CONV_RELU, None, 0, None))
     torch.cuda.synchronize()
     tol = 2e-5 if dtype == "fp32" else 1.5e-2
+    ref = torch.cat([ref[:, :craw], F.conv2d(x, ws_[2])], dim=1)
     assert rel(from_nhwc(out1, couts[0], off1), ref[:, :couts[0]]) <= tol
     assert rel(from_nhwc(out2, ctot - couts[0], off2), ref[:, couts[0]:]) <= tol
     assert float(out1[..., :off1].float().min()) == 7.0 and float(out1[..., off1 + couts[0]:].float().min()) == 7.0
