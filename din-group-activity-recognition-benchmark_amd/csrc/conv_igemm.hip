@@ -627,6 +627,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
         const bool act = co < p.Cout && rr < RPP;
         T* __restrict__ outp = reinterpret_cast<T*>(p.out);
         const T* __restrict__ maskp = reinterpret_cast<const T*>(p.mask);
+        if (!(p.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM))) {
+            // plain stores (every forward launch): one pass over the thread's rows.  (Routing these through the batched form below cost
+            // the short-K, store-bound layers 15-20 %: Conv2d_3b forward 558 -> 635 us.)
+            __syncthreads();
+            if (act) {
+                const bool second = p.csplit > 0 && co >= p.csplit;
+                T* __restrict__ dstp = second ? reinterpret_cast<T*>(p.out2) : outp;
+                const int ldd = second ? p.ldo2 : p.ldo, offd = second ? p.cooff2 + (co - p.csplit) : p.cooff + co;
+                for (int row = rr; row < BM; row += RPP) {
+                    const int m = m_first + row;
+                    if (m >= p.M) break;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(smem_raw + row * CPITCH + c * 16);
+                    *reinterpret_cast<u32x4*>(dstp + out_pixel(p, m) * ldd + offd) = v;
+                }
+            }
+            return;
+        }
         // ReLU-backward mask / accumulate inputs of ALL this thread's rows are requested before the staged tile is read back: one
         // memory latency per tile instead of one per row (the per-row load -> wait -> store chain cost 60-80 us per launch on the
         // 288-channel dgrads; profiles/r01_stream_probe.txt)
