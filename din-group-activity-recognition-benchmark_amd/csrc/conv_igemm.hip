@@ -644,6 +644,43 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
             }
             return;
         }
+        if (p.flags & 0x100) {                                       // tuning aid (DIN_CONV_EPI_BATCH=0): per-row load -> combine -> store
+            __syncthreads();
+            if (act) {
+                for (int row = rr; row < BM; row += RPP) {
+                    const int m = m_first + row;
+                    if (m >= p.M) break;
+                    u32x4 v = *reinterpret_cast<const u32x4*>(smem_raw + row * CPITCH + c * 16);
+                    const int64_t px = out_pixel(p, m);
+                    const int64_t o = px * p.ldo + p.cooff + co;
+                    u32x4 mk = {0u, 0u, 0u, 0u}, old = {0u, 0u, 0u, 0u};
+                    if (p.flags & DIN_CONV_MASK) mk = *reinterpret_cast<const u32x4*>(maskp + px * p.ldm + p.moff + co);
+                    if (p.flags & DIN_CONV_ACCUM) old = *reinterpret_cast<const u32x4*>(outp + o);
+                    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = __uint_as_float(v[e]);
+                            if ((p.flags & DIN_CONV_MASK) && !(__uint_as_float(mk[e]) > 0.f)) x = 0.f;
+                            if (p.flags & DIN_CONV_ACCUM) x += __uint_as_float(old[e]);
+                            v[e] = __float_as_uint(x);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+                            if (p.flags & DIN_CONV_MASK) {
+                                if (!(__uint_as_float(mk[e] << 16) > 0.f)) lo = 0.f;
+                                if (!(__uint_as_float(mk[e] & 0xffff0000u) > 0.f)) hi = 0.f;
+                            }
+                            if (p.flags & DIN_CONV_ACCUM) { lo += __uint_as_float(old[e] << 16); hi += __uint_as_float(old[e] & 0xffff0000u); }
+                            v[e] = pack_bf16x2(lo, hi);
+                        }
+                    }
+                    *reinterpret_cast<u32x4*>(outp + o) = v;
+                }
+            }
+            return;
+        }
         // ReLU-backward mask / accumulate inputs of ALL this thread's rows are requested before the staged tile is read back: one
         // memory latency per tile instead of one per row (the per-row load -> wait -> store chain cost 60-80 us per launch on the
         // 288-channel dgrads; profiles/r01_stream_probe.txt)
@@ -2634,6 +2671,7 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
         k.korder = (want && fast && !k.remap && g.splitk == 1 && (g.cpt % KC) == 0 && k.kh * k.kw > 1) ? 1 : 0;
     }
     k.splitk = g.splitk; k.ks_per_split = g.ks_per_split; k.n_co_tiles = g.n_co_tiles;
+    if (const char* eb = getenv("DIN_CONV_EPI_BATCH")) { if (atoi(eb) == 0) k.flags |= 0x100; }
     if (getenv("DIN_DEBUG_PLAN"))
         fprintf(stderr, "[din] %s M=%d NB=%d HxW=%dx%d Cin=%d Cout=%d k=%dx%d ay=%d cy=%d tile=%dx%d splitk=%d korder=%d remap=%d flags=%d dtype=%d\n", what,
                 k.M, k.NB, k.H, k.W, k.Cin, k.Cout, k.kh, k.kw, k.ay, k.cy, g.bm, g.bn, g.splitk, k.korder, k.remap, k.flags, dtype);
