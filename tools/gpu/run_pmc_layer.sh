@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 L=${1:-inc_6e_7x1}
 W=${2:-fwd}
 K=${3:-conv_gather}
-OUT=gpurun_out/pmc_$L_$W
+OUT=gpurun_out/pmc_${L}_${W}
 rm -rf $OUT; mkdir -p $OUT
 python tools/conv_bench.py --layer $L --which $W --iters 20 2>&1 | grep -v amdgpu.ids | tee $OUT/timing.txt
 i=0
