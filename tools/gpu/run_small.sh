@@ -1,7 +1,7 @@
-for e in 1 0; do
-echo epi_batch=$e
-for l in inc_6e_7x1 inc_5b_5x5 inc_3b_1x1_80 inc_6a_3x3 inc_6e_1x1_768 inc_4a_3x3; do
-DIN_CONV_HALO=0 DIN_CONV_EPI_BATCH=$e python tools/conv_bench.py --layer $l --which dgrad --iters 10 2>&1 | grep -v amdgpu.ids | cut -c1-80
-done
-DIN_CONV_EPI_BATCH=$e timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-180
-done
+timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/b5.json; python - <<'PY'
+import json
+j=json.loads(open('gpurun_out/b5.json').read()); r=j['roofline']
+print(j['value'], j['ms_per_step'], r['kernel'], r['achieved'], r['frac'], r['launches'], r['avg_launch_ms'], r.get('sampled_in'), r.get('traffic'), r['all_conv_launches'], j.get('conv_time_frac_sampled_step'))
+PY
+timeout 600 python bench.py --steps 5 --warmup 0 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
+timeout 600 python bench.py --steps 3 --warmup 1 --global-batch 4 --no-cpu-baseline --per-layer gpurun_out/pl_test.txt 2>&1 | tail -1 | cut -c1-200; head -3 gpurun_out/pl_test.txt
