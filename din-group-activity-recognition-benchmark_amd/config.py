@@ -1,6 +1,7 @@
 """Config(dataset_name): attribute bag with the field names and defaults the DIN path reads from the reference's
 config.py:10-104 (only the fields that exist on the hot path; dataset paths and the other methods' knobs are omitted).
-Extra field: backbone_dtype ('fp32' | 'bf16')."""
+Extra fields: backbone_dtype ('fp32' | 'bf16'); hier_dropout_p (the reference hard-codes F.dropout's defaults -- p = 0.5, always on --
+at dynamic_infer_module.py:495; 0.5 keeps that, 0.0 switches it off)."""
 from __future__ import annotations
 
 import os
@@ -20,7 +21,7 @@ _DEFAULTS = dict(
     stride=1, ST_kernel_size=3, dynamic_sampling=True, sampling_ratio=[1, 3], group=1, scale_factor=True, beta_factor=True,
     load_backbone_stage2=False, parallel_inference=False, hierarchical_inference=False, lite_dim=None, num_DIM=1,
     load_stage2model=False, stage2model=None,
-    backbone_dtype="fp32",
+    backbone_dtype="fp32", hier_dropout_p=0.5,
 )
 
 

@@ -88,8 +88,7 @@ class _DynamicBase(nn.Module):
 
     def _dropout_seed(self):
         self._step = getattr(self, "_step", 0) + 1
-        base = int(getattr(self.cfg, "train_random_seed", 0))
-        return (base * 1000003 + self._step * 7919) & 0x7FFFFFFFFFFFFFFF
+        return ops.mask_seed(int(getattr(self.cfg, "train_random_seed", 0)), self._step)
 
 
 class Dynamic_volleyball(_DynamicBase):

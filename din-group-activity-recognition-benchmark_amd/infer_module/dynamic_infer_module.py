@@ -104,11 +104,14 @@ class Multi_Dynamic_Inference(nn.Module):
 
 
 class Hierarchical_Dynamic_Inference(nn.Module):
-    """DPI_1 -> LayerNorm(person_mat_shape + (C,)) -> ReLU -> dropout(p=0.5, always on: F.dropout default at :495)
-    -> DPI_2.  The reference crashes here (tuple fed to LayerNorm, :492-493); this is the intended dataflow."""
+    """DPI_1 -> LayerNorm(person_mat_shape + (C,)) -> ReLU -> dropout -> DPI_2.  The reference crashes here (tuple fed to LayerNorm,
+    :492-493); this is the intended dataflow.  The reference's dropout is `F.dropout(x)` with the functional defaults (:495): p = 0.5 and
+    training=True, i.e. ALWAYS on, also under model.eval().  That is kept as the default; `hier_dropout_p` (ctor argument, or
+    `cfg.hier_dropout_p` when a cfg is given) makes it explicit -- 0.0 gives the deterministic module the golden vectors were taken with."""
 
     def __init__(self, in_dim, person_mat_shape, stride=1, kernel_size=[(3, 3)], dynamic_sampling=False,
-                 sampling_ratio=[1], group=1, scale_factor=False, beta_factor=False, parallel_inference=False, cfg=None):
+                 sampling_ratio=[1], group=1, scale_factor=False, beta_factor=False, parallel_inference=False, cfg=None,
+                 hier_dropout_p=None):
         super().__init__()
         assert len(kernel_size) == 2
         mk = lambda k: Dynamic_Person_Inference(in_dim, person_mat_shape, stride, k, dynamic_sampling, sampling_ratio,
@@ -116,15 +119,14 @@ class Hierarchical_Dynamic_Inference(nn.Module):
         self.DPI_1 = mk(kernel_size[0])
         self.hier_LN = nn.LayerNorm(tuple(person_mat_shape) + (in_dim,))
         self.DPI_2 = mk(kernel_size[1])
-        self.hier_dropout_p = 0.5
-        self._step = 0
+        if hier_dropout_p is None:
+            hier_dropout_p = getattr(cfg, "hier_dropout_p", 0.5) if cfg is not None else 0.5
+        self.hier_dropout_p = float(hier_dropout_p)
+        self._step = 0              # dropout-mask counter (saved / restored by train_net with the checkpoint, see ops.mask_seed)
 
     def forward(self, person_features):
         h, _ = self.DPI_1(person_features)
-        p = self.hier_dropout_p if (self.training or True) and self.hier_dropout_p > 0 else 0.0
-        if getattr(self, "deterministic", False):
-            p = 0.0
         self._step += 1
-        h = ops.layer_norm(h, self.hier_LN.weight, self.hier_LN.bias, relu=True, drop_p=p,
-                           seed=0x9E3779B1 * self._step + 17)
+        h = ops.layer_norm(h, self.hier_LN.weight, self.hier_LN.bias, relu=True, drop_p=self.hier_dropout_p,
+                           seed=ops.mask_seed(0x9E3779B1, self._step))
         return self.DPI_2(h)

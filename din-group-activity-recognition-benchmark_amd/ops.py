@@ -198,6 +198,16 @@ class LayerNormFunction(torch.autograd.Function):
         return dx, (dx if ctx.has_res else None), dgamma, dbeta, None, None, None, None
 
 
+def mask_seed(base: int, step: int) -> int:
+    """Seed of one dropout mask: (stream id `base`, this process' rank, call counter).  Every rank draws different masks (the reference's
+    DataParallel replicas share one host RNG stream, so their masks differ too), and a resumed run continues the sequence when the
+    caller restores its counter."""
+    rank = 0
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        rank = torch.distributed.get_rank()
+    return (int(base) * 1000003 + rank * 0x9E3779B97F4A7C15 + int(step) * 7919) & 0x7FFFFFFFFFFFFFFF
+
+
 def layer_norm(x, gamma, beta, res=None, relu=False, drop_p=0.0, seed=0):
     return LayerNormFunction.apply(x, res, gamma, beta, gamma.dim(), relu, drop_p, seed)
 

@@ -270,8 +270,10 @@ def prep_case(refutils, out_dir):
 
 
 def model_case(name, refim, refcfg, out_dir, *, backbone, H, W, OH, OW, D, B, T, N, NFB, kernels, ratios,
-               num_dim=1, beta=False, lite=None, seed=0, dtype=torch.float32, hier=False):
-    """Whole Dynamic_volleyball forward (+ backward of CE loss) from the reference."""
+               num_dim=1, beta=False, lite=None, seed=0, dtype=torch.float32, hier=False, full_grads_upto=0, refdin=None):
+    """Whole Dynamic_volleyball forward (+ backward of CE loss) from the reference.  full_grads_upto: parameter gradients with at most
+    that many elements are stored whole (`g.<name>`) next to the per-tensor sums.  hier=True applies the no-source-patch recipe of
+    hier_case (DPI_1 wrapped to return ft, the always-on functional dropout neutralised) to the whole model."""
     cfg = refcfg.Config("volleyball")
     cfg.log_path = None
     cfg.backbone = backbone
@@ -296,16 +298,31 @@ def model_case(name, refim, refcfg, out_dir, *, backbone, H, W, OH, OW, D, B, T,
                        hierarchical_inference=hier)
     shapes = O.model_param_shapes(ocfg)
     p = O.synth_params(shapes, seed=seed + 3, din_std=0.02, dtype=dtype)
+    if hier:
+        g_ = torch.Generator().manual_seed(seed + 11)
+        p["DPI.hier_LN.weight"] = 0.75 + 0.5 * torch.rand(p["DPI.hier_LN.weight"].shape, generator=g_)
+        p["DPI.hier_LN.bias"] = 0.1 * torch.randn(p["DPI.hier_LN.bias"].shape, generator=g_)
     missing, unexpected = model.load_state_dict(p, strict=False)
-    bad = [k for k in missing if "num_batches_tracked" not in k]
+    bad = [k for k in missing if "num_batches_tracked" not in k and "zero_padding" not in k]
     assert not unexpected and not bad, (bad, unexpected)
     images, boxes, labels = O.synth_inputs(B, T, N, H, W, OH, OW, 8, seed=seed)
     images = images.to(dtype)
     boxes = boxes.to(dtype)
-    ret = model((images, boxes))
-    loss = F.cross_entropy(ret["activities"], labels)
-    loss.backward()
-    ref_grads = {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}
+    realF = None
+    if hier:
+        model.DPI.DPI_1 = _First(model.DPI.DPI_1)
+        realF = refdin.F
+        shim = types.SimpleNamespace(**{k: getattr(realF, k) for k in dir(realF) if not k.startswith("__")})
+        shim.dropout = lambda x, *a, **k: x
+        refdin.F = shim
+    try:
+        ret = model((images, boxes))
+        loss = F.cross_entropy(ret["activities"], labels)
+        loss.backward()
+    finally:
+        if realF is not None:
+            refdin.F = realF
+    ref_grads = {k.replace("DPI_1.m.", "DPI_1."): v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}
 
     po = {k: v.clone().requires_grad_("running_" not in k) for k, v in p.items()}
     oret, inter = O.dynamic_volleyball_forward(ocfg, po, images, boxes, return_intermediates=True)
@@ -329,6 +346,9 @@ def model_case(name, refim, refcfg, out_dir, *, backbone, H, W, OH, OW, D, B, T,
         rec["gabs." + k] = np.float64(v.double().abs().sum().item())
     for k in ("fc_activities.weight", "fc_activities.bias", "nl_emb_1.weight"):
         rec["g." + k] = ref_grads[k].numpy()
+    for k, v in ref_grads.items():
+        if v.numel() <= full_grads_upto and "g." + k not in rec:
+            rec["g." + k] = v.numpy()
     np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
     print(f"[model] {name}: logits rel err {e:.2e}, worst grad rel err {eg:.2e}, loss {loss.item():.6f}")
 
@@ -486,7 +506,14 @@ def main():
                    D=512, B=2, T=3, N=12, NFB=1024, kernels=[(3, 3)], ratios=[1], seed=103)
         # Inception-v3: 299x299-ish small frame; OHxOW follows the layer arithmetic
         model_case("model_inv3_139x203_nfb64", refim, refcfg, a.out, backbone="inv3", H=139, W=203, OH=15, OW=23,
-                   D=1056, B=1, T=3, N=6, NFB=64, kernels=[(3, 3)], ratios=[1], seed=104)
+                   D=1056, B=1, T=3, N=6, NFB=64, kernels=[(3, 3)], ratios=[1], seed=104, full_grads_upto=9216)
+        # BASELINE configs[2]: lite-DIN on Inception-v3 (lite_dim=128)
+        model_case("model_inv3_139x203_lite128", refim, refcfg, a.out, backbone="inv3", H=139, W=203, OH=15, OW=23,
+                   D=1056, B=1, T=3, N=6, NFB=256, kernels=[(3, 3)], ratios=[1], lite=128, seed=105, full_grads_upto=9216)
+        # BASELINE configs[3]: ST-factorised hierarchical DIN, whole model; T=10, N=12, NFB=1024 are forced by the reference's
+        # hier_LN = LayerNorm((10, 12, 1024)) (dynamic_infer_module.py:476, infer_model.py:88-101)
+        model_case("model_vgg16_64x96_hier_t10", refim, refcfg, a.out, backbone="vgg16", H=64, W=96, OH=2, OW=3, D=512,
+                   B=1, T=10, N=12, NFB=1024, kernels=[(1, 3), (3, 1)], ratios=[1], hier=True, seed=106, refdin=refdin)
     if not a.skip_big:
         hier_case("hier_k13_k31_t10_c1024", refdin, a.out)
     collective_case("collective_vgg16_96x160", refim, refcfg, a.out)
