@@ -61,8 +61,6 @@ SIGNATURES: Dict[str, tuple] = {
     "din_conv_pack_multi": (_I, [_P, _P, _P, _I, _I, _P]),
     "din_conv_kernel_tile": (_I, [_CD, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "din_conv_kernel_variant": (_I, [_CD, _I, C.POINTER(C.c_int32)]),
-    "din_wgrad_set_reduce_stream": (_I, [_P]),
-    "din_wgrad_reduce_join": (_I, [_P]),
     "din_conv_workspace_bytes": (_L, [_CD, _I]),
     "din_conv_fwd": (_I, [_CD, _P, _P, _P, _P, _I, _P, _L, _P]),
     "din_conv_fwd2": (_I, [_CD, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
@@ -74,6 +72,11 @@ SIGNATURES: Dict[str, tuple] = {
     "din_bn_fold_bwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "din_bn_fold_multi": (_I, [_P, _P, _I, _I, _F, _P, _P, _P]),
     "din_bn_fold_bwd_multi": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P, _P]),
+    "din_bn_stats": (_I, [_P, _I, _L, _I, _I, _I, _P, _P]),
+    "din_bn_finalize": (_I, [_P, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "din_bn_apply": (_I, [_P, _I, _L, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P]),
+    "din_bn_bwd_stats": (_I, [_P, _I, _I, _P, _I, _I, _I, _L, _I, _P, _P, _P, _P]),
+    "din_bn_bwd_apply": (_I, [_P, _I, _I, _P, _I, _I, _I, _L, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "din_maxpool_fwd": (_I, [_PD, _P, _P, _P, _P]),
     "din_maxpool_bwd": (_I, [_PD, _P, _P, _P, _P, _I, _I, _P]),
     "din_avgpool_fwd": (_I, [_PD, _P, _P, _P, _I, _P]),

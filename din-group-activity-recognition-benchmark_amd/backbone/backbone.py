@@ -64,7 +64,17 @@ class _GraphBackbone(nn.Module):
     def forward_nhwc(self, images: torch.Tensor, prenormalised: bool = False):
         """images [NB,3,H,W] (uint8 or float, 0..255 unless prenormalised).  Returns (list of NHWC buffers, graph)."""
         graph, dt = self.graph_for(images.shape[2], images.shape[3])
-        outs = NHWCGraphFunction.apply(graph, dt, images, prenormalised, *self._ordered_params(graph))
+        # BatchNorm mode as in torch: a BatchNorm2d module in training mode normalises with batch statistics and updates its running
+        # statistics; `model.apply(set_bn_eval)` (train_net_dynamic.py:17-20) puts the modules in eval mode -> running statistics, folded
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        bn_train = any(m.training for m in bns)
+        if bn_train and not all(m.training for m in bns):
+            raise L.DinError("BatchNorm modules of one backbone must all be in the same mode (all train or all eval)")
+        outs = NHWCGraphFunction.apply(graph, dt, images, prenormalised, bn_train, *self._ordered_params(graph))
+        if bn_train:
+            with torch.no_grad():
+                for m in bns:
+                    m.num_batches_tracked += 1
         if not isinstance(outs, tuple):
             outs = (outs,)
         return list(outs), graph
@@ -154,8 +164,9 @@ def _inception_specs():
 class MyInception_v3(_GraphBackbone):
     """reference backbone/backbone.py:10-85: Inception-v3 truncated after Mixed_6e, outputs [Mixed_5d, Mixed_6e].
 
-    BatchNorm runs with running statistics (the reference's `set_bn_eval` mode, train_net_dynamic.py:17-20), folded into
-    the packed filters; gamma/beta still receive gradients.  Batch-statistics BN is not implemented."""
+    BatchNorm follows the modules' mode like torch: eval() (the reference's `set_bn_eval`, train_net_dynamic.py:17-20) = running
+    statistics, folded into the packed filters, gamma / beta still receive gradients; train() (the reference's stage-2 default,
+    config.py:80) = batch statistics over the B*T frames of this process + running-statistics update (csrc/bn.hip)."""
 
     def __init__(self, transform_input: bool = False, pretrained: bool = False, compute_dtype: str = "fp32"):
         super().__init__(compute_dtype)

@@ -1,0 +1,245 @@
+// Batch-statistics BatchNorm for the NHWC conv graph (gfx950).
+//
+// The reference trains the Inception-v3 backbone with model.train() and cfg.set_bn_eval = False (train_net_dynamic.py:98-100,170-172,
+// config.py:80): every BasicConv2d normalises with the statistics of the current B*T frames and updates running_mean / running_var.
+// Folding BatchNorm into the filters (din_bn_fold*) only covers the running-statistics mode; these kernels are the other one:
+//   forward : raw conv output y [M][C]  ->  per-channel sum / sum of squares (din_bn_stats)  ->  mean, rstd, running statistics,
+//             a = gamma * rstd, b = beta - mean * a (din_bn_finalize)  ->  z = relu(a * y + b) written into the consumer's view (din_bn_apply)
+//   backward: masked gradient gz and y  ->  s1 = sum gz, s2 = sum gz * yhat (din_bn_bwd_stats)  ->
+//             dy = gamma * rstd * (gz - s1 / M - yhat * s2 / M), dgamma = s2, dbeta = s1 (din_bn_bwd_apply)
+// All four passes are HBM-bound streams over [M][C] views (pixel stride ld, channel offset coff): 16-byte lanes along the channels,
+// fp32 partial sums per thread, one fp64 atomic per channel per workgroup (native global_atomic_add_f64), so the statistics do not
+// depend on M in precision.  torch.nn.functional.batch_norm is the arithmetic being replaced (reached from torchvision BasicConv2d).
+#include "din_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BN_ROWS_PER_BLOCK = 2048;
+
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+    static constexpr int V = 4;
+    __device__ static void load(const float* p, float (&v)[4]) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(p);
+        v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+    }
+    __device__ static void store(float* p, const float (&v)[4]) { *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]}; }
+};
+template <> struct Vec<bf16_t> {
+    static constexpr int V = 8;
+    __device__ static void load(const bf16_t* p, float (&v)[8]) {
+        const u32x4 x = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(x[e] << 16); v[2 * e + 1] = __uint_as_float(x[e] & 0xffff0000u); }
+    }
+    __device__ static void store(bf16_t* p, const float (&v)[8]) {
+        *reinterpret_cast<u32x4*>(p) = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    }
+};
+
+// thread t of a 256-thread workgroup owns channel chunk t % cv and walks rows t / cv, + rpp, ... of the workgroup's row range
+// (cv = C / V chunks per row, rpp = 256 / cv rows per pass; threads beyond rpp * cv idle)
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int ldx, int cxoff, const T* __restrict__ g, int ldg, int cgoff,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd, int64_t M, int C,
+                                                       double* __restrict__ sums) {
+    constexpr int V = Vec<T>::V;
+    extern __shared__ float red[];                                  // [2][C]
+    const int cv = C / V, rpp = 256 / cv;
+    const int tid = threadIdx.x, ch = tid % cv, rl = tid / cv;
+    for (int i = tid; i < 2 * C; i += 256) red[i] = 0.f;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS_PER_BLOCK;
+    int64_t r1 = r0 + BN_ROWS_PER_BLOCK;
+    if (r1 > M) r1 = M;
+    float s1[V], s2[V], mu[V], rs[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { s1[e] = 0.f; s2[e] = 0.f; mu[e] = 0.f; rs[e] = 1.f; }
+    if (rl < rpp) {
+        if (BWD) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) { mu[e] = mean[ch * V + e]; rs[e] = rstd[ch * V + e]; }
+        }
+        for (int64_t r = r0 + rl; r < r1; r += rpp) {
+            float xv[V];
+            Vec<T>::load(x + r * ldx + cxoff + ch * V, xv);
+            if (BWD) {
+                float gv[V];
+                Vec<T>::load(g + r * ldg + cgoff + ch * V, gv);
+#pragma unroll
+                for (int e = 0; e < V; ++e) { s1[e] += gv[e]; s2[e] += gv[e] * ((xv[e] - mu[e]) * rs[e]); }
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e) { s1[e] += xv[e]; s2[e] += xv[e] * xv[e]; }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) { atomicAdd(&red[ch * V + e], s1[e]); atomicAdd(&red[C + ch * V + e], s2[e]); }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * C; i += 256) atomicAdd(&sums[i], (double)red[i]);
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t M, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ a, float* __restrict__ b, float* __restrict__ mean,
+                                   float* __restrict__ rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = sums[c] / (double)M;
+    double var = sums[C + c] / (double)M - mu * mu;                 // biased (normalisation) variance
+    if (var < 0.0) var = 0.0;
+    const float r = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)mu; rstd[c] = r;
+    const float av = gamma[c] * r;
+    a[c] = av; b[c] = beta[c] - (float)mu * av;
+    if (running_mean) {                                             // torch: running = (1 - momentum) * running + momentum * batch (unbiased var)
+        const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ldx, int cxoff, const float* __restrict__ a,
+                                                       const float* __restrict__ b, int relu, T* __restrict__ y, int ldy, int cyoff,
+                                                       int64_t M, int C) {
+    constexpr int V = Vec<T>::V;
+    const int cv = C / V;
+    const int64_t total = M * cv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cv;
+        const int ch = (int)(i - r * cv);
+        float v[V];
+        Vec<T>::load(x + r * ldx + cxoff + ch * V, v);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float z = v[e] * a[ch * V + e] + b[ch * V + e];
+            v[e] = relu ? fmaxf(z, 0.f) : z;
+        }
+        Vec<T>::store(y + r * ldy + cyoff + ch * V, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ g, int ldg, int cgoff, const T* __restrict__ x, int ldx, int cxoff,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const double* __restrict__ sums,
+                                                           T* __restrict__ dy, int ldy, int cyoff, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int64_t M, int C) {
+    constexpr int V = Vec<T>::V;
+    const int cv = C / V;
+    const int64_t total = M * cv;
+    const float invM = 1.f / (float)M;
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += 256) { dbeta[c] = (float)sums[c]; dgamma[c] = (float)sums[C + c]; }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cv;
+        const int ch = (int)(i - r * cv);
+        float gv[V], xv[V];
+        Vec<T>::load(g + r * ldg + cgoff + ch * V, gv);
+        Vec<T>::load(x + r * ldx + cxoff + ch * V, xv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int c = ch * V + e;
+            const float xh = (xv[e] - mean[c]) * rstd[c];
+            gv[e] = gamma[c] * rstd[c] * (gv[e] - (float)sums[c] * invM - xh * ((float)sums[C + c] * invM));
+        }
+        Vec<T>::store(dy + r * ldy + cyoff + ch * V, gv);
+    }
+}
+
+int check_view(int dtype, int64_t rows, int c, int ld, int coff, const char* what) {
+    DIN_REQUIRE(dtype == DIN_F32 || dtype == DIN_BF16, "%s: bad dtype", what);
+    const int v = dtype == DIN_F32 ? 4 : 8;
+    DIN_REQUIRE(rows > 0 && c > 0 && c % v == 0 && c / v <= 256, "%s: channel count %d must be a multiple of %d (at most %d)", what, c, v, 256 * v);
+    DIN_REQUIRE(ld % v == 0 && coff % v == 0 && coff >= 0 && ld >= coff + c, "%s: pixel stride / channel offset must be multiples of %d", what, v);
+    return DIN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int din_bn_stats(const void* x, int dtype, int64_t rows, int c, int ld, int coff, double* sums, void* stream) {
+    DIN_REQUIRE(x && sums, "bn_stats: null pointer");
+    if (int e = check_view(dtype, rows, c, ld, coff, "bn_stats")) return e;
+    const int blocks = (int)ceil_div64(rows, BN_ROWS_PER_BLOCK);
+    const size_t lds = 2 * (size_t)c * sizeof(float);
+    if (dtype == DIN_F32)
+        hipLaunchKernelGGL((bn_stats_kernel<float, false>), dim3(blocks), dim3(256), lds, as_stream(stream), (const float*)x, ld, coff,
+                           (const float*)nullptr, 0, 0, (const float*)nullptr, (const float*)nullptr, rows, c, sums);
+    else
+        hipLaunchKernelGGL((bn_stats_kernel<bf16_t, false>), dim3(blocks), dim3(256), lds, as_stream(stream), (const bf16_t*)x, ld, coff,
+                           (const bf16_t*)nullptr, 0, 0, (const float*)nullptr, (const float*)nullptr, rows, c, sums);
+    DIN_CHECK_LAUNCH("bn_stats");
+    return DIN_OK;
+}
+
+int din_bn_finalize(const double* sums, int64_t rows, int c, const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var, float* a, float* b, float* mean, float* rstd, void* stream) {
+    DIN_REQUIRE(sums && gamma && beta && a && b && mean && rstd && rows > 0 && c > 0, "bn_finalize: bad argument");
+    DIN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running_mean and running_var go together");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), sums, rows, c, gamma, beta, eps, momentum,
+                       running_mean, running_var, a, b, mean, rstd);
+    DIN_CHECK_LAUNCH("bn_finalize");
+    return DIN_OK;
+}
+
+int din_bn_apply(const void* x, int dtype, int64_t rows, int c, int ldx, int cxoff, const float* a, const float* b, int relu, void* y,
+                 int ldy, int cyoff, void* stream) {
+    DIN_REQUIRE(x && y && a && b, "bn_apply: null pointer");
+    if (int e = check_view(dtype, rows, c, ldx, cxoff, "bn_apply(x)")) return e;
+    if (int e = check_view(dtype, rows, c, ldy, cyoff, "bn_apply(y)")) return e;
+    const int v = dtype == DIN_F32 ? 4 : 8;
+    const int blocks = grid_1d(rows * (c / v), 256, 256 * 16);
+    if (dtype == DIN_F32)
+        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)x, ldx, cxoff, a, b, relu,
+                           (float*)y, ldy, cyoff, rows, c);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), (const bf16_t*)x, ldx, cxoff, a, b, relu,
+                           (bf16_t*)y, ldy, cyoff, rows, c);
+    DIN_CHECK_LAUNCH("bn_apply");
+    return DIN_OK;
+}
+
+int din_bn_bwd_stats(const void* gz, int ldg, int cgoff, const void* x, int ldx, int cxoff, int dtype, int64_t rows, int c,
+                     const float* mean, const float* rstd, double* sums, void* stream) {
+    DIN_REQUIRE(gz && x && mean && rstd && sums, "bn_bwd_stats: null pointer");
+    if (int e = check_view(dtype, rows, c, ldg, cgoff, "bn_bwd_stats(gz)")) return e;
+    if (int e = check_view(dtype, rows, c, ldx, cxoff, "bn_bwd_stats(x)")) return e;
+    const int blocks = (int)ceil_div64(rows, BN_ROWS_PER_BLOCK);
+    const size_t lds = 2 * (size_t)c * sizeof(float);
+    if (dtype == DIN_F32)
+        hipLaunchKernelGGL((bn_stats_kernel<float, true>), dim3(blocks), dim3(256), lds, as_stream(stream), (const float*)x, ldx, cxoff,
+                           (const float*)gz, ldg, cgoff, mean, rstd, rows, c, sums);
+    else
+        hipLaunchKernelGGL((bn_stats_kernel<bf16_t, true>), dim3(blocks), dim3(256), lds, as_stream(stream), (const bf16_t*)x, ldx, cxoff,
+                           (const bf16_t*)gz, ldg, cgoff, mean, rstd, rows, c, sums);
+    DIN_CHECK_LAUNCH("bn_bwd_stats");
+    return DIN_OK;
+}
+
+int din_bn_bwd_apply(const void* gz, int ldg, int cgoff, const void* x, int ldx, int cxoff, int dtype, int64_t rows, int c,
+                     const float* gamma, const float* mean, const float* rstd, const double* sums, void* dy, int ldy, int cyoff,
+                     float* dgamma, float* dbeta, void* stream) {
+    DIN_REQUIRE(gz && x && gamma && mean && rstd && sums && dy && dgamma && dbeta, "bn_bwd_apply: null pointer");
+    if (int e = check_view(dtype, rows, c, ldg, cgoff, "bn_bwd_apply(gz)")) return e;
+    if (int e = check_view(dtype, rows, c, ldx, cxoff, "bn_bwd_apply(x)")) return e;
+    if (int e = check_view(dtype, rows, c, ldy, cyoff, "bn_bwd_apply(dy)")) return e;
+    const int v = dtype == DIN_F32 ? 4 : 8;
+    const int blocks = grid_1d(rows * (c / v), 256, 256 * 16);
+    if (dtype == DIN_F32)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)gz, ldg, cgoff,
+                           (const float*)x, ldx, cxoff, gamma, mean, rstd, sums, (float*)dy, ldy, cyoff, dgamma, dbeta, rows, c);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), (const bf16_t*)gz, ldg, cgoff,
+                           (const bf16_t*)x, ldx, cxoff, gamma, mean, rstd, sums, (bf16_t*)dy, ldy, cyoff, dgamma, dbeta, rows, c);
+    DIN_CHECK_LAUNCH("bn_bwd_apply");
+    return DIN_OK;
+}
+
+}  // extern "C"

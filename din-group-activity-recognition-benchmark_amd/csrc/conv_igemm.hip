@@ -18,6 +18,7 @@
 // Replaces the arithmetic of torch.nn.Conv2d / nn.Linear reached from the reference at
 // backbone/backbone.py:44-99, infer_model.py:184,190,226 and infer_module/dynamic_infer_module.py:149,191,195.
 #include "din_common.h"
+#include "conv_wgrad.h"
 #include <unordered_map>
 #include <mutex>
 #include <stdlib.h>
@@ -26,6 +27,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+using din_wgrad::WgradK;
+using din_wgrad::lds_dma16;
 
 namespace {
 
@@ -87,16 +91,6 @@ template <> struct Mma<bf16_t> {
 // ------------------------------------------------------------------------------------------------
 // fwd / dgrad gather kernels
 // ------------------------------------------------------------------------------------------------
-// One wave-level LDS-DMA: 64 lanes x 16 B land at LDS byte address `lds_addr` + lane*16 (lane-linear; out-of-range lanes write
-// zeros -- measured, profiles/r01_probe_lds_dma.txt).  Issued through inline asm on purpose: with the builtin, hipcc tracks the LDS
-// write, cannot tell the ring stages apart and drains vmcnt(0) before the next barrier/ds_read, which serialises the pipeline.
-// Here the compiler does not see the transfer at all; completion is counted by hand (s_waitcnt vmcnt(N) + s_barrier in the loop).
-// M0 carries the LDS destination; it is declared clobbered (3 instructions per transfer instead of 5 with a save / restore pair).
-__device__ __forceinline__ void lds_dma16(uint32_t lds_addr, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
-}
-
 // One k-step of the FASTK loop: NA pixel-tile + NB filter-tile wave-level DMAs into consecutive STRIDE-byte slots of a ring stage, as
 // ONE asm statement: M0 is written once and then advanced (declared clobbered instead of saved/restored around every transfer),
 // 3 instructions per transfer instead of 5 -- the scalar unit is shared by the CU's 16 waves and was 40 % busy (SQ_ACTIVE_INST_SCA).
@@ -1303,16 +1297,6 @@ __global__ __launch_bounds__(256) void conv_pack_multi_kernel(const din_pack_des
 // 128 (co) x 128 (k columns) tile per workgroup, reduction over a slice of the pixels; partials to a
 // workspace [slice][cout_pad][kcols_pad] fp32, reduced (and un-permuted to [cout][cin][kh][kw]) afterwards.
 // ------------------------------------------------------------------------------------------------
-struct WgradK {
-    const void* in; const void* g; float* partial; float* dbias;
-    int NB, H, W, Cin, ldi, cioff;
-    int OH, OW, Cout, ldo, cooff;
-    int kh, kw, sh, sw, ph, pw, dh, dw;
-    int cin_pad, kcols, kcols_pad, cout_pad;   // kcols = kh*kw*cin_pad
-    int M, n_co_tiles, n_k_tiles, slices, m_per_slice;
-    int probe;      // diagnostics (env DIN_WGRAD_PROBE): 1 = stream only (no transpose reads / MFMA), 2 = compute only (one DMA stage)
-};
-
 constexpr int WG_TILE = 128;
 
 // fp32: 16 pixels per k-step, operands read with ds_read_b32 (lane k-index = pixel row)
@@ -2399,10 +2383,11 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype, bool str
     return g;
 }
 
-struct WgradPlan { int cin_pad, kcols, kcols_pad, cout_pad, n_co_tiles, n_k_tiles, slices, m_per_slice, bco, v2, small, ring, bk; int64_t ws_bytes; };
+struct WgradPlan { int cin_pad, kcols, kcols_pad, cout_pad, n_co_tiles, n_k_tiles, slices, m_per_slice, bco, v2, small, ring, bk, pipe, atomic; int64_t ws_bytes; };
 constexpr int WGRAD_SMALL_GRID = 512;
 WgradPlan plan_wgrad(const din_conv_desc* d) {
     WgradPlan w;
+    w.pipe = w.atomic = 0;
     int epc = epc_of(d->dtype);
     // bf16 v2 kernel needs whole 16-byte channel chunks on both operands; otherwise the tail kernel (conv1: cin = 3)
     w.v2 = d->dtype == DIN_BF16 && d->cin % 8 == 0 && d->cout % 8 == 0 && d->ldi % 8 == 0 && d->cioff % 8 == 0;
@@ -2475,6 +2460,12 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
         if (!w.ring && w.v2 && mode != 0 && (mode == 3 || w.bco == 64 || w.bco == 96)) { w.ring = 1; ring_bk = 128; }
     }
     const int bk = w.ring ? ring_bk : WG_TILE;
+    {   // BCO x 256 ring tiles whose wave tile is whole 32x32 MFMA tiles run the software-pipelined kernel (conv_wgrad_pipe.hip)
+        const char* pe = getenv("DIN_WGRAD_PIPE");          // (read per call: the tests switch them inside one process)
+        const char* ae = getenv("DIN_WGRAD_ATOMIC");
+        const int pipe_env = pe ? atoi(pe) : 1, atomic_env = ae ? atoi(ae) : 0;
+        if (w.ring && ring_bk == 256 && (w.bco == 128 || w.bco == 192) && pipe_env) { w.pipe = 1; w.atomic = atomic_env; }
+    }
     int pk = d->dtype == DIN_F32 ? 16 : (w.ring ? 32 : (w.v2 ? 64 : 32));
     w.bk = bk;
     w.kcols_pad = pad_to(w.kcols, bk);
@@ -2837,7 +2828,7 @@ int din_conv_pack_multi(const din_pack_desc* table, const int32_t* layer_of, con
 
 int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t* bn) {
     DIN_REQUIRE(d && bm && bn && which >= 0 && which <= 2, "conv_kernel_tile: bad argument");
-    if (which == 2) { WgradPlan wp = plan_wgrad(d); *bm = wp.small ? 0 : wp.bco; *bn = wp.small ? wp.bco : (wp.ring ? 1000 + wp.bk : WG_TILE); return DIN_OK; }
+    if (which == 2) { WgradPlan wp = plan_wgrad(d); *bm = wp.small ? 0 : wp.bco; *bn = wp.small ? wp.bco : (wp.pipe ? 2000 + wp.bk : wp.ring ? 1000 + wp.bk : WG_TILE); return DIN_OK; }
     const bool strided = which == 1 && (d->sh > 1 || d->sw > 1);
     GatherPlan g = which == 0 ? plan_gather(d->nb * d->oh * d->ow, d->cin, d->cout, d->kh * d->kw, d->dtype)
                               : plan_gather(d->nb * (strided ? (d->h + d->sh - 1) / d->sh * ((d->w + d->sw - 1) / d->sw) : d->h * d->w),
@@ -3056,37 +3047,6 @@ int din_conv1x1_dgrad_multi(int nsrc, const din_conv_src* srcs, int dtype, int n
     return DIN_OK;
 }
 
-// ---- slice reduce on a second stream ------------------------------------------------------------------------------------------
-// The slice reduce of layer l only feeds the parameter gradient, which nobody needs before the end of backward (or the next gradient
-// bucket); it is a short memory-bound kernel, the dgrad that follows it on the main stream is MFMA-bound.  With a reduce stream set
-// (din_wgrad_set_reduce_stream) the reduce is enqueued there, ordered after the wgrad kernel by an event; the NEXT wgrad kernel waits
-// for it (it overwrites the partial-sum workspace), and din_wgrad_reduce_join makes any consumer stream wait for the last one.
-// The caller must give wgrad a workspace that no other kernel writes in between (split-K forward / dgrad launches use their own).
-static std::mutex g_reduce_mu;
-static hipStream_t g_reduce_stream = nullptr;
-static hipEvent_t g_ev_kernel = nullptr, g_ev_reduce = nullptr;
-static bool g_reduce_pending = false;
-
-int din_wgrad_set_reduce_stream(void* stream) {
-    std::lock_guard<std::mutex> lk(g_reduce_mu);
-    if (stream && !g_ev_kernel) {
-        if (hipEventCreateWithFlags(&g_ev_kernel, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&g_ev_reduce, hipEventDisableTiming) != hipSuccess)
-            DIN_FAIL(DIN_E_LAUNCH, "wgrad_set_reduce_stream: event creation failed");
-    }
-    g_reduce_stream = as_stream(stream);
-    if (!stream) g_reduce_pending = false;
-    return DIN_OK;
-}
-
-int din_wgrad_reduce_join(void* stream) {
-    std::lock_guard<std::mutex> lk(g_reduce_mu);
-    if (g_reduce_stream && g_reduce_pending) {
-        if (hipStreamWaitEvent(as_stream(stream), g_ev_reduce, 0) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "wgrad_reduce_join: wait failed");
-    }
-    return DIN_OK;
-}
-
 int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, float* dw, float* dbias, const float* scale,
                    const float* w, float* wdot, int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
     if (int e = check_desc(d)) return e;
@@ -3098,11 +3058,6 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
     WgradPlan wp = plan_wgrad(d);
     if (workspace_bytes < wp.ws_bytes || !workspace)
         DIN_FAIL(DIN_E_WORKSPACE, "conv_wgrad: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)wp.ws_bytes);
-    {   // the previous layer's reduce may still be reading the workspace this launch overwrites
-        std::lock_guard<std::mutex> lk(g_reduce_mu);
-        if (g_reduce_stream && g_reduce_stream != st && g_reduce_pending && hipStreamWaitEvent(st, g_ev_reduce, 0) != hipSuccess)
-            DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: wait for the previous reduce failed");
-    }
     WgradK k{};
     k.in = in; k.g = dout; k.partial = reinterpret_cast<float*>(workspace); k.dbias = nullptr;
     k.NB = d->nb; k.H = d->h; k.W = d->w; k.Cin = d->cin; k.ldi = d->ldi; k.cioff = d->cioff;
@@ -3135,6 +3090,16 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
             if (wp.small == 1) launch(conv_wgrad_small_kernel<4, 32, 1>);
             else if (wp.small == 2) launch(conv_wgrad_small_kernel<4, 64, 1>);
             else launch(conv_wgrad_small_kernel<1, 32, 2>);
+        } else if (wp.pipe) {
+            if (dbias) {
+                if (!prezeroed && hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
+                k.dbias = dbias;
+                bias_fused = true;
+            }
+            k.atomic = wp.atomic;
+            if (wp.atomic && hipMemsetAsync(k.partial, 0, sizeof(float) * (size_t)wp.cout_pad * wp.kcols_pad, st) != hipSuccess)
+                DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
+            if (int e = din_wgrad::launch_wgrad_pipe(k, wp.bco, wp.bk, grid, st)) return e;
         } else if (wp.ring) {
             if (dbias) {
                 if (!prezeroed && hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
@@ -3180,24 +3145,11 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
     {
         int kc_total = d->kh * d->kw * wp.cin_pad;
         dim3 rgrid(d->cout, (kc_total + 255) / 256);
-        const int nsg = wp.slices >= 64 ? 16 : wp.slices >= 8 ? 4 : 1;
-        hipStream_t rst = st;
-        {
-            std::lock_guard<std::mutex> lk(g_reduce_mu);
-            if (g_reduce_stream && g_reduce_stream != st) {
-                if (hipEventRecord(g_ev_kernel, st) != hipSuccess || hipStreamWaitEvent(g_reduce_stream, g_ev_kernel, 0) != hipSuccess)
-                    DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: reduce-stream hand-over failed");
-                rst = g_reduce_stream;
-            }
-        }
-        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, rgrid, dim3(64, nsg), 0, rst, k.partial, dw, scale, w, wdot,
-                           d->cout, d->cin, d->kh, d->kw, wp.cin_pad, wp.cout_pad, wp.kcols_pad, wp.slices, accumulate);
+        const int rslices = (wp.pipe && wp.atomic) ? 1 : wp.slices;
+        const int nsg = rslices >= 64 ? 16 : rslices >= 8 ? 4 : 1;
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, rgrid, dim3(64, nsg), 0, st, k.partial, dw, scale, w, wdot,
+                           d->cout, d->cin, d->kh, d->kw, wp.cin_pad, wp.cout_pad, wp.kcols_pad, (wp.pipe && wp.atomic) ? 1 : wp.slices, accumulate);
         DIN_CHECK_LAUNCH("conv_wgrad_reduce");
-        if (rst != st) {
-            std::lock_guard<std::mutex> lk(g_reduce_mu);
-            if (hipEventRecord(g_ev_reduce, rst) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: reduce event");
-            g_reduce_pending = true;
-        }
     }
     if (dbias && !bias_fused) {
         if (int e = launch_colsum(d->dtype, dout, dbias, k.M, d->cout, d->ldo, d->cooff, st)) return e;

@@ -1,0 +1,33 @@
+// Shared between conv_igemm.hip and conv_wgrad_pipe.hip: the weight-gradient kernel argument block and the wave-level LDS-DMA helper.
+#pragma once
+#include "din_common.h"
+
+namespace din_wgrad {
+
+// wgrad:  dW[co][(r,s,ci)] = sum_pix G[pix][co] * im2col(X)[pix][(r,s,ci)]
+struct WgradK {
+    const void* in; const void* g; float* partial; float* dbias;
+    int NB, H, W, Cin, ldi, cioff;
+    int OH, OW, Cout, ldo, cooff;
+    int kh, kw, sh, sw, ph, pw, dh, dw;
+    int cin_pad, kcols, kcols_pad, cout_pad;   // kcols = kh*kw*cin_pad
+    int M, n_co_tiles, n_k_tiles, slices, m_per_slice;
+    int probe;      // diagnostics (env DIN_WGRAD_PROBE): 1 = stream only (no transpose reads / MFMA), 2 = compute only (one DMA stage)
+    int atomic;     // pipe kernel: 1 = every workgroup ADDS its tile into slice 0 of `partial` (fp32 atomics, buffer zeroed by the host)
+};
+
+// One wave-level LDS-DMA: 64 lanes x 16 B land at LDS byte address `lds_addr` + lane*16 (lane-linear; out-of-range lanes write
+// zeros -- measured, profiles/r01_probe_lds_dma.txt).  Issued through inline asm on purpose: with the builtin, hipcc tracks the LDS
+// write, cannot tell the ring stages apart and drains vmcnt(0) before the next barrier/ds_read, which serialises the pipeline.
+// Here the compiler does not see the transfer at all; completion is counted by hand (s_waitcnt vmcnt(N) + s_barrier in the loop).
+// M0 carries the LDS destination; it is declared clobbered (3 instructions per transfer instead of 5 with a save / restore pair).
+__device__ __forceinline__ void lds_dma16(uint32_t lds_addr, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
+
+// host entry of conv_wgrad_pipe.hip: launches the software-pipelined 32x32x16 ring kernel for a plan with pipe != 0
+int launch_wgrad_pipe(const WgradK& k, int bco, int bk, dim3 grid, hipStream_t st);
+size_t wgrad_pipe_lds_bytes(int bco, int bk);
+
+}  // namespace din_wgrad

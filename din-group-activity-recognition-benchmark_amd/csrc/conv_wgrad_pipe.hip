@@ -1,0 +1,332 @@
+// Weight gradient of the wide filter banks (bf16 operands, fp32 accumulation) for gfx950 -- software-pipelined ring kernel.
+//
+//   dW[co][(r,s,ci)] = sum_pix G[pix][co] * im2col(X)[pix][(r,s,ci)]        (reference: autograd of torch.nn.Conv2d reached from
+//   backbone/backbone.py:44-99; both operands are stored [pixel][channel], i.e. the reduction index is the STRIDED one on both sides)
+//
+// Same data movement as conv_wgrad_ring_kernel (conv_igemm.hip): BCO x 256 output tile per 8-wave workgroup, 32-pixel stages in a
+// 4-slot LDS ring filled by LDS-DMA three stages ahead, operands read with the transposing ds_read_b64_tr_b16.  What changes is the
+// schedule inside a wave -- the round-1 counters (profiles/r01_wgrad_ring.txt: MFMA busy 33 %, LDS conflicts 26 % of LDS cycles,
+// 2.7 SALU + 2.0 VALU per MFMA) showed every wave doing "barrier -> 4 DMA issues -> 20 transpose reads -> wait -> 24 MFMAs" in
+// lock-step, so the matrix pipe idled through the first three phases:
+//   * v_mfma_f32_32x32x16_bf16: 12 instead of 24 MFMAs per stage, 32 cycles each -- room for ~5 other issues behind every one;
+//   * two fragment register sets: the transpose reads of half-stage h+1 are in flight while the MFMAs of half-stage h run, and the
+//     DMA issues of stage s+3 sit between MFMAs instead of in front of them (no LDS or DMA-issue latency on the critical path);
+//   * both operand tiles use a 512-byte LDS row pitch with the 64-byte slots of row r rotated by (r & 3): every 32-lane half of a
+//     transpose read then touches 4 rows x 64 B = all 64 banks exactly once (the 384-byte rows of the 192-filter G tile could not be
+//     made conflict-free by rotation alone: a wrapped slot lands 128 B off its bank group);
+//   * per-stage coordinate updates are branch-free when a feature-map row holds at least one stage (OW >= 32);
+//   * the bias gradient (BatchNorm shift gradient) is a packed dot product against ones on the VALU (v_dot2c_f32_bf16, 4 per
+//     half-stage per wave, spread over the waves of the k_tile == 0 workgroups) instead of 25 % extra MFMAs on a quarter of the waves;
+//   * optionally (WgradK::atomic) the workgroups add their tiles into ONE fp32 tile buffer with native atomics, so the slice
+//     partials (25-80 MB per launch whatever the batch) are neither written nor read back.
+#include "conv_wgrad.h"
+#include <unordered_map>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace din_wgrad {
+namespace {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ s16x4 tr_read(uint32_t byte_addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) s16x4*>(byte_addr));
+}
+#endif
+
+template <int V> struct IC { static constexpr int value = V; };
+
+template <int BCO, int BK, bool WIDE>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_pipe_kernel(WgradK p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int PK = 32, NS = 4, NWV = 8;
+    constexpr int ROWB = 512;                                      // LDS row pitch of both operand tiles (bytes)
+    static_assert(BK == 256 && BCO % 64 == 0 && BCO <= 256, "tile");
+    constexpr int CG = BCO / 8;                                    // real 16-byte chunks of a G row (of 32 slots)
+    constexpr int OPG = PK * ROWB, STAGE = 2 * OPG;                // 16 KiB per operand, 32 KiB per stage
+    constexpr int TI = BCO / 64, XJ = BK / 128;                    // 32x32 MFMA tiles per wave (wave tile = BCO/2 x BK/4)
+    constexpr int NM = TI * XJ;                                    // MFMAs per half-stage
+    constexpr int NDMA = 4;                                        // wave-level DMAs per stage per wave: 2 G + 2 X
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: lives in an SGPR, branches on it are scalar
+    const int wm = wid >> 2, wn = wid & 3;
+    int bx_, by_;
+    xcd_block(bx_, by_);
+    const int k_tile = bx_ % p.n_k_tiles, co_tile = bx_ / p.n_k_tiles;
+    const int slice = by_;
+    const int m_begin = slice * p.m_per_slice;                     // multiple of PK
+    int m_end = m_begin + p.m_per_slice;
+    if (m_end > p.M) m_end = p.M;
+
+    const int ohw = p.OH * p.OW;
+    const int n_first = m_begin / ohw;
+    const long long img_bytes = (long long)p.H * p.W * p.ldi * 2ll;
+    const long long x_off = (long long)n_first * img_bytes;
+    long long x_rem = (long long)p.NB * img_bytes - x_off;
+    if (x_rem > 0x7fffffffll) x_rem = 0x7fffffffll;
+    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.in)) + x_off, 0, (int)x_rem, 0x00020000);
+    const long long g_off = (long long)m_begin * p.ldo * 2ll;
+    long long g_rem = (long long)p.M * p.ldo * 2ll - g_off;
+    if (g_rem > 0x7fffffffll) g_rem = 0x7fffffffll;
+    __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.g)) + g_off, 0, (int)g_rem, 0x00020000);
+
+    // ---- DMA plan.  A wave-level transfer is 1 KiB lane-linear = 2 tile rows x 32 slots of 16 B; transfer t of wave w covers rows
+    //      2 (w + 8 t) + (lane >> 5).  Slot s of row r holds the row's logical chunk (s - 4 (r & 3)) mod 32: the rotation is applied on
+    //      the source side (the lane fetches the chunk that belongs at its slot) and again in the transpose-read addresses.
+    const int drow = 2 * wid + (lane >> 5);                       // rows drow, drow + 16 ((row & 3) is the same for both)
+    const int lchunk = ((lane & 31) - 4 * (drow & 3)) & 31;       // logical chunk at this lane's slot
+    unsigned voffG[2];
+    {
+        const int gco = co_tile * BCO + lchunk * 8;
+        const bool ok = lchunk < CG && gco + 7 < p.Cout;          // Cout % 8 == 0 enforced by the host
+#pragma unroll
+        for (int t = 0; t < 2; ++t) voffG[t] = ok ? (unsigned)(((drow + 16 * t) * p.ldo + p.cooff + gco) * 2) : OOB;
+    }
+    const int kcol = k_tile * BK + lchunk * 8;
+    const bool kok = kcol < p.kcols;
+    const int tap = kok ? kcol / p.cin_pad : 0;
+    const int ci = kcol - tap * p.cin_pad;
+    const int tr_ = tap / p.kw, ts_ = tap - tr_ * p.kw;
+    const bool ci_ok = kok && ci + 7 < p.Cin;                      // Cin % 8 == 0 enforced by the host
+    const int dy0 = -p.ph + tr_ * p.dh, dx0 = -p.pw + ts_ * p.dw;  // iy = oy*sh + dy0, ix = ox*sw + dx0
+    // per-transfer cursor of this lane's pixel row: output column px, input coordinates (ix, iy) of the lane's tap, byte offset `off` of
+    // that input pixel (+ channel) from the resource base, rows left in the slice.  One stage = +32 output pixels.
+    const int step32 = PK * p.sw * p.ldi * 2, dix32 = PK * p.sw;
+    const int wrap_off = (p.sh * p.W - p.OW * p.sw) * p.ldi * 2;   // back to column 0 of the next output row
+    const int wrap_ix = p.OW * p.sw;
+    const int img_off = (p.H - p.OH * p.sh) * p.W * p.ldi * 2;     // extra when wrapping to the next image
+    const int img_iy = p.OH * p.sh;
+    int px[2], py[2], ix[2], iy[2], off[2], left[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int m = m_begin + drow + 16 * t;
+        const int n = m / ohw, rem = m - n * ohw;
+        py[t] = rem / p.OW; px[t] = rem - py[t] * p.OW;
+        iy[t] = py[t] * p.sh + dy0; ix[t] = px[t] * p.sw + dx0;
+        off[t] = (((n - n_first) * p.H + iy[t]) * p.W + ix[t]) * p.ldi * 2 + (p.cioff + ci) * 2;
+        left[t] = ci_ok ? m_end - m : 0;                           // <= 0: nothing (more) to fetch for this row
+    }
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw;
+    const uint32_t ldsW = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(wid * 1024));
+    auto issue_g = [&](int slot, int st) {                          // stage st -> ring slot
+        const uint32_t Gd = ldsW + (uint32_t)(slot * STAGE);
+        const int soffG = st * PK * p.ldo * 2;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) lds_dma16(Gd + (uint32_t)(t * 1024 * NWV), rsG, (int)voffG[t], soffG);   // rows past M: out of range -> zeros
+    };
+    auto issue_x = [&](int slot, int t) {                           // called once per stage and t, stages in order (the cursor advances)
+        const uint32_t Xd = ldsW + (uint32_t)(slot * STAGE + OPG + t * 1024 * NWV);
+        const bool ok = (left[t] > 0) & ((unsigned)iy[t] < (unsigned)p.H) & ((unsigned)ix[t] < (unsigned)p.W);
+        lds_dma16(Xd, rsX, ok ? off[t] : (int)OOB, 0);
+        px[t] += PK; ix[t] += dix32; off[t] += step32; left[t] -= PK;
+        if constexpr (WIDE) {                                       // OW >= 32: at most one row wrap per stage, and a wave's two rows
+            if (__builtin_amdgcn_ballot_w64(px[t] >= p.OW)) {      // of a transfer are neighbours -> the wrap is (nearly) wave-uniform
+                const bool wrap = px[t] >= p.OW;
+                px[t] -= wrap ? p.OW : 0; ix[t] -= wrap ? wrap_ix : 0; off[t] += wrap ? wrap_off : 0;
+                iy[t] += wrap ? p.sh : 0; py[t] += wrap ? 1 : 0;
+                const bool wimg = py[t] == p.OH;
+                py[t] = wimg ? 0 : py[t]; iy[t] -= wimg ? img_iy : 0; off[t] += wimg ? img_off : 0;
+            }
+        } else {
+            while (px[t] >= p.OW) {
+                px[t] -= p.OW; ix[t] -= wrap_ix; off[t] += wrap_off; iy[t] += p.sh;
+                if (++py[t] == p.OH) { py[t] = 0; iy[t] -= img_iy; off[t] += img_off; }
+            }
+        }
+    };
+
+    f32x16 acc[TI][XJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < XJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // bias gradient: wave wn of a k_tile == 0 workgroup sums G-tile wn of its filter half (tiles beyond TI: none)
+    const bool do_bias = p.dbias != nullptr && k_tile == 0 && wn < TI;        // wave-uniform
+    float bsum = 0.f;
+
+    // ---- transpose-read addressing for the 32x32x16 operand layout (A: row l & 31, B: column l & 31; k = 8 (l >> 5) .. +7).  Lane
+    //      l = 16 q + i RECEIVES channel 16 (q & 1) + i of a 32-channel tile for the 8 pixels 8 (q >> 1) .. +7 of the half-stage and
+    //      ADDRESSES pixel row 8 (q >> 1) + 4 r + (i >> 2) (r = 0, 1: the two reads), 4 channels at 4 (i & 3) of its 16-channel group
+    //      (ds_read_b64_tr_b16 lane map: profiles/r01_probe_ds_read_tr_b16.txt).  (row & 3) == i >> 2 for every read.  Two address
+    //      registers per tile (ring slots 0-1 / 2-3): everything else of an address is an immediate (16-bit offset field).
+    const int li = lane & 15, lq = lane >> 4;
+    const uint32_t lrow = lds_base + (uint32_t)((8 * (lq >> 1) + (li >> 2)) * ROWB + 32 * (lq & 1) + 8 * (li & 3));
+    uint32_t colG[2][TI], colX[2][XJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        colG[0][i] = lrow + (uint32_t)((64 * (wm * TI + i) + 64 * (li >> 2)) & (ROWB - 1));
+        colG[1][i] = colG[0][i] + 2 * STAGE;
+    }
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+        colX[0][j] = lrow + (uint32_t)(OPG + ((64 * (wn * XJ + j) + 64 * (li >> 2)) & (ROWB - 1)));
+        colX[1][j] = colX[0][j] + 2 * STAGE;
+    }
+
+    bf16x8 ga[2][TI], xb[2][XJ];                                   // two fragment sets
+    auto frag = [&](uint32_t addr) {                               // one operand fragment: pixels 0..3 and 4..7 of the lane's octet
+        const s16x4 lo = tr_read(addr), hi = tr_read(addr + 4 * ROWB);
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    // fragment q (G tiles first, then X tiles) of half-stage u of ring slot SLOT -> set
+    auto load_frag = [&](auto slot_c, int set, int u, int q) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        const uint32_t imm = (uint32_t)((SLOT & 1) * STAGE + u * 16 * ROWB);
+        if (q < TI) ga[set][q] = frag(colG[SLOT >> 1][q] + imm);
+        else xb[set][q - TI] = frag(colX[SLOT >> 1][q - TI] + imm);
+    };
+    auto mma = [&](int set, int m) {                               // MFMA m of a half-stage: tile (m / XJ, m % XJ)
+        acc[m / XJ][m % XJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[set][m / XJ], xb[set][m % XJ], acc[m / XJ][m % XJ], 0, 0, 0);
+    };
+    // (inline asm on purpose: with the builtin the compiler merges the per-tile branches below into one indexed access of the fragment
+    // array, which then lives in scratch memory -- and scratch traffic would also break the hand-counted vmcnt of the DMA ring)
+    auto ones_dot = [&](const bf16x8& f) {
+        const u32x4 v = __builtin_bit_cast(u32x4, f);
+        asm volatile("v_dot2c_f32_bf16 %0, %1, %2\n\tv_dot2c_f32_bf16 %0, %1, %3\n\tv_dot2c_f32_bf16 %0, %1, %4\n\tv_dot2c_f32_bf16 %0, %1, %5"
+                     : "+v"(bsum) : "s"(0x3f803f80u), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+    };
+    auto bias = [&](int set) {                                     // scalar branches: wn lives in an SGPR
+        if (do_bias) {
+            if (wn == 0) ones_dot(ga[set][0]);
+            if constexpr (TI > 1) { if (wn == 1) ones_dot(ga[set][1]); }
+            if constexpr (TI > 2) { if (wn == 2) ones_dot(ga[set][2]); }
+            if constexpr (TI > 3) { if (wn == 3) ones_dot(ga[set][3]); }
+        }
+    };
+
+    const int nst = (m_end - m_begin + PK - 1) / PK;               // stages of this slice (>= 0)
+    // One stage (ring slot SLOT).  On entry its first half-stage's fragments (set 0) are already requested.
+    auto stage = [&](auto slot_c, int s) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        constexpr int NEXT = (SLOT + 1) & (NS - 1), FILL = (SLOT + NS - 1) & (NS - 1);
+        const bool more = s + NS - 1 < nst;
+        // ---- first half: request the second half's fragments (set 1), then the MFMAs of set 0 with the DMA issues of stage s+3
+        //      between them (they go to the ring slot of stage s-1: every wave finished reading it before the last barrier)
+#pragma unroll
+        for (int q = 0; q < TI + XJ; ++q) load_frag(slot_c, 1, 1, q);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            mma(0, m);
+            if (m == 1 || m == NM / 2 || m == NM - 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    if (m == 1) issue_g(FILL, s + NS - 1);
+                    if (m == NM / 2) issue_x(FILL, 0);
+                    if (m == NM - 2) issue_x(FILL, 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        bias(0);
+        // ---- stage s+1 landed (own share) + all transpose reads of stage s returned, then the workgroup barrier: afterwards
+        //      stage s+1 is complete in LDS and nobody reads this stage's ring slot any more
+        if (s + 3 < nst) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * NDMA) : "memory");
+        else if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- second half: MFMAs of set 1 with the requests for the next stage's first half (set 0) between them
+        //      (unconditionally: behind the last stage they fetch stale ring contents that nobody uses)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            mma(1, m);
+            if (m < TI + XJ) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_frag(IC<NEXT>{}, 0, 0, m);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        static_assert(NM >= TI + XJ, "one fragment request behind each MFMA");
+        bias(1);
+    };
+    if (nst > 0) {
+#pragma unroll
+        for (int s0 = 0; s0 < NS - 1; ++s0)
+            if (s0 < nst) { issue_g(s0, s0); issue_x(s0, 0); issue_x(s0, 1); }
+        if (nst >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NDMA) : "memory");
+        else if (nst == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < TI + XJ; ++q) load_frag(IC<0>{}, 0, 0, q);
+        for (int s = 0; s < nst; s += NS) {
+            stage(IC<0>{}, s);
+            if (s + 1 < nst) stage(IC<1>{}, s + 1);
+            if (s + 2 < nst) stage(IC<2>{}, s + 2);
+            if (s + 3 < nst) stage(IC<3>{}, s + 3);
+        }
+    }
+
+    // ---- epilogue.  32x32 accumulator layout: element e of lane l is row 8 (e >> 2) + 4 (l >> 5) + (e & 3), column l & 31
+    float* dst = p.partial + (p.atomic ? (int64_t)0 : (int64_t)slice * p.cout_pad * p.kcols_pad);
+    const int co0 = co_tile * BCO + wm * (BCO / 2) + 4 * (lane >> 5);
+    const int kc0 = k_tile * BK + wn * (BK / 4) + (lane & 31);
+    if (p.atomic) {
+        if (nst > 0) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < XJ; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        atomicAdd(dst + (int64_t)(co0 + 32 * i + 8 * (e >> 2) + (e & 3)) * p.kcols_pad + kc0 + 32 * j, acc[i][j][e]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < XJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    dst[(int64_t)(co0 + 32 * i + 8 * (e >> 2) + (e & 3)) * p.kcols_pad + kc0 + 32 * j] = acc[i][j][e];
+    }
+    if (do_bias) {
+        // lanes l and l ^ 32 hold the two pixel-octets' sums of the same channel
+        bsum += __shfl_xor(bsum, 32, 64);
+        const int co = co_tile * BCO + wm * (BCO / 2) + 32 * wn + (lane & 31);
+        if (lane < 32 && co < p.Cout) atomicAdd(p.dbias + co, bsum);
+    }
+#endif
+}
+
+template <typename K>
+void raise_lds(K kern, size_t lds) {
+    static thread_local std::unordered_map<const void*, size_t> granted;
+    size_t& g = granted[reinterpret_cast<const void*>(kern)];
+    if (g < lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        g = lds;
+    }
+}
+
+}  // namespace
+
+size_t wgrad_pipe_lds_bytes(int, int) { return 4 * 2 * 32 * 512; }
+
+int launch_wgrad_pipe(const WgradK& k, int bco, int bk, dim3 grid, hipStream_t st) {
+    DIN_REQUIRE(bk == 256 && (bco == 128 || bco == 192 || bco == 256), "wgrad pipe kernel: tile %dx%d not instantiated", bco, bk);
+    const size_t lds = wgrad_pipe_lds_bytes(bco, bk);
+    auto launch = [&](auto kern) {
+        raise_lds(kern, lds);
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, k);
+    };
+    const bool wide = k.OW >= 32;                                  // a feature-map row holds at least one 32-pixel stage
+    if (bco == 128) { if (wide) launch(conv_wgrad_pipe_kernel<128, 256, true>); else launch(conv_wgrad_pipe_kernel<128, 256, false>); }
+    else if (bco == 192) { if (wide) launch(conv_wgrad_pipe_kernel<192, 256, true>); else launch(conv_wgrad_pipe_kernel<192, 256, false>); }
+    else { if (wide) launch(conv_wgrad_pipe_kernel<256, 256, true>); else launch(conv_wgrad_pipe_kernel<256, 256, false>); }
+    return DIN_OK;
+}
+
+}  // namespace din_wgrad

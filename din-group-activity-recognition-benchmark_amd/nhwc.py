@@ -88,6 +88,8 @@ class _timed:
         if self.kind == "wgrad":
             if bm.value == 0:
                 return f"conv_wgrad_small_kernel<..., {bn.value}, ...>"
+            if bn.value >= 2000:
+                return f"conv_wgrad_pipe_kernel<{bm.value}, {bn.value - 2000}>"
             if bn.value >= 1000:
                 return f"conv_wgrad_ring_kernel<{bm.value}, {bn.value - 1000}>"
             return f"conv_wgrad_bf16_kernel<{bm.value}>" if d.dtype == L.DIN_BF16 else "conv_wgrad_f32_kernel"
@@ -135,29 +137,6 @@ _WS: Dict[Tuple[int, str], torch.Tensor] = {}
 
 _SIDE: Dict[int, "torch.cuda.Stream"] = {}
 WGRAD_SIDE_STREAM = _os.environ.get("DIN_WGRAD_STREAM", "0") != "0"     # opt-in: measured 472 -> 351 clips/s (the LDS-heavy kernels of the two streams evict each other)
-
-
-REDUCE_SIDE_STREAM = _os.environ.get("DIN_REDUCE_STREAM", "0") != "0"   # opt-in: wgrad slice reduces on a second stream.  Measured SLOWER
-# (4-clip step 11.94 -> 12.79 ms, 32 clips 493 -> 486 clips/s): two event hand-overs per layer cost more than the 10 us reduce they hide
-_REDUCE_SET: Dict[int, bool] = {}
-
-
-def reduce_stream_setup(device) -> bool:
-    """Register this device's side stream with the library as the stream of the wgrad slice reduces (once per process)."""
-    if not REDUCE_SIDE_STREAM or WGRAD_SIDE_STREAM:
-        return False
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    if key not in _REDUCE_SET:
-        L.check(L.load().din_wgrad_set_reduce_stream(side_stream(device).cuda_stream), "wgrad_set_reduce_stream")
-        _REDUCE_SET[key] = True
-    return True
-
-
-def reduce_join(stream=None) -> None:
-    """Make `stream` (default: the current one) wait for the last enqueued slice reduce: call before reading a conv weight gradient."""
-    if _REDUCE_SET:
-        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-        L.check(L.load().din_wgrad_reduce_join(st), "wgrad_reduce_join")
 
 
 def side_stream(device) -> "torch.cuda.Stream":
@@ -474,8 +453,31 @@ def _pack_cache(g: Graph, params: Sequence[torch.Tensor], dt: int, dev, with_tra
     return pc
 
 
-def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tensor], dt: int, save_for_backward: bool = True):
-    """Run the graph.  image_buf: NHWC [nb,h,w,cpad] of dtype dt.  Returns (bufs, aux) for backward."""
+BN_MOMENTUM = 0.1  # torch.nn.BatchNorm2d default (torchvision BasicConv2d)
+
+
+def _bn_train_forward(lib, raw: torch.Tensor, dt: int, rows: int, cout: int, gamma, beta, mean, var, relu: bool, dst: torch.Tensor,
+                      ldd: int, coffd: int, st):
+    """batch-statistics BatchNorm (+ReLU) of a raw conv output [rows][cout] into the channel view (ldd, coffd) of dst; updates the
+    running statistics in place; returns (batch mean, rstd) for the backward pass"""
+    dev = raw.device
+    sums = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
+    ab = torch.empty(4 * cout, dtype=torch.float32, device=dev)
+    a, b, bmean, rstd = ab[:cout], ab[cout:2 * cout], ab[2 * cout:3 * cout], ab[3 * cout:]
+    L.check(lib.din_bn_stats(_ptr(raw), dt, rows, cout, cout, 0, _ptr(sums), st), "bn_stats")
+    L.check(lib.din_bn_finalize(_ptr(sums), rows, cout, _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(var), _ptr(a), _ptr(b),
+                                _ptr(bmean), _ptr(rstd), st), "bn_finalize")
+    L.check(lib.din_bn_apply(_ptr(raw), dt, rows, cout, cout, 0, _ptr(a), _ptr(b), int(relu), _ptr(dst), ldd, coffd, st), "bn_apply")
+    return bmean, rstd
+
+
+def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tensor], dt: int, save_for_backward: bool = True,
+                  bn_train: bool = False):
+    """Run the graph.  image_buf: NHWC [nb,h,w,cpad] of dtype dt.  Returns (bufs, aux) for backward.
+    bn_train: BatchNorm layers normalise with the statistics of this batch and update their running statistics (the reference's stage-2
+    default for Inception-v3: model.train() without set_bn_eval, train_net_dynamic.py:98-100,170-172).  Each BasicConv2d then runs as
+    conv (unscaled filters, raw output kept for backward) -> statistics -> normalise + ReLU into the consumer's view; the folded-BN
+    fusions (sibling launches, shift in the conv / pool epilogue) do not apply."""
     lib = L.load()
     nb = image_buf.shape[0]
     dev = image_buf.device
@@ -487,14 +489,18 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
     st = _stream()
     bn = _bn_tables(g, params, dev)
     pc = _pack_cache(g, params, dt, dev, save_for_backward, bn)
-    if bn is not None:
+    bn_train = bool(bn_train) and bn is not None
+    if bn_train:
+        bn_scale, bn_shift = pc.bn_scale, pc.bn_shift
+        bn_scale.fill_(1.0)                                   # filters are packed unscaled: the normalisation happens after the conv
+    elif bn is not None:
         # every BatchNorm layer of the graph folded in ONE launch into flat scale / shift arrays (views per layer below)
         bn_scale, bn_shift = pc.bn_scale, pc.bn_shift
         L.check(lib.din_bn_fold_multi(_ptr(bn.ptrs), _ptr(bn.offs), bn.n, bn.total, BN_EPS, _ptr(bn_scale), _ptr(bn_shift), st), "bn_fold_multi")
     # ... and every filter bank (forward and, when training, dgrad orientation) repacked with the folded scale in ONE launch
     L.check(lib.din_conv_pack_multi(_ptr(pc.table), _ptr(pc.layer_of), _ptr(pc.chunk_index), pc.nblocks, PACK_CHUNK, st), "conv_pack_multi")
     bn_i = 0
-    group_of = {grp[0]: grp for grp in g.fwd_groups} if FUSE_FWD_SIBLINGS else {}
+    group_of = {grp[0]: grp for grp in g.fwd_groups} if (FUSE_FWD_SIBLINGS and not bn_train) else {}
     fused_done = set()                                     # members whose output the group launch already produced
     for oi, op in enumerate(g.ops):
         td = g.tensors[op.dst.tid]
@@ -514,6 +520,28 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
                 bias = shift
             else:
                 bias = next(it) if op.bias else None
+            if op.bn and bn_train:
+                # conv -> raw [nb,oh,ow,cout] (-> commuted pool: also linear, so avgpool(conv(x)) == conv(avgpool(x)) holds before the
+                # normalisation) -> batch statistics -> normalise + ReLU into dst's view
+                dR = _conv_desc(g, op, nb, dt, cin)
+                dR.ldo, dR.cooff = op.dst.c, 0
+                raw = torch.empty((nb, g.tensors[op.src.tid].h if op.pooled is not None else td.h,
+                                   g.tensors[op.src.tid].w if op.pooled is not None else td.w, op.dst.c), dtype=tdt, device=dev)
+                if op.pooled is not None:
+                    dR.oh, dR.ow = raw.shape[1], raw.shape[2]
+                ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(dR), 0), dev)
+                with _timed("fwd", dR, op.name):
+                    L.check(lib.din_conv_fwd(C.byref(dR), _ptr(src), _ptr(pc.wpk[oi]), None, _ptr(raw), 0, _ptr(ws), wsb, st), "conv_fwd " + op.name)
+                if op.pooled is not None:
+                    _, pd = _pooled_descs(g, op, nb, dt)
+                    pd.ldo, pd.cooff = op.dst.c, 0
+                    pooled_raw = torch.empty((nb, td.h, td.w, op.dst.c), dtype=tdt, device=dev)
+                    L.check(lib.din_avgpool_fwd(C.byref(pd), _ptr(raw), _ptr(pooled_raw), None, 0, st), "avgpool_fwd(raw)")
+                    raw = pooled_raw
+                bmean, rstd = _bn_train_forward(lib, raw, dt, nb * td.h * td.w, op.dst.c, gamma, beta, mean, var, op.relu, dst, td.c,
+                                                op.dst.coff, st)
+                aux.append((None, raw if save_for_backward else None, bmean, rstd))
+                continue
             if oi in fused_done:
                 if op.pooled is not None:                   # the group launch left the raw conv output in `mid`: pool + shift + ReLU into dst
                     _, pd = _pooled_descs(g, op, nb, dt)
@@ -581,7 +609,7 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
 
 
 def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
-                   out_grads: Dict[int, torch.Tensor], need_param_grad: Sequence[bool]):
+                   out_grads: Dict[int, torch.Tensor], need_param_grad: Sequence[bool], bn_train: bool = False):
     """Reverse pass.  out_grads: tid -> gradient buffer (same geometry/dtype as the tensor, already ReLU-masked where
     the tensor is relu_masked).  Returns the list of parameter gradients aligned with `params` (None for buffers)."""
     lib = L.load()
@@ -591,8 +619,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
     st = _stream()
     main = torch.cuda.current_stream()
     side = side_stream(dev) if (WGRAD_SIDE_STREAM and PROFILE is None) else None
-    rs = reduce_stream_setup(dev)                      # slice reduces run on the side stream; wgrad then owns its own workspace
-    wtag = "wgrad" if rs else ""
+    wtag = ""
     gbufs: Dict[int, torch.Tensor] = dict(out_grads)
 
     def on_side(tensors):
@@ -709,7 +736,8 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
     # sibling groups: the members behind the first one share a tensor -> one wgrad launch, issued when the LAST of them comes up (the
     # reverse pass reaches it first; by then the consumers of every member have written their slice of the shared gradient buffer)
     wgrad_group = {}
-    if FUSE_WGRAD_SIBLINGS:
+    bn_train = bool(bn_train) and bn is not None
+    if FUSE_WGRAD_SIBLINGS and not bn_train:
         for grp in g.fwd_groups:
             mem = tuple(i for i in grp[1:] if g.ops[i].pooled is None)      # (a commuted-pool member keeps its own wgrad: its gradient
             if len(mem) >= 2:                                               #  operand is the un-pooled map, a separate buffer)
@@ -731,10 +759,32 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
             d = _conv_desc(g, op, nb, dt, cin)
             po = offsets[oi]
             w = params[po]
-            (scale,) = aux[oi]
+            scale = aux[oi][0]
             g_ld, g_coff = g.tensors[op.dst.tid].c, op.dst.coff        # where the gradient at the conv output lives
             dshift_pre = None
-            if op.pooled is not None:
+            bn_live = op.bn and bn_train
+            if bn_live:
+                # batch-statistics BatchNorm backward: gz (masked by the ReLU that follows) -> dy at the raw conv output, dgamma, dbeta
+                _, raw, bmean, rstd = aux[oi]
+                td_ = g.tensors[op.dst.tid]
+                rows = nb * td_.h * td_.w
+                sums = torch.zeros(2 * op.dst.c, dtype=torch.float64, device=dev)
+                L.check(lib.din_bn_bwd_stats(_ptr(gout), g_ld, g_coff, _ptr(raw), op.dst.c, 0, dt, rows, op.dst.c, _ptr(bmean), _ptr(rstd),
+                                             _ptr(sums), st), "bn_bwd_stats")
+                dy = torch.empty((nb, td_.h, td_.w, op.dst.c), dtype=tdt, device=dev)
+                dgb = torch.empty(2 * op.dst.c, dtype=torch.float32, device=dev)
+                L.check(lib.din_bn_bwd_apply(_ptr(gout), g_ld, g_coff, _ptr(raw), op.dst.c, 0, dt, rows, op.dst.c, _ptr(params[po + 1]), _ptr(bmean),
+                                             _ptr(rstd), _ptr(sums), _ptr(dy), op.dst.c, 0, _ptr(dgb), _ptr(dgb[op.dst.c:]), st), "bn_bwd_apply")
+                grads[po + 1], grads[po + 2] = dgb[:op.dst.c], dgb[op.dst.c:]
+                gout, g_ld, g_coff = dy, op.dst.c, 0
+                d.ldo, d.cooff = op.dst.c, 0                           # the gradient operand of wgrad / dgrad is the contiguous dy
+                if op.pooled is not None:
+                    d, pd = _pooled_descs(g, op, nb, dt)
+                    gtmp = torch.empty((nb, pd.h, pd.w, pd.c), dtype=tdt, device=dev)
+                    pd.ldo, pd.cooff = op.dst.c, 0                     # the pooled-side gradient is the contiguous dy
+                    L.check(lib.din_avgpool_bwd(C.byref(pd), _ptr(gout), _ptr(gtmp), None, 0, st), "avgpool_bwd(raw)")
+                    gout = gtmp
+            elif op.pooled is not None:
                 # y = relu(avgpool(conv1x1(x)) + shift): shift gradient = column sums of gout, conv-output gradient = avgpool^T(gout)
                 d, pd = _pooled_descs(g, op, nb, dt)
                 td_ = g.tensors[op.dst.tid]
@@ -778,6 +828,13 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 wgrad_done.update(mem)
             if oi in wgrad_done:
                 dw = grads[po]
+            elif bn_live:
+                dw = torch.empty_like(w)
+                ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 2), dev, wtag)
+                with _timed("wgrad", d, op.name):
+                    L.check(lib.din_conv_wgrad(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dw), None, None, None, None, 0,
+                                               _ptr(ws), wsb, st), "conv_wgrad " + op.name)
+                grads[po] = dw
             elif op.bn:
                 dw = torch.empty_like(w)
                 wsbytes = lib.din_conv_workspace_bytes(C.byref(d), 2)
@@ -850,9 +907,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
             gbufs.pop(op.dst.tid, None)
     if side is not None:
         main.wait_stream(side)                        # parameter gradients are complete for whoever runs next on the main stream
-    if rs:
-        reduce_join(st)                               # ... and so are the slice reduces of the last layers
-    if bn is not None and bn_touched:
+    if bn is not None and bn_touched and not bn_train:
         # BatchNorm parameter gradients of every layer in one launch: dgamma = (wdot - dshift * mean) * rstd, dbeta = dshift
         bn_out = torch.empty(2 * bn.total, dtype=torch.float32, device=dev)
         L.check(lib.din_bn_fold_bwd_multi(_ptr(bn.ptrs), _ptr(bn.offs), bn.n, bn.total, BN_EPS, _ptr(bn_wdot), _ptr(bn_dshift),
@@ -868,7 +923,7 @@ class NHWCGraphFunction(torch.autograd.Function):
     """images (uint8|fp32 NCHW, 0..255) -> output NHWC buffers.  One autograd node for the whole conv stack."""
 
     @staticmethod
-    def forward(ctx, graph: Graph, dt: int, images: torch.Tensor, prenormalised: bool, *params):
+    def forward(ctx, graph: Graph, dt: int, images: torch.Tensor, prenormalised: bool, bn_train: bool, *params):
         lib = L.load()
         require_gpu(images, *params)
         nb, _, h, w = images.shape
@@ -888,8 +943,8 @@ class NHWCGraphFunction(torch.autograd.Function):
                 L.check(lib.din_prep_images_nhwc(_ptr(images.float().contiguous()), 0, _ptr(img), dt, nb, h, w, ti.c, st),
                         "prep_nhwc")
         with torch.no_grad():
-            bufs, aux = graph_forward(graph, img, params, dt, save_for_backward=any(p.requires_grad for p in params))
-        ctx.graph, ctx.dt, ctx.bufs, ctx.aux = graph, dt, bufs, aux
+            bufs, aux = graph_forward(graph, img, params, dt, save_for_backward=any(p.requires_grad for p in params), bn_train=bn_train)
+        ctx.graph, ctx.dt, ctx.bufs, ctx.aux, ctx.bn_train = graph, dt, bufs, aux, bn_train
         ctx.params = params
         ctx.need = [p.requires_grad for p in params]
         outs = tuple(bufs[t] for t in graph.output_tids)
@@ -904,7 +959,7 @@ class NHWCGraphFunction(torch.autograd.Function):
             if go is not None:
                 og[tid] = go.contiguous()
         with torch.no_grad():
-            grads = graph_backward(graph, ctx.bufs, ctx.aux, ctx.params, ctx.dt, og, ctx.need)
+            grads = graph_backward(graph, ctx.bufs, ctx.aux, ctx.params, ctx.dt, og, ctx.need, ctx.bn_train)
         ctx.bufs = ctx.aux = None
         grads = [gr if need else None for gr, need in zip(grads, ctx.need)]
-        return (None, None, None, None, *grads)
+        return (None, None, None, None, None, *grads)

@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib as L
-from .nhwc import _ptr, _stream, din_dtype, reduce_join, require_gpu, workspace
+from .nhwc import _ptr, _stream, din_dtype, require_gpu, workspace
 
 
 # ------------------------------------------------------------------------------------------------
@@ -147,7 +147,6 @@ class GridConvFunction(torch.autograd.Function):
             L.check(lib.din_conv_dgrad(C.byref(d), _ptr(gy), _ptr(wpt), _ptr(dx), None, 0, 0, 0, _ptr(ws), wsb, st), "grid_conv_dgrad")
             if ctx.lowp:
                 dx = dx.float()
-        reduce_join(st)                                 # dw is handed to autograd right away: wait for its slice reduce (if on the side stream)
         return dx, dw, db, None, None
 
 

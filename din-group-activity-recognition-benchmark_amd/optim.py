@@ -1,7 +1,9 @@
 """FusedAdam: torch.optim.Adam semantics (train_net_dynamic.py:104: lr, weight_decay, default betas/eps) with the update
 of the WHOLE parameter list done by one din_adam_step_multi launch (fp32 moments; pointer / chunk tables live on the
 device, only the gradient addresses are refreshed per step).  Exposes `param_groups[i]['lr']` so the reference's
-adjust_lr (train_net_dynamic.py:22-25) works unchanged."""
+adjust_lr (train_net_dynamic.py:22-25) works unchanged, and `state_dict()` / `load_state_dict()` in torch.optim.Adam's
+own format, so the `'optimizer'` entry of a reference stage-2 checkpoint (train_net_dynamic.py:141-147) resumes here
+and a checkpoint written here loads into torch.optim.Adam."""
 from __future__ import annotations
 
 import torch
@@ -18,9 +20,13 @@ class FusedAdam:
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.params = [p for p in params]
         self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
-        self.state = {}
-        self.step_count = 0
-        self._tables = None     # (key, ptrs_cpu, ptrs_dev, sizes_dev, chunk_tensor_dev, chunk_index_dev, nchunks)
+        self.state = {}         # param -> (exp_avg, exp_avg_sq)
+        self.steps = {}         # param -> number of updates it received (bias correction is per parameter, as in torch)
+        self._tables = {}       # step value -> (key, ptrs_cpu, ptrs_dev, sizes_dev, chunk_tensor_dev, chunk_index_dev, nchunks)
+
+    @property
+    def step_count(self) -> int:
+        return max(self.steps.values(), default=0)
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
@@ -32,23 +38,35 @@ class FusedAdam:
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0):
         g = self.param_groups[0]
-        self.step_count += 1
         live = [p for p in self.params if p.grad is not None]
         if not live:
             return
         for p in live:
             if p not in self.state:
                 self.state[p] = (torch.zeros_like(p, dtype=torch.float32), torch.zeros_like(p, dtype=torch.float32))
+            self.steps[p] = self.steps.get(p, 0) + 1
         fused = all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in live)
         if not fused:
             for p in live:
                 st = self.state[p]
                 ops.adam_step(p.data, p.grad.contiguous(), st[0], st[1], g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                              g["weight_decay"], self.step_count, grad_scale)
+                              g["weight_decay"], self.steps[p], grad_scale)
             return
+        # one launch per distinct step count (normally one: every trainable parameter gets a gradient every step; a parameter whose
+        # first gradient arrives later keeps its own bias correction)
+        groups = {}
+        for p in live:
+            groups.setdefault(self.steps[p], []).append(p)
+        self._keep = []
+        for step, plist in groups.items():
+            self._launch(plist, step, g, grad_scale)
+
+    def _launch(self, live, step, g, grad_scale):
         dev = live[0].device
         key = tuple(id(p) for p in live)
-        if self._tables is None or self._tables[0] != key:
+        slot = len(live)                                         # table cache slot: keyed by the group's size (stable across steps)
+        tb = self._tables.get(slot)
+        if tb is None or tb[0] != key:
             sizes = torch.tensor([p.numel() for p in live], dtype=torch.int64)
             ct, ci = [], []
             for t, p in enumerate(live):
@@ -58,22 +76,52 @@ class FusedAdam:
             ptrs_cpu = torch.zeros((len(live), 4), dtype=torch.int64).pin_memory()
             for t, p in enumerate(live):
                 ptrs_cpu[t, 0], ptrs_cpu[t, 2], ptrs_cpu[t, 3] = p.data_ptr(), self.state[p][0].data_ptr(), self.state[p][1].data_ptr()
-            self._tables = (key, ptrs_cpu, torch.empty((len(live), 4), dtype=torch.int64, device=dev), sizes.to(dev),
-                            torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(ci, dtype=torch.int32, device=dev), len(ct))
-        _, ptrs_cpu, ptrs_dev, sizes_dev, ct_dev, ci_dev, nchunks = self._tables
+            tb = self._tables[slot] = [key, ptrs_cpu, torch.empty((len(live), 4), dtype=torch.int64, device=dev), sizes.to(dev),
+                                       torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(ci, dtype=torch.int32, device=dev),
+                                       len(ct), None]
+        _, ptrs_cpu, ptrs_dev, sizes_dev, ct_dev, ci_dev, nchunks, copied = tb
         grads = [p.grad if p.grad.is_contiguous() and p.grad.dtype == torch.float32 else p.grad.float().contiguous() for p in live]
-        if getattr(self, "_copied", None) is not None:
-            self._copied.synchronize()          # the previous step's table upload must have left the pinned buffer
+        if copied is not None:
+            copied.synchronize()                # the previous step's table upload must have left the pinned buffer
         ptrs_cpu[:, 1] = torch.tensor([gr.data_ptr() for gr in grads], dtype=torch.int64)
         ptrs_dev.copy_(ptrs_cpu, non_blocking=True)
-        self._copied = torch.cuda.Event()
-        self._copied.record()
+        tb[7] = torch.cuda.Event()
+        tb[7].record()
         L.check(L.load().din_adam_step_multi(C.c_void_p(ptrs_dev.data_ptr()), C.c_void_p(sizes_dev.data_ptr()),
                                              C.c_void_p(ct_dev.data_ptr()), C.c_void_p(ci_dev.data_ptr()), nchunks, CHUNK,
-                                             g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count,
+                                             g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], step,
                                              grad_scale, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "adam_step_multi")
-        self._keep = grads      # the launch reads these asynchronously
+        self._keep.append(grads)      # the launch reads these asynchronously
 
+    # ---- checkpoint format of torch.optim.Adam (state by parameter index; 'step' as a float32 scalar tensor) ----------------------
     def state_dict(self):
-        return dict(step=self.step_count, lr=self.param_groups[0]["lr"],
-                    moments=[tuple(t.cpu() for t in self.state[p]) if p in self.state else None for p in self.params])
+        state = {}
+        for i, p in enumerate(self.params):
+            if p in self.state:
+                m, v = self.state[p]
+                state[i] = {"step": torch.tensor(float(self.steps.get(p, 0))), "exp_avg": m.detach().clone(), "exp_avg_sq": v.detach().clone()}
+        g = self.param_groups[0]
+        group = dict(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"], amsgrad=False, maximize=False,
+                     foreach=None, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False,
+                     params=list(range(len(self.params))))
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
+            raise ValueError("FusedAdam.load_state_dict: expected one parameter group with %d parameters" % len(self.params))
+        if groups[0].get("amsgrad", False):
+            raise ValueError("FusedAdam.load_state_dict: amsgrad state is not supported")
+        g = self.param_groups[0]
+        for k in ("lr", "betas", "eps", "weight_decay"):
+            if k in groups[0]:
+                g[k] = tuple(groups[0][k]) if k == "betas" else groups[0][k]
+        index_of = {pid: i for i, pid in enumerate(groups[0]["params"])}
+        self.state, self.steps, self._tables = {}, {}, {}
+        for pid, st in sd["state"].items():
+            p = self.params[index_of[int(pid)]]
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError("FusedAdam.load_state_dict: moment shape %s != parameter shape %s" % (tuple(st["exp_avg"].shape), tuple(p.shape)))
+            self.state[p] = (st["exp_avg"].to(device=p.device, dtype=torch.float32).clone().contiguous(),
+                             st["exp_avg_sq"].to(device=p.device, dtype=torch.float32).clone().contiguous())
+            self.steps[p] = int(round(float(st["step"])))

@@ -132,13 +132,11 @@ class GradBuckets:
         if key not in self._by_ptr:
             return
         self._hook_order.append(key)
-        if self._learned is None:
-            return                                               # first step: only learn the order
+        if self._learned is None or not dist.is_initialized() or dist.get_world_size() == 1:
+            return                                               # first step: only learn the order (single process: nothing to send)
         self._got[key] = grad
         bi, _ = self._slot[key]
         if bi < self._early and bi not in self._inflight and all(q.data_ptr() in self._got for q in self.buckets[bi]):
-            from . import nhwc as _nhwc
-            _nhwc.reduce_join()                                  # the bucket's last slice reduces may still be running on the side stream
             flat = self._pack(bi, [self._got[q.data_ptr()] for q in self.buckets[bi]])
             self._inflight[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
@@ -147,6 +145,7 @@ class GradBuckets:
         backbone has ~220 parameter tensors, most of them BatchNorm vectors), one asynchronous all-reduce, one scale; afterwards
         every `p.grad` IS a view of the flat buffer (no copy back) -- the optimizer reads the views."""
         if not dist.is_initialized() or dist.get_world_size() == 1:
+            self._hook_order.clear()
             return
         world = world or dist.get_world_size()
         handles = []

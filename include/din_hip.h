@@ -113,12 +113,6 @@ int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t
 /* which instantiation of conv_gather_fast_kernel a fwd (0) / dgrad (1) launch resolves to: flags bit 0 = FASTK (scalar k-walk), bit 1 = 8 waves
  * (4 x 2) instead of 4 (2 x 2) -- so that a profiler-side caller can spell the exact kernel name rocprofv3 prints */
 int din_conv_kernel_variant(const din_conv_desc* d, int which, int32_t* flags);
-/* Optional: run the slice-reduce kernel of din_conv_wgrad on `stream` (NULL: back on the caller's stream).  The reduce is ordered after its
- * wgrad kernel by an event and the next din_conv_wgrad waits for it before it overwrites the workspace, so wgrad must then own a workspace
- * that no other launch writes in between.  din_wgrad_reduce_join(stream) makes `stream` wait for the last enqueued reduce: call it before
- * anything reads a weight gradient (end of backward, gradient bucket hand-over).  Process-wide setting (one process per GPU). */
-int din_wgrad_set_reduce_stream(void* stream);
-int din_wgrad_reduce_join(void* stream);
 /* workspace bytes needed by fwd / dgrad / wgrad for this descriptor (split-K partial sums) */
 int64_t din_conv_workspace_bytes(const din_conv_desc* d, int which /*0 fwd,1 dgrad,2 wgrad*/);
 
@@ -165,6 +159,27 @@ int din_bn_fold_multi(const uint64_t* ptrs, const int32_t* offs, int n, int tota
                       void* stream);
 int din_bn_fold_bwd_multi(const uint64_t* ptrs, const int32_t* offs, int n, int total, float eps, const float* wdot,
                           const float* dshift, float* dgamma, float* dbeta, void* stream);
+
+/* BatchNorm with BATCH statistics: the reference's default for the Inception-v3 backbone in stage 2 -- model.train() without
+ * set_bn_eval (train_net_dynamic.py:98-100,170-172; config.py:80) -> torch.nn.functional.batch_norm(training=True) inside torchvision's
+ * BasicConv2d.  Views are [rows][c] with pixel stride ld and channel offset coff (elements; multiples of 4 fp32 / 8 bf16).
+ *   din_bn_stats     : sums[0..c) += sum_rows x, sums[c..2c) += sum_rows x^2           (fp64 accumulators, zeroed by the caller)
+ *   din_bn_finalize  : mean, rstd = 1/sqrt(biased var + eps); a = gamma*rstd, b = beta - mean*a; running_mean/var (may be NULL) updated
+ *                      in place with `momentum` and the unbiased variance, as torch does
+ *   din_bn_apply     : y = a*x + b (relu != 0: max(.,0)) -- x and y may be views of different tensors
+ *   din_bn_bwd_stats : sums[0..c) += sum gz, sums[c..2c) += sum gz*xhat, xhat = (x - mean)*rstd   (gz: gradient at the BN output,
+ *                      already masked by the ReLU that follows)
+ *   din_bn_bwd_apply : dy = gamma*rstd*(gz - s1/rows - xhat*s2/rows); dgamma = s2, dbeta = s1                                   */
+int din_bn_stats(const void* x, int dtype, int64_t rows, int c, int ld, int coff, double* sums, void* stream);
+int din_bn_finalize(const double* sums, int64_t rows, int c, const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var, float* a, float* b, float* mean, float* rstd, void* stream);
+int din_bn_apply(const void* x, int dtype, int64_t rows, int c, int ldx, int cxoff, const float* a, const float* b, int relu,
+                 void* y, int ldy, int cyoff, void* stream);
+int din_bn_bwd_stats(const void* gz, int ldg, int cgoff, const void* x, int ldx, int cxoff, int dtype, int64_t rows, int c,
+                     const float* mean, const float* rstd, double* sums, void* stream);
+int din_bn_bwd_apply(const void* gz, int ldg, int cgoff, const void* x, int ldx, int cxoff, int dtype, int64_t rows, int c,
+                     const float* gamma, const float* mean, const float* rstd, const double* sums, void* dy, int ldy, int cyoff,
+                     float* dgamma, float* dbeta, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pools / resize (backbone.py:51,57 max_pool2d; torchvision InceptionA/C avg_pool2d(3,1,1), InceptionB

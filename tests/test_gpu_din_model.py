@@ -95,8 +95,12 @@ def test_whole_model_logits_match_reference_golden(gpu, path):
     named = dict(model.named_parameters())
     for k in z.files:
         if k.startswith("g."):                   # gradients the fixture stores whole (head + every small backbone tensor): elementwise
-            tol = 1e-3 if not k.startswith("g.backbone.") else 5e-3
-            assert rel(named[k[2:]].grad, z[k]) <= tol, k
+            # backbone tensors below a max-pool: the fp32 reference itself is 6e-3 away from its fp64 self there (pool / ReLU routing
+            # flips, see test_inception_backbone_grads_match_oracle_elementwise) -> 3e-2; above the pools 5e-3; head 1e-3
+            tol = 1e-3 if not k.startswith("g.backbone.") else (3e-2 if k.startswith("g.backbone.Conv2d_") else 5e-3)
+            assert rel(named[k[2:]].grad, z[k]) <= tol, (k, rel(named[k[2:]].grad, z[k]))
+            a_, b_ = named[k[2:]].grad.detach().cpu().double().flatten(), torch.as_tensor(z[k]).double().flatten()
+            assert float(a_ @ b_ / (a_.norm() * b_.norm() + 1e-300)) >= 0.9999, k
         if k.startswith("gsum."):
             name = k[5:]
             got = named[name].grad.double()
@@ -307,15 +311,22 @@ def test_collective_model_matches_reference_golden(gpu, golden_dir):
             assert abs(got.sum().item() - float(z[k])) <= 2e-3 * float(z["gabs." + k[5:]]) + 1e-6, k
 
 
+INCEPTION_STAGES = (("Conv2d_1a", "Conv2d_2a", "Conv2d_2b"), ("Conv2d_3b", "Conv2d_4a"), ("Mixed_5b", "Mixed_5c", "Mixed_5d", "Mixed_6a"),
+                    ("Mixed_6b", "Mixed_6c", "Mixed_6d", "Mixed_6e"))      # separated by the max-pools of the backbone
+
+
 @pytest.mark.parametrize("commute", ["1", "0"], ids=["pool_commuted", "reference_op_order"])
 def test_inception_backbone_grads_match_oracle_elementwise(gpu, monkeypatch, commute):
-    """Row I backward: EVERY Inception-v3 parameter gradient (conv filters, BN gamma / beta of all 94 layers) and both output maps
-    against the CPU oracle's autograd (oracle.inception_v3_features, running-statistics BN = the folded form), elementwise, fp32, with
-    the branch_pool commute on and off.  A gradient routed to the wrong channel range / tap / parity class inside a tensor (fused
-    multi-source 1x1 dgrad, stride-2 parity-class dgrad, sibling wgrad, bn_fold_bwd_multi offsets) is an O(1) elementwise error here.
-    Tolerances: forward 1e-4 max-rel.  Gradients: relative L2 error <= 2e-3 and cosine >= 0.99999 for every tensor; max-rel <= 2e-3
-    above the last max-pool (Mixed_6b..6e), <= 3e-2 below it -- there a 1e-7 activation difference (fp32 summation order) can flip a
-    near-tied pool window or a ReLU at zero and re-route single elements, as in test_backbone_grads_match_oracle_small."""
+    """Row I backward: EVERY Inception-v3 parameter gradient (conv filters, BN gamma / beta of all 70 layers) and both output maps
+    against the CPU oracle's autograd (oracle.inception_v3_features, running-statistics BN = the folded form), elementwise, with the
+    branch_pool commute on and off.  A gradient routed to the wrong channel range / tap / parity class inside a tensor (fused multi-source
+    1x1 dgrad, stride-2 parity-class dgrad, sibling wgrad, bn_fold_bwd_multi offsets) is an O(1) elementwise error here.
+
+    Tolerances.  Forward 1e-4 max-rel.  Gradients are compared with the oracle run in FLOAT64, and the yardstick is the oracle itself:
+    the fp32 oracle differs from the fp64 one by up to 6e-3 rel-L2 in the stem (a 1e-7 activation difference flips a near-tied max-pool
+    window or a ReLU at zero and re-routes single elements; every flip above a layer reaches its gradient) but only ~1e-6 above the last
+    max-pool.  Per stage between max-pools, the HIP path must stay within 3x the fp32 oracle's own worst error against fp64 (floor 1e-4
+    rel-L2, i.e. the top stage is held to 1e-4), and every tensor keeps cosine >= 0.9999."""
     monkeypatch.setenv("DIN_POOL_COMMUTE", commute)
     from din_amd.backbone.backbone import MyInception_v3
     shapes = O.inception_v3_param_shapes(prefix="")
@@ -323,33 +334,177 @@ def test_inception_backbone_grads_match_oracle_elementwise(gpu, monkeypatch, com
     g = torch.Generator().manual_seed(78)
     images = torch.randint(0, 256, (3, 3, 139, 203), generator=g, dtype=torch.uint8)
     x = O.prep_images(images.float())
-    po = {k: v.clone().requires_grad_("running_" not in k) for k, v in p.items()}
-    ref = O.inception_v3_features(x, po, prefix="")
-    cots = [torch.randn(f.shape, generator=g) / f.numel() ** 0.5 for f in ref]
-    sum((f * c).sum() for f, c in zip(ref, cots)).backward()
+    cots, refg, ref32 = None, {}, None
+    for dt in (torch.float32, torch.float64):
+        po = {k: v.to(dt).clone().requires_grad_("running_" not in k) for k, v in p.items()}
+        ref = O.inception_v3_features(x.to(dt), po, prefix="")
+        if cots is None:
+            cots = [torch.randn(f.shape, generator=g) / f.numel() ** 0.5 for f in ref]
+            ref32 = [f.detach() for f in ref]
+        sum((f * c.to(dt)).sum() for f, c in zip(ref, cots)).backward()
+        refg[dt] = {k: v.grad.double().flatten() for k, v in po.items() if v.grad is not None}
     m = MyInception_v3(compute_dtype="fp32")
     missing, unexpected = m.load_state_dict(p, strict=False)
     assert not unexpected and all("num_batches_tracked" in k for k in missing)
     m = m.to(gpu).eval()
     feats = m(x.to(gpu))
     sum((f * c.to(gpu)).sum() for f, c in zip(feats, cots)).backward()
-    for f, r in zip(feats, ref):
+    for f, r in zip(feats, ref32):
         assert f.shape == r.shape and rel(f, r) <= 1e-4
-    worst = {}
-    n = 0
+    l2 = lambda a, b: float((a - b).norm() / (b.norm() + 1e-300))
+    stage_of = lambda k: next(i for i, names in enumerate(INCEPTION_STAGES) if k.startswith(names))
+    yard = [0.0] * len(INCEPTION_STAGES)                       # fp32 oracle vs fp64 oracle, worst tensor of each stage
+    for k, b in refg[torch.float64].items():
+        yard[stage_of(k)] = max(yard[stage_of(k)], l2(refg[torch.float32][k], b))
+    worst = [(0.0, "")] * len(INCEPTION_STAGES)
+    bad, n = [], 0
     for k, v in m.named_parameters():
         assert v.grad is not None, k
-        a, b = v.grad.detach().cpu().double().flatten(), po[k].grad.double().flatten()
+        a, b = v.grad.detach().cpu().double().flatten(), refg[torch.float64][k]
         assert a.shape == b.shape
-        l2 = float((a - b).norm() / (b.norm() + 1e-300))
-        cos = float(a @ b / (a.norm() * b.norm() + 1e-300))
-        r = rel(a, b)
-        top = k.startswith(("Mixed_6b", "Mixed_6c", "Mixed_6d", "Mixed_6e"))
-        worst[k] = (r, l2, cos)
-        assert l2 <= 2e-3 and cos >= 0.99999, (k, r, l2, cos)
-        assert r <= (2e-3 if top else 3e-2), (k, r, l2, cos)
+        e, cos = l2(a, b), float(a @ b / (a.norm() * b.norm() + 1e-300))
+        st = stage_of(k)
+        worst[st] = max(worst[st], (e, k))
+        if e > max(1e-4, 3 * yard[st]) or cos < 0.9999:
+            bad.append((k, e, cos, yard[st]))
         n += 1
-    assert n == 94 * 3
-    wk = max(worst, key=lambda k_: worst[k_][0])
-    print(f"inception grads vs oracle (commute={commute}): worst max-rel {worst[wk][0]:.2e} at {wk}, "
-          f"worst rel-L2 {max(w[1] for w in worst.values()):.2e}")
+    print(f"inception grads vs fp64 oracle (commute={commute}), rel-L2 per stage [HIP worst | fp32-oracle worst]: " +
+          ", ".join(f"{w[0]:.1e} ({w[1]}) | {y:.1e}" for w, y in zip(worst, yard)))
+    assert n == 70 * 3
+    assert not bad, bad[:8]
+
+
+def test_inception_batch_statistics_bn_matches_oracle(gpu):
+    """Row I in the reference's stage-2 default mode (model.train(), set_bn_eval = False: train_net_dynamic.py:98-100,170-172, config.py:80):
+    BatchNorm normalises with the statistics of the batch and updates running_mean / running_var / num_batches_tracked.  The HIP path
+    (conv -> din_bn_stats -> din_bn_finalize -> din_bn_apply; backward din_bn_bwd_stats / din_bn_bwd_apply) against the oracle's
+    F.batch_norm(training=True): features 1e-4 max-rel, running statistics 1e-5, every parameter gradient against the FLOAT64 oracle with
+    the fp32 oracle's own error as yardstick per stage (as in test_inception_backbone_grads_match_oracle_elementwise)."""
+    from din_amd.backbone.backbone import MyInception_v3
+    shapes = O.inception_v3_param_shapes(prefix="")
+    p = O.synth_params(shapes, seed=91)
+    g = torch.Generator().manual_seed(92)
+    images = torch.randint(0, 256, (4, 3, 139, 203), generator=g, dtype=torch.uint8)
+    x = O.prep_images(images.float())
+    cots, refg, ref32, stats32 = None, {}, None, None
+    for dt in (torch.float32, torch.float64):
+        po = {k: v.to(dt).clone().requires_grad_("running_" not in k) for k, v in p.items()}
+        ref = O.inception_v3_features(x.to(dt), po, prefix="", bn_train=True)       # updates po's running statistics in place, like torch
+        if cots is None:
+            cots = [torch.randn(f.shape, generator=g) / f.numel() ** 0.5 for f in ref]
+            ref32 = [f.detach() for f in ref]
+            stats32 = {k: v.detach().clone() for k, v in po.items() if "running_" in k}
+        sum((f * c.to(dt)).sum() for f, c in zip(ref, cots)).backward()
+        refg[dt] = {k: v.grad.double().flatten() for k, v in po.items() if v.grad is not None}
+    assert any(not torch.equal(stats32[k], p[k]) for k in stats32), "oracle did not update the running statistics"
+    m = MyInception_v3(compute_dtype="fp32")
+    m.load_state_dict(p, strict=False)
+    m = m.to(gpu).train()
+    feats = m(x.to(gpu))
+    sum((f * c.to(gpu)).sum() for f, c in zip(feats, cots)).backward()
+    for f, r in zip(feats, ref32):
+        assert rel(f, r) <= 1e-4
+    sd = m.state_dict()
+    for k, v in stats32.items():
+        assert rel(sd[k], v) <= 1e-5, k
+    assert all(int(v) == 1 for k, v in sd.items() if k.endswith("num_batches_tracked"))
+    l2 = lambda a, b: float((a - b).norm() / (b.norm() + 1e-300))
+    stage_of = lambda k: next(i for i, names in enumerate(INCEPTION_STAGES) if k.startswith(names))
+    yard = [0.0] * len(INCEPTION_STAGES)
+    for k, b in refg[torch.float64].items():
+        yard[stage_of(k)] = max(yard[stage_of(k)], l2(refg[torch.float32][k], b))
+    worst, bad = [(0.0, "")] * len(INCEPTION_STAGES), []
+    for k, v in m.named_parameters():
+        assert v.grad is not None, k
+        a, b = v.grad.detach().cpu().double().flatten(), refg[torch.float64][k]
+        e, cos = l2(a, b), float(a @ b / (a.norm() * b.norm() + 1e-300))
+        st = stage_of(k)
+        worst[st] = max(worst[st], (e, k))
+        if e > max(2e-4, 3 * yard[st]) or cos < 0.9999:
+            bad.append((k, e, cos, yard[st]))
+    print("batch-stat BN grads vs fp64 oracle, rel-L2 per stage [HIP worst | fp32-oracle worst]: " +
+          ", ".join(f"{w[0]:.1e} ({w[1]}) | {y:.1e}" for w, y in zip(worst, yard)))
+    assert not bad, bad[:8]
+    # eval() afterwards uses the UPDATED running statistics (folded path)
+    m.eval()
+    with torch.no_grad():
+        fe = m(x.to(gpu))
+    pe = {k: (sd[k].cpu() if k in sd else v) for k, v in p.items()}
+    re_ = O.inception_v3_features(x, pe, prefix="")
+    for f, r in zip(fe, re_):
+        assert rel(f, r) <= 1e-4
+
+
+def _trainer_cfg(dataset, tmp_path):
+    from din_amd.config import Config
+    cfg = Config(dataset)
+    cfg.backbone, cfg.image_size, cfg.out_size, cfg.emb_features = "vgg16", (64, 96), (2, 3), 512
+    cfg.num_boxes, cfg.num_frames, cfg.num_features_boxes, cfg.num_features_gcn = 4, 2, 32, 32
+    cfg.ST_kernel_size, cfg.sampling_ratio, cfg.beta_factor, cfg.train_backbone = [(3, 3)], [1], False, True
+    cfg.training_stage, cfg.batch_size, cfg.test_batch_size, cfg.max_epoch, cfg.test_interval_epoch = 2, 2, 2, 2, 1
+    cfg.train_dropout_prob, cfg.train_learning_rate, cfg.lr_plan = 0.0, 1e-3, {}
+    cfg.result_path = str(tmp_path)
+    return cfg
+
+
+def test_train_net_two_steps_match_oracle_and_torch_adam(gpu, tmp_path):
+    """Row S end to end through the drop-in entry point: train_net (checkpoint resume via cfg.load_stage2model, train_volleyball,
+    test_volleyball, FusedAdam, checkpoint write) for two optimizer steps on two synthetic clips, against the CPU oracle's forward /
+    backward + torch.optim.Adam on the same clips (reference train_net_dynamic.py:27-157,159-235).  Dropout off; one batch = the whole
+    set, so the shuffle order is irrelevant.  Checks: both training losses 1e-4; every parameter's two-step UPDATE has cosine >= 0.99
+    with the oracle's (Adam's first steps are lr * sign-like, so single near-zero gradients may flip an element's update) and the
+    head's update matches to 2 %; the written checkpoint resumes (epoch, optimizer moments) and loads into torch.optim.Adam."""
+    from din_amd.train_net_dynamic import SyntheticVolleyball, train_net
+    cfg = _trainer_cfg("volleyball", tmp_path)
+    ocfg = O.OracleCfg(image_size=(64, 96), out_size=(2, 3), num_boxes=4, num_frames=2, num_features_boxes=32)
+    p0 = O.synth_params(O.model_param_shapes(ocfg), seed=12, din_std=0.05)
+    start = str(tmp_path / "start.pth")
+    torch.save({"epoch": 0, "state_dict": {"module." + k: v for k, v in p0.items()}}, start)
+    cfg.load_stage2model, cfg.stage2model = True, start
+    ds = SyntheticVolleyball(cfg, length=2, seed=3)
+    infos = train_net(cfg, ds, ds)
+    assert len(infos) == 2 and set(infos[0]) == {"train", "test"}
+    for key in ("time", "epoch", "loss", "activities_acc", "activities_conf", "activities_MPCA"):
+        assert key in infos[0]["train"] and key in infos[0]["test"]
+    # oracle: the same two steps
+    images = torch.stack([ds[i][0] for i in range(2)]).float()
+    boxes = torch.stack([ds[i][1] for i in range(2)])
+    labels = torch.stack([ds[i][3][0] for i in range(2)])
+    po = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
+    opt = torch.optim.Adam(list(po.values()), lr=cfg.train_learning_rate)
+    losses = []
+    for _ in range(2):
+        opt.zero_grad()
+        loss = F.cross_entropy(O.dynamic_volleyball_forward(ocfg, po, images, boxes)["activities"], labels)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    for got, want in zip((infos[0]["train"]["loss"], infos[1]["train"]["loss"]), losses):
+        assert abs(got - want) <= 1e-4 * max(1.0, abs(want)), (got, want)
+    import glob
+    ck = sorted(glob.glob(str(tmp_path / "stage2_epoch2_*.pth")))
+    assert ck, "train_net wrote no checkpoint"
+    state = torch.load(ck[0], map_location="cpu", weights_only=False)
+    assert set(state) >= {"epoch", "state_dict", "optimizer"} and state["epoch"] == 2
+    for k, v0 in p0.items():
+        du, dr = (state["state_dict"][k] - v0).double().flatten(), (po[k].detach() - v0).double().flatten()
+        cos = float(du @ dr / (du.norm() * dr.norm() + 1e-300))
+        assert cos >= 0.99, (k, cos)
+    assert rel(state["state_dict"]["fc_activities.weight"] - p0["fc_activities.weight"], po["fc_activities.weight"].detach() - p0["fc_activities.weight"]) <= 2e-2
+    torch.optim.Adam([torch.nn.Parameter(v.clone()) for v in p0.values()]).load_state_dict(state["optimizer"])
+    # resume: epoch counter and Adam moments continue
+    cfg.stage2model, cfg.max_epoch = ck[0], 1
+    more = train_net(cfg, ds, ds)
+    assert more[0]["train"]["epoch"] == 3
+
+
+def test_train_net_collective_runs_through_the_collective_loops(gpu, tmp_path):
+    """cfg.dataset_name == 'collective' -> train_collective / test_collective (reference train_net_dynamic.py:106-109,315-471) with the
+    3-tuple (images, boxes, bboxes_num) model input and per-clip actor counts"""
+    from din_amd.train_net_dynamic import train_net
+    cfg = _trainer_cfg("collective", tmp_path)
+    cfg.inference_module_name, cfg.num_activities, cfg.max_epoch, cfg.ST_kernel_size = "dynamic_collective", 5, 1, (3, 3)
+    infos = train_net(cfg)
+    tr, te = infos[0]["train"], infos[0]["test"]
+    assert np.isfinite(tr["loss"]) and np.isfinite(te["loss"]) and tr["activities_conf"].shape == (5, 5)
+    assert int(tr["activities_conf"].sum()) == 4 and int(te["activities_conf"].sum()) == 2

@@ -217,45 +217,6 @@ def test_conv_fwd_two_destinations(env, dtype):
     assert float(out2[..., :off2].float().min()) == 7.0 and float(out2[..., off2 + ctot - couts[0]:].float().min()) == 7.0
 
 
-def test_wgrad_reduce_on_second_stream_matches(env):
-    """din_wgrad_set_reduce_stream / din_wgrad_reduce_join: the slice reduce enqueued on a second stream gives the same dW bit for bit,
-    back-to-back launches that share the workspace stay ordered, and NULL restores the single-stream behaviour."""
-    lib, L, nhwc, ops = env
-    g = torch.Generator().manual_seed(11)
-    nb, h, w, cin, cout = 3, 40, 56, 64, 96
-    d = L.ConvDesc()
-    d.nb, d.h, d.w, d.cin, d.oh, d.ow, d.cout = nb, h, w, cin, h, w, cout
-    d.kh = d.kw = 3
-    d.sh = d.sw = d.ph = d.pw = d.dh = d.dw = 1
-    d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = cin, 0, cout, 0, L.DIN_BF16
-    xs = [torch.randn(nb, h, w, cin, generator=g).bfloat16().cuda() for _ in range(3)]
-    gs = [torch.randn(nb, h, w, cout, generator=g).bfloat16().cuda() for _ in range(3)]
-    wsb = lib.din_conv_workspace_bytes(C.byref(d), 2)
-    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device="cuda")
-
-    def run():
-        outs = [torch.empty(cout, cin, 3, 3, device="cuda") for _ in range(3)]
-        dbs = [torch.empty(cout, device="cuda") for _ in range(3)]
-        for x, gy, dw, db in zip(xs, gs, outs, dbs):          # three launches through ONE workspace
-            L.check(lib.din_conv_wgrad(C.byref(d), x.data_ptr(), gy.data_ptr(), dw.data_ptr(), db.data_ptr(), None, None, None, 0,
-                                       ws.data_ptr(), wsb, None))
-        L.check(lib.din_wgrad_reduce_join(None))
-        torch.cuda.synchronize()
-        return outs
-
-    base = run()
-    side = torch.cuda.Stream()
-    L.check(lib.din_wgrad_set_reduce_stream(side.cuda_stream))
-    try:
-        other = run()
-    finally:
-        L.check(lib.din_wgrad_set_reduce_stream(None))
-    for a, b in zip(base, other):
-        assert torch.equal(a, b)
-    ref = torch.nn.grad.conv2d_weight(xs[0].float().permute(0, 3, 1, 2), (cout, cin, 3, 3), gs[0].float().permute(0, 3, 1, 2), padding=1)
-    assert rel(base[0], ref) <= 2e-2
-
-
 def test_conv_kernel_variant_names_the_instantiation(env):
     """din_conv_kernel_variant: bit 0 = FASTK, bit 1 = 8 waves -- the flags bench.py spells the rocprofv3 kernel name from."""
     lib, L, nhwc, ops = env
@@ -587,3 +548,53 @@ def test_conv1x1_dgrad_multi_source(env, dtype):
                                         L.CONV_MASK | L.CONV_ACCUM, None))
     torch.cuda.synchronize()
     assert rel(from_nhwc(dx, cin), xr.grad + xr.grad * (x > 0).float()) <= 2 * tol
+
+
+PIPE_CASES = [
+    # name, nb, cin, h, w, cout, k, s, p          (bf16 wgrad shapes that the planner gives to conv_wgrad_pipe_kernel)
+    ("pipe192_3x3_p0_tail", 2, 80, 61, 97, 192, (3, 3), (1, 1), (0, 0)),          # 192-filter tile, 720 k columns (ragged last k tile), M % 32 != 0
+    ("pipe192_7x1", 3, 160, 43, 78, 192, (7, 1), (1, 1), (3, 0)),                 # Mixed_6 7x1: row padding taps
+    ("pipe192_1x7_narrow", 4, 64, 20, 24, 192, (1, 7), (1, 1), (0, 3)),           # OW < 32: the general (looping) cursor update
+    ("pipe384_3x3_s2", 2, 96, 47, 63, 384, (3, 3), (2, 2), (0, 0)),               # Mixed_6a.branch3x3: two filter tiles, stride 2
+    ("pipe128_1x1", 2, 512, 30, 40, 256, (1, 1), (1, 1), (0, 0)),                 # 128-filter tiles
+]
+
+
+@pytest.mark.parametrize("atomic", ["0", "1"], ids=["slices", "atomic"])
+@pytest.mark.parametrize("case", PIPE_CASES, ids=[c[0] for c in PIPE_CASES])
+def test_wgrad_pipe_kernel(env, case, atomic, monkeypatch):
+    """The software-pipelined 32x32x16 weight-gradient kernel (conv_wgrad_pipe.hip), both epilogues (slice partials + reduce, fp32 atomics
+    into one tile buffer), against autograd of F.conv2d on bf16-rounded operands; bias gradient (packed dot-product path) included."""
+    lib, L, nhwc, ops = env
+    name, nb, cin, h, w, cout, k, s, p = case
+    monkeypatch.setenv("DIN_WGRAD_PIPE", "1")
+    monkeypatch.setenv("DIN_WGRAD_ATOMIC", atomic)
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    x = torch.randn(nb, cin, h, w, generator=g).relu().bfloat16().float()
+    wt = torch.randn(cout, cin, *k, generator=g).requires_grad_(True)
+    br = torch.zeros(cout, requires_grad=True)
+    y = F.conv2d(x, wt, br, stride=s, padding=p)
+    oh, ow = y.shape[2:]
+    gz = torch.randn(y.shape, generator=g).bfloat16().float()
+    y.backward(gz)
+    ldi, ldo, coff = cin + 8, cout + 16, 8
+    d = L.ConvDesc()
+    d.nb, d.h, d.w, d.cin, d.oh, d.ow, d.cout = nb, h, w, cin, oh, ow, cout
+    d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.dh, d.dw = k[0], k[1], s[0], s[1], p[0], p[1], 1, 1
+    d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = ldi, 0, ldo, coff, L.DIN_BF16
+    bm, bn = C.c_int32(0), C.c_int32(0)
+    lib.din_conv_kernel_tile(C.byref(d), 2, C.byref(bm), C.byref(bn))
+    assert bn.value >= 2000, f"planner did not pick the pipe kernel for {name}: tile {bm.value} x {bn.value}"
+    xin = to_nhwc(x, torch.bfloat16, ldi)
+    gzd = to_nhwc(gz, torch.bfloat16, ldo, coff)
+    dw = torch.empty(cout, cin, *k, device="cuda")
+    db = torch.empty(cout, device="cuda")
+    wsb = lib.din_conv_workspace_bytes(C.byref(d), 2)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device="cuda")
+    for _ in range(2):                                      # twice: the atomic epilogue must not depend on what the workspace held before
+        ws.fill_(0x7f)
+        L.check(lib.din_conv_wgrad(C.byref(d), xin.data_ptr(), gzd.data_ptr(), dw.data_ptr(), db.data_ptr(), None, None, None, 0,
+                                   ws.data_ptr(), wsb, None))
+        torch.cuda.synchronize()
+        assert rel(dw, wt.grad) <= 2e-3                     # bf16 operands are exact in the reference too: only fp32 summation order differs
+        assert rel(db, br.grad) <= 2e-3

@@ -164,3 +164,128 @@ def test_gloo_world2_gradient_allreduce(tmp_path):
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-3000:]
     assert "RANK_OK_0" in res.stdout and "RANK_OK_1" in res.stdout
+
+
+def _small_cfg(dataset="volleyball"):
+    from din_amd.config import Config
+    cfg = Config(dataset)
+    cfg.backbone, cfg.image_size, cfg.out_size, cfg.emb_features = "vgg16", (64, 96), (2, 3), 512
+    cfg.num_boxes, cfg.num_frames, cfg.num_features_boxes, cfg.num_features_gcn = 4, 2, 32, 32
+    cfg.ST_kernel_size, cfg.sampling_ratio, cfg.beta_factor, cfg.train_backbone = [(3, 3)], [1], False, True
+    cfg.training_stage = 2
+    return cfg
+
+
+def test_loadmodel_roundtrips_a_stage1_checkpoint(tmp_path):
+    """reference base_model.py:46-63 writes {'backbone_state_dict', 'fc_emb_state_dict', ...}; infer_model.py:126-130 reads the first two"""
+    from din_amd.infer_model import Dynamic_volleyball
+    cfg = _small_cfg()
+    src, dst = Dynamic_volleyball(cfg), Dynamic_volleyball(cfg)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for p in src.parameters():
+            p.copy_(torch.randn(p.shape, generator=g))
+    path = str(tmp_path / "stage1.pth")
+    torch.save({"backbone_state_dict": src.backbone.state_dict(), "fc_emb_state_dict": src.fc_emb_1.state_dict(),
+                "fc_actions_state_dict": {}, "fc_activities_state_dict": {}}, path)
+    dst.loadmodel(path)
+    for (k, a), (_, b) in zip(src.backbone.state_dict().items(), dst.backbone.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert torch.equal(src.fc_emb_1.weight, dst.fc_emb_1.weight) and torch.equal(src.fc_emb_1.bias, dst.fc_emb_1.bias)
+    assert not torch.equal(src.fc_activities.weight, dst.fc_activities.weight)      # the head is NOT part of a stage-1 hand-over
+
+
+def test_stage2_checkpoint_with_dataparallel_prefix_loads(tmp_path):
+    """reference train_net_dynamic.py:82-88 / :141-147: {'epoch', 'state_dict', 'optimizer'}; keys saved through nn.DataParallel carry 'module.'"""
+    from din_amd.infer_model import Dynamic_volleyball
+    from din_amd.train_net_dynamic import load_stage2_state
+    cfg = _small_cfg()
+    src, dst = Dynamic_volleyball(cfg), Dynamic_volleyball(cfg)
+    with torch.no_grad():
+        for p in src.parameters():
+            p.add_(1.0)
+    path = str(tmp_path / "stage2.pth")
+    torch.save({"epoch": 3, "state_dict": {"module." + k: v for k, v in src.state_dict().items()}, "optimizer": {}}, path)
+    state = load_stage2_state(dst, path)
+    assert state["epoch"] == 3
+    for (k, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert torch.equal(a, b), k
+    torch.save({"epoch": 1, "state_dict": {"not_a_key": torch.zeros(1)}}, path)
+    with pytest.raises(RuntimeError):
+        load_stage2_state(dst, path)
+
+
+def test_fused_adam_state_is_torch_adam_compatible():
+    """the 'optimizer' entry of a checkpoint (train_net_dynamic.py:144) must travel both ways between FusedAdam and torch.optim.Adam"""
+    from din_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(1)
+    ps = [torch.nn.Parameter(torch.randn(3, 4, generator=g)), torch.nn.Parameter(torch.randn(5, generator=g))]
+    ref = torch.optim.Adam(ps, lr=3e-4, weight_decay=0.01)
+    for _ in range(3):
+        for p in ps:
+            p.grad = torch.randn(p.shape, generator=g)
+        ref.step()
+    fa = FusedAdam(ps, lr=1.0)
+    fa.load_state_dict(ref.state_dict())
+    assert fa.param_groups[0]["lr"] == 3e-4 and fa.param_groups[0]["weight_decay"] == 0.01 and fa.step_count == 3
+    for p in ps:
+        assert torch.equal(fa.state[p][0], ref.state[p]["exp_avg"]) and torch.equal(fa.state[p][1], ref.state[p]["exp_avg_sq"])
+        assert fa.steps[p] == 3
+    back = torch.optim.Adam(ps, lr=1.0)
+    back.load_state_dict(fa.state_dict())                      # torch validates group / parameter counts itself
+    assert back.param_groups[0]["lr"] == 3e-4
+    for p in ps:
+        assert torch.equal(back.state[p]["exp_avg"], ref.state[p]["exp_avg"]) and float(back.state[p]["step"]) == 3.0
+    with pytest.raises(ValueError):
+        FusedAdam(ps[:1]).load_state_dict(ref.state_dict())
+
+
+def test_set_bn_eval_and_bn_mode_of_the_backbone():
+    """train_net_dynamic.py:17-20: set_bn_eval puts exactly the BatchNorm modules in eval mode; the backbone reads the mode from them"""
+    from din_amd.backbone.backbone import MyInception_v3
+    from din_amd.train_net_dynamic import set_bn_eval
+    net = MyInception_v3()
+    net.train()
+    bns = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    assert len(bns) == 70 and all(m.training for m in bns)
+    net.apply(set_bn_eval)
+    assert net.training and not any(m.training for m in bns)
+
+
+def test_synthetic_datasets_have_the_reference_tuple_layout():
+    from din_amd.train_net_dynamic import SyntheticCollective, SyntheticVolleyball
+    cfg = _small_cfg("collective")
+    cfg.num_boxes = 5
+    v = SyntheticVolleyball(cfg, length=2)[1]
+    assert [tuple(t.shape) for t in v] == [(2, 3, 64, 96), (2, 5, 4), (2, 5), (2,)] and v[0].dtype == torch.uint8
+    c = SyntheticCollective(cfg, length=3)[2]
+    assert [tuple(t.shape) for t in c] == [(2, 3, 64, 96), (2, 5, 4), (2, 5), (2,), (2,)]
+    n = int(c[4][0])
+    assert 1 <= n <= 5 and bool((c[4] == n).all()) and float(c[1][:, n:].abs().sum()) == 0.0
+
+
+def test_grad_bucket_order_is_rank_independent_and_late_hooks_do_not_deadlock():
+    """GradBuckets learns the bucket layout from the order the conv executor reports weight gradients in.  That order is a property of
+    the graph, so it must not depend on the rank; and a gradient reported late (after allreduce() already ran, e.g. a layer that did not
+    take part in this backward) must not leave a half-filled bucket in flight."""
+    from din_amd.parallel import GradBuckets
+    def learn(order):
+        lin = torch.nn.Sequential(*[torch.nn.Linear(4, 4) for _ in range(4)])
+        b = GradBuckets(lin.parameters(), bucket_bytes=64, overlap=False)
+        ws = [lin[i].weight for i in order]
+        for w in ws:
+            w.grad = torch.zeros_like(w)
+            b._on_grad(w, w.grad)
+        b._learned = list(dict.fromkeys(b._hook_order))
+        hooked = [b._by_ptr[k] for k in b._learned]
+        rest = [p for p in reversed(b.params) if p.data_ptr() not in set(b._learned)]
+        b._build(hooked + rest, len(hooked))
+        index = {p.data_ptr(): i for i, p in enumerate(lin.parameters())}
+        return [[index[p.data_ptr()] for p in bk] for bk in b.buckets], b
+    layout0, b = learn([3, 2, 1, 0])
+    layout1, _ = learn([3, 2, 1, 0])
+    assert layout0 == layout1 and layout0[0][0] == 6          # the last layer's weight leads the first bucket on every rank
+    # single process: allreduce() is a no-op and must leave no state behind even if hooks fired
+    b._on_grad(b.params[0], torch.zeros_like(b.params[0]))
+    b.allreduce()
+    assert not b._inflight and not b._got
