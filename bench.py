@@ -69,6 +69,17 @@ def synth_weights(model, seed=3):
                 b.copy_(0.1 * torch.randn(b.shape, generator=g))
 
 
+def synth_boxes_labels(b, t, n, oh, ow, num_classes=8, seed=0):
+    """player-shaped boxes in feature-map pixels + activity labels (SURVEY 8d recipe; the same for every rank count)"""
+    import numpy as np
+    r1 = np.random.default_rng(seed + 1)
+    cx, cy = r1.uniform(0.05, 0.95, (b, t, n)) * ow, r1.uniform(0.3, 0.9, (b, t, n)) * oh
+    bw, bh = r1.uniform(0.03, 0.08, (b, t, n)) * ow, r1.uniform(0.15, 0.35, (b, t, n)) * oh
+    boxes = np.stack([np.clip(cx - bw / 2, 0, ow), np.clip(cy - bh / 2, 0, oh), np.clip(cx + bw / 2, 0, ow), np.clip(cy + bh / 2, 0, oh)], -1)
+    labels = np.random.default_rng(seed + 2).integers(0, num_classes, size=(b,)).astype(np.int64)
+    return torch.from_numpy(boxes.astype(np.float32)), torch.from_numpy(labels)
+
+
 def cpu_baseline(workload, T, N, H, W, budget_s=25.0):
     """Oracle fwd+bwd on the host cores for a bounded sample (B=1 clip per step).
 
@@ -128,6 +139,9 @@ def main():
     ap.add_argument("--host-images", action="store_true", help="clips start in pinned host memory every step (uint8): the PCIe-inclusive rate, never the headline value")
     ap.add_argument("--forward-only", action="store_true", help="evaluation path (SURVEY 8f-3): model.eval(), torch.no_grad(), forward + loss only")
     ap.add_argument("--per-layer", default="", help="write the per-layer conv launch table of the sampled step to this file")
+    ap.add_argument("--bn-mode", default="eval", choices=["eval", "batch"],
+                    help="Inception BatchNorm: 'eval' = cfg.set_bn_eval (running statistics, folded; results independent of the GPU count), "
+                         "'batch' = the reference's stage-2 default (batch statistics of the rank's frames + running-stat update)")
     a = ap.parse_args()
 
     from din_amd import nhwc, parallel
@@ -141,10 +155,14 @@ def main():
     T, N, H, W = a.frames, 12, 720, 1280
     backbone, dtype, (OH, OW), D = WORKLOADS[a.workload]
     cfg = make_cfg(a.workload, T, N, H, W)
+    cfg.set_bn_eval = a.bn_mode == "eval"
     torch.manual_seed(0)
     model = Dynamic_volleyball(cfg)
     synth_weights(model)
     model = model.to(dev).train()
+    if cfg.set_bn_eval:
+        from din_amd.train_net_dynamic import set_bn_eval
+        model.apply(set_bn_eval)                               # reference train_net_dynamic.py:98-100
     parallel.broadcast_parameters(model)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = FusedAdam(params, lr=1e-4, weight_decay=0.0)
@@ -152,10 +170,9 @@ def main():
 
     mine = parallel.shard_range(a.global_batch, rank, world)
     B = len(mine)
-    from oracle.din_oracle import synth_inputs          # input generator only (numpy RNG recipe of SURVEY 8d), not a checker use
     g = torch.Generator().manual_seed(1000 + rank)
     images = torch.randint(0, 256, (B, T, 3, H, W), dtype=torch.uint8, generator=g).to(dev)     # uint8, HBM-resident
-    _, boxes, labels = synth_inputs(a.global_batch, T, N, 8, 8, OH, OW, 8, seed=0)
+    boxes, labels = synth_boxes_labels(a.global_batch, T, N, OH, OW, 8, seed=0)
     boxes, labels = boxes[mine.start:mine.stop].to(dev), labels[mine.start:mine.stop].to(dev)
 
     if a.forward_only:
@@ -315,7 +332,8 @@ def main():
                        "includes": "fwd + cross-entropy (eval mode, no_grad)" if a.forward_only else
                                    "fwd + cross-entropy + bwd" + (" + RCCL grad all-reduce" if world > 1 else "")
                                    + ("" if a.no_adam else " + fused Adam"),
-                       "bn_mode": "running statistics (set_bn_eval)" if backbone == "inv3" else "n/a"},
+                       "bn_mode": ("running statistics (set_bn_eval)" if cfg.set_bn_eval else "batch statistics (reference stage-2 default)")
+                                  if backbone == "inv3" else "n/a"},
             "roofline": roofline,
             "conv_time_frac_sampled_step": round(conv_time / (elapsed / a.steps), 4),
             "final_loss": round(float(loss.item()), 5),

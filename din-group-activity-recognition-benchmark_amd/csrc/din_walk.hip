@@ -23,11 +23,21 @@ struct WalkK {
     const float* gz; float* dx; float* scratch;          // backward only
     int cp, b, t, n, c, kh, kw, ratio, scale_factor;
     int pt, pl, hp, wp, k2, ky0, kx0;
+    const int32_t* n_per_clip;        // optional [b]: clip i is a T x n_per_clip[i] grid stored in the first columns of its T x n slab
+                                      // (Dynamic_collective, infer_model.py:1286-1293); columns beyond it are zero padding
 };
+
+// actors of clip b (1..p.n)
+__device__ __forceinline__ int clip_n(const WalkK& p, int b) {
+    if (!p.n_per_clip) return p.n;
+    const int v = p.n_per_clip[b];
+    return v < 1 ? 1 : (v > p.n ? p.n : v);
+}
 
 struct Corner { int ly, ry, lx, rx; float py, px, py0, px0; };
 
-__device__ __forceinline__ Corner corners(const WalkK& p, int tt, int nn, int k, float oy, float ox) {
+// wpc: padded width of THIS clip's grid (n_b + 2 pl): the x clamp range; the LDS tile keeps the row pitch p.wp of the widest clip
+__device__ __forceinline__ Corner corners(const WalkK& p, int wpc, int tt, int nn, int k, float oy, float ox) {
     const int r = k / p.kw, s = k - r * p.kw;
     const float base_y = (float)(p.pt + tt + p.ky0 + r * p.ratio);     // pos_0 + pos_k : exact small integers
     const float base_x = (float)(p.pl + nn + p.kx0 + s * p.ratio);
@@ -35,7 +45,7 @@ __device__ __forceinline__ Corner corners(const WalkK& p, int tt, int nn, int k,
     c.py0 = __fadd_rn(base_y, oy);
     c.px0 = __fadd_rn(base_x, ox);
     const float fy = floorf(c.py0), fx = floorf(c.px0);
-    const float hy = (float)(p.hp - 1), hx = (float)(p.wp - 1);
+    const float hy = (float)(p.hp - 1), hx = (float)(wpc - 1);
     c.ly = (int)fminf(fmaxf(fy, 0.f), hy);
     c.ry = (int)fminf(fmaxf(fy + 1.f, 0.f), hy);
     c.lx = (int)fminf(fmaxf(fx, 0.f), hx);
@@ -50,11 +60,12 @@ __device__ __forceinline__ float coef(float p, int c) { return __fsub_rn(1.f, fa
 __device__ __forceinline__ void stage_tile(const WalkK& p, const float* __restrict__ src, int b, int c0, float* tile) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool cok = c0 + lane < p.c;
+    const int nb = clip_n(p, b);
     for (int cell = w; cell < p.hp * p.wp; cell += (int)blockDim.x / 64) {
         int y = cell / p.wp, xx = cell - y * p.wp;
         int tt = y - p.pt, nn = xx - p.pl;
         float v = 0.f;
-        if (cok && tt >= 0 && tt < p.t && nn >= 0 && nn < p.n)
+        if (cok && tt >= 0 && tt < p.t && nn >= 0 && nn < nb)
             v = src[((int64_t)(b * p.t + tt) * p.n + nn) * p.c + c0 + lane];
         tile[cell * CH + lane] = v;
     }
@@ -93,6 +104,7 @@ __global__ __launch_bounds__(WALK_THREADS) void din_walk_fwd_kernel(WalkK p) {
     const int nchunks = (p.c + CH - 1) / CH;
     const int b = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks, c0 = chunk * CH;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nb = clip_n(p, b), wpc = nb + 2 * p.pl;
     stage_tile(p, p.x, b, c0, tile);
     stage_relation(p, b, a_s);
     stage_offsets(p, b, off_s);
@@ -103,7 +115,7 @@ __global__ __launch_bounds__(WALK_THREADS) void din_walk_fwd_kernel(WalkK p) {
             int pos = i / p.k2, k = i - pos * p.k2;
             int tt = pos / p.n, nn = pos - tt * p.n;
             const float* pr = off_s + pos * 2 * p.k2;
-            Corner c = corners(p, tt, nn, k, pr[k], pr[p.k2 + k]);
+            Corner c = corners(p, wpc, tt, nn, k, pr[k], pr[p.k2 + k]);
             int64_t o = ((int64_t)b * p.t * p.n + pos) * p.k2 + k;
             p.a[o] = a_s[i];
             if (p.idx) { p.idx[o * 4 + 0] = c.ly; p.idx[o * 4 + 1] = c.ry; p.idx[o * 4 + 2] = c.lx; p.idx[o * 4 + 3] = c.rx; }
@@ -114,8 +126,12 @@ __global__ __launch_bounds__(WALK_THREADS) void din_walk_fwd_kernel(WalkK p) {
         int tt = pos / p.n, nn = pos - tt * p.n;
         const float* pr = off_s + pos * 2 * p.k2;
         float zacc = 0.f;
+        if (nn >= nb) {                                    // padding actor of a shorter clip: defined output (0), no walk
+            if (cok) p.z[((int64_t)b * p.t * p.n + pos) * p.c + c0 + lane] = 0.f;
+            continue;
+        }
         for (int k = 0; k < p.k2; ++k) {
-            Corner c = corners(p, tt, nn, k, pr[k], pr[p.k2 + k]);
+            Corner c = corners(p, wpc, tt, nn, k, pr[k], pr[p.k2 + k]);
             float wy_l = coef(c.py, c.ly), wy_r = coef(c.py, c.ry), wx_l = coef(c.px, c.lx), wx_r = coef(c.px, c.rx);
             float v_lt = tile[(c.ly * p.wp + c.lx) * CH + lane], v_rb = tile[(c.ry * p.wp + c.rx) * CH + lane];
             float v_lb = tile[(c.ry * p.wp + c.lx) * CH + lane], v_rt = tile[(c.ly * p.wp + c.rx) * CH + lane];
@@ -136,37 +152,55 @@ __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f 
 // wave, so the k2 dependent steps of a position are the whole critical path and a 4-clip batch still fills the chip (the first version ran
 // all T*N positions of a clip chunk in one workgroup: 64 workgroups, 139 us).  Feature gradients of the groups meet in dx through native
 // fp32 atomics (dx is zeroed by the call); offset / relation gradients are per-(chunk) partial sums, plain stores.
+// GLOBAL_DX: the second LDS tile (dP) does not fit next to P (large T x N grids with wide / dilated kernels: 5x5 with ratio >= 2, 7x7,
+// ratio 4 at T = 10): the feature gradient then goes straight to dx with global fp32 atomics (cells outside the clip's grid are dropped
+// at the source).  Slower per position, but any grid whose forward tile fits can also be trained.
 constexpr int WALK_BWD_WAVES = 4;
+template <bool GLOBAL_DX>
 __global__ __launch_bounds__(WALK_BWD_WAVES * 64) void din_walk_bwd_kernel(WalkK p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int cells = p.hp * p.wp;
     float* tile = smem;                       // P
-    float* dtile = tile + cells * CH;         // dP
-    float* off_s = dtile + cells * CH;        // t*n*2*k2 offsets
+    float* dtile = tile + cells * CH;         // dP (LDS mode only)
+    float* off_s = dtile + (GLOBAL_DX ? 0 : cells * CH);        // t*n*2*k2 offsets
     float* a_s = off_s + p.t * p.n * 2 * p.k2; // t*n*k2 saved relation weights
     const int nchunks = (p.c + CH - 1) / CH;
     const int ngroups = (p.t * p.n + WALK_BWD_WAVES - 1) / WALK_BWD_WAVES;
     const int grp = blockIdx.x % ngroups, bc = blockIdx.x / ngroups;
     const int b = bc / nchunks, chunk = bc % nchunks, c0 = chunk * CH;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nb = clip_n(p, b), wpc = nb + 2 * p.pl;
     stage_tile(p, p.x, b, c0, tile);
     stage_offsets(p, b, off_s);
     for (int i = threadIdx.x; i < p.t * p.n * p.k2; i += (int)blockDim.x) a_s[i] = p.a[(int64_t)b * p.t * p.n * p.k2 + i];
-    for (int i = threadIdx.x; i < cells * CH; i += (int)blockDim.x) dtile[i] = 0.f;
+    if (!GLOBAL_DX)
+        for (int i = threadIdx.x; i < cells * CH; i += (int)blockDim.x) dtile[i] = 0.f;
     __syncthreads();
     const bool cok = c0 + lane < p.c;
+    // feature-gradient scatter of one corner: LDS tile, or dx itself when the tile does not fit
+    auto scatter = [&](int cy, int cx, float v) {
+        if (!GLOBAL_DX) { atomicAdd(&dtile[(cy * p.wp + cx) * CH + lane], v); return; }
+        const int tt2 = cy - p.pt, nn2 = cx - p.pl;
+        if (cok && tt2 >= 0 && tt2 < p.t && nn2 >= 0 && nn2 < nb && v != 0.f)
+            atomicAdd(&p.dx[((int64_t)(b * p.t + tt2) * p.n + nn2) * p.c + c0 + lane], v);
+    };
     // per-chunk partial sums, plain stores (each (chunk, position, k) is written exactly once): scratch[chunk][ d_off [b,t,n,2k2] | d_a [b,t,n,k2] ];
     // din_walk_bwd_finish_kernel adds the chunks in a fixed order
     float* d_off = p.scratch + (int64_t)chunk * p.b * p.t * p.n * 3 * p.k2;
     float* d_a = d_off + (int64_t)p.b * p.t * p.n * 2 * p.k2;
     const int pos = grp * WALK_BWD_WAVES + w;
-    if (pos < p.t * p.n) {
+    if (pos < p.t * p.n && pos % p.n >= nb) {             // padding actor: no gradient (the finish kernel sums every chunk's slot)
+        const int64_t gpos = (int64_t)b * p.t * p.n + pos;
+        for (int j = lane; j < 3 * p.k2; j += 64) {
+            if (j < 2 * p.k2) d_off[gpos * 2 * p.k2 + j] = 0.f; else d_a[gpos * p.k2 + (j - 2 * p.k2)] = 0.f;
+        }
+    } else if (pos < p.t * p.n) {
         int tt = pos / p.n, nn = pos - tt * p.n;
         const int64_t gpos = (int64_t)b * p.t * p.n + pos;
         const float* pr = off_s + pos * 2 * p.k2;
         const float g = cok ? p.gz[gpos * p.c + c0 + lane] : 0.f;
         for (int k = 0; k < p.k2; ++k) {
-            Corner c = corners(p, tt, nn, k, pr[k], pr[p.k2 + k]);
+            Corner c = corners(p, wpc, tt, nn, k, pr[k], pr[p.k2 + k]);
             const float ak = a_s[pos * p.k2 + k];
             float wy_l = coef(c.py, c.ly), wy_r = coef(c.py, c.ry), wx_l = coef(c.px, c.lx), wx_r = coef(c.px, c.rx);
             const int i_lt = (c.ly * p.wp + c.lx) * CH + lane, i_rb = (c.ry * p.wp + c.rx) * CH + lane;
@@ -175,17 +209,17 @@ __global__ __launch_bounds__(WALK_BWD_WAVES * 64) void din_walk_bwd_kernel(WalkK
             float sk = v_lt * (wy_l * wx_l) + v_rb * (wy_r * wx_r) + v_lb * (wy_r * wx_l) + v_rt * (wy_l * wx_r);
             // feature gradient: scatter-add a_k * w_corner * gz into the padded tile (LDS atomics; waves may collide)
             const float ag = ak * g;
-            atomicAdd(&dtile[i_lt], ag * (wy_l * wx_l));
-            atomicAdd(&dtile[i_rb], ag * (wy_r * wx_r));
-            atomicAdd(&dtile[i_lb], ag * (wy_r * wx_l));
-            atomicAdd(&dtile[i_rt], ag * (wy_l * wx_r));
+            scatter(c.ly, c.lx, ag * (wy_l * wx_l));
+            scatter(c.ry, c.rx, ag * (wy_r * wx_r));
+            scatter(c.ry, c.lx, ag * (wy_r * wx_l));
+            scatter(c.ly, c.rx, ag * (wy_l * wx_r));
             // per-corner <gz, P_corner> and <gz, S_k> over this channel chunk
             float d_s = wave_sum(g * sk);
             float d_lt = wave_sum(g * v_lt), d_rb = wave_sum(g * v_rb), d_lb = wave_sum(g * v_lb), d_rt = wave_sum(g * v_rt);
             if (lane == 0) {
                 // d/d py of (1-|py-cy|) = -sign(py-cy); clamp passes gradient on the closed interval (Q8, Q9)
                 const float my = (c.py0 >= 0.f && c.py0 <= (float)(p.hp - 1)) ? 1.f : 0.f;
-                const float mx = (c.px0 >= 0.f && c.px0 <= (float)(p.wp - 1)) ? 1.f : 0.f;
+                const float mx = (c.px0 >= 0.f && c.px0 <= (float)(wpc - 1)) ? 1.f : 0.f;
                 const float sy_l = -sgn(c.py - (float)c.ly), sy_r = -sgn(c.py - (float)c.ry);
                 const float sx_l = -sgn(c.px - (float)c.lx), sx_r = -sgn(c.px - (float)c.rx);
                 float doy = d_lt * sy_l * wx_l + d_rb * sy_r * wx_r + d_lb * sy_r * wx_l + d_rt * sy_l * wx_r;
@@ -196,10 +230,12 @@ __global__ __launch_bounds__(WALK_BWD_WAVES * 64) void din_walk_bwd_kernel(WalkK
             }
         }
     }
+    if (GLOBAL_DX) return;
     __syncthreads();
     // un-pad and add this group's share: dx[b,t,n,c] += dP[pt+t][pl+n][c]
     for (int q = w; q < p.t * p.n; q += WALK_BWD_WAVES) {
         int tt = q / p.n, nn = q - tt * p.n;
+        if (nn >= nb) continue;                            // cells beyond the clip's grid are zero padding: their gradient is dropped
         const float v = dtile[((p.pt + tt) * p.wp + p.pl + nn) * CH + lane];
         if (cok && v != 0.f) atomicAdd(&p.dx[((int64_t)b * p.t * p.n + q) * p.c + c0 + lane], v);
     }
@@ -251,14 +287,15 @@ int fill(WalkK& p, int cp, int b, int t, int n, int c, int kh, int kw, int ratio
 extern "C" {
 
 int din_walk_fwd(const float* x, const float* pred, int cp, int b, int t, int n, int c, int kh, int kw, int ratio,
-                 int scale_factor, float* z, float* a, int32_t* idx, float* mad, void* stream) {
+                 int scale_factor, const int32_t* n_per_clip, float* z, float* a, int32_t* idx, float* mad, void* stream) {
     DIN_REQUIRE(x && pred && z && a, "din_walk_fwd: null pointer");
     WalkK p{};
     if (int e = fill(p, cp, b, t, n, c, kh, kw, ratio, scale_factor)) return e;
-    p.x = x; p.pred = pred; p.z = z; p.a = a; p.idx = idx; p.mad = mad;
+    p.x = x; p.pred = pred; p.z = z; p.a = a; p.idx = idx; p.mad = mad; p.n_per_clip = n_per_clip;
     size_t lds = ((size_t)p.hp * p.wp * CH + (size_t)t * n * 3 * p.k2) * sizeof(float);
     DIN_REQUIRE(lds <= 160 * 1024, "din_walk_fwd: T x N grid too large for one LDS tile (%zu bytes)", lds);
-    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(din_walk_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(din_walk_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        DIN_FAIL(DIN_E_LAUNCH, "din_walk_fwd: cannot raise the dynamic LDS limit to %zu bytes", lds);
     int nchunks = (c + CH - 1) / CH;
     hipLaunchKernelGGL(din_walk_fwd_kernel, dim3(b * nchunks), dim3(WALK_THREADS), lds, as_stream(stream), p);
     DIN_CHECK_LAUNCH("din_walk_fwd");
@@ -266,20 +303,29 @@ int din_walk_fwd(const float* x, const float* pred, int cp, int b, int t, int n,
 }
 
 int din_walk_bwd(const float* x, const float* pred, int cp, const float* a, const float* gz, int b, int t, int n, int c,
-                 int kh, int kw, int ratio, int scale_factor, float* dx, float* dpred, float* scratch, void* stream) {
+                 int kh, int kw, int ratio, int scale_factor, const int32_t* n_per_clip, float* dx, float* dpred, float* scratch,
+                 void* stream) {
     DIN_REQUIRE(x && pred && a && gz && dx && dpred && scratch, "din_walk_bwd: null pointer");
     WalkK p{};
     if (int e = fill(p, cp, b, t, n, c, kh, kw, ratio, scale_factor)) return e;
-    p.x = x; p.pred = pred; p.a = const_cast<float*>(a); p.gz = gz; p.dx = dx; p.scratch = scratch;
+    p.x = x; p.pred = pred; p.a = const_cast<float*>(a); p.gz = gz; p.dx = dx; p.scratch = scratch; p.n_per_clip = n_per_clip;
     hipStream_t st = as_stream(stream);
     int64_t positions = (int64_t)b * t * n;
-    size_t lds = ((size_t)2 * p.hp * p.wp * CH + (size_t)t * n * 3 * p.k2) * sizeof(float);
-    DIN_REQUIRE(lds <= 160 * 1024, "din_walk_bwd: T x N grid too large for the LDS tiles (%zu bytes)", lds);
-    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(din_walk_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t tile_b = (size_t)p.hp * p.wp * CH * sizeof(float), tab_b = (size_t)t * n * 3 * p.k2 * sizeof(float);
+    const bool global_dx = 2 * tile_b + tab_b > 160 * 1024;        // the dP tile does not fit: scatter into dx directly
+    const size_t lds = (global_dx ? 1 : 2) * tile_b + tab_b;
+    DIN_REQUIRE(lds <= 160 * 1024, "din_walk_bwd: T x N grid too large for one LDS tile (%zu bytes)", lds);
+    auto raise = [&](const void* fn) -> int {
+        if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            DIN_FAIL(DIN_E_LAUNCH, "din_walk_bwd: cannot raise the dynamic LDS limit to %zu bytes", lds);
+        return DIN_OK;
+    };
+    if (int e = raise(global_dx ? reinterpret_cast<const void*>(din_walk_bwd_kernel<true>) : reinterpret_cast<const void*>(din_walk_bwd_kernel<false>))) return e;
     if (hipMemsetAsync(dx, 0, sizeof(float) * positions * c, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "din_walk_bwd: memset");
     int nchunks = (c + CH - 1) / CH;
     const int ngroups = (t * n + WALK_BWD_WAVES - 1) / WALK_BWD_WAVES;
-    hipLaunchKernelGGL(din_walk_bwd_kernel, dim3(b * nchunks * ngroups), dim3(WALK_BWD_WAVES * 64), lds, st, p);
+    if (global_dx) hipLaunchKernelGGL(din_walk_bwd_kernel<true>, dim3(b * nchunks * ngroups), dim3(WALK_BWD_WAVES * 64), lds, st, p);
+    else hipLaunchKernelGGL(din_walk_bwd_kernel<false>, dim3(b * nchunks * ngroups), dim3(WALK_BWD_WAVES * 64), lds, st, p);
     DIN_CHECK_LAUNCH("din_walk_bwd");
     const int fin_threads = (3 * p.k2 + 63) / 64 * 64;
     hipLaunchKernelGGL(din_walk_bwd_finish_kernel, dim3((unsigned)positions), dim3(fin_threads), 0, st, scratch, a, dpred,

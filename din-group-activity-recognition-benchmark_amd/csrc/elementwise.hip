@@ -129,6 +129,16 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, int64_t hw, in
         if (p < hw && cc < c) store_from_f32(out, dtype, (n * hw + p) * ld + coff + cc, tile[threadIdx.x][r]);
     }
 }
+// out[b,t,i,:] = i < n_per_clip[b] ? x[b,t,i,:] : 0   (the padding actors of a Collective clip; also the backward of itself)
+__global__ void mask_actors_kernel(const float* __restrict__ x, const int32_t* __restrict__ n_per_clip, float* __restrict__ out, int t, int n,
+                                   int c, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / c;                       // (b, t, actor)
+        const int actor = (int)(row % n);
+        const int b = (int)(row / ((int64_t)t * n));
+        out[i] = actor < n_per_clip[b] ? x[i] : 0.f;
+    }
+}
 __global__ void frame_index_kernel(int32_t* out, int bt, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < bt * n) out[i] = i / n;
@@ -217,6 +227,13 @@ int din_axpby(const float* x, const float* y, float* out, float alpha, float bet
     if (n == 0) return DIN_OK;
     hipLaunchKernelGGL(axpby_kernel, dim3(grid_1d(n, 256)), dim3(256), 0, as_stream(stream), x, y, out, alpha, beta, n);
     DIN_CHECK_LAUNCH("axpby");
+    return DIN_OK;
+}
+int din_mask_actors(const float* x, const int32_t* n_per_clip, int b, int t, int n, int c, float* out, void* stream) {
+    DIN_REQUIRE(x && n_per_clip && out && b > 0 && t > 0 && n > 0 && c > 0, "mask_actors: bad argument");
+    const int64_t total = (int64_t)b * t * n * c;
+    hipLaunchKernelGGL(mask_actors_kernel, dim3(grid_1d(total, 256)), dim3(256), 0, as_stream(stream), x, n_per_clip, out, t, n, c, total);
+    DIN_CHECK_LAUNCH("mask_actors");
     return DIN_OK;
 }
 int din_scale_by_param(const float* x, const float* scalar, int idx, float* out, int accumulate, int64_t n, void* stream) {

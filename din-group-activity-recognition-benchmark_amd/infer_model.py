@@ -46,6 +46,7 @@ class _DynamicBase(nn.Module):
         if not cfg.train_backbone:
             for p in self.backbone.parameters():
                 p.requires_grad = False
+        self._step = 0                  # dropout-mask counter (ops.mask_seed); train_net saves / restores it with the checkpoint
         self.roi_align = RoIAlign(*cfg.crop_size)
         self.fc_emb_1 = nn.Linear(K * K * D, NFB)
         self.nl_emb_1 = nn.LayerNorm([NFB])
@@ -87,7 +88,7 @@ class _DynamicBase(nn.Module):
         return x
 
     def _dropout_seed(self):
-        self._step = getattr(self, "_step", 0) + 1
+        self._step += 1
         return ops.mask_seed(int(getattr(self.cfg, "train_random_seed", 0)), self._step)
 
 
@@ -151,7 +152,8 @@ class Dynamic_collective(_DynamicBase):
 
     The reference crashes here (tuple/tensor mismatch, SURVEY section 0 bug 3); this implements the intended dataflow:
     per clip b with N_b = bboxes_num[b,0] valid boxes: DIN on [1,T,N_b,C] -> +x -> LayerNorm([T,C]) per actor -> ReLU ->
-    dropout -> max over actors -> fc -> mean over T."""
+    dropout -> max over actors -> fc -> mean over T -- as ONE launch set per batch: the DIN walk, and the head take the per-clip
+    actor counts as a device array (`n_per_clip`), padding actors are zeroed once (din_mask_actors)."""
 
     def __init__(self, cfg):
         super().__init__()
@@ -183,16 +185,16 @@ class Dynamic_collective(_DynamicBase):
         if cfg.lite_dim:
             x = ops.GridConvFunction.apply(x, self.point_conv.weight, self.point_conv.bias, 1)
             x = ops.layer_norm(x, self.point_ln.weight, self.point_ln.bias, relu=True)
-        counts = bboxes_num_in.reshape(B, T)[:, 0].to("cpu").tolist()                 # one host read per batch (reference: per clip)
+        # Variable actors per clip WITHOUT a host loop or a device->host read (the reference loops over clips and slices
+        # boxes_features_all[b, :, :N], infer_model.py:1284-1316): the per-clip counts stay on the device and the kernels take them.
+        n_per_clip = bboxes_num_in.reshape(B, T)[:, 0].to(torch.int32).clamp(1, MAX_N).contiguous()
+        xm = ops.MaskActorsFunction.apply(x, n_per_clip)                              # padding actors -> 0 (== zero padding of the grid)
+        g, _ = self.DPI(xm, n_per_clip)                                               # clip b: DIN on its T x n_b grid (:1291)
         p = cfg.train_dropout_prob if self.training else 0.0
-        outs = []
-        for b in range(B):
-            nb = int(counts[b])
-            xb = x[b:b + 1, :, :nb].contiguous()                                      # [1,T,nb,C]
-            g, _ = self.DPI(xb)
-            # LayerNorm([T,C]) per actor: rows = actors -> permute to [nb,T,C]
-            sb = ops.AxpbyFunction.apply(g, xb, 1.0, 1.0)[0].permute(1, 0, 2).contiguous()
-            sb = ops.layer_norm(sb, self.dpi_nl.weight, self.dpi_nl.bias, relu=True, drop_p=p, seed=self._dropout_seed())
-            sb = sb.permute(1, 0, 2).contiguous().unsqueeze(0)                        # [1,T,nb,C]
-            outs.append(ops.HeadFunction.apply(sb, self.fc_activities.weight, self.fc_activities.bias, None))
-        return {"activities": torch.cat(outs, 0)}
+        # (g + x) -> [B, N, T, C]: LayerNorm([T, C]) per actor (:1295-1297), ReLU, dropout fused; padding actors' rows are never read
+        s = ops.AxpbyFunction.apply(g, xm, 1.0, 1.0).permute(0, 2, 1, 3).contiguous()
+        s = ops.layer_norm(s, self.dpi_nl.weight, self.dpi_nl.bias, relu=True, drop_p=p, seed=self._dropout_seed())
+        s = s.permute(0, 2, 1, 3).contiguous()                                        # [B, T, N, C]
+        # max over the clip's n_b actors, fc, mean over T (:1306-1309)
+        scores = ops.HeadFunction.apply(s, self.fc_activities.weight, self.fc_activities.bias, n_per_clip)
+        return {"activities": scores}

@@ -55,7 +55,7 @@ class Dynamic_Person_Inference(nn.Module):
                 nn.init.zeros_(sc.weight), nn.init.zeros_(sc.bias)
                 self.scale_conv[str(r)] = sc
 
-    def _ratio(self, x, r):
+    def _ratio(self, x, r, n_per_clip=None):
         kh, kw = self.kernel_size
         pc = self.p_conv[str(r)]
         if self.scale_factor:
@@ -65,15 +65,17 @@ class Dynamic_Person_Inference(nn.Module):
         else:
             w, b = pc.weight, pc.bias
         pred = ops.GridConvFunction.apply(x, w, b, r)                       # [B,T,N,pad4(3*k2)]
-        z, a, idx, mad = ops.DynamicWalkFunction.apply(x, pred, kh, kw, r, self.scale_factor, self.return_mad)
+        z, a, idx, mad = ops.DynamicWalkFunction.apply(x, pred, kh, kw, r, self.scale_factor, self.return_mad, n_per_clip)
         return z, mad, a, idx
 
-    def forward(self, person_features):
+    def forward(self, person_features, n_per_clip=None):
+        """n_per_clip (optional int32 [B] on the device): clip b is the T x n_per_clip[b] grid in the first columns of its slab and
+        `person_features` is zero beyond it (Dynamic_collective; the reference calls the module once per clip, infer_model.py:1286-1293)"""
         x = person_features.contiguous()
         agg, mad = None, None
         nr = len(self.sampling_ratio)
         for i, r in enumerate(self.sampling_ratio):
-            z, mad, _a, _idx = self._ratio(x, r)
+            z, mad, _a, _idx = self._ratio(x, r, n_per_clip)
             if self.beta_factor:
                 z = ops.ScaleByParamFunction.apply(z, self.beta, i)
                 agg = z if agg is None else ops.AxpbyFunction.apply(agg, z, 1.0, 1.0)

@@ -218,10 +218,10 @@ class DynamicWalkFunction(torch.autograd.Function):
     """(x [b,t,n,c], pred [b,t,n,cp]) -> z [b,t,n,c]   (+ non-differentiable a, idx, optional mad)."""
 
     @staticmethod
-    def forward(ctx, x, pred, kh: int, kw: int, ratio: int, scale_factor: bool, want_mad: bool):
+    def forward(ctx, x, pred, kh: int, kw: int, ratio: int, scale_factor: bool, want_mad: bool, n_per_clip=None):
         lib = L.load()
         x, pred = x.contiguous(), pred.contiguous()
-        require_gpu(x, pred)
+        require_gpu(x, pred, n_per_clip)
         b, t, n, c = x.shape
         cp = pred.shape[-1]
         k2 = kh * kw
@@ -229,9 +229,10 @@ class DynamicWalkFunction(torch.autograd.Function):
         a = torch.empty((b, t, n, k2), dtype=torch.float32, device=x.device)
         idx = torch.empty((b, t, n, k2, 4), dtype=torch.int32, device=x.device)
         mad = torch.empty((b, t, n, k2, c), dtype=torch.float32, device=x.device) if want_mad else None
-        L.check(lib.din_walk_fwd(_ptr(x), _ptr(pred), cp, b, t, n, c, kh, kw, ratio, int(scale_factor), _ptr(z), _ptr(a), _ptr(idx),
-                                 _ptr(mad), _stream()), "din_walk_fwd")
+        L.check(lib.din_walk_fwd(_ptr(x), _ptr(pred), cp, b, t, n, c, kh, kw, ratio, int(scale_factor), _ptr(n_per_clip), _ptr(z), _ptr(a),
+                                 _ptr(idx), _ptr(mad), _stream()), "din_walk_fwd")
         ctx.save_for_backward(x, pred, a)
+        ctx.n_per_clip = n_per_clip
         ctx.geom = (kh, kw, ratio, scale_factor)
         if mad is None:
             mad = x.new_empty(0)
@@ -249,9 +250,33 @@ class DynamicWalkFunction(torch.autograd.Function):
         dx = torch.empty_like(x)
         dpred = torch.zeros_like(pred)
         scratch = torch.empty(((c + 63) // 64) * b * t * n * 3 * kh * kw, dtype=torch.float32, device=x.device)
-        L.check(lib.din_walk_bwd(_ptr(x), _ptr(pred), cp, _ptr(a), _ptr(gz), b, t, n, c, kh, kw, ratio, int(scale_factor), _ptr(dx),
-                                 _ptr(dpred), _ptr(scratch), _stream()), "din_walk_bwd")
-        return dx, dpred, None, None, None, None, None
+        L.check(lib.din_walk_bwd(_ptr(x), _ptr(pred), cp, _ptr(a), _ptr(gz), b, t, n, c, kh, kw, ratio, int(scale_factor),
+                                 _ptr(ctx.n_per_clip), _ptr(dx), _ptr(dpred), _ptr(scratch), _stream()), "din_walk_bwd")
+        return dx, dpred, None, None, None, None, None, None
+
+
+class MaskActorsFunction(torch.autograd.Function):
+    """x [b,t,n,c] with actors >= n_per_clip[b] zeroed (Dynamic_collective: the reference slices boxes_features_all[b, :, :N])."""
+
+    @staticmethod
+    def forward(ctx, x, n_per_clip):
+        lib = L.load()
+        x = x.contiguous()
+        require_gpu(x, n_per_clip)
+        b, t, n, c = x.shape
+        out = torch.empty_like(x)
+        L.check(lib.din_mask_actors(_ptr(x), _ptr(n_per_clip), b, t, n, c, _ptr(out), _stream()), "mask_actors")
+        ctx.n_per_clip = n_per_clip
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.load()
+        g = g.contiguous()
+        b, t, n, c = g.shape
+        out = torch.empty_like(g)
+        L.check(lib.din_mask_actors(_ptr(g), _ptr(ctx.n_per_clip), b, t, n, c, _ptr(out), _stream()), "mask_actors")
+        return out, None
 
 
 class AxpbyFunction(torch.autograd.Function):

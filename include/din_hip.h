@@ -261,14 +261,19 @@ int din_layernorm_bwd(const float* dy, const float* x, const float* res, const f
  *   idx [b,t,n,k2,4]   int32 (ly,ry,lx,rx) clamped corners (:208-223)  -- bit-exact row
  *   mad (nullable) [b,t,n,k2,c] = S (ft_infer_MAD, :259); not materialised when NULL.
  * ---------------------------------------------------------------------------------------------- */
+/*   n_per_clip (nullable) int32 [b]: clip i is a T x n_per_clip[i] grid held in the first columns of its T x n slab (Dynamic_collective,
+ *   infer_model.py:1286-1293 runs the module per clip on boxes_features_all[b, :, :N]); columns beyond it are zero padding: they are
+ *   read as zeros, get z = 0 and no gradient, and the x clamp range is the clip's own padded width.  x must already be zero there.
+ *   The forward needs ONE padded (t+2pt) x (n+2pl) x 64-channel fp32 tile in LDS (<= 160 KiB, else DIN_E_ARG); the backward keeps a
+ *   second one for the feature gradient when it fits and scatters into dx with global atomics when it does not.                 */
 int din_walk_fwd(const float* x, const float* pred, int cp, int b, int t, int n, int c,
-                 int kh, int kw, int ratio, int scale_factor,
+                 int kh, int kw, int ratio, int scale_factor, const int32_t* n_per_clip,
                  float* z, float* a, int32_t* idx, float* mad, void* stream);
 /* gz [b,t,n,c] -> dx_walk [b,t,n,c] (overwritten), dpred [b,t,n,cp] (first 3*k2 channels written):
  * d offset through the |.| coefficients with detached floor (Q4), inclusive clamp pass-through (Q9),
  * sign(0)=0 (Q8); d logits through the softmax.  scratch: fp32 [ceil(c/64)][b,t,n,3*k2] (per-channel-chunk partial sums, written by the call).     */
 int din_walk_bwd(const float* x, const float* pred, int cp, const float* a, const float* gz,
-                 int b, int t, int n, int c, int kh, int kw, int ratio, int scale_factor,
+                 int b, int t, int n, int c, int kh, int kw, int ratio, int scale_factor, const int32_t* n_per_clip,
                  float* dx, float* dpred, float* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -288,6 +293,9 @@ int din_head_bwd(const float* dscores, const float* s, const float* w, const int
  * ---------------------------------------------------------------------------------------------- */
 /* out = alpha*x + beta*y (fp32, elementwise) -- ratio mean / beta-weighted sum (:144-147), residual sums */
 int din_axpby(const float* x, const float* y, float* out, float alpha, float beta, int64_t n, void* stream);
+/* out[b,t,i,:] = i < n_per_clip[b] ? x[b,t,i,:] : 0 -- zeroes the padding actors of Collective clips so that the batched T x MAX_N grid
+ * behaves like the reference's per-clip slices boxes_features_all[b, :, :N] (infer_model.py:1286-1288); its own backward */
+int din_mask_actors(const float* x, const int32_t* n_per_clip, int b, int t, int n, int c, float* out, void* stream);
 /* out (+)= x * scalar[idx] with a DEVICE scalar (learnable beta, :42-44,145); out[idx] += <x,y> for its gradient */
 int din_scale_by_param(const float* x, const float* scalar, int idx, float* out, int accumulate, int64_t n, void* stream);
 int din_dot_accum(const float* x, const float* y, float* out, int idx, int64_t n, void* stream);

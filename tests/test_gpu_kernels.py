@@ -598,3 +598,135 @@ def test_wgrad_pipe_kernel(env, case, atomic, monkeypatch):
         torch.cuda.synchronize()
         assert rel(dw, wt.grad) <= 2e-3                     # bf16 operands are exact in the reference too: only fp32 summation order differs
         assert rel(db, br.grad) <= 2e-3
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_batch_stat_bn_kernels(env, dtype):
+    """din_bn_stats / din_bn_finalize / din_bn_apply / din_bn_bwd_stats / din_bn_bwd_apply on channel views against torch's
+    F.batch_norm(training=True) + ReLU in float64 (on the storage-rounded input): output, batch mean / rstd, running statistics
+    (momentum 0.1, unbiased variance), dy, dgamma, dbeta."""
+    lib, L, nhwc, ops = env
+    dt = L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
+    tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    g = torch.Generator().manual_seed(7)
+    rows, c, ldx, cxoff, ldy, cyoff = 4 * 37 * 53 + 5, 96, 112, 8, 160, 32
+    x = (torch.randn(rows, c, generator=g) * 1.7 + 0.4).to(tdt)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2
+    rmean, rvar = torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5
+    cot = torch.randn(rows, c, generator=g).to(tdt)
+    # reference in float64
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm64, rv64 = rmean.double().clone(), rvar.double().clone()
+    xn = x64.t().reshape(1, c, rows, 1)
+    y64 = F.relu(F.batch_norm(xn, rm64, rv64, g64, b64, training=True, momentum=0.1, eps=1e-3)).reshape(c, rows).t()
+    gz64 = cot.double() * (y64 > 0)                                   # the gradient the producing kernels hand over is already masked
+    (y64 * cot.double()).sum().backward()
+    xb = torch.zeros(rows, ldx, dtype=tdt, device="cuda")
+    xb[:, cxoff:cxoff + c] = x.cuda()
+    yb = torch.full((rows, ldy), 7.0, dtype=tdt, device="cuda")
+    sums = torch.zeros(2 * c, dtype=torch.float64, device="cuda")
+    a, b, mean, rstd = (torch.empty(c, device="cuda") for _ in range(4))
+    gd, bd, rmd, rvd = gamma.cuda(), beta.cuda(), rmean.cuda(), rvar.cuda()
+    L.check(lib.din_bn_stats(xb.data_ptr(), dt, rows, c, ldx, cxoff, sums.data_ptr(), None))
+    L.check(lib.din_bn_finalize(sums.data_ptr(), rows, c, gd.data_ptr(), bd.data_ptr(), 1e-3, 0.1, rmd.data_ptr(), rvd.data_ptr(), a.data_ptr(),
+                                b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None))
+    L.check(lib.din_bn_apply(xb.data_ptr(), dt, rows, c, ldx, cxoff, a.data_ptr(), b.data_ptr(), 1, yb.data_ptr(), ldy, cyoff, None))
+    torch.cuda.synchronize()
+    tol = 1e-5 if dtype == "fp32" else 6e-3                            # bf16: output rounding only (statistics are exact sums of bf16 values)
+    assert rel(yb[:, cyoff:cyoff + c].float().cpu(), y64.detach()) <= tol
+    assert float(yb[:, :cyoff].float().min()) == 7.0 and float(yb[:, cyoff + c:].float().min()) == 7.0
+    assert rel(mean.cpu(), x.double().mean(0)) <= 1e-5 and rel(rstd.cpu(), 1.0 / (x.double().var(0, unbiased=False) + 1e-3).sqrt()) <= 1e-5
+    assert rel(rmd.cpu(), rm64) <= 1e-5 and rel(rvd.cpu(), rv64) <= 1e-5
+    gzb = torch.zeros(rows, ldy, dtype=tdt, device="cuda")
+    gzb[:, cyoff:cyoff + c] = gz64.to(tdt).cuda()
+    gz_used = gzb[:, cyoff:cyoff + c].double().cpu()                   # what the kernel actually sees (bf16-rounded)
+    sums.zero_()
+    dy = torch.empty(rows, c, dtype=tdt, device="cuda")
+    dgamma, dbeta = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    L.check(lib.din_bn_bwd_stats(gzb.data_ptr(), ldy, cyoff, xb.data_ptr(), ldx, cxoff, dt, rows, c, mean.data_ptr(), rstd.data_ptr(),
+                                 sums.data_ptr(), None))
+    L.check(lib.din_bn_bwd_apply(gzb.data_ptr(), ldy, cyoff, xb.data_ptr(), ldx, cxoff, dt, rows, c, gd.data_ptr(), mean.data_ptr(),
+                                 rstd.data_ptr(), sums.data_ptr(), dy.data_ptr(), c, 0, dgamma.data_ptr(), dbeta.data_ptr(), None))
+    torch.cuda.synchronize()
+    # closed form in float64 on the gradient the kernel saw
+    mu, var = x.double().mean(0), x.double().var(0, unbiased=False)
+    rs = 1.0 / (var + 1e-3).sqrt()
+    xh = (x.double() - mu) * rs
+    s1, s2 = gz_used.sum(0), (gz_used * xh).sum(0)
+    want = gamma.double() * rs * (gz_used - s1 / rows - xh * s2 / rows)
+    assert rel(dy.float().cpu(), want) <= (1e-5 if dtype == "fp32" else 6e-3)
+    assert rel(dgamma.cpu(), s2) <= 1e-5 and rel(dbeta.cpu(), s1) <= 1e-5
+    if dtype == "fp32":                                                # and autograd agrees with the closed form
+        assert rel(dy.cpu(), x64.grad) <= 1e-5 and rel(dgamma.cpu(), g64.grad) <= 1e-5 and rel(dbeta.cpu(), b64.grad) <= 1e-5
+
+
+def test_din_walk_variable_actors_matches_per_clip_runs(env):
+    """din_walk_{fwd,bwd} with n_per_clip (Dynamic_collective's batched form) against running the module on each clip's own
+    [1, T, n_b, C] slice, as the reference does (infer_model.py:1284-1293): outputs and gradients agree to fp32 rounding on the valid
+    actors (the contractions around the walk tile differently for the two batch shapes), exactly 0 / no gradient on the padding actors."""
+    lib, L, nhwc, ops = env
+    from din_amd.infer_module.dynamic_infer_module import Dynamic_Person_Inference
+    g = torch.Generator().manual_seed(3)
+    B, T, N, Cc = 4, 3, 7, 96
+    counts = torch.tensor([7, 1, 4, 2], dtype=torch.int32)
+    mod = Dynamic_Person_Inference(in_dim=Cc, person_mat_shape=(10, 12), kernel_size=(3, 3), dynamic_sampling=True, sampling_ratio=[1, 2],
+                                   scale_factor=True, beta_factor=True).cuda()
+    with torch.no_grad():
+        for name, p in mod.named_parameters():
+            if "p_conv" in name or "scale_conv" in name:
+                p.copy_((torch.randn(p.shape, generator=g) * 0.08).cuda())
+    x = torch.randn(B, T, N, Cc, generator=g)
+    for b in range(B):
+        x[b, :, int(counts[b]):] = 0.0
+    cot = torch.randn(B, T, N, Cc, generator=g)
+    xd = x.cuda().requires_grad_(True)
+    out, _ = mod(xd, counts.cuda())
+    (out * cot.cuda()).sum().backward()
+    batched = {k: p.grad.clone() for k, p in mod.named_parameters()}
+    gx = xd.grad.clone()
+    for p in mod.parameters():
+        p.grad = None
+    outs, gxs = [], []
+    for b in range(B):
+        nb = int(counts[b])
+        xb = x[b:b + 1, :, :nb].contiguous().cuda().requires_grad_(True)
+        ob, _ = mod(xb)
+        (ob * cot[b:b + 1, :, :nb].cuda()).sum().backward()
+        outs.append(ob.detach())
+        gxs.append(xb.grad)
+    for b in range(B):
+        nb = int(counts[b])
+        assert rel(out[b:b + 1, :, :nb], outs[b]) <= 2e-6, f"clip {b}: batched output differs from the per-clip run"
+        assert float(out[b, :, nb:].abs().sum()) == 0.0
+        assert rel(gx[b:b + 1, :, :nb], gxs[b]) <= 1e-6
+        assert float(gx[b, :, nb:].abs().sum()) == 0.0
+    for k, p in mod.named_parameters():
+        assert rel(batched[k], p.grad) <= 2e-5, k               # parameter gradients: sums over clips in a different order
+
+
+def test_din_walk_bwd_large_kernel_uses_global_scatter(env):
+    """at T=10, N=12 a 5x5 ST kernel with ratio 2 needs two 92-KiB padded tiles in the backward (> 160 KiB of LDS): the
+    backward then scatters the feature gradient with global atomics instead of failing.  Checked against the oracle's autograd."""
+    lib, L, nhwc, ops = env
+    from oracle import din_oracle as O
+    g = torch.Generator().manual_seed(11)
+    B, T, N, Cc, k, r = 2, 10, 12, 64, (5, 5), 2
+    k2 = 25
+    x = torch.randn(B, T, N, Cc, generator=g)
+    pw, pb = torch.randn(2 * k2, Cc, 5, 5, generator=g) * 0.02, torch.randn(2 * k2, generator=g) * 0.3
+    sw, sb = torch.randn(k2, Cc, 5, 5, generator=g) * 0.02, torch.randn(k2, generator=g) * 0.1
+    cot = torch.randn(B, T, N, Cc, generator=g)
+    ins = [t.clone().requires_grad_(True) for t in (x, pw, pb, sw, sb)]
+    z_ref, _ = O.din_ratio_forward(ins[0], ins[1], ins[2], ins[3], ins[4], k, r)[:2]
+    (z_ref * cot).sum().backward()
+    xd = x.cuda().requires_grad_(True)
+    wd = torch.cat([pw, sw], 0).cuda().requires_grad_(True)
+    bd = torch.cat([pb, sb], 0).cuda().requires_grad_(True)
+    pred = ops.GridConvFunction.apply(xd, wd, bd, r)
+    z, a, idx, mad = ops.DynamicWalkFunction.apply(xd, pred, 5, 5, r, True, False)
+    (z * cot.cuda()).sum().backward()
+    assert rel(z, z_ref) <= 1e-4
+    assert rel(xd.grad, ins[0].grad) <= 2e-4
+    assert rel(wd.grad, torch.cat([ins[1].grad, ins[3].grad], 0)) <= 2e-4
+    assert rel(bd.grad, torch.cat([ins[2].grad, ins[4].grad], 0)) <= 2e-4
