@@ -37,20 +37,30 @@ WORKLOADS = {
     "inv3_fp32": ("inv3", "fp32", (87, 157), 1056),
     "vgg16_bf16": ("vgg16", "bf16", (22, 40), 512),
     "vgg16_fp32": ("vgg16", "fp32", (22, 40), 512),
+    # BASELINE configs[4]: Collective Activity stage-2 DIN (scripts/train_collective_stage2_dynamic.py: 480x720 frames, T = 10, up to 13
+    # actors, 4 activities, dropout 0.5; its VGG16 option -- the res18 default is not a hot-path backbone), variable actors per clip
+    "collective_bf16": ("vgg16", "bf16", (15, 22), 512),
+    "collective_fp32": ("vgg16", "fp32", (15, 22), 512),
 }
+COLLECTIVE = {"H": 480, "W": 720, "N": 13, "T": 10, "activities": 4, "global_batch": 8, "dropout": 0.5}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
 
 
-def make_cfg(workload, T=3, N=12, H=720, W=1280, lite=None):
+def make_cfg(workload, T=3, N=12, H=720, W=1280, lite=None, hierarchical=False):
     from din_amd.config import Config
     backbone, dt, out_size, D = WORKLOADS[workload]
-    cfg = Config("volleyball")
+    collective = workload.startswith("collective")
+    cfg = Config("collective" if collective else "volleyball")
     cfg.backbone, cfg.backbone_dtype, cfg.out_size, cfg.emb_features = backbone, dt, out_size, D
     cfg.image_size, cfg.num_frames, cfg.num_boxes = (H, W), T, N
-    cfg.ST_kernel_size, cfg.sampling_ratio, cfg.num_DIM = [(3, 3)], [1], 1
+    # BASELINE configs[3]: ST-factorised kernels [(1,3),(3,1)] run hierarchically (DPI_1 -> LN -> ReLU -> dropout -> DPI_2)
+    cfg.ST_kernel_size = [(1, 3), (3, 1)] if hierarchical else ((3, 3) if collective else [(3, 3)])
+    cfg.sampling_ratio, cfg.num_DIM = [1], 1
     cfg.dynamic_sampling, cfg.scale_factor, cfg.beta_factor = True, True, False
-    cfg.lite_dim, cfg.hierarchical_inference, cfg.train_backbone = lite, False, True
+    cfg.lite_dim, cfg.hierarchical_inference, cfg.train_backbone = lite, hierarchical, True
     cfg.train_dropout_prob, cfg.set_bn_eval = 0.3, True
+    if collective:
+        cfg.inference_module_name, cfg.num_activities, cfg.train_dropout_prob = "dynamic_collective", COLLECTIVE["activities"], COLLECTIVE["dropout"]
     return cfg
 
 
@@ -80,7 +90,7 @@ def synth_boxes_labels(b, t, n, oh, ow, num_classes=8, seed=0):
     return torch.from_numpy(boxes.astype(np.float32)), torch.from_numpy(labels)
 
 
-def cpu_baseline(workload, T, N, H, W, budget_s=25.0):
+def cpu_baseline(workload, T, N, H, W, budget_s=25.0, lite=None, hierarchical=False):
     """Oracle fwd+bwd on the host cores for a bounded sample (B=1 clip per step).
 
     torch-CPU does not scale to every SMT thread of a 2-socket host (256 threads measured 40x SLOWER than 64 on the
@@ -89,17 +99,27 @@ def cpu_baseline(workload, T, N, H, W, budget_s=25.0):
     from oracle import din_oracle as O
     backbone, _dt, (OH, OW), D = WORKLOADS[workload]
     ncpu = os.cpu_count() or 1
-    ocfg = O.OracleCfg(backbone=backbone, image_size=(H, W), out_size=(OH, OW), emb_features=D, num_boxes=N, num_frames=T)
+    collective = workload.startswith("collective")
+    ocfg = O.OracleCfg(backbone=backbone, image_size=(H, W), out_size=(OH, OW), emb_features=D, num_boxes=N, num_frames=T,
+                       lite_dim=lite, hierarchical_inference=hierarchical,
+                       ST_kernel_size=[(1, 3), (3, 1)] if hierarchical else ((3, 3) if collective else [(3, 3)]),
+                       collective=collective, num_activities=COLLECTIVE["activities"] if collective else 8)
     p = O.synth_params(O.model_param_shapes(ocfg), seed=3, din_std=0.02)
     p = {k: v.requires_grad_("running_" not in k) for k, v in p.items()}
     B = 1
-    images, boxes, labels = O.synth_inputs(B, T, N, H, W, OH, OW, 8, seed=0)
+    images, boxes, labels = O.synth_inputs(B, T, N, H, W, OH, OW, ocfg.num_activities, seed=0)
     images = images.float()
+    counts = torch.full((B, T), max(1, N // 2), dtype=torch.int32)
+    if collective:
+        boxes[:, :, N // 2:] = 0.0
 
     def step():
         for v in p.values():
             v.grad = None
-        out = O.dynamic_volleyball_forward(ocfg, p, images, boxes)
+        if collective:
+            out = O.dynamic_collective_forward(ocfg, p, images, boxes, counts)
+        else:
+            out = O.dynamic_volleyball_forward(ocfg, p, images, boxes)
         F.cross_entropy(out["activities"], labels).backward()
 
     cands = sorted({max(1, min(ncpu, c)) for c in (ncpu // 4, ncpu // 8, 32)})
@@ -122,7 +142,9 @@ def cpu_baseline(workload, T, N, H, W, budget_s=25.0):
     dt = (time.time() - t0) / n
     dt = min(dt, best_t)
     return {"value": B / dt, "unit": "clips/sec", "cores": best_th, "kind": "port", "host_logical_cpus": ncpu,
-            "sample": f"{n} timed fwd+bwd step(s) of B={B} clip (T={T}, {H}x{W}, {backbone}, fp32 torch-CPU oracle) at the fastest of "
+            "sample": f"{n} timed fwd+bwd step(s) of B={B} clip (T={T}, {H}x{W}, {backbone}" + (f", lite_dim={lite}" if lite else "") +
+                      (", hierarchical" if hierarchical else "") + (f", collective with {max(1, N // 2)} of {N} actors" if collective else "") +
+                      ", fp32 torch-CPU oracle) at the fastest of "
                       f"threads={cands} (1 probe step each)"}
 
 
@@ -132,8 +154,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="inv3_bf16", choices=sorted(WORKLOADS))
-    ap.add_argument("--global-batch", type=int, default=32)
-    ap.add_argument("--frames", type=int, default=3)
+    ap.add_argument("--global-batch", type=int, default=None, help="clips per step over all ranks (default 32; collective workloads 8)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per clip T (default 3; collective and --hierarchical 10)")
+    ap.add_argument("--lite-dim", type=int, default=None, help="BASELINE configs[2]: lite-DIN projection width (128 in the reference)")
+    ap.add_argument("--hierarchical", action="store_true", help="BASELINE configs[3]: ST-factorised [(1,3),(3,1)] hierarchical DIN (T defaults to 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adam", action="store_true")
     ap.add_argument("--host-images", action="store_true", help="clips start in pinned host memory every step (uint8): the PCIe-inclusive rate, never the headline value")
@@ -145,19 +169,24 @@ def main():
     a = ap.parse_args()
 
     from din_amd import nhwc, parallel
-    from din_amd.infer_model import Dynamic_volleyball
+    from din_amd.infer_model import Dynamic_collective, Dynamic_volleyball
     from din_amd.optim import FusedAdam
 
     rank, local, world = parallel.init_from_env()
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    T, N, H, W = a.frames, 12, 720, 1280
+    collective = a.workload.startswith("collective")
+    if a.frames is None:
+        a.frames = COLLECTIVE["T"] if collective else (10 if a.hierarchical else 3)
+    if a.global_batch is None:
+        a.global_batch = COLLECTIVE["global_batch"] if collective else 32
+    T, N, H, W = (a.frames, COLLECTIVE["N"], COLLECTIVE["H"], COLLECTIVE["W"]) if collective else (a.frames, 12, 720, 1280)
     backbone, dtype, (OH, OW), D = WORKLOADS[a.workload]
-    cfg = make_cfg(a.workload, T, N, H, W)
+    cfg = make_cfg(a.workload, T, N, H, W, lite=a.lite_dim, hierarchical=a.hierarchical)
     cfg.set_bn_eval = a.bn_mode == "eval"
     torch.manual_seed(0)
-    model = Dynamic_volleyball(cfg)
+    model = (Dynamic_collective if collective else Dynamic_volleyball)(cfg)
     synth_weights(model)
     model = model.to(dev).train()
     if cfg.set_bn_eval:
@@ -172,23 +201,40 @@ def main():
     B = len(mine)
     g = torch.Generator().manual_seed(1000 + rank)
     images = torch.randint(0, 256, (B, T, 3, H, W), dtype=torch.uint8, generator=g).to(dev)     # uint8, HBM-resident
-    boxes, labels = synth_boxes_labels(a.global_batch, T, N, OH, OW, 8, seed=0)
+    boxes, labels = synth_boxes_labels(a.global_batch, T, N, OH, OW, cfg.num_activities, seed=0)
+    counts = None
+    if collective:                                         # 1..N actors per clip, the same count in all of a clip's frames; padding boxes zero
+        import numpy as np
+        cn = np.random.default_rng(5).integers(1, N + 1, size=(a.global_batch,))
+        for b_ in range(a.global_batch):
+            boxes[b_, :, int(cn[b_]):] = 0.0
+        counts = torch.from_numpy(np.repeat(cn[:, None], T, 1).astype(np.int32))[mine.start:mine.stop].to(dev)
     boxes, labels = boxes[mine.start:mine.stop].to(dev), labels[mine.start:mine.stop].to(dev)
+    batch = lambda im: (im, boxes, counts) if collective else (im, boxes)
 
     if a.forward_only:
         model.eval()
 
-    images_host = images.cpu().pin_memory() if a.host_images else None
+    feed = None
+    if a.host_images:
+        # every step's clips start in pinned host memory and cross PCIe on the copy stream of din_amd.input_feed.DeviceFeed while the
+        # previous step computes (double buffer); 8.3 MB per clip
+        from din_amd.input_feed import DeviceFeed
+        images_host = images.cpu().pin_memory()
+        def _forever():
+            while True:
+                yield images_host
+        feed = iter(DeviceFeed(_forever(), dev))
 
     def step():
         nonlocal images
-        if images_host is not None:
-            images = images_host.to(dev, non_blocking=True)      # 8.3 MB per clip over PCIe, on the compute stream (not overlapped)
+        if feed is not None:
+            images = next(feed)
         if a.forward_only:
             with torch.no_grad():
-                return F.cross_entropy(model((images, boxes))["activities"], labels)
+                return F.cross_entropy(model(batch(images))["activities"], labels)
         opt.zero_grad()
-        ret = model((images, boxes))
+        ret = model(batch(images))
         loss = F.cross_entropy(ret["activities"], labels)
         loss.backward()
         if buckets is not None:
@@ -323,11 +369,15 @@ def main():
     if rank == 0:
         clips = a.global_batch * a.steps if world > 1 else B * a.steps
         out = {
-            "metric": "clips/sec (fwd only, eval), Volleyball DIN stage-2, BxTx12 actors" if a.forward_only else "clips/sec (fwd+bwd), Volleyball DIN stage-2, BxTx12 actors",
+            "metric": ("clips/sec (fwd only, eval), " if a.forward_only else "clips/sec (fwd+bwd), ") +
+                      (f"Collective DIN stage-2, BxTx<={N} actors" if collective else "Volleyball DIN stage-2, BxTx12 actors"),
             "value": round(clips / elapsed, 3), "unit": "clips/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic" + (" (uint8 clips copied from pinned host memory every step)" if a.host_images else ""),
-            "config": {"workload": f"Volleyball stage-2 DIN, {backbone}, T={T}, ST_kernel=(3,3), N=12, 720x1280, {dtype}",
+            "config": {"workload": (f"Collective stage-2 DIN, {backbone}, T={T}, ST_kernel=(3,3), 1..{N} actors per clip, {H}x{W}, {dtype}" if collective else
+                                    f"Volleyball stage-2 DIN, {backbone}, T={T}, " +
+                                    ("ST_kernel=[(1,3),(3,1)] hierarchical" if a.hierarchical else "ST_kernel=(3,3)") +
+                                    (f", lite_dim={a.lite_dim}" if a.lite_dim else "") + f", N=12, {H}x{W}, {dtype}"),
                        "global_batch": a.global_batch, "clips_per_gpu": B, "frames": T, "parallelism": f"dp{world}",
                        "includes": "fwd + cross-entropy (eval mode, no_grad)" if a.forward_only else
                                    "fwd + cross-entropy + bwd" + (" + RCCL grad all-reduce" if world > 1 else "")
@@ -339,7 +389,7 @@ def main():
             "final_loss": round(float(loss.item()), 5),
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.workload, T, N, H, W)
+            out["cpu_baseline"] = cpu_baseline(a.workload, T, N, H, W, lite=a.lite_dim, hierarchical=a.hierarchical)
             out["vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
     if world > 1:

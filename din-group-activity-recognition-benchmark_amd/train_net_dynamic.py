@@ -24,6 +24,7 @@ import torch.nn.functional as F
 import torch.utils.data as data
 
 from . import parallel
+from .input_feed import DeviceFeed
 from .infer_model import Dynamic_collective, Dynamic_volleyball
 from .optim import FusedAdam
 from .utils import AverageMeter, Timer, print_log
@@ -116,13 +117,12 @@ class _Epoch:
 
 def _train_pass(data_loader, model, device, optimizer, epoch, cfg, grad_buckets, collective, max_batches=None):
     meters = _Epoch(cfg, device)
-    for bi, batch_data in enumerate(data_loader):
+    for bi, batch_data in enumerate(DeviceFeed(data_loader, device)):      # batch k+1 crosses PCIe on the copy stream during step k
         if max_batches is not None and bi >= max_batches:
             break
         model.train()
         if cfg.set_bn_eval or collective:                              # reference :170-172 / :323-324
             model.apply(set_bn_eval)
-        batch_data = [b.to(device=device, non_blocking=True) for b in batch_data]
         batch_size, num_frames = batch_data[0].shape[0], batch_data[0].shape[1]
         activities_in = batch_data[3].reshape((batch_size, num_frames))[:, 0].reshape((batch_size,))
         inputs = (batch_data[0], batch_data[1], batch_data[4]) if collective else (batch_data[0], batch_data[1])
@@ -142,8 +142,7 @@ def _test_pass(data_loader, model, device, epoch, cfg, collective):
     model.eval()
     meters = _Epoch(cfg, device)
     with torch.no_grad():
-        for batch_data in data_loader:
-            batch_data = [b.to(device=device) for b in batch_data]
+        for batch_data in DeviceFeed(data_loader, device):
             batch_size, num_frames = batch_data[0].shape[0], batch_data[0].shape[1]
             activities_in = batch_data[3].reshape((batch_size, num_frames))[:, 0].reshape((batch_size,))
             inputs = (batch_data[0], batch_data[1], batch_data[4]) if collective else (batch_data[0], batch_data[1])

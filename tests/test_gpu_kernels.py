@@ -681,7 +681,7 @@ def test_din_walk_variable_actors_matches_per_clip_runs(env):
         x[b, :, int(counts[b]):] = 0.0
     cot = torch.randn(B, T, N, Cc, generator=g)
     xd = x.cuda().requires_grad_(True)
-    out, _ = mod(xd, counts.cuda())
+    out, _ = mod(ops.MaskActorsFunction.apply(xd, counts.cuda()), counts.cuda())      # as Dynamic_collective.forward does
     (out * cot.cuda()).sum().backward()
     batched = {k: p.grad.clone() for k, p in mod.named_parameters()}
     gx = xd.grad.clone()
@@ -698,8 +698,8 @@ def test_din_walk_variable_actors_matches_per_clip_runs(env):
     for b in range(B):
         nb = int(counts[b])
         assert rel(out[b:b + 1, :, :nb], outs[b]) <= 2e-6, f"clip {b}: batched output differs from the per-clip run"
-        assert float(out[b, :, nb:].abs().sum()) == 0.0
-        assert rel(gx[b:b + 1, :, :nb], gxs[b]) <= 1e-6
+        assert float(out[b, :, nb:].detach().abs().sum()) == 0.0
+        assert rel(gx[b:b + 1, :, :nb], gxs[b]) <= 2e-6
         assert float(gx[b, :, nb:].abs().sum()) == 0.0
     for k, p in mod.named_parameters():
         assert rel(batched[k], p.grad) <= 2e-5, k               # parameter gradients: sums over clips in a different order
