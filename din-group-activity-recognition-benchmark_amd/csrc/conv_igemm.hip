@@ -19,6 +19,7 @@
 // backbone/backbone.py:44-99, infer_model.py:184,190,226 and infer_module/dynamic_infer_module.py:149,191,195.
 #include "din_common.h"
 #include "conv_wgrad.h"
+#include "conv_gather.h"
 #include <unordered_map>
 #include <mutex>
 #include <stdlib.h>
@@ -30,47 +31,15 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 using din_wgrad::WgradK;
 using din_wgrad::lds_dma16;
+using din_gather::ConvK;
+using din_gather::out_pixel;
+using din_gather::staged_tile_store;
 
 namespace {
 
 constexpr int BM = 128;      // pixels per workgroup tile
 constexpr int KC = 8;        // 16-byte chunks per k-step (=> 128 B per tile row)
 constexpr int NTHREADS = 256;
-
-struct ConvK {
-    const void* in; const void* w; void* out; const float* bias; const void* mask; float* partial;
-    int NB, H, W, Cin, ldi, cioff;
-    int OH, OW, Cout, ldo, cooff;
-    int kh, kw;
-    int ay, by, cy, divy;       // ty = oy*ay + by + r*cy ; needs ty % divy == 0 ; iy = ty / divy
-    int ax, bx, cx, divx;
-    int cpt, Q, nk, M, wld;     // chunks per tap, total chunks, k-steps, pixels, packed row length (chunks)
-    int flags, ldm, moff;
-    int splitk, ks_per_split, n_co_tiles;
-    long long in_bytes, w_bytes;    // extents for the buffer resources
-    // output pixel of tile row m=(n,a,b): ((n*out_H + a*out_sy + out_y0)*out_W + b*out_sx + out_x0); identity when out_sy==0
-    int out_sy, out_sx, out_y0, out_x0, out_H, out_W;
-    int korder;                     // 1: reduction runs channel-chunk outer / tap inner (uniform taps only): consecutive k-steps
-                                    //    re-read nearly the same pixels (shifted by one tap) -> L1 hits instead of L2 traffic
-    int remap;                      // 1: filter tap t of this launch is tap wtap[t] of the packed bank (tap subsets)
-    unsigned char wtap[32];
-    // multi-source 1x1 gather (fused dgrad of several 1x1 convs that read the same tensor): the reduction runs over the
-    // concatenation of the sources' channels; source b = its own tensor (pixel stride, channel offset) + its own filter bank
-    int nsrc;
-    struct Src { const void* in; const void* w; long long in_bytes, w_bytes; int cpt, ld, coff, wld; } src[4];
-    // second destination (fused sibling convs that read one tensor): produced channels >= csplit go to out2 (pixel stride ldo2, channel
-    // offset cooff2 + (channel - csplit)); csplit == 0: single destination.  Staged (aligned) epilogue only, no mask / accumulate.
-    void* out2; int ldo2, cooff2, csplit;
-    int craw;                       // > 0: produced channels >= craw get neither bias nor ReLU (a sibling whose epilogue runs later, after its pool)
-};
-
-__device__ __forceinline__ int64_t out_pixel(const ConvK& p, int m) {
-    if (p.out_sy == 0) return m;
-    int n = m / (p.OH * p.OW);
-    int rem = m - n * (p.OH * p.OW);
-    int a = rem / p.OW, b = rem - a * p.OW;
-    return ((int64_t)n * p.out_H + a * p.out_sy + p.out_y0) * p.out_W + b * p.out_sx + p.out_x0;
-}
 
 __device__ __forceinline__ int lds_slot(int row, int chunk) { return row * KC + (chunk ^ ((row >> 1) & 7)); }
 
@@ -611,120 +580,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
             }
         }
     }
-    {
-        constexpr int CPR = BN * (int)sizeof(T) / 16;                // 16-byte chunks per tile row
-        constexpr int RPP = NT / CPR;                                // rows per pass (threads beyond RPP*CPR idle when CPR !| NT)
-        constexpr int NROW = (BM + RPP - 1) / RPP;                   // rows per thread
-        const int c = tid % CPR, rr = tid / CPR;
-        const int co = co_tile * BN + c * EPC;
-        const bool act = co < p.Cout && rr < RPP;
-        T* __restrict__ outp = reinterpret_cast<T*>(p.out);
-        const T* __restrict__ maskp = reinterpret_cast<const T*>(p.mask);
-        if (!(p.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM))) {
-            // plain stores (every forward launch): one pass over the thread's rows.  (Routing these through the batched form below cost
-            // the short-K, store-bound layers 15-20 %: Conv2d_3b forward 558 -> 635 us.)
-            __syncthreads();
-            if (act) {
-                const bool second = p.csplit > 0 && co >= p.csplit;
-                T* __restrict__ dstp = second ? reinterpret_cast<T*>(p.out2) : outp;
-                const int ldd = second ? p.ldo2 : p.ldo, offd = second ? p.cooff2 + (co - p.csplit) : p.cooff + co;
-                for (int row = rr; row < BM; row += RPP) {
-                    const int m = m_first + row;
-                    if (m >= p.M) break;
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(smem_raw + row * CPITCH + c * 16);
-                    *reinterpret_cast<u32x4*>(dstp + out_pixel(p, m) * ldd + offd) = v;
-                }
-            }
-            return;
-        }
-        if (p.flags & 0x100) {                                       // tuning aid (DIN_CONV_EPI_BATCH=0): per-row load -> combine -> store
-            __syncthreads();
-            if (act) {
-                for (int row = rr; row < BM; row += RPP) {
-                    const int m = m_first + row;
-                    if (m >= p.M) break;
-                    u32x4 v = *reinterpret_cast<const u32x4*>(smem_raw + row * CPITCH + c * 16);
-                    const int64_t px = out_pixel(p, m);
-                    const int64_t o = px * p.ldo + p.cooff + co;
-                    u32x4 mk = {0u, 0u, 0u, 0u}, old = {0u, 0u, 0u, 0u};
-                    if (p.flags & DIN_CONV_MASK) mk = *reinterpret_cast<const u32x4*>(maskp + px * p.ldm + p.moff + co);
-                    if (p.flags & DIN_CONV_ACCUM) old = *reinterpret_cast<const u32x4*>(outp + o);
-                    if constexpr (sizeof(T) == 4) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float x = __uint_as_float(v[e]);
-                            if ((p.flags & DIN_CONV_MASK) && !(__uint_as_float(mk[e]) > 0.f)) x = 0.f;
-                            if (p.flags & DIN_CONV_ACCUM) x += __uint_as_float(old[e]);
-                            v[e] = __float_as_uint(x);
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
-                            if (p.flags & DIN_CONV_MASK) {
-                                if (!(__uint_as_float(mk[e] << 16) > 0.f)) lo = 0.f;
-                                if (!(__uint_as_float(mk[e] & 0xffff0000u) > 0.f)) hi = 0.f;
-                            }
-                            if (p.flags & DIN_CONV_ACCUM) { lo += __uint_as_float(old[e] << 16); hi += __uint_as_float(old[e] & 0xffff0000u); }
-                            v[e] = pack_bf16x2(lo, hi);
-                        }
-                    }
-                    *reinterpret_cast<u32x4*>(outp + o) = v;
-                }
-            }
-            return;
-        }
-        // ReLU-backward mask / accumulate inputs of ALL this thread's rows are requested before the staged tile is read back: one
-        // memory latency per tile instead of one per row (the per-row load -> wait -> store chain cost 60-80 us per launch on the
-        // 288-channel dgrads; profiles/r01_stream_probe.txt)
-        u32x4 mkv[NROW], oldv[NROW];
-        int opx[NROW];
-#pragma unroll
-        for (int q = 0; q < NROW; ++q) {
-            mkv[q] = u32x4{0u, 0u, 0u, 0u}; oldv[q] = u32x4{0u, 0u, 0u, 0u}; opx[q] = -1;
-            const int row = rr + q * RPP, m = m_first + row;
-            if (act && row < BM && m < p.M) {
-                const int64_t px = out_pixel(p, m);
-                opx[q] = (int)px;
-                if (p.flags & DIN_CONV_MASK) mkv[q] = *reinterpret_cast<const u32x4*>(maskp + px * p.ldm + p.moff + co);
-                if (p.flags & DIN_CONV_ACCUM) oldv[q] = *reinterpret_cast<const u32x4*>(outp + px * p.ldo + p.cooff + co);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < NROW; ++q) {
-            if (opx[q] < 0) continue;
-            const int row = rr + q * RPP;
-            u32x4 v = *reinterpret_cast<const u32x4*>(smem_raw + row * CPITCH + c * 16);
-            const bool second = p.csplit > 0 && co >= p.csplit;
-            if (second) outp = reinterpret_cast<T*>(p.out2);
-            const int64_t o = second ? (int64_t)opx[q] * p.ldo2 + p.cooff2 + (co - p.csplit) : (int64_t)opx[q] * p.ldo + p.cooff + co;
-            if (p.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM)) {
-                const u32x4 mk = mkv[q], old = oldv[q];
-                if constexpr (sizeof(T) == 4) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = __uint_as_float(v[e]);
-                        if ((p.flags & DIN_CONV_MASK) && !(__uint_as_float(mk[e]) > 0.f)) x = 0.f;
-                        if (p.flags & DIN_CONV_ACCUM) x += __uint_as_float(old[e]);
-                        v[e] = __float_as_uint(x);
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
-                        if (p.flags & DIN_CONV_MASK) {
-                            if (!(__uint_as_float(mk[e] << 16) > 0.f)) lo = 0.f;
-                            if (!(__uint_as_float(mk[e] & 0xffff0000u) > 0.f)) hi = 0.f;
-                        }
-                        if (p.flags & DIN_CONV_ACCUM) { lo += __uint_as_float(old[e] << 16); hi += __uint_as_float(old[e] & 0xffff0000u); }
-                        v[e] = pack_bf16x2(lo, hi);
-                    }
-                }
-            }
-            *reinterpret_cast<u32x4*>(outp + o) = v;
-        }
-    }
+    staged_tile_store<T, BM, BN, NT>(p, smem_raw, tid, co_tile, m_first);
 #endif
 }
 
@@ -2340,7 +2196,7 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype, bool str
             if (tl < best_tiles || (tl == best_tiles && pad < best_pad)) { best = bnc; best_tiles = tl; best_pad = pad; }
         }
         g.bn = best;
-        if (const char* fb = getenv("DIN_CONV_BN")) { const int v = atoi(fb); if (v == 96 || v == 160 || v == 192) g.bn = v; }   // tuning override
+        if (const char* fb = getenv("DIN_CONV_BN")) { const int v = atoi(fb); if (v == 96 || v == 128 || v == 160 || v == 192 || v == 256) g.bn = v; }   // tuning / test override
         // parity classes of a strided dgrad write every other pixel of dX: each tile's epilogue is a scattered write, and more, narrower
         // tiles per CU overlap it better -- 3 x 96 beats 2 x 160 on the 288-channel stride-2 dgrad (1642 -> 1427 us)
         if (strided_out && g.bn == 160 && cprod % 96 == 0) g.bn = 96;
@@ -2646,6 +2502,16 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
     else { if (pipe == 1) launch_fast<T, 128, 128, 2, 2, 4, 4>(k, grid, st); else if (pipe != 4 && sizeof(T) == 2) launch_wave8<T, 128>(k, grid, st); else launch_fast<T, 128, 128, 2, 2, 8, 2>(k, grid, st); }
 }
 
+// 256-pixel software-pipelined tiles (conv_gather_pipe.hip): bf16 launches with whole 32-channel blocks per tap whose filter tile the
+// planner set to 128 / 192 / 256 and that still give every CU at least two tiles.  DIN_GATHER_PIPE=0 keeps the 128-pixel kernels.
+bool want_gather_pipe(int dtype, int64_t M, int cred, int taps, int bn, int splitk, int n_co_tiles) {
+    const char* ev = getenv("DIN_GATHER_PIPE");
+    const int mode = ev ? atoi(ev) : 1;
+    if (!mode || dtype != DIN_BF16 || cred % 32 != 0 || taps > 32 || taps < 1 || splitk != 1 || !din_gather::gather_pipe_tile_ok(bn)) return false;
+    const int64_t tiles = (M + 255) / 256 * n_co_tiles;
+    return tiles >= (mode == 2 ? 1 : 512);
+}
+
 int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_bytes, hipStream_t st, const char* what) {
     const bool fast = k.divy == 1 && k.divx == 1 && k.kh * k.kw <= 32;
     if (!fast && g.bn != 64 && g.bn != 128) { g.bn = 128; g.n_co_tiles = (k.Cout + 127) / 128; }
@@ -2731,6 +2597,14 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
             DIN_CHECK_LAUNCH(what);
             return DIN_OK;
         }
+    }
+    if (fast && !k.remap && k.nsrc == 0 && want_gather_pipe(dtype, k.M, k.Cin, k.kh * k.kw, g.bn, g.splitk, (k.Cout + g.bn - 1) / g.bn) &&
+        g.cpt % 4 == 0 && k.Cout % 8 == 0 && k.cooff % 8 == 0 && k.ldo % 8 == 0 &&
+        (!(k.flags & DIN_CONV_MASK) || (k.ldm % 8 == 0 && k.moff % 8 == 0)) && (k.csplit == 0 || (k.csplit % 8 == 0 && k.ldo2 % 8 == 0 && k.cooff2 % 8 == 0))) {
+        k.n_co_tiles = (k.Cout + g.bn - 1) / g.bn;
+        if (int e = din_gather::launch_gather_pipe(k, g.bn, (k.M + 255) / 256, st)) return e;
+        DIN_CHECK_LAUNCH(what);
+        return DIN_OK;
     }
     if (dtype == DIN_F32) launch_gather<float>(k, g.n_px_tiles, g.bm, g.bn, st);
     else launch_gather<bf16_t>(k, g.n_px_tiles, g.bm, g.bn, st);
@@ -2835,6 +2709,12 @@ int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t
                                             d->cout, d->cin, d->kh * d->kw, d->dtype, strided);
     if (g.bm == 256 && (strided || g.splitk > 1)) { g.bm = 128; if (g.bn == 256) g.bn = 128; }
     *bm = g.bm; *bn = g.bn;
+    {   // conv_gather_pipe_kernel<BN>: bm = 2 (the halo / stem kernels below still take precedence, as in run_gather)
+        const int cred = which == 0 ? d->cin : d->cout, cprod = which == 0 ? d->cout : d->cin;
+        const int64_t M = which == 0 ? (int64_t)d->nb * d->oh * d->ow : (int64_t)d->nb * d->h * d->w;
+        if (!strided && d->dh == 1 && d->dw == 1 && want_gather_pipe(d->dtype, M, cred, d->kh * d->kw, g.bn, g.splitk, (cprod + g.bn - 1) / g.bn) &&
+            cprod % 8 == 0 && (which == 0 ? d->cooff % 8 == 0 && d->ldo % 8 == 0 : d->cioff % 8 == 0 && d->ldi % 8 == 0)) *bm = 2;
+    }
     {   // mid-network multi-tap layers run conv_halo_kernel: bm = 1
         HaloPlan hp;
         const int cred = which == 0 ? d->cin : d->cout, cprod = which == 0 ? d->cout : d->cin;

@@ -97,12 +97,14 @@ class _timed:
             return f"conv_small_kernel<..., {bn.value}, ...>"
         if bm.value == 1:
             return f"conv_halo_kernel<{bn.value}, ...>"
+        if bm.value == 2 and not (self.kind == "dgrad" and "+" in self.name):
+            return f"conv_gather_pipe_kernel<{bn.value}>"
         # the exact instantiation: <T, BM, BN, WM, WN, KCS, NS, MULTI, FASTK>
         fl = C.c_int32(0)
         multi = self.kind == "dgrad" and "+" in self.name
         if not multi:
             L.load().din_conv_kernel_variant(C.byref(d), which, C.byref(fl))
-        BM, BN = bm.value, bn.value
+        BM, BN = (128 if bm.value == 2 else bm.value), bn.value      # (multi-source launches stay on the 128-pixel kernel)
         if BM == 256:
             geo = "4, 1, 4, 4" if BN == 64 else ("2, 2, 8, 2" if BN in (96, 160) else "4, 2, 8, 2")
         elif multi:

@@ -69,6 +69,15 @@ CONV_CASES = [
     ("halo_5x5_48_64", 6, 48, 87, 157, 64, (5, 5), (1, 1), (2, 2), 1),
     ("halo_1x7_128_160", 20, 128, 43, 78, 160, (1, 7), (1, 1), (0, 3), 1),
     ("halo_7x1_160_192", 20, 160, 43, 78, 192, (7, 1), (1, 1), (3, 0), 1),
+    # 256-pixel software-pipelined tiles (conv_gather_pipe_kernel<128 | 192 | 256>, bf16; forced on these small shapes with DIN_GATHER_PIPE=2):
+    # ragged pixel tiles, row / column padding taps, two filter tiles, filter tile wider than the bank, dgrad through the same kernel
+    ("gp192_1x1", 2, 96, 24, 41, 192, (1, 1), (1, 1), (0, 0), 1),
+    ("gp192_7x1", 8, 160, 43, 78, 192, (7, 1), (1, 1), (3, 0), 1),
+    ("gp192_1x7_384", 4, 192, 43, 78, 384, (1, 7), (1, 1), (0, 3), 1),
+    ("gp128_3x3", 3, 128, 61, 70, 256, (3, 3), (1, 1), (1, 1), 1),
+    ("gp256_3x3_p0", 2, 64, 83, 79, 512, (3, 3), (1, 1), (0, 0), 1),          # DIN_CONV_BN=256: the 256-filter tile (VGG conv3+)
+    ("gp192_dgrad_3x3", 4, 192, 80, 78, 192, (3, 3), (1, 1), (1, 1), 1),
+    ("gp128_5x5_176", 4, 64, 80, 78, 176, (5, 5), (1, 1), (2, 2), 1),
 ]
 
 
@@ -79,6 +88,12 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
     name, nb, cin, h, w, cout, k, s, p, dil = case
     if name.startswith("halo_"):
         monkeypatch.setenv("DIN_CONV_HALO", "2")        # the planner only picks the halo kernel where it wins; cover every instantiation
+    if name.startswith("gp"):
+        monkeypatch.setenv("DIN_GATHER_PIPE", "2")      # ... and the 256-pixel pipelined tiles only on launches that fill the chip
+        monkeypatch.setenv("DIN_CONV_HALO", "0")
+        monkeypatch.setenv("DIN_CONV_TILE", "0")
+        if name.startswith("gp256"):
+            monkeypatch.setenv("DIN_CONV_BN", "256")
     dt = L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
     tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
     epc = 4 if dtype == "fp32" else 8
@@ -107,6 +122,10 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
     d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.dh, d.dw = k[0], k[1], s[0], s[1], p[0], p[1], dil, dil
     d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = ldi, 0, ldo, coff, dt
     st = None
+    if name.startswith("gp") and dtype == "bf16":
+        bm, bn = C.c_int32(0), C.c_int32(0)
+        lib.din_conv_kernel_tile(C.byref(d), 0, C.byref(bm), C.byref(bn))
+        assert bm.value == 2, f"{name}: forward not on the pipelined gather kernel (tile {bm.value} x {bn.value})"
     xin = to_nhwc(x, tdt, ldi)
     wdev, bdev = wt.cuda(), bias.cuda()
     wpk = torch.empty(lib.din_conv_packed_elems(C.byref(d), 0), dtype=tdt, device="cuda")
@@ -151,11 +170,14 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
         assert rel(from_nhwc(dx, cin), want) <= 2 * tolg
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_conv_fwd_two_destinations(env, dtype):
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_pipe"])
+def test_conv_fwd_two_destinations(env, dtype, monkeypatch):
     """din_conv_fwd2: sibling 1x1 convs of one input as ONE launch -- channels [0, csplit) into the first tensor's view, the rest into a second
-    tensor; equals the separate convs, and nothing outside the two channel ranges is touched."""
+    tensor; equals the separate convs, and nothing outside the two channel ranges is touched.  bf16_pipe: through the 256-pixel tiles."""
     lib, L, nhwc, ops = env
+    if dtype == "bf16_pipe":
+        monkeypatch.setenv("DIN_GATHER_PIPE", "2")
+        dtype = "bf16"
     dt = L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
     tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
     g = torch.Generator().manual_seed(21)
