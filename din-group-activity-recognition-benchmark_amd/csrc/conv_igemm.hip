@@ -2503,10 +2503,13 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
 }
 
 // 256-pixel software-pipelined tiles (conv_gather_pipe.hip): bf16 launches with whole 32-channel blocks per tap whose filter tile the
-// planner set to 128 / 192 / 256 and that still give every CU at least two tiles.  DIN_GATHER_PIPE=0 keeps the 128-pixel kernels.
+// planner set to 128 / 192 / 256 and that still give every CU at least two tiles.  OPT-IN (DIN_GATHER_PIPE=1; 2 = also on small launches,
+// used by the tests): measured against the 128-pixel 8-wave kernels at two workgroups per CU it is +5 % on the 7x1 forward but -2..-10 %
+// on 1x1 / 1x7 forwards and on every dgrad (one workgroup per CU: no prologue / epilogue overlap; 64-byte instead of 128-byte gather
+// segments per pixel), 520 vs 523 clips/s end to end (profiles/r02_gather_pipe_experiment.txt).
 bool want_gather_pipe(int dtype, int64_t M, int cred, int taps, int bn, int splitk, int n_co_tiles) {
     const char* ev = getenv("DIN_GATHER_PIPE");
-    const int mode = ev ? atoi(ev) : 1;
+    const int mode = ev ? atoi(ev) : 0;
     if (!mode || dtype != DIN_BF16 || cred % 32 != 0 || taps > 32 || taps < 1 || splitk != 1 || !din_gather::gather_pipe_tile_ok(bn)) return false;
     const int64_t tiles = (M + 255) / 256 * n_co_tiles;
     return tiles >= (mode == 2 ? 1 : 512);

@@ -92,7 +92,7 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
         monkeypatch.setenv("DIN_GATHER_PIPE", "2")      # ... and the 256-pixel pipelined tiles only on launches that fill the chip
         monkeypatch.setenv("DIN_CONV_HALO", "0")
         monkeypatch.setenv("DIN_CONV_TILE", "0")
-        if name.startswith("gp256"):
+        if name.startswith("gp256") and dtype == "bf16":
             monkeypatch.setenv("DIN_CONV_BN", "256")
     dt = L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
     tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
