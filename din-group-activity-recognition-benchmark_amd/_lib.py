@@ -90,8 +90,8 @@ SIGNATURES: Dict[str, tuple] = {
     "din_boxes_frame_index": (_I, [_P, _I, _I, _P]),
     "din_layernorm_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _L, _L, _I, _F, _U64, _P]),
     "din_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _F, _U64, _P]),
-    "din_walk_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
-    "din_walk_bwd": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "din_walk_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "din_walk_bwd": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "din_head_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "din_head_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "din_axpby": (_I, [_P, _P, _P, _F, _F, _L, _P]),

@@ -23,6 +23,10 @@ struct WalkK {
     const float* gz; float* dx; float* scratch;          // backward only
     int cp, b, t, n, c, kh, kw, ratio, scale_factor;
     int pt, pl, hp, wp, k2, ky0, kx0;
+    int plain;                        // 1: no walk -- S_k is the feature AT lattice point k (plain_infer_ratio / the relation half of parallel_infer,
+                                      // dynamic_infer_module.py:154-181,285-298); offsets are ignored and get no gradient
+    int ihy, ihx, phy, phx;           // clamp maxima of the corner indices / of the sampling position; -1 = the padded grid's (hp-1, wpc-1), which
+                                      // is what dynamic_infer_ratio uses (:216-226); parallel_infer clamps with person_mat_shape instead (:307-317)
     const int32_t* n_per_clip;        // optional [b]: clip i is a T x n_per_clip[i] grid stored in the first columns of its T x n slab
                                       // (Dynamic_collective, infer_model.py:1286-1293); columns beyond it are zero padding
 };
@@ -45,13 +49,13 @@ __device__ __forceinline__ Corner corners(const WalkK& p, int wpc, int tt, int n
     c.py0 = __fadd_rn(base_y, oy);
     c.px0 = __fadd_rn(base_x, ox);
     const float fy = floorf(c.py0), fx = floorf(c.px0);
-    const float hy = (float)(p.hp - 1), hx = (float)(wpc - 1);
+    const float hy = (float)(p.ihy >= 0 ? p.ihy : p.hp - 1), hx = (float)(p.ihx >= 0 ? p.ihx : wpc - 1);
     c.ly = (int)fminf(fmaxf(fy, 0.f), hy);
     c.ry = (int)fminf(fmaxf(fy + 1.f, 0.f), hy);
     c.lx = (int)fminf(fmaxf(fx, 0.f), hx);
     c.rx = (int)fminf(fmaxf(fx + 1.f, 0.f), hx);
-    c.py = fminf(fmaxf(c.py0, 0.f), hy);
-    c.px = fminf(fmaxf(c.px0, 0.f), hx);
+    c.py = fminf(fmaxf(c.py0, 0.f), p.phy >= 0 ? (float)p.phy : hy);
+    c.px = fminf(fmaxf(c.px0, 0.f), p.phx >= 0 ? (float)p.phx : hx);
     return c;
 }
 __device__ __forceinline__ float coef(float p, int c) { return __fsub_rn(1.f, fabsf(__fsub_rn(p, (float)c))); }
@@ -115,7 +119,8 @@ __global__ __launch_bounds__(WALK_THREADS) void din_walk_fwd_kernel(WalkK p) {
             int pos = i / p.k2, k = i - pos * p.k2;
             int tt = pos / p.n, nn = pos - tt * p.n;
             const float* pr = off_s + pos * 2 * p.k2;
-            Corner c = corners(p, wpc, tt, nn, k, pr[k], pr[p.k2 + k]);
+            Corner c = corners(p, wpc, tt, nn, k, p.plain ? 0.f : pr[k], p.plain ? 0.f : pr[p.k2 + k]);
+            if (p.plain) { c.ry = c.ly; c.rx = c.lx; }
             int64_t o = ((int64_t)b * p.t * p.n + pos) * p.k2 + k;
             p.a[o] = a_s[i];
             if (p.idx) { p.idx[o * 4 + 0] = c.ly; p.idx[o * 4 + 1] = c.ry; p.idx[o * 4 + 2] = c.lx; p.idx[o * 4 + 3] = c.rx; }
@@ -131,14 +136,20 @@ __global__ __launch_bounds__(WALK_THREADS) void din_walk_fwd_kernel(WalkK p) {
             continue;
         }
         for (int k = 0; k < p.k2; ++k) {
+            float sk;
+            if (p.plain) {                                 // the feature at the lattice point itself (pos_0 + pos_k: integers inside the padded grid)
+                const int r = k / p.kw, s = k - r * p.kw;
+                sk = tile[((p.pt + tt + p.ky0 + r * p.ratio) * p.wp + p.pl + nn + p.kx0 + s * p.ratio) * CH + lane];
+            } else {
             Corner c = corners(p, wpc, tt, nn, k, pr[k], pr[p.k2 + k]);
             float wy_l = coef(c.py, c.ly), wy_r = coef(c.py, c.ry), wx_l = coef(c.px, c.lx), wx_r = coef(c.px, c.rx);
             float v_lt = tile[(c.ly * p.wp + c.lx) * CH + lane], v_rb = tile[(c.ry * p.wp + c.rx) * CH + lane];
             float v_lb = tile[(c.ry * p.wp + c.lx) * CH + lane], v_rt = tile[(c.ly * p.wp + c.rx) * CH + lane];
             // same association as the reference: lt*coe_lt + rb*coe_rb + lb*coe_lb + rt*coe_rt  (:255-258)
-            float sk = v_lt * (wy_l * wx_l) + v_rb * (wy_r * wx_r);
+            sk = v_lt * (wy_l * wx_l) + v_rb * (wy_r * wx_r);
             sk = sk + v_lb * (wy_r * wx_l);
             sk = sk + v_rt * (wy_l * wx_r);
+            }
             if (p.mad && cok) p.mad[(((int64_t)b * p.t * p.n + pos) * p.k2 + k) * p.c + c0 + lane] = sk;
             zacc += sk * a_s[pos * p.k2 + k];
         }
@@ -200,8 +211,17 @@ __global__ __launch_bounds__(WALK_BWD_WAVES * 64) void din_walk_bwd_kernel(WalkK
         const float* pr = off_s + pos * 2 * p.k2;
         const float g = cok ? p.gz[gpos * p.c + c0 + lane] : 0.f;
         for (int k = 0; k < p.k2; ++k) {
-            Corner c = corners(p, wpc, tt, nn, k, pr[k], pr[p.k2 + k]);
             const float ak = a_s[pos * p.k2 + k];
+            if (p.plain) {
+                const int r = k / p.kw, s2 = k - r * p.kw;
+                const int cy = p.pt + tt + p.ky0 + r * p.ratio, cx = p.pl + nn + p.kx0 + s2 * p.ratio;
+                const float sk = tile[(cy * p.wp + cx) * CH + lane];
+                scatter(cy, cx, ak * g);
+                const float d_s = wave_sum(g * sk);
+                if (lane == 0) { d_off[gpos * 2 * p.k2 + k] = 0.f; d_off[gpos * 2 * p.k2 + p.k2 + k] = 0.f; d_a[gpos * p.k2 + k] = d_s; }
+                continue;
+            }
+            Corner c = corners(p, wpc, tt, nn, k, pr[k], pr[p.k2 + k]);
             float wy_l = coef(c.py, c.ly), wy_r = coef(c.py, c.ry), wx_l = coef(c.px, c.lx), wx_r = coef(c.px, c.rx);
             const int i_lt = (c.ly * p.wp + c.lx) * CH + lane, i_rb = (c.ry * p.wp + c.rx) * CH + lane;
             const int i_lb = (c.ry * p.wp + c.lx) * CH + lane, i_rt = (c.ly * p.wp + c.rx) * CH + lane;
@@ -218,8 +238,8 @@ __global__ __launch_bounds__(WALK_BWD_WAVES * 64) void din_walk_bwd_kernel(WalkK
             float d_lt = wave_sum(g * v_lt), d_rb = wave_sum(g * v_rb), d_lb = wave_sum(g * v_lb), d_rt = wave_sum(g * v_rt);
             if (lane == 0) {
                 // d/d py of (1-|py-cy|) = -sign(py-cy); clamp passes gradient on the closed interval (Q8, Q9)
-                const float my = (c.py0 >= 0.f && c.py0 <= (float)(p.hp - 1)) ? 1.f : 0.f;
-                const float mx = (c.px0 >= 0.f && c.px0 <= (float)(wpc - 1)) ? 1.f : 0.f;
+                const float my = (c.py0 >= 0.f && c.py0 <= (float)(p.phy >= 0 ? p.phy : (p.ihy >= 0 ? p.ihy : p.hp - 1))) ? 1.f : 0.f;
+                const float mx = (c.px0 >= 0.f && c.px0 <= (float)(p.phx >= 0 ? p.phx : (p.ihx >= 0 ? p.ihx : wpc - 1))) ? 1.f : 0.f;
                 const float sy_l = -sgn(c.py - (float)c.ly), sy_r = -sgn(c.py - (float)c.ry);
                 const float sx_l = -sgn(c.px - (float)c.lx), sx_r = -sgn(c.px - (float)c.rx);
                 float doy = d_lt * sy_l * wx_l + d_rb * sy_r * wx_r + d_lb * sy_r * wx_l + d_rt * sy_l * wx_r;
@@ -269,7 +289,8 @@ __global__ void din_walk_bwd_finish_kernel(const float* __restrict__ scratch, co
     }
 }
 
-int fill(WalkK& p, int cp, int b, int t, int n, int c, int kh, int kw, int ratio, int scale_factor) {
+int fill(WalkK& p, int cp, int b, int t, int n, int c, int kh, int kw, int ratio, int scale_factor, int plain, const int32_t* clamp,
+         const int32_t* n_per_clip) {
     DIN_REQUIRE(b > 0 && t > 0 && n > 0 && c > 0 && kh > 0 && kw > 0 && ratio > 0, "din_walk: bad shape");
     DIN_REQUIRE(kh * kw <= MAXK2, "din_walk: ST kernel larger than %d taps unsupported", MAXK2);
     DIN_REQUIRE(cp >= (scale_factor ? 3 : 2) * kh * kw, "din_walk: pred pixel stride too small");
@@ -279,6 +300,16 @@ int fill(WalkK& p, int cp, int b, int t, int n, int c, int kh, int kw, int ratio
     // lattice start = floor(-((k-1)*ratio) / 2)   (dynamic_infer_module.py:388-389)
     auto fl2 = [](int v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); };
     p.ky0 = fl2(-((kh - 1) * ratio)); p.kx0 = fl2(-((kw - 1) * ratio));
+    p.plain = plain ? 1 : 0;
+    p.ihy = p.ihx = p.phy = p.phx = -1;
+    p.n_per_clip = n_per_clip;
+    if (clamp) {
+        DIN_REQUIRE(!n_per_clip, "din_walk: clamp overrides and n_per_clip are mutually exclusive");
+        // index maxima can never leave the LDS tile (the reference would index outside its padded map there: undefined)
+        p.ihy = clamp[0] < p.hp - 1 ? clamp[0] : p.hp - 1; p.ihx = clamp[1] < p.wp - 1 ? clamp[1] : p.wp - 1;
+        p.phy = clamp[2]; p.phx = clamp[3];
+        DIN_REQUIRE(p.ihy >= 0 && p.ihx >= 0 && p.phy >= 0 && p.phx >= 0, "din_walk: negative clamp maximum");
+    }
     return DIN_OK;
 }
 
@@ -287,11 +318,12 @@ int fill(WalkK& p, int cp, int b, int t, int n, int c, int kh, int kw, int ratio
 extern "C" {
 
 int din_walk_fwd(const float* x, const float* pred, int cp, int b, int t, int n, int c, int kh, int kw, int ratio,
-                 int scale_factor, const int32_t* n_per_clip, float* z, float* a, int32_t* idx, float* mad, void* stream) {
+                 int scale_factor, int plain, const int32_t* clamp, const int32_t* n_per_clip, float* z, float* a, int32_t* idx, float* mad,
+                 void* stream) {
     DIN_REQUIRE(x && pred && z && a, "din_walk_fwd: null pointer");
     WalkK p{};
-    if (int e = fill(p, cp, b, t, n, c, kh, kw, ratio, scale_factor)) return e;
-    p.x = x; p.pred = pred; p.z = z; p.a = a; p.idx = idx; p.mad = mad; p.n_per_clip = n_per_clip;
+    if (int e = fill(p, cp, b, t, n, c, kh, kw, ratio, scale_factor, plain, clamp, n_per_clip)) return e;
+    p.x = x; p.pred = pred; p.z = z; p.a = a; p.idx = idx; p.mad = mad;
     size_t lds = ((size_t)p.hp * p.wp * CH + (size_t)t * n * 3 * p.k2) * sizeof(float);
     DIN_REQUIRE(lds <= 160 * 1024, "din_walk_fwd: T x N grid too large for one LDS tile (%zu bytes)", lds);
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(din_walk_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -303,12 +335,12 @@ int din_walk_fwd(const float* x, const float* pred, int cp, int b, int t, int n,
 }
 
 int din_walk_bwd(const float* x, const float* pred, int cp, const float* a, const float* gz, int b, int t, int n, int c,
-                 int kh, int kw, int ratio, int scale_factor, const int32_t* n_per_clip, float* dx, float* dpred, float* scratch,
-                 void* stream) {
+                 int kh, int kw, int ratio, int scale_factor, int plain, const int32_t* clamp, const int32_t* n_per_clip, float* dx,
+                 float* dpred, float* scratch, void* stream) {
     DIN_REQUIRE(x && pred && a && gz && dx && dpred && scratch, "din_walk_bwd: null pointer");
     WalkK p{};
-    if (int e = fill(p, cp, b, t, n, c, kh, kw, ratio, scale_factor)) return e;
-    p.x = x; p.pred = pred; p.a = const_cast<float*>(a); p.gz = gz; p.dx = dx; p.scratch = scratch; p.n_per_clip = n_per_clip;
+    if (int e = fill(p, cp, b, t, n, c, kh, kw, ratio, scale_factor, plain, clamp, n_per_clip)) return e;
+    p.x = x; p.pred = pred; p.a = const_cast<float*>(a); p.gz = gz; p.dx = dx; p.scratch = scratch;
     hipStream_t st = as_stream(stream);
     int64_t positions = (int64_t)b * t * n;
     const size_t tile_b = (size_t)p.hp * p.wp * CH * sizeof(float), tab_b = (size_t)t * n * 3 * p.k2 * sizeof(float);

@@ -10,8 +10,10 @@ keys (`hidden_weight.weight`, `p_conv.<ratio>.{weight,bias}`, `scale_conv.<ratio
 `ft_infer_MAD` is only materialised when `return_mad=True` (both reference callers discard it: infer_model.py:199).
 
 Reference behaviours kept on purpose: Q2 channel order, Q3 clamp double-count, Q4 detached floor,
-Q5 zero init, Q8/Q9 sub-gradients.  Reference crashes NOT kept: dynamic_sampling=False / parallel_inference=True
-(Q1, UnboundLocalError at :151) raise NotImplementedError here; Hierarchical uses the intended semantics.
+Q5 zero init, Q8/Q9 sub-gradients.  `dynamic_sampling=False` (plain_infer_ratio, :154-181) and `parallel_inference=True`
+(parallel_infer, :285-341) run their per-ratio arithmetic through the same walk kernel (lattice-gather mode / person_mat_shape
+clamps); the reference's forward then dies on an unbound `ft_infer_MAD` (Q1, :151) -- here the MAD slot of the returned tuple is None.
+Hierarchical uses the intended semantics.
 """
 from __future__ import annotations
 
@@ -28,9 +30,9 @@ class Dynamic_Person_Inference(nn.Module):
         super().__init__()
         if stride != 1 or group != 1:
             raise NotImplementedError("only stride=1, group=1 is ever used by the reference (config.py:84,88)")
-        if not dynamic_sampling or parallel_inference:
-            raise NotImplementedError("dynamic_sampling=False / parallel_inference=True crash in the reference "
-                                      "(dynamic_infer_module.py:130-151); not part of the hot path")
+        if parallel_inference and not (dynamic_sampling and scale_factor):
+            raise AssertionError("parallel_inference needs dynamic_sampling and scale_factor (dynamic_infer_module.py:130)")
+        self.dynamic_sampling, self.parallel_inference = bool(dynamic_sampling), bool(parallel_inference)
         self.T, self.N = person_mat_shape
         self.kernel_size = tuple(kernel_size)
         self.sampling_ratio = list(sampling_ratio)
@@ -42,14 +44,16 @@ class Dynamic_Person_Inference(nn.Module):
         nn.init.kaiming_normal_(self.hidden_weight.weight)
         if beta_factor:
             self.beta = nn.Parameter(torch.ones(len(self.sampling_ratio)))
-        self.p_conv = nn.ModuleDict()
+        if dynamic_sampling:                                   # (:47-48: the offset predictors exist only with dynamic sampling)
+            self.p_conv = nn.ModuleDict()
         if scale_factor:
             self.scale_conv = nn.ModuleDict()
         for r in self.sampling_ratio:
             pad = ((kh - 1) // 2 * r, (kw - 1) // 2 * r)
-            pc = nn.Conv2d(in_dim, 2 * kh * kw, self.kernel_size, dilation=r, padding=pad)
-            nn.init.zeros_(pc.weight), nn.init.zeros_(pc.bias)
-            self.p_conv[str(r)] = pc
+            if dynamic_sampling:
+                pc = nn.Conv2d(in_dim, 2 * kh * kw, self.kernel_size, dilation=r, padding=pad)
+                nn.init.zeros_(pc.weight), nn.init.zeros_(pc.bias)
+                self.p_conv[str(r)] = pc
             if scale_factor:
                 sc = nn.Conv2d(in_dim, kh * kw, self.kernel_size, dilation=r, padding=pad)
                 nn.init.zeros_(sc.weight), nn.init.zeros_(sc.bias)
@@ -57,6 +61,18 @@ class Dynamic_Person_Inference(nn.Module):
 
     def _ratio(self, x, r, n_per_clip=None):
         kh, kw = self.kernel_size
+        k2 = kh * kw
+        if not self.dynamic_sampling:
+            # plain_infer_ratio (:154-181): features AT the lattice points, weighted by the relation softmax (or averaged)
+            if self.scale_factor:
+                sc = self.scale_conv[str(r)]
+                w = torch.cat([sc.weight.new_zeros((2 * k2,) + tuple(sc.weight.shape[1:])), sc.weight], 0)     # offset channels unused
+                b = torch.cat([sc.bias.new_zeros(2 * k2), sc.bias], 0)
+                pred = ops.GridConvFunction.apply(x, w, b, r)
+            else:
+                pred = x.new_zeros(x.shape[:3] + (2 * k2,))
+            z, a, idx, mad = ops.DynamicWalkFunction.apply(x, pred, kh, kw, r, self.scale_factor, False, n_per_clip, True, None)
+            return z, None, a, idx
         pc = self.p_conv[str(r)]
         if self.scale_factor:
             sc = self.scale_conv[str(r)]
@@ -65,6 +81,15 @@ class Dynamic_Person_Inference(nn.Module):
         else:
             w, b = pc.weight, pc.bias
         pred = ops.GridConvFunction.apply(x, w, b, r)                       # [B,T,N,pad4(3*k2)]
+        if self.parallel_inference:
+            # parallel_infer (:285-341): relation-weighted lattice gather + MEAN over k2 of the dynamic walk, the latter clamped with
+            # person_mat_shape: indices to (T + 2r - 1, N + 2r - 1), positions to (T + 2r, N + 2r)   (:307-317)
+            if n_per_clip is not None:
+                raise NotImplementedError("parallel_inference with per-clip actor counts")
+            zs, a, idx, _ = ops.DynamicWalkFunction.apply(x, pred, kh, kw, r, True, False, None, True, None)
+            clamp = (self.T + 2 * r - 1, self.N + 2 * r - 1, self.T + 2 * r, self.N + 2 * r)
+            zw, _, idx, _ = ops.DynamicWalkFunction.apply(x, pred, kh, kw, r, False, False, None, False, clamp)
+            return ops.AxpbyFunction.apply(zs, zw, 1.0, 1.0), None, a, idx
         z, a, idx, mad = ops.DynamicWalkFunction.apply(x, pred, kh, kw, r, self.scale_factor, self.return_mad, n_per_clip)
         return z, mad, a, idx
 

@@ -218,7 +218,10 @@ class DynamicWalkFunction(torch.autograd.Function):
     """(x [b,t,n,c], pred [b,t,n,cp]) -> z [b,t,n,c]   (+ non-differentiable a, idx, optional mad)."""
 
     @staticmethod
-    def forward(ctx, x, pred, kh: int, kw: int, ratio: int, scale_factor: bool, want_mad: bool, n_per_clip=None):
+    def forward(ctx, x, pred, kh: int, kw: int, ratio: int, scale_factor: bool, want_mad: bool, n_per_clip=None, plain: bool = False,
+                clamp=None):
+        """plain: lattice gather without walk (plain_infer_ratio / relation half of parallel_infer).  clamp: (iy_max, ix_max, py_max,
+        px_max) clamp maxima of parallel_infer's walk half (person_mat_shape based, dynamic_infer_module.py:307-317)."""
         lib = L.load()
         x, pred = x.contiguous(), pred.contiguous()
         require_gpu(x, pred, n_per_clip)
@@ -229,10 +232,11 @@ class DynamicWalkFunction(torch.autograd.Function):
         a = torch.empty((b, t, n, k2), dtype=torch.float32, device=x.device)
         idx = torch.empty((b, t, n, k2, 4), dtype=torch.int32, device=x.device)
         mad = torch.empty((b, t, n, k2, c), dtype=torch.float32, device=x.device) if want_mad else None
-        L.check(lib.din_walk_fwd(_ptr(x), _ptr(pred), cp, b, t, n, c, kh, kw, ratio, int(scale_factor), _ptr(n_per_clip), _ptr(z), _ptr(a),
-                                 _ptr(idx), _ptr(mad), _stream()), "din_walk_fwd")
+        cl = (C.c_int32 * 4)(*[int(v) for v in clamp]) if clamp is not None else None
+        L.check(lib.din_walk_fwd(_ptr(x), _ptr(pred), cp, b, t, n, c, kh, kw, ratio, int(scale_factor), int(plain), cl, _ptr(n_per_clip),
+                                 _ptr(z), _ptr(a), _ptr(idx), _ptr(mad), _stream()), "din_walk_fwd")
         ctx.save_for_backward(x, pred, a)
-        ctx.n_per_clip = n_per_clip
+        ctx.n_per_clip, ctx.plain, ctx.clamp = n_per_clip, bool(plain), clamp
         ctx.geom = (kh, kw, ratio, scale_factor)
         if mad is None:
             mad = x.new_empty(0)
@@ -250,9 +254,10 @@ class DynamicWalkFunction(torch.autograd.Function):
         dx = torch.empty_like(x)
         dpred = torch.zeros_like(pred)
         scratch = torch.empty(((c + 63) // 64) * b * t * n * 3 * kh * kw, dtype=torch.float32, device=x.device)
-        L.check(lib.din_walk_bwd(_ptr(x), _ptr(pred), cp, _ptr(a), _ptr(gz), b, t, n, c, kh, kw, ratio, int(scale_factor),
+        cl = (C.c_int32 * 4)(*[int(v) for v in ctx.clamp]) if ctx.clamp is not None else None
+        L.check(lib.din_walk_bwd(_ptr(x), _ptr(pred), cp, _ptr(a), _ptr(gz), b, t, n, c, kh, kw, ratio, int(scale_factor), int(ctx.plain), cl,
                                  _ptr(ctx.n_per_clip), _ptr(dx), _ptr(dpred), _ptr(scratch), _stream()), "din_walk_bwd")
-        return dx, dpred, None, None, None, None, None, None
+        return dx, dpred, None, None, None, None, None, None, None, None
 
 
 class MaskActorsFunction(torch.autograd.Function):

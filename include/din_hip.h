@@ -266,15 +266,20 @@ int din_layernorm_bwd(const float* dy, const float* x, const float* res, const f
  *   read as zeros, get z = 0 and no gradient, and the x clamp range is the clip's own padded width.  x must already be zero there.
  *   The forward needs ONE padded (t+2pt) x (n+2pl) x 64-channel fp32 tile in LDS (<= 160 KiB, else DIN_E_ARG); the backward keeps a
  *   second one for the feature gradient when it fits and scatters into dx with global atomics when it does not.                 */
+/*   plain != 0: no walk -- S_k is the feature at lattice point k itself (plain_infer_ratio :154-181 and the relation half of
+ *   parallel_infer :285-298); the offset channels of pred are ignored and receive no gradient.
+ *   clamp (nullable HOST array of 4 ints {iy_max, ix_max, py_max, px_max}): clamp maxima of the corner indices and of the sampling
+ *   position, for parallel_infer's walk half, which clamps with person_mat_shape (T + 2 ratio - 1, N + 2 ratio - 1; T + 2 ratio,
+ *   N + 2 ratio: :307-317) instead of the padded grid; index maxima are additionally held inside the padded grid.              */
 int din_walk_fwd(const float* x, const float* pred, int cp, int b, int t, int n, int c,
-                 int kh, int kw, int ratio, int scale_factor, const int32_t* n_per_clip,
+                 int kh, int kw, int ratio, int scale_factor, int plain, const int32_t* clamp, const int32_t* n_per_clip,
                  float* z, float* a, int32_t* idx, float* mad, void* stream);
 /* gz [b,t,n,c] -> dx_walk [b,t,n,c] (overwritten), dpred [b,t,n,cp] (first 3*k2 channels written):
  * d offset through the |.| coefficients with detached floor (Q4), inclusive clamp pass-through (Q9),
  * sign(0)=0 (Q8); d logits through the softmax.  scratch: fp32 [ceil(c/64)][b,t,n,3*k2] (per-channel-chunk partial sums, written by the call).     */
 int din_walk_bwd(const float* x, const float* pred, int cp, const float* a, const float* gz,
-                 int b, int t, int n, int c, int kh, int kw, int ratio, int scale_factor, const int32_t* n_per_clip,
-                 float* dx, float* dpred, float* scratch, void* stream);
+                 int b, int t, int n, int c, int kh, int kw, int ratio, int scale_factor, int plain, const int32_t* clamp,
+                 const int32_t* n_per_clip, float* dx, float* dpred, float* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row H  head (infer_model.py:224-232): max over actors -> fc_activities -> mean over frames.

@@ -388,16 +388,88 @@ def din_ratio_forward(x: Tensor, p_w: Tensor, p_b: Tensor, s_w: Optional[Tensor]
     return z, s
 
 
+def _din_padded(x: Tensor, kernel: Tuple[int, int], ratio: int):
+    b, t, n, c = x.shape
+    kh, kw = kernel
+    pt, pl = (kh - 1) // 2 * ratio, (kw - 1) // 2 * ratio
+    hp, wp = t + 2 * pt, n + 2 * pl
+    xc = x.permute(0, 3, 1, 2)
+    pad = F.pad(xc, (pl, pl, pt, pt)).permute(0, 2, 3, 1).reshape(b, hp * wp, c)
+    return xc, pad, pt, pl, hp, wp
+
+
+def din_plain_ratio_forward(x: Tensor, s_w: Optional[Tensor], s_b: Optional[Tensor], kernel: Tuple[int, int], ratio: int) -> Tensor:
+    """plain_infer_ratio (:154-181): the features AT the k2 lattice points pos_0 + pos_k (no offsets, no interpolation),
+    weighted by the relation softmax (scale_factor) or averaged."""
+    b, t, n, c = x.shape
+    kh, kw = kernel
+    k2 = kh * kw
+    xc, pad, pt, pl, hp, wp = _din_padded(x, kernel, ratio)
+    ky, kx = din_lattice(kernel, ratio)
+    cy = (torch.arange(t) + pt).view(1, t, 1, 1) + torch.tensor(ky).view(1, 1, 1, k2)          # integers inside the padded grid
+    cx = (torch.arange(n) + pl).view(1, 1, n, 1) + torch.tensor(kx).view(1, 1, 1, k2)
+    lin = (cy * wp + cx).expand(b, t, n, k2).reshape(b, t * n * k2, 1).expand(b, t * n * k2, c)
+    ft = pad.gather(1, lin).reshape(b, t, n, k2, c)
+    if s_w is not None:
+        a = torch.softmax(F.conv2d(xc, s_w, s_b, padding=(pt, pl), dilation=ratio).permute(0, 2, 3, 1), dim=-1)
+        return (ft * a.unsqueeze(-1)).sum(3)
+    return ft.mean(3)
+
+
+def din_parallel_ratio_forward(x: Tensor, p_w: Tensor, p_b: Tensor, s_w: Tensor, s_b: Tensor, kernel: Tuple[int, int], ratio: int,
+                               mat_shape: Tuple[int, int]) -> Tensor:
+    """parallel_infer (:285-341): relation-weighted lattice gather + the MEAN over k2 of the dynamic walk.  The walk half clamps with
+    person_mat_shape (self.T, self.N) and 2 * ratio whatever the kernel: corner indices to [0, T + 2r - 1] / [0, N + 2r - 1], the
+    position to [0, T + 2r] / [0, N + 2r] (:307-317) -- restated as written; index maxima are additionally held inside the padded map
+    (where the reference would read outside its tensor)."""
+    b, t, n, c = x.shape
+    kh, kw = kernel
+    k2 = kh * kw
+    z_scale = din_plain_ratio_forward(x, s_w, s_b, kernel, ratio)
+    xc, pad, pt, pl, hp, wp = _din_padded(x, kernel, ratio)
+    offset = F.conv2d(xc, p_w, p_b, padding=(pt, pl), dilation=ratio).permute(0, 2, 3, 1)
+    ky, kx = din_lattice(kernel, ratio)
+    dt = offset.dtype
+    py0 = (torch.arange(t, dtype=dt) + pt).view(1, t, 1, 1) + torch.tensor(ky, dtype=dt).view(1, 1, 1, k2) + offset[..., :k2]
+    px0 = (torch.arange(n, dtype=dt) + pl).view(1, 1, n, 1) + torch.tensor(kx, dtype=dt).view(1, 1, 1, k2) + offset[..., k2:]
+    tm, nm = mat_shape
+    iy, ix = min(tm + 2 * ratio - 1, hp - 1), min(nm + 2 * ratio - 1, wp - 1)
+    fy, fx = py0.detach().floor(), px0.detach().floor()
+    ly, ry, lx, rx = fy.clamp(0, iy), (fy + 1).clamp(0, iy), fx.clamp(0, ix), (fx + 1).clamp(0, ix)
+    py, px = py0.clamp(0, tm + 2 * ratio), px0.clamp(0, nm + 2 * ratio)
+
+    def fetch(cy, cx):
+        lin = (cy.long() * wp + cx.long()).reshape(b, t * n * k2, 1).expand(b, t * n * k2, c)
+        return pad.gather(1, lin).reshape(b, t, n, k2, c)
+
+    def w(cy, cx):
+        return (1 - (py - cy).abs()) * (1 - (px - cx).abs())
+
+    s = None
+    for cy, cx in ((ly, lx), (ry, rx), (ry, lx), (ly, rx)):
+        term = fetch(cy, cx) * w(cy, cx).unsqueeze(-1)
+        s = term if s is None else s + term
+    return z_scale + s.mean(3)
+
+
 def din_person_inference(x: Tensor, p: Params, prefix: str, kernel: Tuple[int, int],
                          ratios: Sequence[int], scale_factor: bool = True,
-                         beta_factor: bool = False) -> Tuple[Tensor, Tensor]:
-    """Dynamic_Person_Inference.forward (:121-151) with dynamic_sampling=True."""
+                         beta_factor: bool = False, dynamic_sampling: bool = True, parallel_inference: bool = False,
+                         mat_shape: Tuple[int, int] = (10, 12)) -> Tuple[Tensor, Tensor]:
+    """Dynamic_Person_Inference.forward (:121-151).  dynamic_sampling=False / parallel_inference=True: the reference computes the
+    per-ratio features and then dies on the unbound `ft_infer_MAD` (:151); the recipe is its own per-ratio methods followed by the
+    combination at :137-147, MAD = None."""
     zs, s_last = [], None
     for r in ratios:
         sw = p.get(f"{prefix}scale_conv.{r}.weight") if scale_factor else None
         sb = p.get(f"{prefix}scale_conv.{r}.bias") if scale_factor else None
-        z, s_last = din_ratio_forward(x, p[f"{prefix}p_conv.{r}.weight"], p[f"{prefix}p_conv.{r}.bias"],
-                                      sw, sb, kernel, r)
+        if parallel_inference:
+            z = din_parallel_ratio_forward(x, p[f"{prefix}p_conv.{r}.weight"], p[f"{prefix}p_conv.{r}.bias"], sw, sb, kernel, r, mat_shape)
+        elif not dynamic_sampling:
+            z = din_plain_ratio_forward(x, sw, sb, kernel, r)
+        else:
+            z, s_last = din_ratio_forward(x, p[f"{prefix}p_conv.{r}.weight"], p[f"{prefix}p_conv.{r}.bias"],
+                                          sw, sb, kernel, r)
         zs.append(z)
     zst = torch.stack(zs, dim=4)
     if beta_factor:

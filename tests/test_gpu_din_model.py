@@ -514,3 +514,30 @@ def test_train_net_collective_runs_through_the_collective_loops(gpu, tmp_path):
     tr, te = infos[0]["train"], infos[0]["test"]
     assert np.isfinite(tr["loss"]) and np.isfinite(te["loss"]) and tr["activities_conf"].shape == (5, 5)
     assert int(tr["activities_conf"].sum()) == 4 and int(te["activities_conf"].sum()) == 2
+
+
+from tests.test_oracle_golden import MODE_CASES, load_mode_case
+
+
+@pytest.mark.parametrize("path", MODE_CASES, ids=[os.path.basename(p)[:-4] for p in MODE_CASES])
+def test_plain_and_parallel_modes_match_reference_golden(gpu, path):
+    """Dynamic_Person_Inference with dynamic_sampling=False (plain_infer_ratio, dynamic_infer_module.py:154-181) and
+    with parallel_inference=True (parallel_infer, :285-341) through the walk kernel's lattice-gather mode and person_mat_shape clamps:
+    output 1e-4, input and parameter gradients 2e-4 against the reference fixtures; state_dict keys as in the reference (no p_conv
+    without dynamic sampling)."""
+    from din_amd.infer_module.dynamic_infer_module import Dynamic_Person_Inference
+    z, m, x, cot, p = load_mode_case(path)
+    par = m["mode"] == "parallel"
+    mod = Dynamic_Person_Inference(in_dim=m["c"], person_mat_shape=(10, 12), kernel_size=m["kernel"], dynamic_sampling=par,
+                                   sampling_ratio=m["ratios"], scale_factor=m["scale"], beta_factor=m["beta"], parallel_inference=par)
+    mod.load_state_dict(p, strict=True)
+    mod = mod.to(gpu)
+    xd = x.to(gpu).requires_grad_(True)
+    out, mad = mod(xd)
+    (out * cot.to(gpu)).sum().backward()
+    assert mad is None
+    assert rel(out, z["out"]) <= 1e-4 and rel(xd.grad, z["gx"]) <= 2e-4
+    named = dict(mod.named_parameters())
+    for k in z.files:
+        if k.startswith("g."):
+            assert rel(named[k[2:]].grad, z[k]) <= 2e-4, k

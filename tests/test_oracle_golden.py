@@ -226,3 +226,32 @@ def test_collective_oracle_matches_reference(golden_dir):
         if k.startswith("gsum."):
             gq = po[k[5:]].grad.double()
             assert abs(gq.sum().item() - float(z[k])) <= 2e-3 * float(z["gabs." + k[5:]]) + 1e-6, k
+
+
+MODE_CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mode_*.npz")))
+
+
+def load_mode_case(path):
+    z = np.load(path)
+    b, t, n, c, beta, scale = [int(v) for v in z["meta"]]
+    meta = dict(mode=str(z["mode"]), kernel=tuple(int(v) for v in z["kernel"]), ratios=[int(r) for r in z["ratios"]], beta=bool(beta),
+                scale=bool(scale), c=c)
+    p = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}
+    return z, meta, torch.from_numpy(z["x"]), torch.from_numpy(z["cot"]), p
+
+
+@pytest.mark.parametrize("path", MODE_CASES, ids=[os.path.basename(p)[:-4] for p in MODE_CASES])
+def test_plain_and_parallel_oracle_matches_reference(path):
+    """dynamic_sampling=False (plain_infer_ratio) and parallel_inference=True (parallel_infer) -- fixtures from the reference's
+    own per-ratio methods combined as dynamic_infer_module.py:137-147 does."""
+    z, m, x, cot, p = load_mode_case(path)
+    assert len(MODE_CASES) >= 3
+    po = {("DPI." + k): v.clone().requires_grad_(True) for k, v in p.items()}
+    xo = x.clone().requires_grad_(True)
+    out, _ = O.din_person_inference(xo, po, "DPI.", m["kernel"], m["ratios"], m["scale"], m["beta"], dynamic_sampling=m["mode"] == "parallel",
+                                    parallel_inference=m["mode"] == "parallel")
+    (out * cot).sum().backward()
+    assert _rel(out.detach(), z["out"]) <= 1e-5 and _rel(xo.grad, z["gx"]) <= 1e-4
+    for k in z.files:
+        if k.startswith("g."):
+            assert _rel(po["DPI." + k[2:]].grad, z[k]) <= 1e-4, k

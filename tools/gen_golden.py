@@ -261,6 +261,51 @@ def din_case(name, refmod, b, t, n, c, kernels, ratios, beta, num_dim, dtype, ou
           f"clamped-row fraction {frac_clamped:.3f}")
 
 
+def din_mode_case(name, refmod, out_dir, *, mode, b, t, n, c, kernel, ratios, beta, scale=True, x_seed=71, w_seed=81, din_std=0.05,
+                  offset_boost=1.0):
+    """dynamic_sampling=False ('plain') and parallel_inference=True ('parallel'): the reference's forward computes the per-ratio
+    features and then raises on the unbound ft_infer_MAD (dynamic_infer_module.py:151).  No-source-patch recipe: call the reference's
+    OWN per-ratio methods (plain_infer_ratio :154-181 / parallel_infer :285-341) and combine them as :137-147 do."""
+    DPI = refmod.Dynamic_Person_Inference
+    torch.manual_seed(0)
+    m = DPI(in_dim=c, person_mat_shape=(10, 12), stride=1, kernel_size=kernel, dynamic_sampling=(mode == "parallel"),
+            sampling_ratio=ratios, group=1, scale_factor=scale, beta_factor=beta, parallel_inference=(mode == "parallel"), cfg=None)
+    shapes = O.din_param_shapes("", c, tuple(kernel), ratios, scale, beta)
+    if mode == "plain":
+        shapes = {k: v for k, v in shapes.items() if "p_conv" not in k}
+    p = O.synth_params(shapes, seed=w_seed, din_std=din_std)
+    for k in p:
+        if "p_conv" in k:
+            p[k] = p[k] * offset_boost
+        if k.endswith("beta"):
+            p[k] = 1.0 + 0.25 * seeded(p[k].shape, w_seed + 7, 1.0)
+    missing, unexpected = m.load_state_dict(p, strict=False)
+    assert not unexpected and not [k for k in missing if "zero_padding" not in k], (missing, unexpected)
+    x = seeded((b, t, n, c), x_seed).requires_grad_(True)
+    cot = seeded((b, t, n, c), x_seed + 1)
+    xc = x.permute(0, 3, 1, 2)
+    feats = [(m.parallel_infer(xc, r) if mode == "parallel" else m.plain_infer_ratio(xc, r)) for r in ratios]
+    st = torch.stack(feats, dim=4)                                    # :137-147
+    dyn = torch.sum(m.beta * st, dim=-1) if beta else torch.mean(st, dim=4)
+    out = m.hidden_weight(dyn)
+    (out * cot).sum().backward()
+    po = {("DPI." + k): v.clone().requires_grad_(True) for k, v in p.items()}
+    xo = x.detach().clone().requires_grad_(True)
+    oo, _ = O.din_person_inference(xo, po, "DPI.", tuple(kernel), ratios, scale, beta, dynamic_sampling=(mode == "parallel"),
+                                   parallel_inference=(mode == "parallel"))
+    (oo * cot).sum().backward()
+    errs = dict(out=close(oo, out, 1e-5, name + ".out"), gx=close(xo.grad, x.grad, 1e-4, name + ".gx"))
+    rec = dict(meta=np.array([b, t, n, c, int(beta), int(scale)], dtype=np.int64), kernel=np.array(kernel, dtype=np.int64),
+               ratios=np.array(ratios, dtype=np.int64), mode=np.array(mode), x=x.detach().numpy(), cot=cot.numpy(),
+               out=out.detach().numpy(), gx=x.grad.numpy())
+    for k, v in m.named_parameters():
+        errs["g_" + k] = close(po["DPI." + k].grad, v.grad, 1e-4, name + ".g_" + k)
+        rec["g." + k] = v.grad.numpy()
+        rec["p." + k] = p[k].numpy()
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
+    print(f"[mode] {name}: oracle-vs-reference rel err max {max(errs.values()):.2e}")
+
+
 def prep_case(refutils, out_dir):
     x = torch.arange(0, 256, dtype=torch.float32)
     y = refutils.prep_images(x)
@@ -494,6 +539,13 @@ def main():
         din_case("din_k33_c1024_smoke_t10", refdin, 1, 10, 12, 1024, [(3, 3)], [1], False, 1, f32, a.out, 32, 42,
                  store_full=False, din_std=0.02, offset_boost=1.0)
 
+    # dynamic_sampling=False (plain_infer_ratio) and parallel_inference=True (parallel_infer): SURVEY 8(f)-4
+    din_mode_case("mode_plain_k33_r12_beta_c32", refdin, a.out, mode="plain", b=2, t=4, n=12, c=32, kernel=(3, 3), ratios=[1, 2], beta=True)
+    din_mode_case("mode_plain_k13_noscale_c32", refdin, a.out, mode="plain", b=1, t=3, n=7, c=32, kernel=(1, 3), ratios=[1], beta=False, scale=False)
+    din_mode_case("mode_parallel_k33_t10_c32", refdin, a.out, mode="parallel", b=2, t=10, n=12, c=32, kernel=(3, 3), ratios=[1, 3], beta=True,
+                  offset_boost=8.0)
+    # (parallel_infer clamps with person_mat_shape = (10, 12): on any other grid the reference gathers outside its padded map --
+    #  "index 73 is out of bounds for dimension 1 with size 70" at T = 3 -- so T = 10, N = 12 is its only valid shape)
     # whole-network fixtures at reduced image sizes (reference wiring: trunk + head)
     model_case("model_vgg16_96x160_nfb64", refim, refcfg, a.out, backbone="vgg16", H=96, W=160, OH=3, OW=5, D=512,
                B=2, T=3, N=12, NFB=64, kernels=[(3, 3)], ratios=[1], seed=100)
