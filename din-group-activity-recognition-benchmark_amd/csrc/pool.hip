@@ -11,6 +11,7 @@
 //   * workgroups walk the tensor in XCD-contiguous order (din_common.h xcd_remap) so the rows a window shares with its
 //     neighbours are L2 hits.
 #include "din_common.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -458,6 +459,47 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(din_pool_desc d, Dec3
         vstore<V>(out, d.dtype, p * d.ldo + d.cooff + cg * V, o);
     }
 }
+// Up-sampling form of the forward (out >= in on both axes, the multiscale fuse: 43x78 -> 87x157): one thread per SOURCE cell
+// (y0, x0, channel group).  It loads the cell's four corners once and produces every output pixel whose source coordinate falls into
+// the cell (about (oh/h) x (ow/w) = 4 of them), so a corner is read 4 times from L2 instead of ~16 and every load feeds ~4 stores.
+// The outputs of a cell are found with the SAME expression bil_coord uses ((int)(sc * o) == y0), so the result is bit-identical to the
+// per-output kernel.
+template <int V>
+__global__ __launch_bounds__(256) void bilinear_fwd_cells_kernel(din_pool_desc d, Dec3 dd, const void* __restrict__ in, void* __restrict__ out) {
+    const int64_t total = (int64_t)d.nb * d.h * d.w * (d.c / V);
+    const float scy = d.oh > 1 ? (float)(d.h - 1) / (float)(d.oh - 1) : 0.f, scx = d.ow > 1 ? (float)(d.w - 1) / (float)(d.ow - 1) : 0.f;
+    DIN_GRID_STRIDE(i, total) {
+        int cg, x0, y0, n; int64_t p;
+        decode(dd, i, cg, x0, y0, n, p);
+        const int y1 = y0 + 1 < d.h ? y0 + 1 : d.h - 1, x1 = x0 + 1 < d.w ? x0 + 1 : d.w - 1;
+        auto at = [&](int y, int x) { return vload<V>(in, d.dtype, ((int64_t)(n * d.h + y) * d.w + x) * d.ldi + d.cioff + cg * V); };
+        const Vec<V> a = at(y0, x0), b = at(y0, x1), c = at(y1, x0), e2 = at(y1, x1);
+        // candidate outputs: o with (int)(sc * o) == cell; start one below the estimate, stop at the first one beyond
+        int oy = scy > 0.f ? (int)((float)y0 / scy) - 1 : 0, ox_first = scx > 0.f ? (int)((float)x0 / scx) - 1 : 0;
+        if (oy < 0) oy = 0;
+        if (ox_first < 0) ox_first = 0;
+        for (; oy < d.oh; ++oy) {
+            int ty0, ty1; float ly;
+            bil_coord(oy, d.h, d.oh, ty0, ty1, ly);
+            if (ty0 < y0) continue;
+            if (ty0 > y0) break;
+            for (int ox = ox_first; ox < d.ow; ++ox) {
+                int tx0, tx1; float lx;
+                bil_coord(ox, d.w, d.ow, tx0, tx1, lx);
+                if (tx0 < x0) continue;
+                if (tx0 > x0) break;
+                Vec<V> o;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float top = a.v[e] * (1.f - lx) + b.v[e] * lx;
+                    const float bot = c.v[e] * (1.f - lx) + e2.v[e] * lx;
+                    o.v[e] = top * (1.f - ly) + bot * ly;
+                }
+                vstore<V>(out, d.dtype, ((int64_t)(n * d.oh + oy) * d.ow + ox) * d.ldo + d.cooff + cg * V, o);
+            }
+        }
+    }
+}
 // gather-form backward: each input cell sums the contributions of the output cells whose 2x2 footprint touches it.  Because the map
 // is monotone, candidate outputs for input row y are those with source coordinate in (y-1, y+1): a short output range per axis.
 template <int V>
@@ -610,6 +652,16 @@ int din_bilinear_fwd(const din_pool_desc* d, const void* in, void* out, void* st
     if (int e = check_pool(d, "bilinear_fwd")) return e;
     DIN_REQUIRE(in && out, "bilinear_fwd: null pointer");
     const int v = wide8(d) ? 8 : 4;
+    const char* ce = getenv("DIN_BILINEAR_CELLS");
+    const int cells_env = ce ? atoi(ce) : 1;
+    if (cells_env && d->oh >= d->h && d->ow >= d->w && d->h > 1 && d->w > 1) {          // up-sampling: one thread per source cell
+        const int64_t total = (int64_t)d->nb * d->h * d->w * (d->c / v);
+        const Dec3 dd = make_dec(d->c / v, d->w, d->h, total);
+        if (v == 8) POOL_LAUNCH(bilinear_fwd_cells_kernel<8>, total, *d, dd, in, out);
+        else POOL_LAUNCH(bilinear_fwd_cells_kernel<4>, total, *d, dd, in, out);
+        DIN_CHECK_LAUNCH("bilinear_fwd");
+        return DIN_OK;
+    }
     const int64_t total = (int64_t)d->nb * d->oh * d->ow * (d->c / v);
     const Dec3 dd = make_dec(d->c / v, d->ow, d->oh, total);
     if (v == 8) POOL_LAUNCH(bilinear_fwd_kernel<8>, total, *d, dd, in, out);

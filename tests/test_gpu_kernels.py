@@ -377,6 +377,35 @@ def test_bilinear_align_corners(env):
     assert rel(from_nhwc(dx, 8), xr.grad) <= 5e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 43, 78, 87, 157, 768, 1056, 288, "bf16"), (3, 5, 9, 5, 31, 16, 16, 0, "fp32"), (1, 7, 4, 20, 4, 8, 24, 8, "fp32")],
+                         ids=["fuse_43x78_to_87x157_bf16", "x_only", "y_only"])
+def test_bilinear_cells_kernel_is_bit_identical(env, shape, monkeypatch):
+    """the up-sampling forward (one thread per source cell, corners loaded once for all of the cell's outputs) writes every output pixel
+    exactly once and reproduces the per-output kernel bit for bit"""
+    lib, L, nhwc, ops = env
+    nb, h, w, oh, ow, c, ldo, coff, dtype = shape
+    tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(nb, h, w, c, generator=g).to(tdt).cuda()
+    d = L.PoolDesc()
+    d.nb, d.h, d.w, d.c, d.oh, d.ow = nb, h, w, c, oh, ow
+    d.k, d.stride, d.pad, d.ldi, d.cioff, d.ldo, d.cooff = 1, 1, 0, c, 0, ldo, coff
+    d.dtype = L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DIN_BILINEAR_CELLS", mode)
+        out = torch.full((nb, oh, ow, ldo), float("nan"), dtype=tdt, device="cuda")
+        L.check(lib.din_bilinear_fwd(C.byref(d), x.data_ptr(), out.data_ptr(), None))
+        torch.cuda.synchronize()
+        outs.append(out)
+    view = slice(coff, coff + c)
+    assert not torch.isnan(outs[1][..., view].float()).any(), "an output pixel was not written"
+    assert torch.equal(outs[0][..., view], outs[1][..., view])
+    if ldo > c:
+        rest = torch.cat([outs[1][..., :coff], outs[1][..., coff + c:]], -1)
+        assert torch.isnan(rest.float()).all(), "wrote outside its channel range"
+
+
 def test_prep_images_bit_exact(env):
     lib, L, nhwc, ops = env
     x = torch.arange(0, 256, dtype=torch.float32)

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Pool / resize kernels on the Inception shapes of the default workload (bf16, 96 frames): time and effective HBM rate (bytes in + out once)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from din_amd import _lib as L
+
+
+def bench(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    lib = L.load()
+    nb = 96
+    bf = torch.bfloat16
+    # multiscale fuse: Mixed_6e 43x78x768 -> channels [288, 1056) of the 87x157 fused map
+    d = L.PoolDesc()
+    d.nb, d.h, d.w, d.c, d.oh, d.ow = nb, 43, 78, 768, 87, 157
+    d.k, d.stride, d.pad, d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = 1, 1, 0, 768, 0, 1056, 288, L.DIN_BF16
+    x = torch.randn(nb, 43, 78, 768, device="cuda").to(bf)
+    out = torch.empty(nb, 87, 157, 1056, device="cuda", dtype=bf)
+    gx = torch.empty_like(x)
+    by = (x.numel() + nb * 87 * 157 * 768) * 2
+    for mode in ("0", "1"):
+        os.environ["DIN_BILINEAR_CELLS"] = mode
+        ms = bench(lambda: L.check(lib.din_bilinear_fwd(C.byref(d), x.data_ptr(), out.data_ptr(), None)))
+        print(f"bilinear fwd cells={mode}: {ms * 1e3:8.1f} us  {by / ms / 1e9:6.2f} TB/s")
+    ms = bench(lambda: L.check(lib.din_bilinear_bwd(C.byref(d), out.data_ptr(), gx.data_ptr(), x.data_ptr(), 0, None)))
+    print(f"bilinear bwd         : {ms * 1e3:8.1f} us  {(by + x.numel() * 2) / ms / 1e9:6.2f} TB/s (incl. mask read)")
+    # max-pools 3x3 / 2: after Conv2d_2b (64 ch, 357x637), after Conv2d_4a (192 ch, 176x316), Mixed_6a pool branch (288 ch, 87x157)
+    for (c, h, w) in ((64, 357, 637), (192, 176, 316), (288, 87, 157)):
+        oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+        p = L.PoolDesc()
+        p.nb, p.h, p.w, p.c, p.oh, p.ow = nb, h, w, c, oh, ow
+        p.k, p.stride, p.pad, p.ldi, p.cioff, p.ldo, p.cooff, p.dtype = 3, 2, 0, c, 0, c, 0, L.DIN_BF16
+        xi = torch.randn(nb, h, w, c, device="cuda").relu().to(bf)
+        yo = torch.empty(nb, oh, ow, c, device="cuda", dtype=bf)
+        am = torch.empty(nb, oh, ow, c, device="cuda", dtype=torch.uint8)
+        gi = torch.empty_like(xi)
+        ms = bench(lambda: L.check(lib.din_maxpool_fwd(C.byref(p), xi.data_ptr(), yo.data_ptr(), am.data_ptr(), None)))
+        b1 = xi.numel() * 2 + yo.numel() * 3
+        print(f"maxpool fwd {c:3d}ch {h}x{w}: {ms * 1e3:8.1f} us  {b1 / ms / 1e9:6.2f} TB/s")
+        ms = bench(lambda: L.check(lib.din_maxpool_bwd(C.byref(p), xi.data_ptr(), am.data_ptr(), yo.data_ptr(), gi.data_ptr(), 1, 0, None)))
+        print(f"maxpool bwd {c:3d}ch {h}x{w}: {ms * 1e3:8.1f} us  {b1 / ms / 1e9:6.2f} TB/s")
+
+
+if __name__ == "__main__":
+    main()
