@@ -351,7 +351,7 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process; they come from the separate rocprofv3
     # --pmc passes over this same command whose per-kernel result is committed under profiles/ (tools/pmc_traffic.py)
     try:
-        tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
+        tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")))
         if tr.get("workload") == a.workload and tr.get("global_batch") == a.global_batch and world == 1:
             prefix = dom.split(", ...>")[0]
             hits = [v for k, v in tr["kernels"].items() if k.startswith(prefix)]
@@ -361,7 +361,7 @@ def main():
                 wr = sum((h["write_bytes_per_launch"] or 0.0) * h["launches"] for h in hits) / n
                 roofline["traffic"] = round(rd + wr)
                 roofline["traffic_detail"] = {"unit": "HBM bytes per launch", "read": round(rd), "write": round(wr),
-                                              "source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"}
+                                              "source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"}
     except (OSError, ValueError, KeyError):
         pass
     conv_time = sum(v[1] for v in agg.values())

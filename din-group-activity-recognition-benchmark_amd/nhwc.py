@@ -89,7 +89,7 @@ class _timed:
             if bm.value == 0:
                 return f"conv_wgrad_small_kernel<..., {bn.value}, ...>"
             if bn.value >= 2000:
-                return f"conv_wgrad_pipe_kernel<{bm.value}, {bn.value - 2000}>"
+                return f"conv_wgrad_pipe_kernel<{bm.value}, {bn.value - 2000}, {'true' if d.ow >= 32 else 'false'}>"
             if bn.value >= 1000:
                 return f"conv_wgrad_ring_kernel<{bm.value}, {bn.value - 1000}>"
             return f"conv_wgrad_bf16_kernel<{bm.value}>" if d.dtype == L.DIN_BF16 else "conv_wgrad_f32_kernel"

@@ -14,7 +14,7 @@ import collections, csv, json, re, sys
 
 def short(name: str) -> str:
     name = re.sub(r"^void ", "", name)
-    name = name.replace("(anonymous namespace)::", "")
+    name = name.replace("(anonymous namespace)::", "").replace("din_wgrad::", "").replace("din_gather::", "")
     return name.split("(")[0]
 
 
