@@ -85,7 +85,7 @@ SIGNATURES: Dict[str, tuple] = {
     "din_bilinear_bwd": (_I, [_PD, _P, _P, _P, _I, _P]),
     "din_roi_align_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P]),
     "din_roi_align_bwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
-    "din_roi_align_bwd_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P, _I, _P]),
+    "din_roi_align_bwd_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P, _I, _P, _P]),
     "din_grad_cast_mask": (_I, [_P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _I, _P]),
     "din_boxes_frame_index": (_I, [_P, _I, _I, _P]),
     "din_layernorm_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _L, _L, _I, _F, _U64, _P]),

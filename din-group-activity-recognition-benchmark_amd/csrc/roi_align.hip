@@ -8,6 +8,7 @@
 #include "din_common.h"
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -118,7 +119,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* __restrict__ dout, int nb, int hf, int wf, int c,
                                                                    const float* __restrict__ boxes, const int32_t* __restrict__ box_ind,
                                                                    int m, int k, const T* __restrict__ fm, int ldf, T* __restrict__ gfm,
-                                                                   int ldg, int cap, int prezeroed) {
+                                                                   int ldg, int cap, int prezeroed, int transposed) {
+    // transposed: dout is the channel-contiguous copy [m][k*k][c] made by roi_transpose_kernel (a lane's V channels are one 16/32-byte
+    // load and a wave reads 2 KiB contiguous); otherwise the reference layout [m][c][k*k] (4-byte loads 100 B apart)
     constexpr int V = 16 / sizeof(T);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* boxid = reinterpret_cast<int*>(smem);                         // [cap] boxes of this frame (batch), ascending
@@ -228,10 +231,20 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
                     for (int t = 0; t < ncl; ++t) {
                         const int off = cl_off[wave][t];
                         const float w = cl_w[wave][t];
-                        const int bq = off / kk;                            // box * kk + sample -> ((box * c + ch) * kk + sample)
-                        const float* src = dout + ((int64_t)bq * c + ch0 * V) * kk + (off - bq * kk);
+                        if (transposed) {                                   // (box * kk + sample) * c + ch: contiguous channels
+                            const float* src = dout + (int64_t)off * c + ch0 * V;
 #pragma unroll
-                        for (int e = 0; e < V; ++e) acc[e] += w * src[(int64_t)e * kk];
+                            for (int e4 = 0; e4 < V / 4; ++e4) {
+                                const f32x4_t v4 = *reinterpret_cast<const f32x4_t*>(src + 4 * e4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[4 * e4 + e] += w * v4[e];
+                            }
+                        } else {
+                            const int bq = off / kk;                        // box * kk + sample -> ((box * c + ch) * kk + sample)
+                            const float* src = dout + ((int64_t)bq * c + ch0 * V) * kk + (off - bq * kk);
+#pragma unroll
+                            for (int e = 0; e < V; ++e) acc[e] += w * src[(int64_t)e * kk];
+                        }
                     }
                 } else if (lane_ok) {                                       // more than CL samples touch this pixel: rescan (rare)
                     for (int a = 0; a < nact; ++a) {
@@ -247,9 +260,11 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
                                 const float wx = (lo == x ? 1.f - l : 0.f) + (hi == x ? l : 0.f);
                                 if (wx == 0.f) continue;
                                 const float w = wy * wx;
-                                const float* src = dout + ((int64_t)b * c + ch0 * V) * kk + qy * k + qx;
+                                const float* src = transposed ? dout + ((int64_t)b * kk + qy * k + qx) * c + ch0 * V
+                                                              : dout + ((int64_t)b * c + ch0 * V) * kk + qy * k + qx;
+                                const int64_t es = transposed ? 1 : kk;
 #pragma unroll
-                                for (int e = 0; e < V; ++e) acc[e] += w * src[(int64_t)e * kk];
+                                for (int e = 0; e < V; ++e) acc[e] += w * src[(int64_t)e * es];
                             }
                         }
                     }
@@ -292,6 +307,22 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
     }
 }
 
+// [m][c][kk] -> [m][kk][c]: the crop gradient arrives in the reference's flatten order (channel-major, infer_model.py:181) because
+// that is the column order of fc_emb_1; the gather backward wants channels contiguous.  One workgroup per (box, 64-channel block).
+__global__ __launch_bounds__(256) void roi_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int c, int kk) {
+    extern __shared__ float tile[];                                   // [64][kk + 1]
+    const int b = blockIdx.x, c0 = blockIdx.y * 64;
+    const int nch = min(64, c - c0);
+    const float* src = in + ((int64_t)b * c + c0) * kk;
+    for (int i = threadIdx.x; i < nch * kk; i += 256) tile[(i / kk) * (kk + 1) + (i % kk)] = src[i];
+    __syncthreads();
+    float* dst = out + (int64_t)b * kk * c + c0;
+    for (int i = threadIdx.x; i < kk * 64; i += 256) {
+        const int s = i >> 6, ch = i & 63;
+        if (ch < nch) dst[(int64_t)s * c + ch] = tile[ch * (kk + 1) + s];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -319,7 +350,7 @@ int din_roi_align_bwd(const float* dout, int nb, int hf, int wf, int c, const fl
 }
 
 int din_roi_align_bwd_nhwc(const float* dout, int nb, int hf, int wf, int c, const float* boxes, const int32_t* box_ind, int m,
-                           int k, const void* fm_mask, int dtype, int ldf, void* gfm, int ldg, void* stream) {
+                           int k, const void* fm_mask, int dtype, int ldf, void* gfm, int ldg, float* scratch, void* stream) {
     DIN_REQUIRE(dout && boxes && box_ind && gfm, "roi_align_bwd_nhwc: null pointer");
     DIN_REQUIRE(nb > 0 && hf > 1 && wf > 1 && c > 0 && k > 0 && k <= 64 && m >= 0, "roi_align_bwd_nhwc: bad shape");
     DIN_REQUIRE(dtype == DIN_F32 || dtype == DIN_BF16, "roi_align_bwd_nhwc: bad dtype");
@@ -336,12 +367,20 @@ int din_roi_align_bwd_nhwc(const float* dout, int nb, int hf, int wf, int c, con
     const int prezeroed = ldg == c ? 1 : 0;
     if (prezeroed && hipMemsetAsync(gfm, 0, (size_t)nb * hf * wf * ldg * (dtype == DIN_F32 ? 4 : 2), as_stream(stream)) != hipSuccess)
         DIN_FAIL(DIN_E_LAUNCH, "roi_align_bwd_nhwc: memset");
+    int transposed = 0;
+    if (scratch && m > 0) {                                            // channel-contiguous copy of the crop gradient (m * c * k * k floats)
+        const int kk = k * k;
+        hipLaunchKernelGGL(roi_transpose_kernel, dim3(m, (c + 63) / 64), dim3(256), (size_t)64 * (kk + 1) * sizeof(float), as_stream(stream),
+                           dout, scratch, c, kk);
+        dout = scratch;
+        transposed = 1;
+    }
     if (dtype == DIN_F32)
         hipLaunchKernelGGL(roi_align_bwd_gather_kernel<float>, dim3(nb * hf), dim3(256), lds, as_stream(stream), dout, nb, hf, wf, c, boxes,
-                           box_ind, m, k, (const float*)fm_mask, ldf, (float*)gfm, ldg, cap, prezeroed);
+                           box_ind, m, k, (const float*)fm_mask, ldf, (float*)gfm, ldg, cap, prezeroed, transposed);
     else
         hipLaunchKernelGGL(roi_align_bwd_gather_kernel<bf16_t>, dim3(nb * hf), dim3(256), lds, as_stream(stream), dout, nb, hf, wf, c, boxes,
-                           box_ind, m, k, (const bf16_t*)fm_mask, ldf, (bf16_t*)gfm, ldg, cap, prezeroed);
+                           box_ind, m, k, (const bf16_t*)fm_mask, ldf, (bf16_t*)gfm, ldg, cap, prezeroed, transposed);
     DIN_CHECK_LAUNCH("roi_align_bwd_nhwc");
     return DIN_OK;
 }

@@ -72,8 +72,10 @@ class RoIAlignFunction(torch.autograd.Function):
         # gather form: the gradient tensor is written once, in the feature map's storage type, already multiplied by the ReLU mask
         # of the cropped tensor (no fp32 scatter buffer, no zero-fill, no cast pass)
         gfm = torch.zeros_like(fm) if ld != c else torch.empty_like(fm)
-        L.check(lib.din_roi_align_bwd_nhwc(_ptr(gout.float()), nb, hf, wf, c, _ptr(boxes), _ptr(box_ind), boxes.shape[0], k,
-                                           _ptr(fm) if ctx.relu_masked else None, din_dtype(fm), ld, _ptr(gfm), ld, st),
+        gout = gout.float()
+        scratch = torch.empty_like(gout)                    # channel-contiguous copy of the crop gradient (made inside the call)
+        L.check(lib.din_roi_align_bwd_nhwc(_ptr(gout), nb, hf, wf, c, _ptr(boxes), _ptr(box_ind), boxes.shape[0], k,
+                                           _ptr(fm) if ctx.relu_masked else None, din_dtype(fm), ld, _ptr(gfm), ld, _ptr(scratch), st),
                 "roi_align_bwd_nhwc")
         return gfm, None, None, None, None, None, None
 

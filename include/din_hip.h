@@ -227,10 +227,12 @@ int din_roi_align_bwd(const float* dout, int nb, int hf, int wf, int c,
 /* Gather form of the same gradient, written once into the feature map's gradient view gfm [nb,hf,wf,ldg] (storage `dtype`, channels
  * [0,c), every pixel -- zeros outside the boxes): no atomics, no fp32 staging tensor, no zero-fill, deterministic summation order.
  * fm_mask (nullable, same dtype, pixel stride ldf): the cropped tensor; gradients are multiplied by (fm_mask > 0) -- the fused
- * backward of the ReLU that produced it.  box_ind may be in any order. */
+ * backward of the ReLU that produced it.  box_ind may be in any order.
+ * scratch (nullable, fp32 [m*c*k*k]): when given, dout ([m][c][k*k], the reference's flatten order = the column order of fc_emb_1) is
+ * first copied channel-contiguous ([m][k*k][c]) and the gather reads 16/32-byte runs instead of 4-byte loads 4*k*k bytes apart. */
 int din_roi_align_bwd_nhwc(const float* dout, int nb, int hf, int wf, int c,
                            const float* boxes, const int32_t* box_ind, int m, int k,
-                           const void* fm_mask, int dtype, int ldf, void* gfm, int ldg, void* stream);
+                           const void* fm_mask, int dtype, int ldf, void* gfm, int ldg, float* scratch, void* stream);
 /* fp32 gradient map -> backbone dtype, fused with the ReLU mask of the feature map that was cropped */
 int din_grad_cast_mask(const float* g, const void* y, void* out, int dtype, int64_t pixels, int c,
                        int ldy, int yoff, int ldo, int ooff, int use_mask, void* stream);

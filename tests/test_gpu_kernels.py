@@ -470,12 +470,16 @@ def test_roi_align_bwd_gather_matches_scatter(env, dtype):
     g32 = torch.zeros(nb, hf, wf, c, device="cuda")
     L.check(lib.din_roi_align_bwd(gout.data_ptr(), nb, hf, wf, c, bd.data_ptr(), idv.data_ptr(), m, k, g32.data_ptr(), None))
     want = g32 * (fm.float() > 0).float()
-    got = torch.full((nb, hf, wf, c), 9.0, dtype=tdt, device="cuda")
-    L.check(lib.din_roi_align_bwd_nhwc(gout.data_ptr(), nb, hf, wf, c, bd.data_ptr(), idv.data_ptr(), m, k, fm.data_ptr(), dt, c,
-                                       got.data_ptr(), c, None))
-    torch.cuda.synchronize()
-    assert rel(got.float(), want) <= (1e-5 if dtype == "fp32" else 1e-2)      # bf16: one rounding per batch
-    assert bool(((want == 0) == (got.float() == 0)).all()), "footprint (zeros outside the boxes, mask) must match"
+    outs = []
+    for scratch in (None, torch.empty_like(gout)):            # reference-layout crop gradient / channel-contiguous staging copy
+        got = torch.full((nb, hf, wf, c), 9.0, dtype=tdt, device="cuda")
+        L.check(lib.din_roi_align_bwd_nhwc(gout.data_ptr(), nb, hf, wf, c, bd.data_ptr(), idv.data_ptr(), m, k, fm.data_ptr(), dt, c,
+                                           got.data_ptr(), c, scratch.data_ptr() if scratch is not None else None, None))
+        torch.cuda.synchronize()
+        assert rel(got.float(), want) <= (1e-5 if dtype == "fp32" else 1e-2)      # bf16: one rounding per batch
+        assert bool(((want == 0) == (got.float() == 0)).all()), "footprint (zeros outside the boxes, mask) must match"
+        outs.append(got)
+    assert torch.equal(outs[0], outs[1]), "the staged copy must not change the summation order"
 
 
 def test_layernorm_variants(env):
