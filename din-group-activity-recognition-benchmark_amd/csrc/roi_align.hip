@@ -40,10 +40,15 @@ __device__ __forceinline__ Sample roi_sample(float c1, float c2, int extent, int
     return s;
 }
 
-// grid: one workgroup per (box, ky); wave w handles kx = w, w+4, ...; lanes stream channels
+// grid: one workgroup per (box, ky); wave w handles kx = w, w+4, ...; lanes stream channels.
+// The crop goes out in the reference's flatten order [m][c][k*k] (the column order of fc_emb_1, infer_model.py:181-184), i.e. a lane's
+// channels are k*k floats apart.  With `row` (dynamic LDS, c * k floats) the workgroup first assembles its k samples channel-by-channel
+// in LDS and then writes [c][k] runs of k contiguous floats; the corner loads take V channels (16 bytes) per lane.
+template <int V>
 __global__ void roi_align_fwd_kernel(const void* __restrict__ fm, int fm_dtype, int nb, int hf, int wf, int c, int ldf,
                                      const float* __restrict__ boxes, const int32_t* __restrict__ box_ind, int m, int k,
                                      float* __restrict__ out, int32_t* __restrict__ idx_out) {
+    extern __shared__ float row[];                                     // [c][k] (V > 1 only)
     const int b = blockIdx.x / k, ky = blockIdx.x % k;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const float x1 = boxes[b * 4 + 0], y1 = boxes[b * 4 + 1], x2 = boxes[b * 4 + 2], y2 = boxes[b * 4 + 3];
@@ -60,17 +65,57 @@ __global__ void roi_align_fwd_kernel(const void* __restrict__ fm, int fm_dtype, 
         const bool dead = sy.oob || sx.oob || n < 0 || n >= nb;
         const int64_t r_tl = ((int64_t)(n * hf + sy.lo) * wf + sx.lo) * ldf, r_tr = ((int64_t)(n * hf + sy.lo) * wf + sx.hi) * ldf;
         const int64_t r_bl = ((int64_t)(n * hf + sy.hi) * wf + sx.lo) * ldf, r_br = ((int64_t)(n * hf + sy.hi) * wf + sx.hi) * ldf;
-        float* dst = out + (int64_t)b * c * k * k + ky * k + kx;
-        for (int ch = lane; ch < c; ch += 64) {
-            float v = 0.f;
-            if (!dead) {
-                float tl = load_as_f32(fm, fm_dtype, r_tl + ch), tr = load_as_f32(fm, fm_dtype, r_tr + ch);
-                float bl = load_as_f32(fm, fm_dtype, r_bl + ch), br = load_as_f32(fm, fm_dtype, r_br + ch);
-                float top = __fadd_rn(tl, __fmul_rn(__fsub_rn(tr, tl), sx.l));
-                float bot = __fadd_rn(bl, __fmul_rn(__fsub_rn(br, bl), sx.l));
-                v = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), sy.l));
+        if constexpr (V == 1) {
+            float* dst = out + (int64_t)b * c * k * k + ky * k + kx;
+            for (int ch = lane; ch < c; ch += 64) {
+                float v = 0.f;
+                if (!dead) {
+                    float tl = load_as_f32(fm, fm_dtype, r_tl + ch), tr = load_as_f32(fm, fm_dtype, r_tr + ch);
+                    float bl = load_as_f32(fm, fm_dtype, r_bl + ch), br = load_as_f32(fm, fm_dtype, r_br + ch);
+                    float top = __fadd_rn(tl, __fmul_rn(__fsub_rn(tr, tl), sx.l));
+                    float bot = __fadd_rn(bl, __fmul_rn(__fsub_rn(br, bl), sx.l));
+                    v = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), sy.l));
+                }
+                dst[(int64_t)ch * k * k] = v;
             }
-            dst[(int64_t)ch * k * k] = v;
+        } else {
+            // V = 8 bf16 / 4 fp32 channels per lane: one 16-byte load per corner
+            for (int ch = lane * V; ch < c; ch += 64 * V) {
+                float tl[V], tr[V], bl[V], br[V];
+                if (!dead) {
+                    if (fm_dtype == DIN_F32) {
+                        const f32x4_t a = *reinterpret_cast<const f32x4_t*>((const float*)fm + r_tl + ch), bq = *reinterpret_cast<const f32x4_t*>((const float*)fm + r_tr + ch);
+                        const f32x4_t cq = *reinterpret_cast<const f32x4_t*>((const float*)fm + r_bl + ch), dq = *reinterpret_cast<const f32x4_t*>((const float*)fm + r_br + ch);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) { tl[e] = a[e & 3]; tr[e] = bq[e & 3]; bl[e] = cq[e & 3]; br[e] = dq[e & 3]; }
+                    } else {
+                        const u32x4_t a = *reinterpret_cast<const u32x4_t*>((const bf16_t*)fm + r_tl + ch), bq = *reinterpret_cast<const u32x4_t*>((const bf16_t*)fm + r_tr + ch);
+                        const u32x4_t cq = *reinterpret_cast<const u32x4_t*>((const bf16_t*)fm + r_bl + ch), dq = *reinterpret_cast<const u32x4_t*>((const bf16_t*)fm + r_br + ch);
+                        auto up = [](const u32x4_t& q, int e) { return (e & 1) ? __uint_as_float(q[(e >> 1) & 3] & 0xffff0000u) : __uint_as_float(q[(e >> 1) & 3] << 16); };
+#pragma unroll
+                        for (int e = 0; e < V; ++e) { tl[e] = up(a, e); tr[e] = up(bq, e); bl[e] = up(cq, e); br[e] = up(dq, e); }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    float v = 0.f;
+                    if (!dead) {
+                        float top = __fadd_rn(tl[e], __fmul_rn(__fsub_rn(tr[e], tl[e]), sx.l));
+                        float bot = __fadd_rn(bl[e], __fmul_rn(__fsub_rn(br[e], bl[e]), sx.l));
+                        v = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), sy.l));
+                    }
+                    row[(ch + e) * k + kx] = v;
+                }
+            }
+        }
+    }
+    if constexpr (V > 1) {
+        __syncthreads();
+        // out[b][ch][ky][0..k): k contiguous floats per channel
+        float* dst = out + (int64_t)b * c * k * k + ky * k;
+        for (int i = threadIdx.x; i < c * k; i += blockDim.x) {
+            const int ch = i / k, kx = i - ch * k;
+            dst[(int64_t)ch * k * k + kx] = row[i];
         }
     }
 }
@@ -333,8 +378,16 @@ int din_roi_align_fwd(const void* fm, int fm_dtype, int nb, int hf, int wf, int 
     DIN_REQUIRE(nb > 0 && hf > 1 && wf > 1 && c > 0 && k > 0 && m >= 0 && ldf >= c, "roi_align_fwd: bad shape");
     DIN_REQUIRE(k <= 64, "roi_align_fwd: crop size > 64 unsupported");
     if (m == 0) return DIN_OK;
-    hipLaunchKernelGGL(roi_align_fwd_kernel, dim3(m * k), dim3(256), 0, as_stream(stream), fm, fm_dtype, nb, hf, wf, c, ldf,
-                       boxes, box_ind, m, k, out, idx_out);
+    const int v = fm_dtype == DIN_F32 ? 4 : 8;
+    const size_t lds = (size_t)c * k * sizeof(float);
+    if (c % v == 0 && ldf % v == 0 && lds <= 64 * 1024) {
+        if (v == 4) hipLaunchKernelGGL(roi_align_fwd_kernel<4>, dim3(m * k), dim3(256), lds, as_stream(stream), fm, fm_dtype, nb, hf, wf, c, ldf,
+                                       boxes, box_ind, m, k, out, idx_out);
+        else hipLaunchKernelGGL(roi_align_fwd_kernel<8>, dim3(m * k), dim3(256), lds, as_stream(stream), fm, fm_dtype, nb, hf, wf, c, ldf,
+                                boxes, box_ind, m, k, out, idx_out);
+    } else
+        hipLaunchKernelGGL(roi_align_fwd_kernel<1>, dim3(m * k), dim3(256), 0, as_stream(stream), fm, fm_dtype, nb, hf, wf, c, ldf,
+                           boxes, box_ind, m, k, out, idx_out);
     DIN_CHECK_LAUNCH("roi_align_fwd");
     return DIN_OK;
 }
