@@ -545,6 +545,57 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(din_pool_desc d, Dec3
     }
 }
 
+// Gather-form backward with the candidate scan hoisted: the <= MAXC output rows / columns whose 2x2 footprint can touch input row iy /
+// column ix get their weights computed ONCE per axis (bil_coord divides; the nested form above recomputes it MAXC^2 times), then only the
+// non-zero (row, column) pairs are loaded.  Same expressions, same summation order (rows outer, columns inner) -> bit-identical.
+template <int V, int MAXC>
+__global__ __launch_bounds__(256) void bilinear_bwd_hoisted_kernel(din_pool_desc d, Dec3 dd, const void* __restrict__ dout, void* __restrict__ din_,
+                                                                   const void* __restrict__ mask, int accumulate) {
+    const int64_t total = (int64_t)d.nb * d.h * d.w * (d.c / V);
+    const float scy = d.oh > 1 ? (float)(d.h - 1) / (float)(d.oh - 1) : 0.f;
+    const float scx = d.ow > 1 ? (float)(d.w - 1) / (float)(d.ow - 1) : 0.f;
+    DIN_GRID_STRIDE(i, total) {
+        int cg, ix, iy, n; int64_t p;
+        decode(dd, i, cg, ix, iy, n, p);
+        int oy_lo = scy > 0.f ? (int)floorf((float)(iy - 1) / scy) : 0, oy_hi = scy > 0.f ? (int)ceilf((float)(iy + 1) / scy) : d.oh - 1;
+        int ox_lo = scx > 0.f ? (int)floorf((float)(ix - 1) / scx) : 0, ox_hi = scx > 0.f ? (int)ceilf((float)(ix + 1) / scx) : d.ow - 1;
+        if (oy_lo < 0) oy_lo = 0;
+        if (ox_lo < 0) ox_lo = 0;
+        if (oy_hi > d.oh - 1) oy_hi = d.oh - 1;
+        if (ox_hi > d.ow - 1) ox_hi = d.ow - 1;
+        float wys[MAXC], wxs[MAXC];
+#pragma unroll
+        for (int a = 0; a < MAXC; ++a) {
+            const int oy = oy_lo + a, ox = ox_lo + a;
+            int i0, i1; float l;
+            wys[a] = 0.f; wxs[a] = 0.f;
+            if (oy <= oy_hi) { bil_coord(oy, d.h, d.oh, i0, i1, l); wys[a] = (i0 == iy ? 1.f - l : 0.f) + (i1 == iy ? l : 0.f); }
+            if (ox <= ox_hi) { bil_coord(ox, d.w, d.ow, i0, i1, l); wxs[a] = (i0 == ix ? 1.f - l : 0.f) + (i1 == ix ? l : 0.f); }
+        }
+        Vec<V> g = vzero<V>();
+#pragma unroll
+        for (int a = 0; a < MAXC; ++a) {
+            if (wys[a] == 0.f) continue;
+#pragma unroll
+            for (int b = 0; b < MAXC; ++b) {
+                if (wxs[b] == 0.f) continue;
+                Vec<V> t = vload<V>(dout, d.dtype, ((int64_t)(n * d.oh + oy_lo + a) * d.ow + ox_lo + b) * d.ldo + d.cooff + cg * V);
+                const float wgt = wys[a] * wxs[b];
+#pragma unroll
+                for (int e = 0; e < V; ++e) g.v[e] += t.v[e] * wgt;
+            }
+        }
+        const int64_t off = p * d.ldi + d.cioff + cg * V;
+        if (mask) { Vec<V> y = vload<V>(mask, d.dtype, off);
+#pragma unroll
+            for (int e = 0; e < V; ++e) g.v[e] = y.v[e] > 0.f ? g.v[e] : 0.f; }
+        if (accumulate) { Vec<V> o = vload<V>(din_, d.dtype, off);
+#pragma unroll
+            for (int e = 0; e < V; ++e) g.v[e] += o.v[e]; }
+        vstore<V>(din_, d.dtype, off, g);
+    }
+}
+
 inline bool wide8(const din_pool_desc* d) {
     return d->dtype == DIN_BF16 && d->c % 8 == 0 && d->ldi % 8 == 0 && d->ldo % 8 == 0 && d->cioff % 8 == 0 && d->cooff % 8 == 0;
 }
@@ -675,7 +726,15 @@ int din_bilinear_bwd(const din_pool_desc* d, const void* dout, void* din_, const
     const int v = wide8(d) ? 8 : 4;
     const int64_t total = (int64_t)d->nb * d->h * d->w * (d->c / v);
     const Dec3 dd = make_dec(d->c / v, d->w, d->h, total);
-    if (v == 8) POOL_LAUNCH(bilinear_bwd_kernel<8>, total, *d, dd, dout, din_, mask, accumulate);
+    // candidate window per axis: outputs with source coordinate in (i - 1, i + 1) -> at most 2 / scale + 3 of them
+    const float scy = d->oh > 1 ? (float)(d->h - 1) / (float)(d->oh - 1) : 0.f, scx = d->ow > 1 ? (float)(d->w - 1) / (float)(d->ow - 1) : 0.f;
+    const char* he = getenv("DIN_BILINEAR_HOIST");
+    const bool hoist = (he ? atoi(he) != 0 : true) && scy > 0.f && scx > 0.f && 2.f / scy + 3.f <= 8.f && 2.f / scx + 3.f <= 8.f;
+    if (hoist) {
+        if (v == 8) POOL_LAUNCH((bilinear_bwd_hoisted_kernel<8, 8>), total, *d, dd, dout, din_, mask, accumulate);
+        else POOL_LAUNCH((bilinear_bwd_hoisted_kernel<4, 8>), total, *d, dd, dout, din_, mask, accumulate);
+    }
+    else if (v == 8) POOL_LAUNCH(bilinear_bwd_kernel<8>, total, *d, dd, dout, din_, mask, accumulate);
     else POOL_LAUNCH(bilinear_bwd_kernel<4>, total, *d, dd, dout, din_, mask, accumulate);
     DIN_CHECK_LAUNCH("bilinear_bwd");
     return DIN_OK;

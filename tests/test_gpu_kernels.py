@@ -404,6 +404,17 @@ def test_bilinear_cells_kernel_is_bit_identical(env, shape, monkeypatch):
     if ldo > c:
         rest = torch.cat([outs[1][..., :coff], outs[1][..., coff + c:]], -1)
         assert torch.isnan(rest.float()).all(), "wrote outside its channel range"
+    # backward: the hoisted candidate scan against the nested form, with the ReLU mask and with accumulation
+    gout = torch.randn(nb, oh, ow, ldo, generator=g).to(tdt).cuda()
+    base = torch.randn(nb, h, w, c, generator=g).to(tdt).cuda()
+    res = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DIN_BILINEAR_HOIST", mode)
+        dx = base.clone()
+        L.check(lib.din_bilinear_bwd(C.byref(d), gout.data_ptr(), dx.data_ptr(), x.data_ptr(), 1, None))
+        torch.cuda.synchronize()
+        res.append(dx)
+    assert torch.equal(res[0], res[1])
 
 
 def test_prep_images_bit_exact(env):

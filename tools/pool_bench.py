@@ -35,8 +35,10 @@ def main():
         os.environ["DIN_BILINEAR_CELLS"] = mode
         ms = bench(lambda: L.check(lib.din_bilinear_fwd(C.byref(d), x.data_ptr(), out.data_ptr(), None)))
         print(f"bilinear fwd cells={mode}: {ms * 1e3:8.1f} us  {by / ms / 1e9:6.2f} TB/s")
-    ms = bench(lambda: L.check(lib.din_bilinear_bwd(C.byref(d), out.data_ptr(), gx.data_ptr(), x.data_ptr(), 0, None)))
-    print(f"bilinear bwd         : {ms * 1e3:8.1f} us  {(by + x.numel() * 2) / ms / 1e9:6.2f} TB/s (incl. mask read)")
+    for mode in ("0", "1"):
+        os.environ["DIN_BILINEAR_HOIST"] = mode
+        ms = bench(lambda: L.check(lib.din_bilinear_bwd(C.byref(d), out.data_ptr(), gx.data_ptr(), x.data_ptr(), 0, None)))
+        print(f"bilinear bwd hoist={mode}: {ms * 1e3:8.1f} us  {(by + x.numel() * 2) / ms / 1e9:6.2f} TB/s (incl. mask read)")
     # max-pools 3x3 / 2: after Conv2d_2b (64 ch, 357x637), after Conv2d_4a (192 ch, 176x316), Mixed_6a pool branch (288 ch, 87x157)
     for (c, h, w) in ((64, 357, 637), (192, 176, 316), (288, 87, 157)):
         oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
