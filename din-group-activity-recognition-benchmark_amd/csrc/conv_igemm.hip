@@ -2348,6 +2348,7 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
     w.m_per_slice = mps;
     w.slices = (M + mps - 1) / mps;
     w.ws_bytes = (int64_t)w.slices * w.cout_pad * w.kcols_pad * 4;
+    if (w.pipe) w.ws_bytes += (int64_t)w.slices * w.n_co_tiles * 8 * 4 + 64;      // pacing words
     return w;
 }
 
@@ -2982,6 +2983,17 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
             k.atomic = wp.atomic;
             if (wp.atomic && hipMemsetAsync(k.partial, 0, sizeof(float) * (size_t)wp.cout_pad * wp.kcols_pad, st) != hipSuccess)
                 DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
+            {   // sibling pacing words behind the partial tiles (workspace sized for them in plan_wgrad)
+                const char* pe = getenv("DIN_WGRAD_PACE");
+                const int want = pe ? atoi(pe) : 1;
+                const size_t words = (size_t)wp.slices * wp.n_co_tiles * 8;                 // rows of 8 words (one s_load_dwordx8)
+                // measured (tools/pace_experiment.sh, profiles/r02_wgrad_pacing.txt): Conv2d_4a (3 k tiles) 6.67 -> 3.12 GB fetched per launch at
+                // unchanged time; with 6+ siblings the naps cost 4-10 % and the L2 hit rate was 74 % anyway -> default: up to 3 siblings
+                if (want && wp.n_k_tiles >= 2 && wp.n_k_tiles <= (want >= 2 ? 8 : 3) && !wp.atomic) {
+                    k.pace = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + (((size_t)wp.slices * wp.cout_pad * wp.kcols_pad * 4 + 31) & ~(size_t)31));
+                    if (hipMemsetAsync(k.pace, 0, words * sizeof(int), st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
+                }
+            }
             if (int e = din_wgrad::launch_wgrad_pipe(k, wp.bco, wp.bk, grid, st)) return e;
         } else if (wp.ring) {
             if (dbias) {

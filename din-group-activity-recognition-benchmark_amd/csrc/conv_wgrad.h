@@ -14,6 +14,10 @@ struct WgradK {
     int M, n_co_tiles, n_k_tiles, slices, m_per_slice;
     int probe;      // diagnostics (env DIN_WGRAD_PROBE): 1 = stream only (no transpose reads / MFMA), 2 = compute only (one DMA stage)
     int atomic;     // pipe kernel: 1 = every workgroup ADDS its tile into slice 0 of `partial` (fp32 atomics, buffer zeroed by the host)
+    int* pace;      // pipe kernel, optional: [slices * n_co_tiles][n_k_tiles] progress words (zeroed by the host).  The k-tile workgroups of
+                    // one (filter tile, pixel slice) stream the same dY rows; each publishes the stage it is at and a workgroup that is
+                    // more than PACE_SLACK stages ahead of the slowest sibling naps (bounded), so the siblings stay inside the window an
+                    // XCD's L2 holds and dY comes from HBM once.  Speed only: no sibling is ever waited for indefinitely.
 };
 
 // One wave-level LDS-DMA: 64 lanes x 16 B land at LDS byte address `lds_addr` + lane*16 (lane-linear; out-of-range lanes write

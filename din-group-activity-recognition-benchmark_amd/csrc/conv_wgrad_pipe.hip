@@ -205,11 +205,32 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_pipe_kernel(WgradK p) {
     };
 
     const int nst = (m_end - m_begin + PK - 1) / PK;               // stages of this slice (>= 0)
+    // ---- sibling pacing (see WgradK::pace): wave 0 publishes / checks every PACE_EVERY stages, the stage barrier holds the others back.
+    //      The siblings' progress words are read with a SCALAR load (glc: past the scalar cache; counted by lgkmcnt): a vector load would
+    //      make the compiler drain vmcnt -- i.e. the three DMA stages in flight -- before its result can be used.  The publishing store
+    //      is one more VMEM op in the stream: the hand-counted vmcnt then waits for at most one younger DMA piece too many (conservative).
+    constexpr int PACE_EVERY = 4, PACE_SLACK = 3, PACE_SPINS = 6, PACE_ROW = 8;
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    int* pace_row = p.pace ? p.pace + (int64_t)(slice * p.n_co_tiles + co_tile) * PACE_ROW : nullptr;
+    auto pace = [&](int s) {
+        if (pace_row == nullptr || wid != 0 || (s & (PACE_EVERY - 1)) != 0) return;      // scalar conditions
+        if (lane == 0) __hip_atomic_store(pace_row + k_tile, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int spin = 0; spin < PACE_SPINS; ++spin) {
+            i32x8 v;
+            asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(pace_row) : "memory");
+            int behind = 0x7fffffff;
+#pragma unroll
+            for (int e = 0; e < PACE_ROW; ++e) behind = (v[e] != 0 && v[e] < behind) ? v[e] : behind;   // 0: not started / no such sibling
+            if (s + 1 - behind <= PACE_SLACK) break;                 // (own word included: behind <= s + 1 once the store landed)
+            __builtin_amdgcn_s_sleep(4);
+        }
+    };
     // One stage (ring slot SLOT).  On entry its first half-stage's fragments (set 0) are already requested.
     auto stage = [&](auto slot_c, int s) {
         constexpr int SLOT = decltype(slot_c)::value;
         constexpr int NEXT = (SLOT + 1) & (NS - 1), FILL = (SLOT + NS - 1) & (NS - 1);
         const bool more = s + NS - 1 < nst;
+        if constexpr (SLOT == 0) pace(s);
         // ---- first half: request the second half's fragments (set 1), then the MFMAs of set 0 with the DMA issues of stage s+3
         //      between them (they go to the ring slot of stage s-1: every wave finished reading it before the last barrier)
 #pragma unroll
