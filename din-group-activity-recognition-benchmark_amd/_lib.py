@@ -18,6 +18,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "din_hip.h")
 
 DIN_F32, DIN_BF16 = 0, 1
+ABI_VERSION = 2
 CONV_BIAS, CONV_RELU, CONV_ACCUM, CONV_MASK = 1, 2, 4, 8
 
 
@@ -141,8 +142,8 @@ def load():
         except AttributeError as e:
             raise DinError(f"libdin_hip.so does not export {name}; stale build?") from e
         fn.restype, fn.argtypes = res, args
-    if lib.din_abi_version() != 1:
-        raise DinError(f"libdin_hip.so ABI version {lib.din_abi_version()} != 1")
+    if lib.din_abi_version() != ABI_VERSION:
+        raise DinError(f"libdin_hip.so ABI version {lib.din_abi_version()} != {ABI_VERSION} (stale build?)")
     if lib.din_build_arch() != b"gfx950":
         raise DinError("libdin_hip.so was not built for gfx950")
     _lib = lib

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DIN_ABI_VERSION 1
+#define DIN_ABI_VERSION 2   /* 2: din_walk_* take plain / clamp / n_per_clip, din_roi_align_bwd_nhwc takes scratch; + bn, mask_actors */
 
 enum { DIN_F32 = 0, DIN_BF16 = 1 };
 
