@@ -163,12 +163,16 @@ def main():
     ap.add_argument("--host-images", action="store_true", help="clips start in pinned host memory every step (uint8): the PCIe-inclusive rate, never the headline value")
     ap.add_argument("--forward-only", action="store_true", help="evaluation path (SURVEY 8f-3): model.eval(), torch.no_grad(), forward + loss only")
     ap.add_argument("--per-layer", default="", help="write the per-layer conv launch table of the sampled step to this file")
+    ap.add_argument("--force-buckets", action="store_true",
+                    help="single process: run the gradient-bucket path anyway (hook bookkeeping, one concatenation per bucket, a 1-rank all-reduce) "
+                         "to measure what it costs on the host and in copy kernels -- compare ms_per_step with and without")
     ap.add_argument("--bn-mode", default="eval", choices=["eval", "batch"],
                     help="Inception BatchNorm: 'eval' = cfg.set_bn_eval (running statistics, folded; results independent of the GPU count), "
                          "'batch' = the reference's stage-2 default (batch statistics of the rank's frames + running-stat update)")
     a = ap.parse_args()
 
-    from din_amd import nhwc, parallel
+    from din_amd import parallel, profiling
+    profiling.install()
     from din_amd.infer_model import Dynamic_collective, Dynamic_volleyball
     from din_amd.optim import FusedAdam
 
@@ -195,7 +199,10 @@ def main():
     parallel.broadcast_parameters(model)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = FusedAdam(params, lr=1e-4, weight_decay=0.0)
-    buckets = parallel.GradBuckets(params) if world > 1 else None
+    if a.force_buckets and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    buckets = parallel.GradBuckets(params, force=a.force_buckets) if (world > 1 or a.force_buckets) else None
 
     mine = parallel.shard_range(a.global_batch, rank, world)
     B = len(mine)
@@ -257,11 +264,11 @@ def main():
     survey = None
     for wi in range(a.warmup):
         if wi == a.warmup - 1:
-            nhwc.PROFILE = []
+            profiling.PROFILE = []
         step()
         if wi == a.warmup - 1:
             torch.cuda.synchronize()
-            survey, nhwc.PROFILE = nhwc.PROFILE, None
+            survey, profiling.PROFILE = profiling.PROFILE, None
     if os.environ.get("DIN_BENCH_TORCH_PROFILE"):          # tuning aid: which host-side torch ops launch the small fill / copy kernels
         from torch.profiler import profile, ProfilerActivity
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
@@ -311,13 +318,13 @@ def main():
     t0 = time.perf_counter()
     for it in range(a.steps):
         if it == a.steps - 1:
-            nhwc.PROFILE, nhwc.PROFILE_ONLY = [], dom_survey
+            profiling.PROFILE, profiling.PROFILE_ONLY = [], dom_survey
         loss = step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    prof, nhwc.PROFILE, nhwc.PROFILE_ONLY = nhwc.PROFILE, None, None
+    prof, profiling.PROFILE, profiling.PROFILE_ONLY = profiling.PROFILE, None, None
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

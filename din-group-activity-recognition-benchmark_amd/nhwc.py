@@ -51,10 +51,17 @@ def require_gpu(*tensors: torch.Tensor) -> None:
 
 
 # ------------------------------------------------------------------------------------------------
-# optional per-launch timing (bench.py roofline): when PROFILE is a list, every conv launch appends
-# (kind, flops, start_event, end_event) recorded on the stream the kernel is launched on.
+# hooks.  LAUNCH_TIMER: optional context-manager factory (kind, desc, name) wrapped around every conv launch -- the measurement side
+# (din_amd/profiling.py, used by bench.py) installs it; the product path itself carries no timing code.
 # ------------------------------------------------------------------------------------------------
-PROFILE = None
+import contextlib as _contextlib
+LAUNCH_TIMER = None
+
+
+def _timed(kind, d, name=""):
+    return LAUNCH_TIMER(kind, d, name) if LAUNCH_TIMER is not None else _contextlib.nullcontext()
+
+
 # Called as GRAD_HOOK(weight, dweight) right after a conv layer's weight gradient has been enqueued (backward order: last layer
 # first).  parallel.GradBuckets uses it to start a bucket's all-reduce while the rest of the backward pass is still running.
 GRAD_HOOK = None
@@ -62,73 +69,6 @@ import os as _os
 FUSE_1X1_DGRAD = _os.environ.get("DIN_FUSE_1X1", "1") != "0"     # fuse the dgrads of 1x1 convs that read the same tensor
 FUSE_FWD_SIBLINGS = _os.environ.get("DIN_FUSE_FWD", "1") != "0"   # run Graph.fwd_groups (sibling 1x1 convs) as one two-destination launch
 FUSE_WGRAD_SIBLINGS = _os.environ.get("DIN_FUSE_WGRAD", "1") != "0"  # ... and the wgrads of the members that share the second tensor as one launch
-
-
-def _conv_flops(d) -> float:
-    return 2.0 * d.nb * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
-
-
-PROFILE_ONLY = None      # str: while PROFILE is a list, bracket only the launches of this kernel (as named below) with events
-
-
-class _timed:
-    """Brackets one conv launch with HIP events when nhwc.PROFILE is a list; names the kernel the launch resolves to exactly as rocprofv3
-    prints it (din_conv_kernel_tile / din_conv_kernel_variant).  With PROFILE_ONLY set, launches of other kernels are left alone, so a
-    timed step that only needs the dominant kernel's launch times pays for ~20 event pairs instead of ~190."""
-    def __init__(self, kind, d, name=""):
-        self.kind, self.d, self.name = kind, d, name
-        self.rec = False
-
-    def _variant(self) -> str:
-        d = self.d
-        bm, bn = C.c_int32(0), C.c_int32(0)
-        which = {"fwd": 0, "dgrad": 1, "wgrad": 2}[self.kind]
-        L.load().din_conv_kernel_tile(C.byref(d), which, C.byref(bm), C.byref(bn))
-        tn = "unsigned short" if d.dtype == L.DIN_BF16 else "float"
-        if self.kind == "wgrad":
-            if bm.value == 0:
-                return f"conv_wgrad_small_kernel<..., {bn.value}, ...>"
-            if bn.value >= 2000:
-                return f"conv_wgrad_pipe_kernel<{bm.value}, {bn.value - 2000}, {'true' if d.ow >= 32 else 'false'}>"
-            if bn.value >= 1000:
-                return f"conv_wgrad_ring_kernel<{bm.value}, {bn.value - 1000}>"
-            return f"conv_wgrad_bf16_kernel<{bm.value}>" if d.dtype == L.DIN_BF16 else "conv_wgrad_f32_kernel"
-        if bm.value == 0:
-            return f"conv_small_kernel<..., {bn.value}, ...>"
-        if bm.value == 1:
-            return f"conv_halo_kernel<{bn.value}, ...>"
-        if bm.value == 2 and not (self.kind == "dgrad" and "+" in self.name):
-            return f"conv_gather_pipe_kernel<{bn.value}>"
-        # the exact instantiation: <T, BM, BN, WM, WN, KCS, NS, MULTI, FASTK>
-        fl = C.c_int32(0)
-        multi = self.kind == "dgrad" and "+" in self.name
-        if not multi:
-            L.load().din_conv_kernel_variant(C.byref(d), which, C.byref(fl))
-        BM, BN = (128 if bm.value == 2 else bm.value), bn.value      # (multi-source launches stay on the 128-pixel kernel)
-        if BM == 256:
-            geo = "4, 1, 4, 4" if BN == 64 else ("2, 2, 8, 2" if BN in (96, 160) else "4, 2, 8, 2")
-        elif multi:
-            geo = "4, 2, 8, 2" if (BN % 64 == 0 and d.dtype == L.DIN_BF16) else "2, 2, 8, 2"
-        else:
-            geo = "4, 2, 8, 2" if fl.value & 2 else "2, 2, 8, 2"
-        return (f"conv_gather_fast_kernel<{tn}, {BM}, {BN}, {geo}, {'true' if multi else 'false'}, "
-                f"{'true' if fl.value & 1 else 'false'}>")
-
-    def __enter__(self):
-        if PROFILE is not None:
-            self.variant = self._variant()
-            if PROFILE_ONLY is None or self.variant == PROFILE_ONLY:
-                self.rec = True
-                self.e0 = torch.cuda.Event(enable_timing=True)
-                self.e1 = torch.cuda.Event(enable_timing=True)
-                self.e0.record(torch.cuda.current_stream())
-        return self
-
-    def __exit__(self, *exc):
-        if self.rec:
-            self.e1.record(torch.cuda.current_stream())
-            PROFILE.append((self.kind, self.variant, _conv_flops(self.d), int(self.d.dtype), self.e0, self.e1, self.name))
-        return False
 
 
 # ------------------------------------------------------------------------------------------------
@@ -620,7 +560,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
     tdt = torch_dtype(dt)
     st = _stream()
     main = torch.cuda.current_stream()
-    side = side_stream(dev) if (WGRAD_SIDE_STREAM and PROFILE is None) else None
+    side = side_stream(dev) if (WGRAD_SIDE_STREAM and LAUNCH_TIMER is None) else None
     wtag = ""
     gbufs: Dict[int, torch.Tensor] = dict(out_grads)
 

@@ -54,7 +54,9 @@ class GradBuckets:
     RCCL then runs over xGMI while the remaining layers are still computing.  Everything else (BatchNorm vectors, which one
     kernel produces at the very end, and the head) goes into the final bucket, reduced in `allreduce()`."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, overlap: bool = True):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, overlap: bool = True, force: bool = False):
+        """force: run the whole bucket path in a 1-rank group too (bench.py --force-buckets: measures its host / copy overhead)"""
+        self.force = bool(force)
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.bucket_bytes = bucket_bytes
         self._by_ptr = {p.data_ptr(): p for p in self.params}
@@ -64,7 +66,7 @@ class GradBuckets:
         self._got: dict = {}                                     # data_ptr -> gradient tensor reported this step
         self._inflight: dict = {}                                # bucket index -> async work handle
         self._build(list(reversed(self.params)), 0)             # backward produces the last layers first
-        if overlap and dist.is_initialized() and dist.get_world_size() > 1:
+        if overlap and dist.is_initialized() and (dist.get_world_size() > 1 or self.force):
             try:
                 from . import nhwc
                 nhwc.GRAD_HOOK = self._on_grad
@@ -132,7 +134,7 @@ class GradBuckets:
         if key not in self._by_ptr:
             return
         self._hook_order.append(key)
-        if self._learned is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        if self._learned is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not self.force):
             return                                               # first step: only learn the order (single process: nothing to send)
         self._got[key] = grad
         bi, _ = self._slot[key]
@@ -144,7 +146,7 @@ class GradBuckets:
         """Average the gradients across ranks.  Per bucket: ONE concatenation into the flat buffer (not one copy per tensor: a
         backbone has ~220 parameter tensors, most of them BatchNorm vectors), one asynchronous all-reduce, one scale; afterwards
         every `p.grad` IS a view of the flat buffer (no copy back) -- the optimizer reads the views."""
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if not dist.is_initialized() or (dist.get_world_size() == 1 and not self.force):
             self._hook_order.clear()
             return
         world = world or dist.get_world_size()
