@@ -245,7 +245,7 @@ def main():
         loss = F.cross_entropy(ret["activities"], labels)
         loss.backward()
         if buckets is not None:
-            buckets.allreduce()
+            buckets.allreduce(scale_in_optimizer=not a.no_adam)
             if os.environ.get("DIN_CHECK_ALLREDUCE") == "1":     # debugging aid: every rank must hold the same averaged gradients
                 chk = torch.stack([p.grad.double().sum() for p in params if p.grad is not None]).sum().reshape(1)
                 lo, hi = chk.clone(), chk.clone()
@@ -255,7 +255,7 @@ def main():
                 if rank == 0:
                     print(f"allreduce check ok: grad checksum {float(chk):.6e}", file=sys.stderr, flush=True)
         if not a.no_adam:
-            opt.step()
+            opt.step(grad_scale=buckets.grad_scale if buckets is not None else 1.0)
         return loss
 
     # The LAST warm-up step is run with every conv launch bracketed by HIP events: it names the dominant kernel (largest summed launch
@@ -399,7 +399,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.workload, T, N, H, W, lite=a.lite_dim, hierarchical=a.hierarchical)
             out["vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or (a.force_buckets and dist.is_initialized()):
         dist.destroy_process_group()
 
 

@@ -65,6 +65,17 @@ def _timed(kind, d, name=""):
 # Called as GRAD_HOOK(weight, dweight) right after a conv layer's weight gradient has been enqueued (backward order: last layer
 # first).  parallel.GradBuckets uses it to start a bucket's all-reduce while the rest of the backward pass is still running.
 GRAD_HOOK = None
+# Called as GRAD_BUFFER(weight) before a conv layer's weight gradient is computed; may return the fp32 tensor (weight's shape) the kernel
+# should write into -- parallel.GradBuckets hands out the weight's slot of its flat all-reduce bucket, so no packing copy is needed.
+GRAD_BUFFER = None
+
+
+def _dw_buffer(w: torch.Tensor) -> torch.Tensor:
+    if GRAD_BUFFER is not None:
+        buf = GRAD_BUFFER(w)
+        if buf is not None:
+            return buf
+    return torch.empty_like(w)
 import os as _os
 FUSE_1X1_DGRAD = _os.environ.get("DIN_FUSE_1X1", "1") != "0"     # fuse the dgrads of 1x1 convs that read the same tensor
 FUSE_FWD_SIBLINGS = _os.environ.get("DIN_FUSE_FWD", "1") != "0"   # run Graph.fwd_groups (sibling 1x1 convs) as one two-destination launch
@@ -771,14 +782,14 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
             if oi in wgrad_done:
                 dw = grads[po]
             elif bn_live:
-                dw = torch.empty_like(w)
+                dw = _dw_buffer(w)
                 ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 2), dev, wtag)
                 with _timed("wgrad", d, op.name):
                     L.check(lib.din_conv_wgrad(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dw), None, None, None, None, 0,
                                                _ptr(ws), wsb, st), "conv_wgrad " + op.name)
                 grads[po] = dw
             elif op.bn:
-                dw = torch.empty_like(w)
+                dw = _dw_buffer(w)
                 wsbytes = lib.din_conv_workspace_bytes(C.byref(d), 2)
                 o0, o1 = bn.off_list[bn_index[oi]], bn.off_list[bn_index[oi] + 1]
                 dshift, wdot = bn_dshift[o0:o1], bn_wdot[o0:o1]          # views of the pre-zeroed flat accumulators
@@ -796,7 +807,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                                                _ptr(w), _ptr(wdot), 2, _ptr(ws), wsb, stw), "conv_wgrad " + op.name)
                 grads[po] = dw
             else:
-                dw = torch.empty_like(w)
+                dw = _dw_buffer(w)
                 wsbytes = lib.din_conv_workspace_bytes(C.byref(d), 2)
                 db = (dshift_pre if dshift_pre is not None else torch.empty_like(params[po + 1])) if op.bias else None
                 if side is not None:

@@ -66,10 +66,13 @@ class GradBuckets:
         self._got: dict = {}                                     # data_ptr -> gradient tensor reported this step
         self._inflight: dict = {}                                # bucket index -> async work handle
         self._build(list(reversed(self.params)), 0)             # backward produces the last layers first
+        self._views: dict = {}                                   # data_ptr -> cached view of the parameter's slot in its flat bucket
+        self.grad_scale = 1.0                                    # what the optimizer must multiply gradients by (scale_in_optimizer mode)
         if overlap and dist.is_initialized() and (dist.get_world_size() > 1 or self.force):
             try:
                 from . import nhwc
                 nhwc.GRAD_HOOK = self._on_grad
+                nhwc.GRAD_BUFFER = self._grad_buffer
             except Exception:                                    # host-only use (CPU tests): no conv executor
                 pass
 
@@ -93,12 +96,29 @@ class GradBuckets:
                 self._early += 1
                 seen += len(bkt)
         self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+        self._views = {}
         self._slot = {}
         for bi, bkt in enumerate(self.buckets):
             off = 0
             for p in bkt:
                 self._slot[p.data_ptr()] = (bi, off)
                 off += p.numel()
+
+    def _view_of(self, p: torch.nn.Parameter) -> torch.Tensor:
+        key = p.data_ptr()
+        v = self._views.get(key)
+        if v is None:
+            bi, off = self._slot[key]
+            v = self._views[key] = self._flat_of(bi)[off:off + p.numel()].view(p.shape)
+        return v
+
+    def _grad_buffer(self, param: torch.Tensor) -> Optional[torch.Tensor]:
+        """the slot of `param` in its flat bucket, once the bucket layout is final (from the second step on): the conv executor writes
+        the weight gradient straight into it and the bucket needs no packing copy"""
+        p = self._by_ptr.get(param.data_ptr()) if self._learned is not None else None
+        if p is None or p.data_ptr() not in self._slot or p.grad is not None:
+            return None                                          # a live .grad would be ACCUMULATED into by autograd: it must not alias the kernel's output
+        return self._view_of(p)
 
     def _flat_of(self, bi: int) -> torch.Tensor:
         bucket = self.buckets[bi]
@@ -111,22 +131,29 @@ class GradBuckets:
 
     def _pack(self, bi: int, grads: List[Optional[torch.Tensor]]) -> torch.Tensor:
         flat = self._flat_of(bi)
-        pieces, off, already = [], 0, True
+        pieces, moved, off = [], [], 0
         for p, g in zip(self.buckets[bi], grads):
             n = p.numel()
             if g is None:
                 g = torch.zeros(n, dtype=torch.float32, device=flat.device)
-            # a gradient that already lives at its slot (previous step's view, accumulated into in place) needs no packing
+            # a gradient that already lives at its slot (written there by the conv executor through nhwc.GRAD_BUFFER, or the previous
+            # step's view accumulated into in place) needs no packing
             if not (g.dtype == torch.float32 and g.is_contiguous() and g.data_ptr() == flat.data_ptr() + 4 * off):
-                already = False
-            pieces.append(g.reshape(-1).float())
+                moved.append((off, n, g))
+            pieces.append(g)
             off += n
-        if not already:
-            lo, hi = flat.data_ptr(), flat.data_ptr() + 4 * off
-            if any(lo <= g.data_ptr() < hi for g in pieces):
-                flat.copy_(torch.cat(pieces))                  # some pieces are views of `flat` itself (kept from the last step)
+        # pack the stragglers (fused sibling groups, BN vectors, FCs): one launch per RUN of adjacent slots, not one per tensor
+        i = 0
+        while i < len(moved):
+            j = i
+            while j + 1 < len(moved) and moved[j + 1][0] == moved[j][0] + moved[j][1]:
+                j += 1
+            o0, o1 = moved[i][0], moved[j][0] + moved[j][1]
+            if j == i:
+                flat[o0:o1].copy_(moved[i][2].reshape(-1))
             else:
-                torch.cat(pieces, out=flat)
+                torch.cat([g.reshape(-1).float() for _, _, g in moved[i:j + 1]], out=flat[o0:o1])
+            i = j + 1
         return flat
 
     def _on_grad(self, param: torch.Tensor, grad: torch.Tensor) -> None:
@@ -142,10 +169,12 @@ class GradBuckets:
             flat = self._pack(bi, [self._got[q.data_ptr()] for q in self.buckets[bi]])
             self._inflight[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
-    def allreduce(self, world: Optional[int] = None, async_op: bool = True) -> None:
+    def allreduce(self, world: Optional[int] = None, async_op: bool = True, scale_in_optimizer: bool = False) -> None:
         """Average the gradients across ranks.  Per bucket: ONE concatenation into the flat buffer (not one copy per tensor: a
         backbone has ~220 parameter tensors, most of them BatchNorm vectors), one asynchronous all-reduce, one scale; afterwards
-        every `p.grad` IS a view of the flat buffer (no copy back) -- the optimizer reads the views."""
+        every `p.grad` IS a view of the flat buffer (no copy back) -- the optimizer reads the views.  scale_in_optimizer: leave the SUM in
+        the buffers and set `self.grad_scale = 1 / world` for the optimizer's fused multiply (FusedAdam.step(grad_scale=...)) instead of
+        one more pass over every bucket."""
         if not dist.is_initialized() or (dist.get_world_size() == 1 and not self.force):
             self._hook_order.clear()
             return
@@ -160,12 +189,11 @@ class GradBuckets:
         for h, bi in handles:
             if h is not None and (async_op or bi in self._inflight):
                 h.wait()
-            flat, off = self._flat[bi], 0
-            flat.div_(world)
+            if not scale_in_optimizer:
+                self._flat[bi].div_(world)
             for p in self.buckets[bi]:
-                n = p.numel()
-                p.grad = flat[off:off + n].view(p.shape)
-                off += n
+                p.grad = self._view_of(p)                        # cached view of the reduced flat buffer (no per-step view construction)
+        self.grad_scale = 1.0 / world if scale_in_optimizer else 1.0
         # ---- bookkeeping for the next step
         self._inflight.clear()
         self._got.clear()

@@ -132,8 +132,10 @@ def _train_pass(data_loader, model, device, optimizer, epoch, cfg, grad_buckets,
         optimizer.zero_grad()
         total_loss.backward()
         if grad_buckets is not None:
-            grad_buckets.allreduce()
-        optimizer.step()
+            grad_buckets.allreduce(scale_in_optimizer=True)        # the 1 / world factor rides in the fused Adam kernel
+            optimizer.step(grad_scale=grad_buckets.grad_scale)
+        else:
+            optimizer.step()
         meters.add(activities_scores.detach(), activities_in, total_loss)
     return meters.info(epoch)
 
