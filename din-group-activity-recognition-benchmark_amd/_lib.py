@@ -18,7 +18,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "din_hip.h")
 
 DIN_F32, DIN_BF16 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 CONV_BIAS, CONV_RELU, CONV_ACCUM, CONV_MASK = 1, 2, 4, 8
 
 
@@ -84,9 +84,10 @@ SIGNATURES: Dict[str, tuple] = {
     "din_avgpool_bwd": (_I, [_PD, _P, _P, _P, _I, _P]),
     "din_bilinear_fwd": (_I, [_PD, _P, _P, _P]),
     "din_bilinear_bwd": (_I, [_PD, _P, _P, _P, _I, _P]),
-    "din_roi_align_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P]),
+    "din_roi_align_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P, _P]),
     "din_roi_align_bwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
-    "din_roi_align_bwd_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P, _I, _P, _P]),
+    "din_roi_crop_grad_transpose": (_I, [_P, _I, _I, _I, _P, _P]),
+    "din_roi_align_bwd_nhwc": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P, _I, _P]),
     "din_grad_cast_mask": (_I, [_P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _I, _P]),
     "din_boxes_frame_index": (_I, [_P, _I, _I, _P]),
     "din_layernorm_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _L, _L, _I, _F, _U64, _P]),

@@ -183,7 +183,9 @@ class MyInception_v3(_GraphBackbone):
                     setattr(mod, part, nn.Module())
                 mod = getattr(mod, part)
             setattr(mod, parts[-1], _BasicConv2d(cin, cout, k))
-        self.fuse_output_size = None      # set by the model: (OH, OW) -> append the fused [5d | resize(6e)] tensor
+        # DIN_ROI_COMPOSE=0: materialise the multi-scale fuse [5d | resize(6e)] (infer_model.py:165-172) inside the graph, as round 1 did.
+        # Default: the graph ends at Mixed_5d / Mixed_6e and RoIAlign samples Mixed_6e through its virtual resize (ops.RoIAlignMultiScale).
+        self.materialise_fuse = os.environ.get("DIN_ROI_COMPOSE", "1") == "0"
 
     def build_graph(self, h, w, dt) -> Graph:
         gb = GraphBuilder(h, w, _cpad_image(dt))
@@ -216,7 +218,7 @@ class MyInception_v3(_GraphBackbone):
         fused_tid = None
         for blk, pf in (("Mixed_5b.", 32), ("Mixed_5c.", 64), ("Mixed_5d.", 64)):
             ctot = 64 + 64 + 96 + pf
-            if blk == "Mixed_5d." :
+            if blk == "Mixed_5d." and self.materialise_fuse:
                 # Mixed_5d writes straight into the fused multi-scale tensor [5d (288) | resize(6e) (768)]
                 fused_tid = gb.tensor(h5, w5, ctot + 768)
                 out_tid, base = fused_tid, 0
@@ -271,13 +273,16 @@ class MyInception_v3(_GraphBackbone):
             bc(blk + "branch7x7dbl_5", t, View(out_tid, 384, 192))
             branch_pool(blk + "branch_pool", v, View(out_tid, 576, 192))
             v = View(out_tid, 0, 768)
-        # multiscale fuse (infer_model.py:165-172): resize Mixed_6e to the Mixed_5d grid into channels [288, 1056)
-        gb.bilinear(v, View(fused_tid, 288, 768))
-        gb.g.tensors[fused_tid].relu_masked = True   # bilinear of non-negative maps: zero output <=> all taps zero
-        gb.g.output_tids = [fused_tid, v.tid]
+        if self.materialise_fuse:
+            # multiscale fuse (infer_model.py:165-172): resize Mixed_6e to the Mixed_5d grid into channels [288, 1056)
+            gb.bilinear(v, View(fused_tid, 288, 768))
+            gb.g.tensors[fused_tid].relu_masked = True   # bilinear of non-negative maps: zero output <=> all taps zero
+            gb.g.output_tids = [fused_tid, v.tid]
+        else:
+            gb.g.output_tids = [v5d.tid, v.tid]
         self._v5d = v5d
         return gb.g
 
     def output_views(self, graph: Graph):
-        fused, t6e = graph.output_tids
-        return [(fused, 0, 288), (t6e, 0, 768)]
+        t5d, t6e = graph.output_tids                     # (t5d is the fused tensor when the fuse is materialised: channels [0, 288) are Mixed_5d)
+        return [(t5d, 0, 288), (t6e, 0, 768)]

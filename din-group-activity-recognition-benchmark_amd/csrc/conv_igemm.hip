@@ -2304,7 +2304,20 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
             // quarter of the MFMAs); at equal tile height the two-workgroups-per-CU v3 kernel is faster
             // (8-wave ring: +25..40 % on 192-row banks, +5..11 % on exact 128 / 256-row banks, behind v3 when rows or k columns pad)
             const int kpad = pad_to(w.kcols, 256);
-            if ((best_pad * 100 <= d->cout * 105 && (best == 192 || kpad * 100 <= w.kcols * 112)) || mode == 2) w.bco = best;
+            const char* pe = getenv("DIN_WGRAD_PIPE");
+            const int pipe_mode = pe ? atoi(pe) : 1;
+            if (pipe_mode == 1) {
+                // every wide bank runs the pipelined kernel, rows padded to the next of {128, 192, 256}: measured against the round-1
+                // choice below (DIN_WGRAD_PIPE=3; profiles/r02_wgrad_ring_vs_pipe_vs_atomic.txt) it is 5-17 % faster on the 128 / 160 /
+                // 256-row banks the padding rule used to send to the two-workgroup kernels, and equal on the 320-row one
+                int pb = 128, pt = (d->cout + 127) / 128, pp = pt * 128;
+                const int pc[2] = {192, 256};
+                for (int ci = 0; ci < 2; ++ci) {
+                    int bc = pc[ci], tl = (d->cout + bc - 1) / bc, pad = tl * bc;
+                    if (tl < pt || (tl == pt && pad < pp)) { pb = bc; pt = tl; pp = pad; }
+                }
+                w.bco = pb;
+            } else if ((best_pad * 100 <= d->cout * 105 && (best == 192 || kpad * 100 <= w.kcols * 112)) || mode == 2) w.bco = best;
             else w.ring = 0;
         }
     }
@@ -2319,8 +2332,8 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
     {   // BCO x 256 ring tiles whose wave tile is whole 32x32 MFMA tiles run the software-pipelined kernel (conv_wgrad_pipe.hip)
         const char* pe = getenv("DIN_WGRAD_PIPE");          // (read per call: the tests switch them inside one process)
         const char* ae = getenv("DIN_WGRAD_ATOMIC");
-        const int pipe_env = pe ? atoi(pe) : 1, atomic_env = ae ? atoi(ae) : 0;
-        if (w.ring && ring_bk == 256 && (w.bco == 128 || w.bco == 192) && pipe_env) { w.pipe = 1; w.atomic = atomic_env; }
+        const int pipe_env = pe ? atoi(pe) : 1, atomic_env = ae ? atoi(ae) : 0;   // 0: ring kernel, 1: pipe (wide choice), 3: pipe (round-1 tile choice)
+        if (w.ring && ring_bk == 256 && (w.bco == 128 || w.bco == 192 || w.bco == 256) && pipe_env) { w.pipe = 1; w.atomic = atomic_env; }
     }
     int pk = d->dtype == DIN_F32 ? 16 : (w.ring ? 32 : (w.v2 ? 64 : 32));
     w.bk = bk;

@@ -429,6 +429,94 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(din_pool_desc d, Dec3 
     }
 }
 
+// ---- 3x3 / 1 / pad 1 box filter, column strips ---------------------------------------------------------------------------------------
+// One thread owns R consecutive rows of one (frame, column, channel group) and keeps the three taps of rows y0-1 .. y0+R in registers
+// (bf16: still packed, 4 registers per tap): a strip costs 3 (R + 2) vector loads for R outputs (3.75 per output at R = 8) instead of
+// 9, all issued before the first sum is needed.  Every output is summed in exactly the order of the one-thread-per-output kernels
+// (= ATen's avg_pool2d loop: rows top-to-bottom, taps left-to-right; backward mirrored), so the results are bit-identical to them --
+// and the commuted branch_pool layers keep the reference's ReLU decisions.
+// Forward (epilogue: * 1/9, + bias, ReLU) and backward (the box filter is its own transpose; epilogue: * 1/9, ReLU mask, accumulate)
+// share the strip; `src`/`dst` pixel strides and channel offsets come from the caller.
+template <int V> struct RawTap;
+template <> struct RawTap<8> {                                          // 8 bf16 channels, kept packed
+    uint4 r;
+    __device__ __forceinline__ void load(const void* base, int, int64_t i) { r = *reinterpret_cast<const uint4*>((const bf16_t*)base + i); }
+    __device__ __forceinline__ float get(int e) const {
+        const uint32_t w = e < 2 ? r.x : e < 4 ? r.y : e < 6 ? r.z : r.w;
+        return (e & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
+    }
+};
+template <> struct RawTap<4> {                                          // 4 channels, fp32 or bf16: converted at load
+    Vec<4> r;
+    __device__ __forceinline__ void load(const void* base, int dtype, int64_t i) { r = vload<4>(base, dtype, i); }
+    __device__ __forceinline__ float get(int e) const { return r.v[e]; }
+};
+
+template <int V, int R, bool BWD>
+__global__ __launch_bounds__(256) void avgpool3_strip_kernel(int nb, int h, int w, int cgroups, Dec3 dd, int dtype, const void* __restrict__ src,
+                                                             int lds_, int soff, void* __restrict__ dst, int ldd, int doff,
+                                                             const float* __restrict__ bias, int flags, const void* __restrict__ mask,
+                                                             int accumulate) {
+    const int strips = (h + R - 1) / R;
+    const int64_t total = (int64_t)nb * strips * w * cgroups;
+    DIN_GRID_STRIDE(i, total) {
+        int cg, x, sy, n; int64_t p;
+        decode(dd, i, cg, x, sy, n, p);                                 // dd built with (cgroups, w, strips)
+        const int y0 = sy * R;
+        float bv[V];                                                    // the bias of this channel group, fetched once per strip
+#pragma unroll
+        for (int e = 0; e < V; ++e) bv[e] = (!BWD && (flags & DIN_CONV_BIAS)) ? bias[cg * V + e] : 0.f;
+        RawTap<V> t[R + 2][3];
+#pragma unroll
+        for (int r = 0; r < R + 2; ++r) {
+            const int yc = min(max(y0 + r - 1, 0), h - 1);
+            const int64_t rowp = ((int64_t)n * h + yc) * w;
+            t[r][0].load(src, dtype, (rowp + max(x - 1, 0)) * lds_ + soff + cg * V);
+            t[r][1].load(src, dtype, (rowp + x) * lds_ + soff + cg * V);
+            t[r][2].load(src, dtype, (rowp + min(x + 1, w - 1)) * lds_ + soff + cg * V);
+        }
+        const bool lok = x > 0, rok = x + 1 < w;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int y = y0 + r;
+            if (y >= h) break;
+            Vec<V> g = vzero<V>();
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {
+                const int q = BWD ? 2 - rr : rr;                        // backward visits rows y+1, y, y-1 and columns x+1, x, x-1
+                const bool yok = y + q - 1 >= 0 && y + q - 1 < h;
+#pragma unroll
+                for (int ss = 0; ss < 3; ++ss) {
+                    const int c = BWD ? 2 - ss : ss;
+                    const bool ok = yok && (c == 0 ? lok : c == 2 ? rok : true);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) g.v[e] += ok ? t[r + q][c].get(e) : 0.f;
+                }
+            }
+            const int64_t off = (((int64_t)n * h + y) * w + x) * ldd + doff + cg * V;
+#pragma unroll
+            for (int e = 0; e < V; ++e) g.v[e] *= (1.f / 9.f);
+            if (!BWD) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    float v = g.v[e];
+                    if (flags & DIN_CONV_BIAS) v += bv[e];
+                    if (flags & DIN_CONV_RELU) v = fmaxf(v, 0.f);
+                    g.v[e] = v;
+                }
+            } else {
+                if (mask) { Vec<V> yv = vload<V>(mask, dtype, off);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) g.v[e] = yv.v[e] > 0.f ? g.v[e] : 0.f; }
+                if (accumulate) { Vec<V> o = vload<V>(dst, dtype, off);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) g.v[e] += o.v[e]; }
+            }
+            vstore<V>(dst, dtype, off, g);
+        }
+    }
+}
+
 // ---- bilinear resize, align_corners=True (infer_model.py:169): src = dst*(in-1)/(out-1) -----------------------------------------
 __device__ __forceinline__ void bil_coord(int o, int in, int out, int& i0, int& i1, float& l) {
     float sc = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
@@ -607,6 +695,7 @@ int check_pool(const din_pool_desc* d, const char* what) {
     DIN_REQUIRE(d->nb > 0 && d->h > 0 && d->w > 0 && d->oh > 0 && d->ow > 0 && d->c > 0, "%s: empty tensor", what);
     return DIN_OK;
 }
+inline int avgpool_strip_rows() { const char* e = getenv("DIN_AVGPOOL_STRIP"); return e ? atoi(e) : 1; }   // 0: one thread per output (round 1)
 inline bool is_box3(const din_pool_desc* d) { return d->k == 3 && d->stride == 1 && d->pad == 1 && d->oh == d->h && d->ow == d->w; }
 constexpr int POOL_GRID_CAP = 32768;
 
@@ -681,6 +770,16 @@ int din_avgpool_fwd(const din_pool_desc* d, const void* in, void* out, const flo
     const int64_t total = (int64_t)d->nb * d->oh * d->ow * (d->c / v);
     const Dec3 dd = make_dec(d->c / v, d->ow, d->oh, total);
     const bool b3 = is_box3(d);
+    if (b3 && avgpool_strip_rows() > 0) {
+        constexpr int R = 8;
+        const int strips = (d->h + R - 1) / R;
+        const int64_t tot = (int64_t)d->nb * strips * d->w * (d->c / v);
+        const Dec3 ds = make_dec(d->c / v, d->w, strips, tot);
+        if (v == 8) POOL_LAUNCH((avgpool3_strip_kernel<8, R, false>), tot, d->nb, d->h, d->w, d->c / v, ds, d->dtype, in, d->ldi, d->cioff, out, d->ldo, d->cooff, bias, flags, (const void*)nullptr, 0);
+        else POOL_LAUNCH((avgpool3_strip_kernel<4, R, false>), tot, d->nb, d->h, d->w, d->c / v, ds, d->dtype, in, d->ldi, d->cioff, out, d->ldo, d->cooff, bias, flags, (const void*)nullptr, 0);
+        DIN_CHECK_LAUNCH("avgpool_fwd");
+        return DIN_OK;
+    }
     if (v == 8) { if (b3) POOL_LAUNCH((avgpool_fwd_kernel<8, true>), total, *d, dd, in, out, bias, flags); else POOL_LAUNCH((avgpool_fwd_kernel<8, false>), total, *d, dd, in, out, bias, flags); }
     else { if (b3) POOL_LAUNCH((avgpool_fwd_kernel<4, true>), total, *d, dd, in, out, bias, flags); else POOL_LAUNCH((avgpool_fwd_kernel<4, false>), total, *d, dd, in, out, bias, flags); }
     DIN_CHECK_LAUNCH("avgpool_fwd");
@@ -694,6 +793,16 @@ int din_avgpool_bwd(const din_pool_desc* d, const void* dout, void* din_, const 
     const int64_t total = (int64_t)d->nb * d->h * d->w * (d->c / v);
     const Dec3 dd = make_dec(d->c / v, d->w, d->h, total);
     const bool b3 = is_box3(d);
+    if (b3 && avgpool_strip_rows() > 0) {                               // the box filter is symmetric: same strip, source = dout view, destination = din view
+        constexpr int R = 8;
+        const int strips = (d->h + R - 1) / R;
+        const int64_t tot = (int64_t)d->nb * strips * d->w * (d->c / v);
+        const Dec3 ds = make_dec(d->c / v, d->w, strips, tot);
+        if (v == 8) POOL_LAUNCH((avgpool3_strip_kernel<8, R, true>), tot, d->nb, d->h, d->w, d->c / v, ds, d->dtype, dout, d->ldo, d->cooff, din_, d->ldi, d->cioff, (const float*)nullptr, 0, mask, accumulate);
+        else POOL_LAUNCH((avgpool3_strip_kernel<4, R, true>), tot, d->nb, d->h, d->w, d->c / v, ds, d->dtype, dout, d->ldo, d->cooff, din_, d->ldi, d->cioff, (const float*)nullptr, 0, mask, accumulate);
+        DIN_CHECK_LAUNCH("avgpool_bwd");
+        return DIN_OK;
+    }
     if (v == 8) { if (b3) POOL_LAUNCH((avgpool_bwd_kernel<8, true>), total, *d, dd, dout, din_, mask, accumulate); else POOL_LAUNCH((avgpool_bwd_kernel<8, false>), total, *d, dd, dout, din_, mask, accumulate); }
     else { if (b3) POOL_LAUNCH((avgpool_bwd_kernel<4, true>), total, *d, dd, dout, din_, mask, accumulate); else POOL_LAUNCH((avgpool_bwd_kernel<4, false>), total, *d, dd, dout, din_, mask, accumulate); }
     DIN_CHECK_LAUNCH("avgpool_bwd");

@@ -40,6 +40,105 @@ __device__ __forceinline__ Sample roi_sample(float c1, float c2, int extent, int
     return s;
 }
 
+// ---- composed sampling: the map the boxes live on is a VIRTUAL align_corners bilinear resize (infer_model.py:165-170, F.interpolate) of a
+// smaller stored map.  Both operations are separable and linear, so a sample's value is a 3 x 3 weighted sum of stored pixels: per axis
+// the sample's two grid cells (weights 1-l, l) each read two stored cells, and because the stored axis is not longer than the grid axis
+// the (at most) four cells are stored cells r0, r0+1, r0+2.  With extent == grid the taps reduce to {lo: 1-l, hi: l} -- the plain RoIAlign.
+struct Tap3 { int r0; float w[3]; bool oob; };
+
+// grid cell g -> stored coordinate g * (extent-1)/(grid-1): same fp32 operations as the resize kernel (pool.hip bil_coord)
+__device__ __forceinline__ void resize_coord(int g, int extent, int grid, int& i0, int& i1, float& l) {
+    const float sc = grid > 1 ? (float)(extent - 1) / (float)(grid - 1) : 0.f;
+    const float src = sc * (float)g;
+    i0 = (int)src;
+    if (i0 > extent - 1) i0 = extent - 1;
+    i1 = i0 + 1 < extent ? i0 + 1 : extent - 1;
+    l = src - (float)i0;
+}
+
+__device__ __forceinline__ Tap3 axis_taps(float c1, float c2, int grid, int extent, int k, int i) {
+    const Sample s = roi_sample(c1, c2, grid, k, i);
+    Tap3 t;
+    t.oob = s.oob;
+    t.w[0] = t.w[1] = t.w[2] = 0.f;
+    if (extent == grid) {
+        t.r0 = s.lo;
+        t.w[0] = 1.f - s.l;
+        if (s.hi == s.lo) t.w[0] += s.l; else t.w[1] = s.l;
+        return t;
+    }
+    int a0, a1, b0, b1; float la, lb;
+    resize_coord(s.lo, extent, grid, a0, a1, la);
+    resize_coord(s.hi, extent, grid, b0, b1, lb);
+    t.r0 = a0;
+    const float wl = 1.f - s.l, wh = s.l;
+    // (indices relative to r0 are 0..2: b0 is a0 or a0 + 1 because one grid step is at most one stored step)
+    const int ia1 = a1 - a0, ib0 = min(b0 - a0, 2), ib1 = min(b1 - a0, 2);
+    t.w[0] += wl * (1.f - la);
+    if (ia1 == 0) t.w[0] += wl * la; else t.w[1] += wl * la;
+    if (ib0 == 0) t.w[0] += wh * (1.f - lb); else if (ib0 == 1) t.w[1] += wh * (1.f - lb); else t.w[2] += wh * (1.f - lb);
+    if (ib1 == 0) t.w[0] += wh * lb; else if (ib1 == 1) t.w[1] += wh * lb; else t.w[2] += wh * lb;
+    return t;
+}
+
+// Forward through a virtually resized map: one workgroup per (box, ky), wave w handles kx = w, w+4, ..., lanes stream 16-byte channel
+// chunks of the 3 x 3 stored pixels.  Output as roi_align_fwd_kernel: out[b][out_coff + ch][ky][kx] of an [m][out_c][k][k] crop tensor.
+template <int V>
+__global__ void roi_align_fwd_composed_kernel(const void* __restrict__ fm, int fm_dtype, int nb, int hf, int wf, int c, int ldf, int gh, int gw,
+                                              const float* __restrict__ boxes, const int32_t* __restrict__ box_ind, int m, int k,
+                                              float* __restrict__ out, int out_c, int out_coff) {
+    extern __shared__ float row[];                                     // [c][k]
+    const int b = blockIdx.x / k, ky = blockIdx.x % k;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const float x1 = boxes[b * 4 + 0], y1 = boxes[b * 4 + 1], x2 = boxes[b * 4 + 2], y2 = boxes[b * 4 + 3];
+    const int n = box_ind[b];
+    const Tap3 ty = axis_taps(y1, y2, gh, hf, k, ky);
+    for (int kx = wave; kx < k; kx += nwaves) {
+        const Tap3 tx = axis_taps(x1, x2, gw, wf, k, kx);
+        const bool dead = ty.oob || tx.oob || n < 0 || n >= nb;
+        for (int ch = lane * V; ch < c; ch += 64 * V) {
+            float acc[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] = 0.f;
+            if (!dead) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int yy = min(ty.r0 + i, hf - 1);
+                    float rowacc[V];
+#pragma unroll
+                    for (int e = 0; e < V; ++e) rowacc[e] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int xx = min(tx.r0 + j, wf - 1);
+                        const int64_t off = ((int64_t)(n * hf + yy) * wf + xx) * ldf + ch;
+                        const float wj = tx.w[j];
+                        if (fm_dtype == DIN_F32) {
+                            const f32x4_t q = *reinterpret_cast<const f32x4_t*>((const float*)fm + off);
+#pragma unroll
+                            for (int e = 0; e < V; ++e) rowacc[e] += wj * q[e & 3];
+                        } else {
+                            const u32x4_t q = *reinterpret_cast<const u32x4_t*>((const bf16_t*)fm + off);
+#pragma unroll
+                            for (int e = 0; e < V; ++e)
+                                rowacc[e] += wj * ((e & 1) ? __uint_as_float(q[(e >> 1) & 3] & 0xffff0000u) : __uint_as_float(q[(e >> 1) & 3] << 16));
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[e] += ty.w[i] * rowacc[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < V; ++e) row[(ch + e) * k + kx] = acc[e];
+        }
+    }
+    __syncthreads();
+    float* dst = out + ((int64_t)b * out_c + out_coff) * k * k + ky * k;
+    for (int i = threadIdx.x; i < c * k; i += blockDim.x) {
+        const int ch = i / k, kx = i - ch * k;
+        dst[(int64_t)ch * k * k + kx] = row[i];
+    }
+}
+
 // grid: one workgroup per (box, ky); wave w handles kx = w, w+4, ...; lanes stream channels.
 // The crop goes out in the reference's flatten order [m][c][k*k] (the column order of fc_emb_1, infer_model.py:181-184), i.e. a lane's
 // channels are k*k floats apart.  With `row` (dynamic LDS, c * k floats) the workgroup first assembles its k samples channel-by-channel
@@ -47,7 +146,7 @@ __device__ __forceinline__ Sample roi_sample(float c1, float c2, int extent, int
 template <int V>
 __global__ void roi_align_fwd_kernel(const void* __restrict__ fm, int fm_dtype, int nb, int hf, int wf, int c, int ldf,
                                      const float* __restrict__ boxes, const int32_t* __restrict__ box_ind, int m, int k,
-                                     float* __restrict__ out, int32_t* __restrict__ idx_out) {
+                                     float* __restrict__ out, int32_t* __restrict__ idx_out, int out_c, int out_coff) {
     extern __shared__ float row[];                                     // [c][k] (V > 1 only)
     const int b = blockIdx.x / k, ky = blockIdx.x % k;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -66,7 +165,7 @@ __global__ void roi_align_fwd_kernel(const void* __restrict__ fm, int fm_dtype, 
         const int64_t r_tl = ((int64_t)(n * hf + sy.lo) * wf + sx.lo) * ldf, r_tr = ((int64_t)(n * hf + sy.lo) * wf + sx.hi) * ldf;
         const int64_t r_bl = ((int64_t)(n * hf + sy.hi) * wf + sx.lo) * ldf, r_br = ((int64_t)(n * hf + sy.hi) * wf + sx.hi) * ldf;
         if constexpr (V == 1) {
-            float* dst = out + (int64_t)b * c * k * k + ky * k + kx;
+            float* dst = out + ((int64_t)b * out_c + out_coff) * k * k + ky * k + kx;
             for (int ch = lane; ch < c; ch += 64) {
                 float v = 0.f;
                 if (!dead) {
@@ -111,8 +210,8 @@ __global__ void roi_align_fwd_kernel(const void* __restrict__ fm, int fm_dtype, 
     }
     if constexpr (V > 1) {
         __syncthreads();
-        // out[b][ch][ky][0..k): k contiguous floats per channel
-        float* dst = out + (int64_t)b * c * k * k + ky * k;
+        // out[b][out_coff + ch][ky][0..k): k contiguous floats per channel
+        float* dst = out + ((int64_t)b * out_c + out_coff) * k * k + ky * k;
         for (int i = threadIdx.x; i < c * k; i += blockDim.x) {
             const int ch = i / k, kx = i - ch * k;
             dst[(int64_t)ch * k * k + kx] = row[i];
@@ -164,16 +263,18 @@ template <typename T>
 __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* __restrict__ dout, int nb, int hf, int wf, int c,
                                                                    const float* __restrict__ boxes, const int32_t* __restrict__ box_ind,
                                                                    int m, int k, const T* __restrict__ fm, int ldf, T* __restrict__ gfm,
-                                                                   int ldg, int cap, int prezeroed, int transposed) {
+                                                                   int ldg, int cap, int prezeroed, int transposed, int gh, int gw,
+                                                                   int dout_c, int dout_coff) {
+    // (gh, gw): the grid the boxes live on; the stored map hf x wf is its virtual align_corners resize source (axis_taps) -- equal extents
+    // give the plain RoIAlign.  dout holds dout_c channels per crop, this map's c channels start at dout_coff.
     // transposed: dout is the channel-contiguous copy [m][k*k][c] made by roi_transpose_kernel (a lane's V channels are one 16/32-byte
     // load and a wave reads 2 KiB contiguous); otherwise the reference layout [m][c][k*k] (4-byte loads 100 B apart)
     constexpr int V = 16 / sizeof(T);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* boxid = reinterpret_cast<int*>(smem);                         // [cap] boxes of this frame (batch), ascending
-    int* xlo = boxid + cap;                                            // [cap * k] x-sample low / high cell (-2: out of range)
-    int* xhi = xlo + cap * k;
-    float* xl = reinterpret_cast<float*>(xhi + cap * k);               // [cap * k] x-sample lerp
-    float* wyv = xl + cap * k;                                         // [cap * k] y-weight of sample ky on this row (0: none)
+    int* xc0 = boxid + cap;                                            // [cap * k] first stored column of x-sample q's three taps (-4: out of range)
+    float* xw = reinterpret_cast<float*>(xc0 + cap * k);               // [cap * k * 3] their weights
+    float* wyv = xw + 3 * cap * k;                                     // [cap * k] y-weight of sample ky on this row (0: none)
     int* xmin = reinterpret_cast<int*>(wyv + cap * k);                 // [cap] x extent of the box's samples
     int* xmax = xmin + cap;
     int* act = xmax + cap;                                             // [cap] slots of the boxes that touch this row
@@ -212,10 +313,12 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
         for (int t = tid; t < found * k; t += 256) {
             const int j = t / k, q = t - j * k;
             const int b = boxid[j];
-            const Sample sx = roi_sample(boxes[b * 4 + 0], boxes[b * 4 + 2], wf, k, q);
-            xlo[t] = sx.oob ? -2 : sx.lo; xhi[t] = sx.oob ? -2 : sx.hi; xl[t] = sx.l;
-            const Sample sy = roi_sample(boxes[b * 4 + 1], boxes[b * 4 + 3], hf, k, q);
-            wyv[t] = sy.oob ? 0.f : ((sy.lo == y ? 1.f - sy.l : 0.f) + (sy.hi == y ? sy.l : 0.f));
+            const Tap3 tx = axis_taps(boxes[b * 4 + 0], boxes[b * 4 + 2], gw, wf, k, q);
+            xc0[t] = tx.oob ? -4 : tx.r0;
+            xw[3 * t] = tx.w[0]; xw[3 * t + 1] = tx.w[1]; xw[3 * t + 2] = tx.w[2];
+            const Tap3 ty = axis_taps(boxes[b * 4 + 1], boxes[b * 4 + 3], gh, hf, k, q);
+            const int dy = y - ty.r0;
+            wyv[t] = (ty.oob || dy < 0 || dy > 2) ? 0.f : ty.w[dy];
         }
         __syncthreads();
         if (tid == 0) {
@@ -224,7 +327,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
                 bool any = false; int lo = 1 << 30, hi = -1;
                 for (int q = 0; q < k; ++q) {
                     any = any || wyv[j * k + q] != 0.f;
-                    if (xlo[j * k + q] >= 0) { lo = min(lo, xlo[j * k + q]); hi = max(hi, xhi[j * k + q]); }
+                    if (xc0[j * k + q] >= 0) { lo = min(lo, xc0[j * k + q]); hi = max(hi, min(xc0[j * k + q] + 2, wf - 1)); }
                 }
                 xmin[j] = lo; xmax[j] = hi;
                 if (any && hi >= 0) { act[na++] = j; rx0 = min(rx0, lo); rx1 = max(rx1, hi); }
@@ -255,9 +358,9 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
                     const float wy = wyv[j * k + qy];
                     if (wy == 0.f) continue;
                     for (int qx = 0; qx < k; ++qx) {
-                        const int lo = xlo[j * k + qx], hi = xhi[j * k + qx];
-                        const float l = xl[j * k + qx];
-                        const float wx = (lo == x ? 1.f - l : 0.f) + (hi == x ? l : 0.f);
+                        const int dx = x - xc0[j * k + qx];
+                        if (dx < 0 || dx > 2) continue;                 // (out-of-range samples: c0 = -4)
+                        const float wx = xw[3 * (j * k + qx) + dx];
                         if (wx == 0.f) continue;
                         if (ncl < CL) { cl_off[wave][ncl] = b * kk + qy * k + qx; cl_w[wave][ncl] = wy * wx; }   // same value from every lane
                         else overflow = true;
@@ -277,7 +380,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
                         const int off = cl_off[wave][t];
                         const float w = cl_w[wave][t];
                         if (transposed) {                                   // (box * kk + sample) * c + ch: contiguous channels
-                            const float* src = dout + (int64_t)off * c + ch0 * V;
+                            const float* src = dout + (int64_t)off * dout_c + dout_coff + ch0 * V;
 #pragma unroll
                             for (int e4 = 0; e4 < V / 4; ++e4) {
                                 const f32x4_t v4 = *reinterpret_cast<const f32x4_t*>(src + 4 * e4);
@@ -286,7 +389,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
                             }
                         } else {
                             const int bq = off / kk;                        // box * kk + sample -> ((box * c + ch) * kk + sample)
-                            const float* src = dout + ((int64_t)bq * c + ch0 * V) * kk + (off - bq * kk);
+                            const float* src = dout + ((int64_t)bq * dout_c + dout_coff + ch0 * V) * kk + (off - bq * kk);
 #pragma unroll
                             for (int e = 0; e < V; ++e) acc[e] += w * src[(int64_t)e * kk];
                         }
@@ -300,13 +403,13 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float* 
                             const float wy = wyv[j * k + qy];
                             if (wy == 0.f) continue;
                             for (int qx = 0; qx < k; ++qx) {
-                                const int lo = xlo[j * k + qx], hi = xhi[j * k + qx];
-                                const float l = xl[j * k + qx];
-                                const float wx = (lo == x ? 1.f - l : 0.f) + (hi == x ? l : 0.f);
+                                const int dx = x - xc0[j * k + qx];
+                                if (dx < 0 || dx > 2) continue;
+                                const float wx = xw[3 * (j * k + qx) + dx];
                                 if (wx == 0.f) continue;
                                 const float w = wy * wx;
-                                const float* src = transposed ? dout + ((int64_t)b * kk + qy * k + qx) * c + ch0 * V
-                                                              : dout + ((int64_t)b * c + ch0 * V) * kk + qy * k + qx;
+                                const float* src = transposed ? dout + ((int64_t)b * kk + qy * k + qx) * dout_c + dout_coff + ch0 * V
+                                                              : dout + ((int64_t)b * dout_c + dout_coff + ch0 * V) * kk + qy * k + qx;
                                 const int64_t es = transposed ? 1 : kk;
 #pragma unroll
                                 for (int e = 0; e < V; ++e) acc[e] += w * src[(int64_t)e * es];
@@ -372,22 +475,35 @@ __global__ __launch_bounds__(256) void roi_transpose_kernel(const float* __restr
 
 extern "C" {
 
-int din_roi_align_fwd(const void* fm, int fm_dtype, int nb, int hf, int wf, int c, int ldf, const float* boxes,
-                      const int32_t* box_ind, int m, int k, float* out, int32_t* idx_out, void* stream) {
+int din_roi_align_fwd(const void* fm, int fm_dtype, int nb, int hf, int wf, int c, int ldf, int gh, int gw, const float* boxes,
+                      const int32_t* box_ind, int m, int k, float* out, int out_c, int out_coff, int32_t* idx_out, void* stream) {
     DIN_REQUIRE(fm && boxes && box_ind && out, "roi_align_fwd: null pointer");
     DIN_REQUIRE(nb > 0 && hf > 1 && wf > 1 && c > 0 && k > 0 && m >= 0 && ldf >= c, "roi_align_fwd: bad shape");
     DIN_REQUIRE(k <= 64, "roi_align_fwd: crop size > 64 unsupported");
+    DIN_REQUIRE(out_coff >= 0 && out_c >= out_coff + c, "roi_align_fwd: channels [%d, %d) do not fit a %d-channel crop", out_coff, out_coff + c, out_c);
+    DIN_REQUIRE(gh >= hf && gw >= wf, "roi_align_fwd: the box grid %dx%d must not be smaller than the stored map %dx%d", gh, gw, hf, wf);
     if (m == 0) return DIN_OK;
     const int v = fm_dtype == DIN_F32 ? 4 : 8;
     const size_t lds = (size_t)c * k * sizeof(float);
+    if (gh != hf || gw != wf) {
+        // boxes on a virtually resized map (multi-scale fuse, infer_model.py:165-172): 3 x 3 stored taps per sample
+        DIN_REQUIRE(!idx_out, "roi_align_fwd: the index record describes the plain (unresized) sampling only");
+        DIN_REQUIRE(c % v == 0 && ldf % v == 0 && lds <= 64 * 1024, "roi_align_fwd: resized sampling needs channels / stride in multiples of %d", v);
+        if (v == 4) hipLaunchKernelGGL(roi_align_fwd_composed_kernel<4>, dim3(m * k), dim3(256), lds, as_stream(stream), fm, fm_dtype, nb, hf, wf, c,
+                                       ldf, gh, gw, boxes, box_ind, m, k, out, out_c, out_coff);
+        else hipLaunchKernelGGL(roi_align_fwd_composed_kernel<8>, dim3(m * k), dim3(256), lds, as_stream(stream), fm, fm_dtype, nb, hf, wf, c,
+                                ldf, gh, gw, boxes, box_ind, m, k, out, out_c, out_coff);
+        DIN_CHECK_LAUNCH("roi_align_fwd(resized)");
+        return DIN_OK;
+    }
     if (c % v == 0 && ldf % v == 0 && lds <= 64 * 1024) {
         if (v == 4) hipLaunchKernelGGL(roi_align_fwd_kernel<4>, dim3(m * k), dim3(256), lds, as_stream(stream), fm, fm_dtype, nb, hf, wf, c, ldf,
-                                       boxes, box_ind, m, k, out, idx_out);
+                                       boxes, box_ind, m, k, out, idx_out, out_c, out_coff);
         else hipLaunchKernelGGL(roi_align_fwd_kernel<8>, dim3(m * k), dim3(256), lds, as_stream(stream), fm, fm_dtype, nb, hf, wf, c, ldf,
-                                boxes, box_ind, m, k, out, idx_out);
+                                boxes, box_ind, m, k, out, idx_out, out_c, out_coff);
     } else
         hipLaunchKernelGGL(roi_align_fwd_kernel<1>, dim3(m * k), dim3(256), 0, as_stream(stream), fm, fm_dtype, nb, hf, wf, c, ldf,
-                           boxes, box_ind, m, k, out, idx_out);
+                           boxes, box_ind, m, k, out, idx_out, out_c, out_coff);
     DIN_CHECK_LAUNCH("roi_align_fwd");
     return DIN_OK;
 }
@@ -402,38 +518,44 @@ int din_roi_align_bwd(const float* dout, int nb, int hf, int wf, int c, const fl
     return DIN_OK;
 }
 
-int din_roi_align_bwd_nhwc(const float* dout, int nb, int hf, int wf, int c, const float* boxes, const int32_t* box_ind, int m,
-                           int k, const void* fm_mask, int dtype, int ldf, void* gfm, int ldg, float* scratch, void* stream) {
+int din_roi_crop_grad_transpose(const float* dout, int m, int c, int k, float* out, void* stream) {
+    DIN_REQUIRE(dout && out, "roi_crop_grad_transpose: null pointer");
+    DIN_REQUIRE(m >= 0 && c > 0 && k > 0 && k <= 64, "roi_crop_grad_transpose: bad shape");
+    if (m == 0) return DIN_OK;
+    const int kk = k * k;
+    hipLaunchKernelGGL(roi_transpose_kernel, dim3(m, (c + 63) / 64), dim3(256), (size_t)64 * (kk + 1) * sizeof(float), as_stream(stream), dout, out, c, kk);
+    DIN_CHECK_LAUNCH("roi_crop_grad_transpose");
+    return DIN_OK;
+}
+
+int din_roi_align_bwd_nhwc(const float* dout, int dout_c, int dout_coff, int transposed, int nb, int hf, int wf, int c, int gh, int gw,
+                           const float* boxes, const int32_t* box_ind, int m, int k, const void* fm_mask, int dtype, int ldf, void* gfm,
+                           int ldg, void* stream) {
     DIN_REQUIRE(dout && boxes && box_ind && gfm, "roi_align_bwd_nhwc: null pointer");
     DIN_REQUIRE(nb > 0 && hf > 1 && wf > 1 && c > 0 && k > 0 && k <= 64 && m >= 0, "roi_align_bwd_nhwc: bad shape");
     DIN_REQUIRE(dtype == DIN_F32 || dtype == DIN_BF16, "roi_align_bwd_nhwc: bad dtype");
+    DIN_REQUIRE(dout_coff >= 0 && dout_c >= dout_coff + c, "roi_align_bwd_nhwc: channels [%d, %d) do not fit a %d-channel crop", dout_coff, dout_coff + c, dout_c);
+    DIN_REQUIRE(gh >= hf && gw >= wf, "roi_align_bwd_nhwc: the box grid %dx%d must not be smaller than the stored map %dx%d", gh, gw, hf, wf);
     const int v = dtype == DIN_F32 ? 4 : 8;
     DIN_REQUIRE(c % v == 0 && ldg % v == 0 && ldg >= c && (!fm_mask || (ldf % v == 0 && ldf >= c)),
                 "roi_align_bwd_nhwc: channels / pixel strides must be multiples of %d", v);
-    // boxes of one frame handled per batch: LDS = cap * (16 + 16 k) bytes, at most 48 KiB
+    DIN_REQUIRE(!transposed || (dout_c % 4 == 0 && dout_coff % 4 == 0), "roi_align_bwd_nhwc: transposed crop gradient needs 16-byte channel groups");
+    // boxes of one frame handled per batch: LDS = cap * (16 + 20 k) bytes, at most 48 KiB
     int cap = m < 1 ? 1 : m;
-    const int cap_max = (48 * 1024) / (16 + 16 * k);
+    const int cap_max = (48 * 1024) / (16 + 20 * k);
     if (cap > cap_max) cap = cap_max;
     if (cap > 256) cap = 256;
-    const size_t lds = (size_t)cap * (16 + 16 * k);
+    const size_t lds = (size_t)cap * (16 + 20 * k);
     // a dense view is cleared with one memset (runs at the HBM write rate) and the kernel only touches the boxes' footprints
     const int prezeroed = ldg == c ? 1 : 0;
     if (prezeroed && hipMemsetAsync(gfm, 0, (size_t)nb * hf * wf * ldg * (dtype == DIN_F32 ? 4 : 2), as_stream(stream)) != hipSuccess)
         DIN_FAIL(DIN_E_LAUNCH, "roi_align_bwd_nhwc: memset");
-    int transposed = 0;
-    if (scratch && m > 0) {                                            // channel-contiguous copy of the crop gradient (m * c * k * k floats)
-        const int kk = k * k;
-        hipLaunchKernelGGL(roi_transpose_kernel, dim3(m, (c + 63) / 64), dim3(256), (size_t)64 * (kk + 1) * sizeof(float), as_stream(stream),
-                           dout, scratch, c, kk);
-        dout = scratch;
-        transposed = 1;
-    }
     if (dtype == DIN_F32)
         hipLaunchKernelGGL(roi_align_bwd_gather_kernel<float>, dim3(nb * hf), dim3(256), lds, as_stream(stream), dout, nb, hf, wf, c, boxes,
-                           box_ind, m, k, (const float*)fm_mask, ldf, (float*)gfm, ldg, cap, prezeroed, transposed);
+                           box_ind, m, k, (const float*)fm_mask, ldf, (float*)gfm, ldg, cap, prezeroed, transposed, gh, gw, dout_c, dout_coff);
     else
         hipLaunchKernelGGL(roi_align_bwd_gather_kernel<bf16_t>, dim3(nb * hf), dim3(256), lds, as_stream(stream), dout, nb, hf, wf, c, boxes,
-                           box_ind, m, k, (const bf16_t*)fm_mask, ldf, (bf16_t*)gfm, ldg, cap, prezeroed, transposed);
+                           box_ind, m, k, (const bf16_t*)fm_mask, ldf, (bf16_t*)gfm, ldg, cap, prezeroed, transposed, gh, gw, dout_c, dout_coff);
     DIN_CHECK_LAUNCH("roi_align_bwd_nhwc");
     return DIN_OK;
 }

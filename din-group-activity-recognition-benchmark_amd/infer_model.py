@@ -75,12 +75,19 @@ class _DynamicBase(nn.Module):
         boxes_flat = boxes_in.reshape(B * T * N, 4)
         boxes_idx = ops.boxes_frame_index(B * T, N, boxes_in.device)                  # infer_model.py:155-157
         bufs, graph = self.backbone.forward_nhwc(images_flat)                        # prep fused (:161-162)
-        fm = bufs[0]                                                                 # multiscale-fused map (:165-172)
-        assert tuple(fm.shape[1:3]) == (OH, OW), f"backbone output {tuple(fm.shape[1:3])} != cfg.out_size {(OH, OW)}"
-        assert fm.shape[3] >= D
-        tid = graph.output_tids[0]
-        crops = self.roi_align(fm, boxes_flat, boxes_idx, nhwc=True, channels=D,
-                               relu_masked=graph.tensors[tid].relu_masked)          # [BTN, D, K, K]  (:178-180)
+        fm = bufs[0]
+        assert tuple(fm.shape[1:3]) == (OH, OW), f"backbone output {tuple(fm.shape[1:3])} != cfg.out_size {(OH, OW)}"   # (:164)
+        views = self.backbone.output_views(graph)
+        if fm.shape[3] >= D:                                                         # one map holds all D channels (VGG; materialised fuse)
+            tid = graph.output_tids[0]
+            crops = self.roi_align(fm, boxes_flat, boxes_idx, nhwc=True, channels=D,
+                                   relu_masked=graph.tensors[tid].relu_masked)      # [BTN, D, K, K]  (:178-180)
+        else:
+            # multi-scale fuse + RoIAlign in one step (:165-180): every backbone output is sampled through its virtual align_corners
+            # resize to (OH, OW); the resized / concatenated map is never built, forward or backward
+            assert sum(c for _, _, c in views) == D, f"backbone outputs hold {sum(c for _, _, c in views)} channels, cfg.emb_features = {D}"
+            maps = [(b, c, graph.tensors[tid].relu_masked) for b, (tid, _coff, c) in zip(bufs, views)]
+            crops = self.roi_align.forward_multiscale(maps, boxes_flat, boxes_idx, (OH, OW))
         feats = crops.reshape(B, T, N, D * K * K)
         x = ops.linear(feats, self.fc_emb_1.weight, self.fc_emb_1.bias,
                        lowp=getattr(self.cfg, "backbone_dtype", "fp32") == "bf16")              # :184

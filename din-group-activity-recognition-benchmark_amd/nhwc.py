@@ -901,7 +901,7 @@ class NHWCGraphFunction(torch.autograd.Function):
         ctx.params = params
         ctx.need = [p.requires_grad for p in params]
         outs = tuple(bufs[t] for t in graph.output_tids)
-        ctx.mark_non_differentiable()
+        ctx.set_materialize_grads(False)                   # an unused output must not cost a zero-filled gradient map (0.5 GB for Mixed_6e)
         return outs if len(outs) > 1 else outs[0]
 
     @staticmethod

@@ -38,6 +38,43 @@ def boxes_frame_index(bt: int, n: int, device) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 # Row R: RoIAlign
 # ------------------------------------------------------------------------------------------------
+def _roi_forward(lib, fms, chans, grid, boxes, box_ind, k, want_index):
+    """crops fp32 [m, sum(chans), k, k]: one launch per stored map, each writes its channel range (the torch.cat of infer_model.py:172)"""
+    m, ctot = boxes.shape[0], sum(chans)
+    out = torch.empty((m, ctot, k, k), dtype=torch.float32, device=boxes.device)
+    idx = torch.empty((m, k, k, 6), dtype=torch.int32, device=boxes.device) if want_index else None
+    coff = 0
+    for fm, c in zip(fms, chans):
+        nb, hf, wf, ld = fm.shape
+        gh, gw = grid if grid is not None else (hf, wf)
+        L.check(lib.din_roi_align_fwd(_ptr(fm), din_dtype(fm), nb, hf, wf, c, ld, gh, gw, _ptr(boxes), _ptr(box_ind), m, k,
+                                      _ptr(out), ctot, coff, _ptr(idx) if (hf, wf) == (gh, gw) else None, _stream()), "roi_align_fwd")
+        coff += c
+    return out, idx
+
+
+def _roi_backward(lib, gout, fms, chans, masked, grid, boxes, box_ind, k):
+    """gather form: every stored map's gradient tensor is written once, in the map's storage type, already multiplied by the ReLU mask
+    of the map (no fp32 scatter buffer, no cast pass); with a larger box grid this is also the backward of the bilinear resize"""
+    st = _stream()
+    m, ctot = boxes.shape[0], sum(chans)
+    gout = gout.contiguous().float()
+    src, transposed = gout, 0
+    if ctot % 4 == 0 and all(c % 4 == 0 for c in chans):
+        src, transposed = torch.empty_like(gout), 1                  # channel-contiguous copy of the crop gradient, shared by the maps
+        L.check(lib.din_roi_crop_grad_transpose(_ptr(gout), m, ctot, k, _ptr(src), st), "roi_crop_grad_transpose")
+    grads, coff = [], 0
+    for fm, c, mk in zip(fms, chans, masked):
+        nb, hf, wf, ld = fm.shape
+        gh, gw = grid if grid is not None else (hf, wf)
+        gfm = torch.zeros_like(fm) if ld != c else torch.empty_like(fm)
+        L.check(lib.din_roi_align_bwd_nhwc(_ptr(src), ctot, coff, transposed, nb, hf, wf, c, gh, gw, _ptr(boxes), _ptr(box_ind), m, k,
+                                           _ptr(fm) if mk else None, din_dtype(fm), ld, _ptr(gfm), ld, st), "roi_align_bwd_nhwc")
+        grads.append(gfm)
+        coff += c
+    return grads
+
+
 class RoIAlignFunction(torch.autograd.Function):
     """fm: NHWC buffer [nb,hf,wf,ld] (fp32|bf16) -> crops fp32 [m, c, k, k] (reference flatten order)."""
 
@@ -48,12 +85,7 @@ class RoIAlignFunction(torch.autograd.Function):
         boxes = boxes.detach().float().contiguous()
         box_ind = box_ind.detach().to(torch.int32).contiguous()
         require_gpu(fm, boxes, box_ind)
-        nb, hf, wf, ld = fm.shape
-        m = boxes.shape[0]
-        out = torch.empty((m, c, k, k), dtype=torch.float32, device=fm.device)
-        idx = torch.empty((m, k, k, 6), dtype=torch.int32, device=fm.device) if want_index else None
-        L.check(lib.din_roi_align_fwd(_ptr(fm), din_dtype(fm), nb, hf, wf, c, ld, _ptr(boxes), _ptr(box_ind), m, k,
-                                      _ptr(out), _ptr(idx), _stream()), "roi_align_fwd")
+        out, idx = _roi_forward(lib, [fm], [c], None, boxes, box_ind, k, want_index)
         ctx.save_for_backward(fm, boxes, box_ind)
         ctx.k, ctx.c, ctx.relu_masked = k, c, relu_masked
         if want_index:
@@ -63,21 +95,33 @@ class RoIAlignFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout, *_):
-        lib = L.load()
         fm, boxes, box_ind = ctx.saved_tensors
-        nb, hf, wf, ld = fm.shape
-        k, c = ctx.k, ctx.c
-        gout = gout.contiguous()
-        st = _stream()
-        # gather form: the gradient tensor is written once, in the feature map's storage type, already multiplied by the ReLU mask
-        # of the cropped tensor (no fp32 scatter buffer, no zero-fill, no cast pass)
-        gfm = torch.zeros_like(fm) if ld != c else torch.empty_like(fm)
-        gout = gout.float()
-        scratch = torch.empty_like(gout)                    # channel-contiguous copy of the crop gradient (made inside the call)
-        L.check(lib.din_roi_align_bwd_nhwc(_ptr(gout), nb, hf, wf, c, _ptr(boxes), _ptr(box_ind), boxes.shape[0], k,
-                                           _ptr(fm) if ctx.relu_masked else None, din_dtype(fm), ld, _ptr(gfm), ld, _ptr(scratch), st),
-                "roi_align_bwd_nhwc")
+        (gfm,) = _roi_backward(L.load(), gout, [fm], [ctx.c], [ctx.relu_masked], None, boxes, box_ind, ctx.k)
         return gfm, None, None, None, None, None, None
+
+
+class RoIAlignMultiScaleFunction(torch.autograd.Function):
+    """RoIAlign over torch.cat([resize(fm_i, grid) for fm_i in fms], channel) without building it (infer_model.py:165-180): boxes are
+    in `grid` = (OH, OW) pixels, every stored map fm_i [nb,h_i,w_i,ld_i] (h_i <= OH, w_i <= OW) is sampled through its virtual
+    align_corners resize, and the backward writes each map's gradient directly.  chans / masked: per-map channel count and "apply the
+    map's ReLU mask" flag.  Returns crops fp32 [m, sum(chans), k, k]."""
+
+    @staticmethod
+    def forward(ctx, boxes: torch.Tensor, box_ind: torch.Tensor, k: int, grid, chans, masked, *fms):
+        lib = L.load()
+        boxes = boxes.detach().float().contiguous()
+        box_ind = box_ind.detach().to(torch.int32).contiguous()
+        require_gpu(boxes, box_ind, *fms)
+        out, _ = _roi_forward(lib, fms, list(chans), tuple(grid), boxes, box_ind, k, False)
+        ctx.save_for_backward(boxes, box_ind, *fms)
+        ctx.k, ctx.grid, ctx.chans, ctx.masked = k, tuple(grid), list(chans), list(masked)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        boxes, box_ind, *fms = ctx.saved_tensors
+        grads = _roi_backward(L.load(), gout, fms, ctx.chans, ctx.masked, ctx.grid, boxes, box_ind, ctx.k)
+        return (None, None, None, None, None, None, *grads)
 
 
 # ------------------------------------------------------------------------------------------------

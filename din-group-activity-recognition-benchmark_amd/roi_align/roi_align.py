@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from ..nhwc import _ptr, _stream
-from ..ops import RoIAlignFunction
+from ..ops import RoIAlignFunction, RoIAlignMultiScaleFunction
 
 
 class _NCHWToNHWC(torch.autograd.Function):
@@ -52,3 +52,10 @@ class RoIAlign(nn.Module):
             fm, c = _NCHWToNHWC.apply(featuremap), featuremap.shape[1]
             relu_masked = False
         return RoIAlignFunction.apply(fm, boxes, box_ind, self.crop_height, c, relu_masked)
+
+    def forward_multiscale(self, maps, boxes, box_ind, grid):
+        """maps: [(NHWC buffer, channels, relu_masked), ...] at their own resolutions; boxes in `grid` = (OH, OW) pixels.  Equals
+        forward(torch.cat([F.interpolate(m, grid, mode='bilinear', align_corners=True) for m in maps], 1), ...) -- the multi-scale fuse of
+        infer_model.py:165-180 -- without materialising the resized / concatenated map."""
+        fms, chans, masked = zip(*maps)
+        return RoIAlignMultiScaleFunction.apply(boxes, box_ind, self.crop_height, tuple(grid), tuple(chans), tuple(masked), *fms)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DIN_ABI_VERSION 2   /* 2: din_walk_* take plain / clamp / n_per_clip, din_roi_align_bwd_nhwc takes scratch; + bn, mask_actors */
+#define DIN_ABI_VERSION 3   /* 2: din_walk_* take plain / clamp / n_per_clip; + bn, mask_actors.  3: din_roi_align_* take the box grid and a crop channel range */
 
 enum { DIN_F32 = 0, DIN_BF16 = 1 };
 
@@ -212,27 +212,36 @@ int din_bilinear_bwd(const din_pool_desc* d, const void* dout, void* din_, const
 
 /* ------------------------------------------------------------------------------------------------
  * Row R  RoIAlign(K,K) = TF crop_and_resize, transform_fpcoor=True (third-party longcw/RoIAlign.pytorch;
- * call site infer_model.py:178-180).  fm: NHWC [nb,hf,wf,c] (dtype fm_dtype, pixel stride ldf);
- * boxes [m,4]=(x1,y1,x2,y2) feature px fp32; box_ind [m] int32; out fp32 [m][c][k][k] (the reference's
- * flatten order d,ky,kx: infer_model.py:181).  idx_out (nullable) int32 [m][k][6] =
- * (top,bottom,left,right,oob_y,oob_x) per sample row/col for bit-exact index tests.
+ * call site infer_model.py:178-180), optionally composed with the multi-scale fuse in front of it
+ * (infer_model.py:165-172: F.interpolate(size=(OH,OW), mode='bilinear', align_corners=True) + torch.cat).
+ * fm: the STORED map, NHWC [nb,hf,wf,c] (dtype fm_dtype, pixel stride ldf).  (gh,gw): the grid the boxes are expressed on.
+ * gh==hf && gw==wf is the plain RoIAlign; a larger grid means "fm virtually resized to gh x gw with align_corners": each sample
+ * is then a 3x3 weighted sum of stored pixels (both operations are separable and linear) and the resized map is never materialised.
+ * boxes [m,4]=(x1,y1,x2,y2) grid px fp32; box_ind [m] int32; out fp32 [m][out_c][k][k] (the reference's flatten order
+ * d,ky,kx: infer_model.py:181), this map's c channels at [out_coff, out_coff+c) -- one call per source of the torch.cat.
+ * idx_out (nullable, plain sampling only) int32 [m][k][6] = (top,bottom,left,right,oob_y,oob_x) per sample row/col for
+ * bit-exact index tests.
  * ---------------------------------------------------------------------------------------------- */
-int din_roi_align_fwd(const void* fm, int fm_dtype, int nb, int hf, int wf, int c, int ldf,
+int din_roi_align_fwd(const void* fm, int fm_dtype, int nb, int hf, int wf, int c, int ldf, int gh, int gw,
                       const float* boxes, const int32_t* box_ind, int m, int k,
-                      float* out, int32_t* idx_out, void* stream);
+                      float* out, int out_c, int out_coff, int32_t* idx_out, void* stream);
 /* dfm fp32 [nb,hf,wf,c] must be zeroed by the caller; 4-corner atomic scatter; no gradient to boxes */
 int din_roi_align_bwd(const float* dout, int nb, int hf, int wf, int c,
                       const float* boxes, const int32_t* box_ind, int m, int k,
                       float* dfm, void* stream);
-/* Gather form of the same gradient, written once into the feature map's gradient view gfm [nb,hf,wf,ldg] (storage `dtype`, channels
+/* crop gradient [m][c][k*k] (the reference's flatten order = the column order of fc_emb_1) -> channel-contiguous [m][k*k][c]: the
+ * gather backward then reads 16/32-byte runs instead of 4-byte loads 4*k*k bytes apart.  One call serves every source map. */
+int din_roi_crop_grad_transpose(const float* dout, int m, int c, int k, float* out, void* stream);
+/* Gather form of the gradient, written once into the stored map's gradient view gfm [nb,hf,wf,ldg] (storage `dtype`, channels
  * [0,c), every pixel -- zeros outside the boxes): no atomics, no fp32 staging tensor, no zero-fill, deterministic summation order.
- * fm_mask (nullable, same dtype, pixel stride ldf): the cropped tensor; gradients are multiplied by (fm_mask > 0) -- the fused
- * backward of the ReLU that produced it.  box_ind may be in any order.
- * scratch (nullable, fp32 [m*c*k*k]): when given, dout ([m][c][k*k], the reference's flatten order = the column order of fc_emb_1) is
- * first copied channel-contiguous ([m][k*k][c]) and the gather reads 16/32-byte runs instead of 4-byte loads 4*k*k bytes apart. */
-int din_roi_align_bwd_nhwc(const float* dout, int nb, int hf, int wf, int c,
-                           const float* boxes, const int32_t* box_ind, int m, int k,
-                           const void* fm_mask, int dtype, int ldf, void* gfm, int ldg, float* scratch, void* stream);
+ * dout: the crop gradient with dout_c channels per crop, this map's at [dout_coff, dout_coff+c); layout [m][dout_c][k*k], or
+ * [m][k*k][dout_c] when `transposed` (din_roi_crop_grad_transpose).  (gh,gw) as in din_roi_align_fwd: with a larger grid this is the
+ * fused backward of RoIAlign AND the bilinear resize.
+ * fm_mask (nullable, same dtype, pixel stride ldf): the stored map; gradients are multiplied by (fm_mask > 0) -- the fused
+ * backward of the ReLU that produced it.  box_ind may be in any order. */
+int din_roi_align_bwd_nhwc(const float* dout, int dout_c, int dout_coff, int transposed, int nb, int hf, int wf, int c,
+                           int gh, int gw, const float* boxes, const int32_t* box_ind, int m, int k,
+                           const void* fm_mask, int dtype, int ldf, void* gfm, int ldg, void* stream);
 /* fp32 gradient map -> backbone dtype, fused with the ReLU mask of the feature map that was cropped */
 int din_grad_cast_mask(const float* g, const void* y, void* out, int dtype, int64_t pixels, int c,
                        int ldy, int yoff, int ldo, int ooff, int use_mask, void* stream);

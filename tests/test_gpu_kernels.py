@@ -417,6 +417,48 @@ def test_bilinear_cells_kernel_is_bit_identical(env, shape, monkeypatch):
     assert torch.equal(res[0], res[1])
 
 
+@pytest.mark.parametrize("shape", [(2, 43, 78, 192, 768, 576, "bf16"), (3, 15, 23, 64, 288, 224, "bf16"), (2, 9, 5, 16, 16, 0, "fp32"),
+                                   (1, 3, 1, 8, 24, 8, "fp32")], ids=["6e_pool_bf16", "5d_pool_bf16", "h_gt_strip_fp32", "one_column_fp32"])
+def test_avgpool_strip_kernel_is_bit_identical(env, shape, monkeypatch):
+    """the column-strip 3x3 box filter (taps of R + 2 rows kept in registers) sums every output in the order of the one-thread-per-output
+    kernel (= ATen's avg_pool2d loop), forward (+ bias, ReLU, strided destination view) and backward (+ ReLU mask, accumulate)"""
+    lib, L, nhwc, ops = env
+    nb, h, w, c, ldo, coff, dtype = shape
+    tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(nb, h, w, c, generator=g).to(tdt).cuda()
+    bias = torch.randn(c, generator=g).cuda()
+    d = L.PoolDesc()
+    d.nb, d.h, d.w, d.c, d.oh, d.ow = nb, h, w, c, h, w
+    d.k, d.stride, d.pad, d.ldi, d.cioff, d.ldo, d.cooff = 3, 1, 1, c, 0, ldo, coff
+    d.dtype = L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
+    for flags, b in ((0, None), (L.CONV_BIAS | L.CONV_RELU, bias.data_ptr())):
+        outs = []
+        for mode in ("0", "1"):
+            monkeypatch.setenv("DIN_AVGPOOL_STRIP", mode)
+            out = torch.full((nb, h, w, ldo), float("nan"), dtype=tdt, device="cuda")
+            L.check(lib.din_avgpool_fwd(C.byref(d), x.data_ptr(), out.data_ptr(), b, flags, None))
+            torch.cuda.synchronize()
+            outs.append(out)
+        view = slice(coff, coff + c)
+        assert not torch.isnan(outs[1][..., view].float()).any(), "an output pixel was not written"
+        assert torch.equal(outs[0][..., view], outs[1][..., view])
+        if ldo > c:
+            rest = torch.cat([outs[1][..., :coff], outs[1][..., coff + c:]], -1)
+            assert torch.isnan(rest.float()).all(), "wrote outside its channel range"
+    gout = torch.randn(nb, h, w, ldo, generator=g).to(tdt).cuda()
+    base = torch.randn(nb, h, w, c, generator=g).to(tdt).cuda()
+    for acc, mask in ((0, None), (1, x.data_ptr())):
+        res = []
+        for mode in ("0", "1"):
+            monkeypatch.setenv("DIN_AVGPOOL_STRIP", mode)
+            dx = base.clone()
+            L.check(lib.din_avgpool_bwd(C.byref(d), gout.data_ptr(), dx.data_ptr(), mask, acc, None))
+            torch.cuda.synchronize()
+            res.append(dx)
+        assert torch.equal(res[0], res[1])
+
+
 def test_prep_images_bit_exact(env):
     lib, L, nhwc, ops = env
     x = torch.arange(0, 256, dtype=torch.float32)
@@ -482,15 +524,61 @@ def test_roi_align_bwd_gather_matches_scatter(env, dtype):
     L.check(lib.din_roi_align_bwd(gout.data_ptr(), nb, hf, wf, c, bd.data_ptr(), idv.data_ptr(), m, k, g32.data_ptr(), None))
     want = g32 * (fm.float() > 0).float()
     outs = []
-    for scratch in (None, torch.empty_like(gout)):            # reference-layout crop gradient / channel-contiguous staging copy
+    for staged in (False, True):                               # reference-layout crop gradient / channel-contiguous staging copy
         got = torch.full((nb, hf, wf, c), 9.0, dtype=tdt, device="cuda")
-        L.check(lib.din_roi_align_bwd_nhwc(gout.data_ptr(), nb, hf, wf, c, bd.data_ptr(), idv.data_ptr(), m, k, fm.data_ptr(), dt, c,
-                                           got.data_ptr(), c, scratch.data_ptr() if scratch is not None else None, None))
+        src = gout
+        if staged:
+            src = torch.empty_like(gout)
+            L.check(lib.din_roi_crop_grad_transpose(gout.data_ptr(), m, c, k, src.data_ptr(), None))
+            assert torch.equal(src.view(m, k * k, c), gout.view(m, c, k * k).transpose(1, 2))
+        L.check(lib.din_roi_align_bwd_nhwc(src.data_ptr(), c, 0, int(staged), nb, hf, wf, c, hf, wf, bd.data_ptr(), idv.data_ptr(), m, k,
+                                           fm.data_ptr(), dt, c, got.data_ptr(), c, None))
         torch.cuda.synchronize()
         assert rel(got.float(), want) <= (1e-5 if dtype == "fp32" else 1e-2)      # bf16: one rounding per batch
         assert bool(((want == 0) == (got.float() == 0)).all()), "footprint (zeros outside the boxes, mask) must match"
         outs.append(got)
     assert torch.equal(outs[0], outs[1]), "the staged copy must not change the summation order"
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("k", [5, 2])
+def test_roi_align_multiscale_equals_resize_cat_crop(env, dtype, k):
+    """RoIAlign through the virtual resize (ops.RoIAlignMultiScaleFunction) == RoIAlign(torch.cat([a, F.interpolate(b, size, 'bilinear',
+    align_corners=True)], 1)) -- the reference's multi-scale fuse, infer_model.py:165-180 -- forward and both maps' gradients (with the maps'
+    ReLU masks), incl. boxes outside / on the border / integer-aligned, and a grid that is not a multiple of the stored map."""
+    lib, L, nhwc, ops = env
+    g = torch.Generator().manual_seed(77 + k)
+    nb, ca, cb, gh, gw, hb, wb, n = 3, 32, 64, 23, 41, 11, 20, 12
+    tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    fa = torch.randn(nb, ca, gh, gw, generator=g).to(tdt).float()
+    fb = torch.randn(nb, cb, hb, wb, generator=g).to(tdt).float()
+    _, boxes, _ = O.synth_inputs(1, nb, n, 8, 8, gh, gw, seed=9)
+    boxes = boxes.reshape(nb * n, 4).clone()
+    boxes[5] = 0.0
+    boxes[6] = torch.tensor([-3.0, 2.0, 50.0, 30.0])
+    boxes[7] = torch.tensor([4.0, 4.0, 9.0, 9.0])
+    boxes[8] = torch.tensor([30.0, 15.0, 40.0, 22.0])              # touches the last row / column of the grid
+    ind = O.boxes_frame_index(nb, n)
+    far, fbr = fa.clone().requires_grad_(True), fb.clone().requires_grad_(True)
+    fused = torch.cat([far, F.interpolate(fbr, size=(gh, gw), mode="bilinear", align_corners=True)], 1)
+    ref = O.roi_align(fused, boxes, ind, k)
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot)
+    fad = to_nhwc(fa, tdt).requires_grad_(True)
+    fbd = to_nhwc(fb, tdt).requires_grad_(True)
+    for masked in (False, True):
+        fad.grad = fbd.grad = None
+        out = ops.RoIAlignMultiScaleFunction.apply(boxes.cuda(), ind.cuda(), k, (gh, gw), (ca, cb), (masked, masked), fad, fbd)
+        assert out.shape == ref.shape
+        assert torch.equal(out[:, :ca].detach().cpu(), ref[:, :ca].detach()), "the unresized map keeps the bit-exact plain sampling"
+        assert rel(out[:, ca:], ref[:, ca:]) <= 2e-6
+        out.backward(cot.cuda())
+        wa = far.grad * ((fa > 0).float() if masked else 1.0)
+        wb = fbr.grad * ((fb > 0).float() if masked else 1.0)
+        tol = 2e-5 if dtype == "fp32" else 1e-2
+        assert rel(fad.grad.float().cpu().permute(0, 3, 1, 2), wa) <= tol
+        assert rel(fbd.grad.float().cpu().permute(0, 3, 1, 2), wb) <= tol
+        assert bool(((wb == 0) == (fbd.grad.float().cpu().permute(0, 3, 1, 2) == 0)).all()), "footprint of the composed backward"
 
 
 def test_layernorm_variants(env):

@@ -23,7 +23,7 @@ def test_library_exports_every_header_symbol():
         assert hasattr(lib, n), f"{n} declared in include/din_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes table out of sync with include/din_hip.h"
     loaded = _lib.load()
-    assert loaded.din_abi_version() == _lib.ABI_VERSION == 2 and loaded.din_build_arch() == b"gfx950"
+    assert loaded.din_abi_version() == _lib.ABI_VERSION == 3 and loaded.din_build_arch() == b"gfx950"
 
 
 def test_conv_planning_is_callable_without_gpu():
@@ -66,9 +66,16 @@ def test_inception_graph_shapes_and_keys():
     from din_amd import _lib
     net = MyInception_v3(compute_dtype="bf16")
     g, dt = net.graph_for(720, 1280)
-    fused, t6e = g.output_tids
-    assert (g.tensors[fused].h, g.tensors[fused].w, g.tensors[fused].c) == (87, 157, 1056)
+    t5d, t6e = g.output_tids                          # the multi-scale fuse is composed into RoIAlign: the graph ends at the two stored maps
+    assert (g.tensors[t5d].h, g.tensors[t5d].w, g.tensors[t5d].c) == (87, 157, 288)
     assert (g.tensors[t6e].h, g.tensors[t6e].w, g.tensors[t6e].c) == (43, 78, 768)
+    assert not any(op.kind == "bilinear" for op in g.ops)
+    net.materialise_fuse = True                       # DIN_ROI_COMPOSE=0: the round-1 graph with the fused [5d | resize(6e)] tensor
+    gm = net.build_graph(720, 1280, dt)
+    fused = gm.output_tids[0]
+    assert (gm.tensors[fused].h, gm.tensors[fused].w, gm.tensors[fused].c) == (87, 157, 1056)
+    assert sum(op.kind == "bilinear" for op in gm.ops) == 1
+    net.materialise_fuse = False
     shapes = O.inception_v3_param_shapes("")
     sd = net.state_dict()
     for k, shp in shapes.items():

@@ -54,6 +54,22 @@ def main():
         print(f"maxpool fwd {c:3d}ch {h}x{w}: {ms * 1e3:8.1f} us  {b1 / ms / 1e9:6.2f} TB/s")
         ms = bench(lambda: L.check(lib.din_maxpool_bwd(C.byref(p), xi.data_ptr(), am.data_ptr(), yo.data_ptr(), gi.data_ptr(), 1, 0, None)))
         print(f"maxpool bwd {c:3d}ch {h}x{w}: {ms * 1e3:8.1f} us  {b1 / ms / 1e9:6.2f} TB/s")
+    # 3x3 / 1 / pad 1 average pools behind the commuted branch_pool 1x1 convs: (channels, h, w, pixel stride of the destination view)
+    for (c, h, w, ldo) in ((32, 87, 157, 256), (64, 87, 157, 288), (64, 87, 157, 1056), (192, 43, 78, 768)):
+        p = L.PoolDesc()
+        p.nb, p.h, p.w, p.c, p.oh, p.ow = nb, h, w, c, h, w
+        p.k, p.stride, p.pad, p.ldi, p.cioff, p.ldo, p.cooff, p.dtype = 3, 1, 1, c, 0, ldo, ldo - c, L.DIN_BF16
+        xi = torch.randn(nb, h, w, c, device="cuda").to(bf)
+        yo = torch.empty(nb, h, w, ldo, device="cuda", dtype=bf)
+        bias = torch.randn(c, device="cuda")
+        ms = bench(lambda: L.check(lib.din_avgpool_fwd(C.byref(p), xi.data_ptr(), yo.data_ptr(), bias.data_ptr(), L.CONV_BIAS | L.CONV_RELU, None)))
+        b1 = xi.numel() * 4
+        print(f"avgpool fwd {c:3d}ch {h}x{w} ldo {ldo}: {ms * 1e3:8.1f} us  {b1 / ms / 1e9:6.2f} TB/s")
+        q = L.PoolDesc()        # backward: dout is the strided view, din the dense conv output gradient
+        q.nb, q.h, q.w, q.c, q.oh, q.ow = nb, h, w, c, h, w
+        q.k, q.stride, q.pad, q.ldi, q.cioff, q.ldo, q.cooff, q.dtype = 3, 1, 1, c, 0, ldo, ldo - c, L.DIN_BF16
+        ms = bench(lambda: L.check(lib.din_avgpool_bwd(C.byref(q), yo.data_ptr(), xi.data_ptr(), None, 0, None)))
+        print(f"avgpool bwd {c:3d}ch {h}x{w} ldo {ldo}: {ms * 1e3:8.1f} us  {b1 / ms / 1e9:6.2f} TB/s")
 
 
 if __name__ == "__main__":

@@ -16,9 +16,15 @@ LAYERS = {  # name: (h, w, cin, cout, k, s, p)
     "Mixed_6e.branch1x1": (43, 78, 768, 192, (1, 1), 1, (0, 0)),
     "Mixed_6e.7x7_1+dbl_1": (43, 78, 768, 384, (1, 1), 1, (0, 0)),
     "Mixed_6b.7x7_1+dbl_1": (43, 78, 768, 256, (1, 1), 1, (0, 0)),
+    "Mixed_6c.7x7_2 (1x7 160)": (43, 78, 160, 160, (1, 7), 1, (0, 3)),
+    "Mixed_6c.7x7dbl_2 (7x1 160)": (43, 78, 160, 160, (7, 1), 1, (3, 0)),
+    "Mixed_6c.7x7_1+dbl_1": (43, 78, 768, 320, (1, 1), 1, (0, 0)),
+    "Mixed_6b.7x7_2 (1x7 128)": (43, 78, 128, 128, (1, 7), 1, (0, 3)),
+    "Mixed_5d.5x5_1+3x3dbl_1": (87, 157, 288, 112, (1, 1), 1, (0, 0)),
+    "Mixed_5c.3x3dbl_3": (87, 157, 96, 96, (3, 3), 1, (1, 1)),
 }
-MODES = [("ring", {"DIN_WGRAD_PIPE": "0"}), ("pipe", {"DIN_WGRAD_PIPE": "1", "DIN_WGRAD_ATOMIC": "0"}),
-         ("pipe+atomic", {"DIN_WGRAD_PIPE": "1", "DIN_WGRAD_ATOMIC": "1"})]
+MODES = [("ring", {"DIN_WGRAD_PIPE": "0"}), ("pipe-r1tiles", {"DIN_WGRAD_PIPE": "3", "DIN_WGRAD_ATOMIC": "0"}),
+         ("pipe", {"DIN_WGRAD_PIPE": "1", "DIN_WGRAD_ATOMIC": "0"})]
 
 
 def main():
