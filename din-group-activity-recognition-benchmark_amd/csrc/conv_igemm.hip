@@ -2426,6 +2426,10 @@ template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS, bool FAS
 void launch_fast(const ConvK& k, dim3 grid, hipStream_t st) {
     constexpr int LR_ = 64 * WM * WN / KCS, BNP_ = (BN + LR_ - 1) / LR_ * LR_;       // filter rows padded to whole loader passes
     size_t stage = (size_t)NS * (BMT + BNP_) * KCS * 16 + (k.remap ? 128 : 0);   // stage ring (+ remap table)
+    // a single k-step (1x1 layers with <= 64 input channels: Conv2d_3b, the 64-channel dgrads) only ever touches ring stage 0: ask for one
+    // stage, so that more of these memory-bound workgroups are resident per CU and their loads / stores overlap (DIN_CONV_ONESTAGE=0: off)
+    static const bool one_stage_ok = !(getenv("DIN_CONV_ONESTAGE") && atoi(getenv("DIN_CONV_ONESTAGE")) == 0);
+    if (one_stage_ok && !k.remap && k.ks_per_split * (8 / KCS) <= 1) stage = (size_t)(BMT + BNP_) * KCS * 16;
     size_t epi = (size_t)BMT * (BN * sizeof(T) + 16);
     size_t lds = stage > epi ? stage : epi;
     auto kern = conv_gather_fast_kernel<T, BMT, BN, WM, WN, KCS, NS, false, FASTK>;
