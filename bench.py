@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--frames", type=int, default=None, help="frames per clip T (default 3; collective and --hierarchical 10)")
     ap.add_argument("--lite-dim", type=int, default=None, help="BASELINE configs[2]: lite-DIN projection width (128 in the reference)")
     ap.add_argument("--hierarchical", action="store_true", help="BASELINE configs[3]: ST-factorised [(1,3),(3,1)] hierarchical DIN (T defaults to 10)")
+    ap.add_argument("--tce", action="store_true", help="Dynamic_TCE_volleyball (SURVEY 8(f)-4; scripts/train_volleyball_stage2_dynamic_tce.py: "
+                    "vgg16 trunk, T defaults to 10): DIN behind the 4-head context-encoding transformer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adam", action="store_true")
     ap.add_argument("--host-images", action="store_true", help="clips start in pinned host memory every step (uint8): the PCIe-inclusive rate, never the headline value")
@@ -173,7 +175,7 @@ def main():
 
     from din_amd import parallel, profiling
     profiling.install()
-    from din_amd.infer_model import Dynamic_collective, Dynamic_volleyball
+    from din_amd.infer_model import Dynamic_collective, Dynamic_TCE_volleyball, Dynamic_volleyball
     from din_amd.optim import FusedAdam
 
     rank, local, world = parallel.init_from_env()
@@ -182,7 +184,7 @@ def main():
     torch.cuda.set_device(dev)
     collective = a.workload.startswith("collective")
     if a.frames is None:
-        a.frames = COLLECTIVE["T"] if collective else (10 if a.hierarchical else 3)
+        a.frames = COLLECTIVE["T"] if collective else (10 if (a.hierarchical or a.tce) else 3)
     if a.global_batch is None:
         a.global_batch = COLLECTIVE["global_batch"] if collective else 32
     T, N, H, W = (a.frames, COLLECTIVE["N"], COLLECTIVE["H"], COLLECTIVE["W"]) if collective else (a.frames, 12, 720, 1280)
@@ -190,7 +192,10 @@ def main():
     cfg = make_cfg(a.workload, T, N, H, W, lite=a.lite_dim, hierarchical=a.hierarchical)
     cfg.set_bn_eval = a.bn_mode == "eval"
     torch.manual_seed(0)
-    model = (Dynamic_collective if collective else Dynamic_volleyball)(cfg)
+    if a.tce:
+        assert a.workload.startswith("vgg16") and not a.lite_dim, "--tce: the reference model only runs on the vgg16 trunk without lite_dim"
+        a.no_cpu_baseline = True                           # (the bounded CPU sample is defined for the DIN models of BASELINE.json only)
+    model = (Dynamic_TCE_volleyball if a.tce else Dynamic_collective if collective else Dynamic_volleyball)(cfg)
     synth_weights(model)
     model = model.to(dev).train()
     if cfg.set_bn_eval:
@@ -382,7 +387,7 @@ def main():
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic" + (" (uint8 clips copied from pinned host memory every step)" if a.host_images else ""),
             "config": {"workload": (f"Collective stage-2 DIN, {backbone}, T={T}, ST_kernel=(3,3), 1..{N} actors per clip, {H}x{W}, {dtype}" if collective else
-                                    f"Volleyball stage-2 DIN, {backbone}, T={T}, " +
+                                    ("Volleyball stage-2 TCE + DIN (Dynamic_TCE_volleyball)" if a.tce else "Volleyball stage-2 DIN") + f", {backbone}, T={T}, " +
                                     ("ST_kernel=[(1,3),(3,1)] hierarchical" if a.hierarchical else "ST_kernel=(3,3)") +
                                     (f", lite_dim={a.lite_dim}" if a.lite_dim else "") + f", N=12, {H}x{W}, {dtype}"),
                        "global_batch": a.global_batch, "clips_per_gpu": B, "frames": T, "parallelism": f"dp{world}",

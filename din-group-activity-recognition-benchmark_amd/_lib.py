@@ -103,6 +103,15 @@ SIGNATURES: Dict[str, tuple] = {
     "din_cast": (_I, [_P, _I, _P, _I, _L, _P]),
     "din_nhwc_to_nchw_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "din_nchw_f32_to_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
+    "din_ctx_scores": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "din_softmax_rows": (_I, [_P, _L, _I, _P]),
+    "din_softmax_rows_bwd": (_I, [_P, _P, _L, _I, _P]),
+    "din_ctx_apply": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "din_ctx_keys_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "din_add_position": (_I, [_P, _I, _P, _P, _L, _L, _P]),
+    "din_add_position_bwd": (_I, [_P, _P, _I, _P, _L, _I, _P]),
+    "din_act_dropout_fwd": (_I, [_P, _P, _L, _I, _F, _U64, _P]),
+    "din_act_dropout_bwd": (_I, [_P, _P, _P, _L, _I, _F, _U64, _P]),
     "din_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
     "din_adam_step_multi": (_I, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _I, _F, _P]),
 }

@@ -80,6 +80,21 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// counter-based dropout: the backward regenerates the forward's keep-mask from (seed, element index)
+__device__ __forceinline__ uint32_t mix32(uint64_t x) {
+    // splitmix64 finaliser -> 32 random bits
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x = x ^ (x >> 31);
+    return (uint32_t)(x >> 32);
+}
+__device__ __forceinline__ float keep_scale(uint64_t seed, int64_t idx, float p) {
+    if (p <= 0.f) return 1.f;
+    float u = (float)(mix32(seed ^ ((uint64_t)idx * 0xD1342543DE82EF95ull)) >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? 1.f / (1.f - p) : 0.f;
+}
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int grid_1d(int64_t n, int block, int cap = 256 * 8) {
     int64_t g = ceil_div64(n, block);

@@ -9,20 +9,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-__device__ __forceinline__ uint32_t mix32(uint64_t x) {
-    // splitmix64 finaliser -> 32 random bits
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    x = x ^ (x >> 31);
-    return (uint32_t)(x >> 32);
-}
-__device__ __forceinline__ float keep_scale(uint64_t seed, int64_t idx, float p) {
-    if (p <= 0.f) return 1.f;
-    float u = (float)(mix32(seed ^ ((uint64_t)idx * 0xD1342543DE82EF95ull)) >> 8) * (1.0f / 16777216.0f);
-    return u >= p ? 1.f / (1.f - p) : 0.f;
-}
-
 template <int NW>
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);

@@ -20,6 +20,8 @@ from . import ops
 from .backbone.backbone import MyInception_v3, MyVGG16
 from .infer_module.dynamic_infer_module import (Dynamic_Person_Inference, Hierarchical_Dynamic_Inference,
                                                 Multi_Dynamic_Inference)
+from .infer_module.positional_encoding import Context_PositionEmbeddingSine
+from .infer_module.TCE_STBiP_module import MultiHeadLayerEmbfeatureContextEncoding
 from .roi_align.roi_align import RoIAlign
 from .utils import print_log
 
@@ -65,7 +67,7 @@ class _DynamicBase(nn.Module):
         print("Load model states from: ", filepath)
 
     # ---- shared front: images -> per-box embeddings [B,T,N,NFB] ------------------------------------------
-    def _embed(self, images_in, boxes_in, N):
+    def _embed(self, images_in, boxes_in, N, return_context: bool = False):
         cfg = self.cfg
         B, T = images_in.shape[0], images_in.shape[1]
         H, W = cfg.image_size
@@ -92,6 +94,10 @@ class _DynamicBase(nn.Module):
         x = ops.linear(feats, self.fc_emb_1.weight, self.fc_emb_1.bias,
                        lowp=getattr(self.cfg, "backbone_dtype", "fp32") == "bf16")              # :184
         x = ops.layer_norm(x, self.nl_emb_1.weight, self.nl_emb_1.bias, relu=True)   # :185-186
+        if return_context:                                                           # the LAST backbone output, pixel-major (:404)
+            tid_last, coff, c = views[-1]
+            assert coff == 0 and bufs[-1].shape[3] == c
+            return x, bufs[-1], graph.tensors[tid_last].relu_masked
         return x
 
     def _dropout_seed(self):
@@ -151,6 +157,71 @@ class Dynamic_volleyball(_DynamicBase):
         else:                                                                         # :203-209
             raise NotImplementedError
         scores = ops.HeadFunction.apply(s, self.fc_activities.weight, self.fc_activities.bias, None)   # :224-232
+        return {"activities": scores}
+
+
+class Dynamic_TCE_volleyball(_DynamicBase):
+    """DIN behind a context-encoding transformer (reference infer_model.py:237-468): every box embedding attends over
+    the pixels of its frame's last backbone map (+ sine position embedding) with 4 heads of 128 features; [embedding | context
+    encoding] (NFB + 512 channels) then goes through the same DIN modules and head as Dynamic_volleyball.
+
+    As in the reference, only the vgg16 / res18 head branches exist (:430-442; 'inv3' leaves `boxes_states` unbound there) and this
+    package has no res18 trunk, so cfg.backbone must be 'vgg16'; and lite_dim cannot be combined with it (the reference sizes
+    fc_activities for lite_dim but feeds it lite_dim + 512 channels, :341-343 vs :410-456)."""
+
+    NUM_HEADS_CONTEXT, NUM_FEATURES_CONTEXT = 4, 128                                   # :244-245
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        if cfg.backbone != "vgg16":
+            raise NotImplementedError("Dynamic_TCE_volleyball: the reference's forward only handles the vgg16 / res18 trunks "
+                                      "(infer_model.py:430-442) and its context transformer expects 512 context channels")
+        if cfg.lite_dim:
+            raise NotImplementedError("Dynamic_TCE_volleyball with lite_dim: the reference model cannot run (fc_activities is sized for "
+                                      "lite_dim, its input has lite_dim + 512 channels)")
+        T, N = cfg.num_frames, cfg.num_boxes
+        NFB, K = cfg.num_features_boxes, cfg.crop_size[0]
+        self._build_trunk(cfg)
+        print_log(getattr(cfg, "log_path", None), "Deactivate lite model inference.")
+        self.multilayer_head_embfeature_context_encoding = MultiHeadLayerEmbfeatureContextEncoding(
+            self.NUM_HEADS_CONTEXT, 1, self.NUM_FEATURES_CONTEXT, NFB, K, N, context_dropout_ratio=0.1)       # :287-292
+        self.context_positionembedding1 = Context_PositionEmbeddingSine(16, 512 / 2)                          # :293
+        context_dim = NFB + self.NUM_HEADS_CONTEXT * self.NUM_FEATURES_CONTEXT                                # :296
+        kernels = _as_kernel_list(cfg.ST_kernel_size)
+        if not cfg.hierarchical_inference:
+            self.DPI = Multi_Dynamic_Inference(in_dim=context_dim, person_mat_shape=(10, 12), stride=cfg.stride,
+                                               kernel_size=kernels, dynamic_sampling=cfg.dynamic_sampling,
+                                               sampling_ratio=cfg.sampling_ratio, group=cfg.group,
+                                               scale_factor=cfg.scale_factor, beta_factor=cfg.beta_factor,
+                                               parallel_inference=cfg.parallel_inference, num_DIM=cfg.num_DIM, cfg=cfg)
+        else:
+            self.DPI = Hierarchical_Dynamic_Inference(in_dim=context_dim, person_mat_shape=(T, N), stride=cfg.stride,
+                                                      kernel_size=kernels, dynamic_sampling=cfg.dynamic_sampling,
+                                                      sampling_ratio=cfg.sampling_ratio, group=cfg.group,
+                                                      scale_factor=cfg.scale_factor, beta_factor=cfg.beta_factor,
+                                                      parallel_inference=cfg.parallel_inference, cfg=cfg)
+        print_log(getattr(cfg, "log_path", None), "Hierarchical Inference : " + str(cfg.hierarchical_inference))
+        self.dpi_nl = nn.LayerNorm([T, N, context_dim])                                                       # :334
+        self.dropout_global = nn.Dropout(p=cfg.train_dropout_prob)
+        self.fc_activities = nn.Linear(context_dim, cfg.num_activities)                                       # :343
+        self._init_linears()
+
+    def forward(self, batch_data):
+        images_in, boxes_in = batch_data
+        cfg = self.cfg
+        B, T, N = images_in.shape[0], images_in.shape[1], cfg.num_boxes
+        x, context, masked = self._embed(images_in, boxes_in, N, return_context=True)       # [B,T,N,NFB], NHWC [BT,OH,OW,512]
+        context = self.context_positionembedding1(context, nhwc=True, relu_masked=masked)    # :404-406 (fp32)
+        enc = self.multilayer_head_embfeature_context_encoding
+        enc.seed_base = int(getattr(cfg, "train_random_seed", 0)) + 101
+        states = enc(x.reshape(B * T * N, -1), context, nhwc=True)                           # :408
+        xc = torch.cat((x, states.reshape(B, T, N, -1)), dim=3)                              # :409-410
+        graph, _mad = self.DPI(xc)                                                           # :414
+        p = cfg.train_dropout_prob if self.training else 0.0
+        s = ops.layer_norm(graph, self.dpi_nl.weight, self.dpi_nl.bias, res=xc, relu=True, drop_p=p,
+                           seed=self._dropout_seed())                                        # vgg16 branch :436-442
+        scores = ops.HeadFunction.apply(s, self.fc_activities.weight, self.fc_activities.bias, None)   # :452-466
         return {"activities": scores}
 
 

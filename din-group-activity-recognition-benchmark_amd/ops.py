@@ -355,6 +355,102 @@ class AxpbyFunction(torch.autograd.Function):
         return ga, gb, None, None
 
 
+# ------------------------------------------------------------------------------------------------
+# context-encoding transformer of Dynamic_TCE_volleyball
+# ------------------------------------------------------------------------------------------------
+class ContextAttentionFunction(torch.autograd.Function):
+    """q [BT,N,H*C] (box queries), kf [BT,P,H*C] (per-pixel keys = values) -> (ctx [BT,N,H*C], att [BT,H,N,P]).
+    att = softmax_P(<q, kf>) per head; ctx = att @ kf (TCE_STBiP_module.py:271-277).  att is returned for inspection (att_map)."""
+
+    @staticmethod
+    def forward(ctx, q: torch.Tensor, kf: torch.Tensor, heads: int):
+        lib = L.load()
+        q, kf = q.contiguous(), kf.contiguous()
+        require_gpu(q, kf)
+        bt, n, hc = q.shape
+        p = kf.shape[1]
+        assert kf.shape[0] == bt and kf.shape[2] == hc and hc % heads == 0, (q.shape, kf.shape, heads)
+        c = hc // heads
+        st = _stream()
+        att = torch.empty((bt, heads, n, p), dtype=torch.float32, device=q.device)
+        out = torch.empty_like(q)
+        L.check(lib.din_ctx_scores(_ptr(q), _ptr(kf), _ptr(att), bt, n, p, heads, c, st), "ctx_scores")
+        L.check(lib.din_softmax_rows(_ptr(att), bt * heads * n, p, st), "softmax_rows")
+        L.check(lib.din_ctx_apply(_ptr(att), _ptr(kf), _ptr(out), bt, n, p, heads, c, st), "ctx_apply")
+        ctx.save_for_backward(q, kf, att)
+        ctx.dims = (bt, n, p, heads, c)
+        ctx.mark_non_differentiable(att)
+        return out, att
+
+    @staticmethod
+    def backward(ctx, gout, _gatt):
+        lib = L.load()
+        q, kf, att = ctx.saved_tensors
+        bt, n, p, heads, c = ctx.dims
+        gout = gout.contiguous()
+        st = _stream()
+        ds = torch.empty_like(att)
+        L.check(lib.din_ctx_scores(_ptr(gout), _ptr(kf), _ptr(ds), bt, n, p, heads, c, st), "ctx_scores(dA)")
+        L.check(lib.din_softmax_rows_bwd(_ptr(att), _ptr(ds), bt * heads * n, p, st), "softmax_rows_bwd")
+        dq, dkf = torch.empty_like(q), torch.empty_like(kf)
+        L.check(lib.din_ctx_apply(_ptr(ds), _ptr(kf), _ptr(dq), bt, n, p, heads, c, st), "ctx_apply(dq)")
+        L.check(lib.din_ctx_keys_grad(_ptr(att), _ptr(ds), _ptr(gout), _ptr(q), _ptr(dkf), bt, n, p, heads, c, st), "ctx_keys_grad")
+        return dq, dkf, None
+
+
+class AddPositionFunction(torch.autograd.Function):
+    """x: backbone output NHWC [BT,OH,OW,C] (fp32 | bf16), pos fp32 [OH,OW,C] -> fp32 x + pos (positional_encoding.py:91).
+    relu_masked: the gradient handed back to the backbone graph is multiplied by (x > 0), as the graph expects for ReLU outputs."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, pos: torch.Tensor, relu_masked: bool):
+        lib = L.load()
+        require_gpu(x, pos)
+        assert x.is_contiguous() and tuple(x.shape[1:]) == tuple(pos.shape), (x.shape, pos.shape)
+        pos = pos.contiguous().float()
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        L.check(lib.din_add_position(_ptr(x), din_dtype(x), _ptr(pos), _ptr(y), x.shape[0], pos.numel(), _stream()), "add_position")
+        ctx.save_for_backward(x)
+        ctx.relu_masked = relu_masked
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = L.load()
+        (x,) = ctx.saved_tensors
+        gy = gy.contiguous().float()
+        gx = torch.empty_like(x)
+        L.check(lib.din_add_position_bwd(_ptr(gy), _ptr(x), din_dtype(x), _ptr(gx), x.numel(), int(ctx.relu_masked), _stream()),
+                "add_position_bwd")
+        return gx, None, None
+
+
+class ActDropoutFunction(torch.autograd.Function):
+    """y = dropout(relu(x)) / dropout(x): the mask is a counter-based hash of (seed, element index), regenerated in the backward"""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, relu: bool, drop_p: float, seed: int):
+        lib = L.load()
+        x = x.contiguous()
+        require_gpu(x)
+        y = torch.empty_like(x)
+        L.check(lib.din_act_dropout_fwd(_ptr(x), _ptr(y), x.numel(), int(relu), float(drop_p), int(seed), _stream()), "act_dropout_fwd")
+        ctx.save_for_backward(x)
+        ctx.args = (relu, drop_p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = L.load()
+        (x,) = ctx.saved_tensors
+        relu, drop_p, seed = ctx.args
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        L.check(lib.din_act_dropout_bwd(_ptr(gy), _ptr(x), _ptr(gx), x.numel(), int(relu), float(drop_p), int(seed), _stream()),
+                "act_dropout_bwd")
+        return gx, None, None, None
+
+
 class ScaleByParamFunction(torch.autograd.Function):
     """out = x * scalar[idx] with the scalar read on the device (no host sync): beta-weighted ratio sum (:144-145)."""
 

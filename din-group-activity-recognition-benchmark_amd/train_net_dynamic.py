@@ -25,7 +25,7 @@ import torch.utils.data as data
 
 from . import parallel
 from .input_feed import DeviceFeed
-from .infer_model import Dynamic_collective, Dynamic_volleyball
+from .infer_model import Dynamic_collective, Dynamic_TCE_volleyball, Dynamic_volleyball
 from .optim import FusedAdam
 from .utils import AverageMeter, Timer, print_log
 
@@ -84,7 +84,8 @@ class SyntheticCollective(SyntheticVolleyball):
 
 
 def build_model(cfg):
-    registry = {"dynamic_volleyball": Dynamic_volleyball, "dynamic_collective": Dynamic_collective}
+    registry = {"dynamic_volleyball": Dynamic_volleyball, "dynamic_tce_volleyball": Dynamic_TCE_volleyball,
+                "dynamic_collective": Dynamic_collective}                            # reference train_net_dynamic.py:66-73
     if cfg.inference_module_name not in registry:
         raise NotImplementedError(f"{cfg.inference_module_name}: only the DIN models are on the MI355X hot path")
     return registry[cfg.inference_module_name](cfg)

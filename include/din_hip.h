@@ -249,6 +249,32 @@ int din_grad_cast_mask(const float* g, const void* y, void* out, int dtype, int6
 int din_boxes_frame_index(int32_t* out, int bt, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * SURVEY 8(f)-4  Context-encoding transformer of Dynamic_TCE_volleyball (infer_model.py:404-410;
+ * infer_module/TCE_STBiP_module.py:252-286 EmbfeatureContextEncodingTransformer, :300-313 the 4-head layer).  fp32.
+ * q [bt][n][heads*c] (emb_roi of every head), kf [bt][p][heads*c] (downsample2 of every head over the p = OH*OW context pixels),
+ * s / a [bt][heads][n][p].  n <= 16 (the reference asserts 12), c a power of two <= 256 (128 in the reference).
+ * ---------------------------------------------------------------------------------------------- */
+/* s = <q, kf> per (frame, head, box, pixel): torch.matmul(emb_roi_feature, image_feature) (:271).  Also the backward's dA = <dctx, kf>. */
+int din_ctx_scores(const float* q, const float* kf, float* s, int bt, int n, int p, int heads, int c, void* stream);
+/* F.softmax(a, dim=2) (:273) in place over rows of `len`; backward in place on da: ds = a * (da - sum(a * da)) */
+int din_softmax_rows(float* s, int64_t rows, int len, void* stream);
+int din_softmax_rows_bwd(const float* a, float* da, int64_t rows, int len, void* stream);
+/* out[bt][n][heads*c] = sum_p a * kf: torch.matmul(A, image_feature) (:277).  Also the backward's dq = sum_p ds * kf. */
+int din_ctx_apply(const float* a, const float* kf, float* out, int bt, int n, int p, int heads, int c, void* stream);
+/* dkf = a^T dctx + ds^T q: the gradient of both uses of the keys, written once */
+int din_ctx_keys_grad(const float* a, const float* ds, const float* dctx, const float* q, float* dkf, int bt, int n, int p, int heads,
+                      int c, void* stream);
+/* Context_PositionEmbeddingSine.forward's last line (positional_encoding.py:91): y[f][i] = float(x[f][i]) + pos[i]; x in the backbone's
+ * storage type (`dtype`), `per_frame` = OH*OW*C elements.  Backward: gx = cast(gy) (* (x > 0) when use_mask: the backbone graph takes
+ * gradients that are already multiplied by the ReLU mask of its output) */
+int din_add_position(const void* x, int dtype, const float* pos, float* y, int64_t frames, int64_t per_frame, void* stream);
+int din_add_position_bwd(const float* gy, const void* x, int dtype, void* gx, int64_t elems, int use_mask, void* stream);
+/* y = dropout(relu?(x)) (nn.ReLU + nn.Dropout of the FFN, TCE_STBiP_module.py:243-247; nn.Dropout on the attended context :277) with the
+ * counter-based keep mask of din_layernorm_* (same seed + element index -> same mask in the backward) */
+int din_act_dropout_fwd(const float* x, float* y, int64_t n, int relu, float drop_p, uint64_t seed, void* stream);
+int din_act_dropout_bwd(const float* gy, const float* x, float* gx, int64_t n, int relu, float drop_p, uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * LayerNorm (+residual, +ReLU, +dropout): nl_emb_1 (infer_model.py:185), point_ln (:192), dpi_nl (:214),
  * hier_LN (dynamic_infer_module.py:493).  x, res: [rows][len]; gamma/beta [len]; eps 1e-5.
  * y = dropout(relu?(LN(x + res?)*gamma + beta)).  stats: [rows][2] = (mean, rstd) saved for backward.

@@ -658,6 +658,153 @@ def dynamic_volleyball_forward(cfg: OracleCfg, p: Params, images: Tensor, boxes:
 
 
 # ----------------------------------------------------------------------------------------
+# SURVEY 8(f)-4 -- Dynamic_TCE_volleyball (infer_model.py:237-468): the DIN trunk with a context-encoding transformer in front
+# ----------------------------------------------------------------------------------------
+TCE_HEADS, TCE_FEATURES = 4, 128                # num_heads_context, num_features_context (infer_model.py:244-245)
+
+
+def context_position_embedding(oh: int, ow: int, downscale: float = 16.0, num_pos_feats: int = 256,
+                               temperature: float = 10000.0, dtype=torch.float32) -> Tensor:
+    """Context_PositionEmbeddingSine(16, 512 / 2) (infer_module/positional_encoding.py:50-92; built at infer_model.py:293): the
+    sine embedding [2 * num_pos_feats, OH, OW] that is ADDED to the context map.  Channels [0, 256) encode y, [256, 512) encode x;
+    inside each half channel 2i is sin, 2i+1 is cos of (coordinate * 16) / T^(2i / 256); coordinates are 1-based (a cumsum of ones)."""
+    y = torch.arange(1, oh + 1, dtype=torch.float32) * downscale                          # [OH]
+    x = torch.arange(1, ow + 1, dtype=torch.float32) * downscale                          # [OW]
+    i = torch.arange(num_pos_feats, dtype=torch.float32)
+    dim_t = temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / num_pos_feats)   # [C]
+    py = y[:, None] / dim_t                                                               # [OH, C]
+    px = x[:, None] / dim_t                                                               # [OW, C]
+    def interleave(a):                                                                    # sin on even, cos on odd channels
+        return torch.stack((a[:, 0::2].sin(), a[:, 1::2].cos()), dim=2).flatten(1)
+    py, px = interleave(py), interleave(px)
+    pos = torch.cat((py[:, None, :].expand(oh, ow, num_pos_feats), px[None, :, :].expand(oh, ow, num_pos_feats)), dim=2)
+    return pos.permute(2, 0, 1).contiguous().to(dtype)                                    # [2C, OH, OW]
+
+
+def tce_param_shapes(nfb: int, prefix: str = "multilayer_head_embfeature_context_encoding.") -> Dict[str, Tuple[int, ...]]:
+    """one layer of TCE_HEADS EmbfeatureContextEncodingTransformer heads (TCE_STBiP_module.py:224-249, 289-297)"""
+    c = TCE_FEATURES
+    shapes = {}
+    for j in range(TCE_HEADS):
+        q = f"{prefix}CET.{j}."
+        shapes[q + "downsample2.weight"] = (c, 512, 1, 1)
+        shapes[q + "downsample2.bias"] = (c,)
+        shapes[q + "emb_roi.weight"] = (c, nfb)
+        shapes[q + "emb_roi.bias"] = (c,)
+        for ln in ("layernorm1", "layernorm2"):
+            shapes[q + ln + ".weight"] = (c,)
+            shapes[q + ln + ".bias"] = (c,)
+        for lin in ("FFN.0", "FFN.3"):
+            shapes[q + lin + ".weight"] = (c, c)
+            shapes[q + lin + ".bias"] = (c,)
+    return shapes
+
+
+def tce_context_encoding(roi_feature: Tensor, context: Tensor, p: Params,
+                         prefix: str = "multilayer_head_embfeature_context_encoding.", return_attention: bool = False):
+    """MultiHeadLayerEmbfeatureContextEncoding, one layer (TCE_STBiP_module.py:252-286, 300-313), dropout off.
+    roi_feature [BT*N, NFB] (or [..., NFB]); context [BT, 512, OH, OW] (position embedding already added) -> [BT*N, HEADS * 128].
+    Per head: keys = values = 1x1 conv of the context (512 -> 128); query = Linear(NFB -> 128) of the box embedding; attention over
+    the OH*OW pixels of the box's own frame; LayerNorm(context + query); + FFN; LayerNorm."""
+    bt, _, oh, ow = context.shape
+    c = TCE_FEATURES
+    roi = roi_feature.reshape(-1, roi_feature.shape[-1])
+    n = roi.shape[0] // bt
+    outs, atts = [], []
+    for j in range(TCE_HEADS):
+        q_ = f"{prefix}CET.{j}."
+        img = F.conv2d(context, p[q_ + "downsample2.weight"], p[q_ + "downsample2.bias"])             # [BT,128,OH,OW]
+        emb = F.linear(roi, p[q_ + "emb_roi.weight"], p[q_ + "emb_roi.bias"])                        # [BT*N,128]
+        keys = img.reshape(bt, c, oh * ow)                                                             # [BT,128,P]
+        a = torch.bmm(emb.reshape(bt, n, c), keys)                                                     # [BT,N,P]
+        att = F.softmax(a, dim=2)
+        ctx = torch.bmm(att, keys.transpose(1, 2)).reshape(bt * n, c)                                  # [BT*N,128]
+        x = F.layer_norm(ctx + emb, (c,), p[q_ + "layernorm1.weight"], p[q_ + "layernorm1.bias"], 1e-5)
+        f = F.linear(F.relu(F.linear(x, p[q_ + "FFN.0.weight"], p[q_ + "FFN.0.bias"])), p[q_ + "FFN.3.weight"], p[q_ + "FFN.3.bias"])
+        x = F.layer_norm(x + f, (c,), p[q_ + "layernorm2.weight"], p[q_ + "layernorm2.bias"], 1e-5)
+        outs.append(x)
+        atts.append(att)
+    out = torch.cat(outs, dim=1)
+    return (out, atts) if return_attention else out
+
+
+def tce_model_param_shapes(cfg: OracleCfg) -> Dict[str, Tuple[int, ...]]:
+    """Dynamic_TCE_volleyball.__init__ (infer_model.py:241-351): the DIN modules, dpi_nl and (non-lite) fc_activities work on
+    context_dim = in_dim + 4 * 128 channels"""
+    t, n = cfg.num_frames, cfg.num_boxes
+    d, k, nfb = cfg.emb_features, cfg.crop_size[0], cfg.num_features_boxes
+    assert cfg.backbone == "vgg16", "the reference's Dynamic_TCE_volleyball.forward only has res18 / vgg16 head branches (infer_model.py:430-442)"
+    assert not cfg.lite_dim, "with lite_dim the reference concatenates lite_dim + 512 channels but sizes fc_activities for lite_dim: it cannot run"
+    shapes = dict(vgg16_param_shapes())
+    shapes["fc_emb_1.weight"] = (nfb, k * k * d)
+    shapes["fc_emb_1.bias"] = (nfb,)
+    shapes["nl_emb_1.weight"] = (nfb,)
+    shapes["nl_emb_1.bias"] = (nfb,)
+    shapes.update(tce_param_shapes(nfb))
+    c = nfb + TCE_HEADS * TCE_FEATURES
+    if cfg.hierarchical_inference:
+        for i, sub in enumerate(("DPI.DPI_1.", "DPI.DPI_2.")):
+            shapes.update(din_param_shapes(sub, c, tuple(cfg.ST_kernel_size[i]), cfg.sampling_ratio, cfg.scale_factor, cfg.beta_factor))
+        shapes["DPI.hier_LN.weight"] = (t, n, c)
+        shapes["DPI.hier_LN.bias"] = (t, n, c)
+    else:
+        for i in range(cfg.num_DIM):
+            shapes.update(din_param_shapes(f"DPI.DIMlist.{i}.", c, tuple(cfg.ST_kernel_size[i]), cfg.sampling_ratio, cfg.scale_factor,
+                                           cfg.beta_factor))
+    shapes["dpi_nl.weight"] = (t, n, c)
+    shapes["dpi_nl.bias"] = (t, n, c)
+    shapes["fc_activities.weight"] = (cfg.num_activities, c)
+    shapes["fc_activities.bias"] = (cfg.num_activities,)
+    return shapes
+
+
+def tce_synth_params(cfg: OracleCfg, seed: int) -> Params:
+    """Seeded parameters of the TCE fixtures (tools/gen_golden.py::tce_case and the tests share this recipe): synth_params for the trunk /
+    DIN / head; for the transformer LayerNorm gains around 1, small random biases, fan-in scaled weights."""
+    shapes = tce_model_param_shapes(cfg)
+    p = synth_params(shapes, seed=seed + 3, din_std=0.02)
+    g_ = torch.Generator().manual_seed(seed + 13)
+    for k in shapes:
+        if "context_encoding" in k:
+            if "layernorm" in k and k.endswith("weight"):
+                p[k] = 0.75 + 0.5 * torch.rand(shapes[k], generator=g_)
+            elif k.endswith("bias"):
+                p[k] = 0.1 * torch.randn(shapes[k], generator=g_)
+            else:
+                fan_in = 1
+                for d_ in shapes[k][1:]:
+                    fan_in *= d_
+                p[k] = torch.randn(shapes[k], generator=g_) * (1.0 / fan_in) ** 0.5
+    return p
+
+
+def dynamic_tce_volleyball_forward(cfg: OracleCfg, p: Params, images: Tensor, boxes: Tensor, return_intermediates: bool = False):
+    """Dynamic_TCE_volleyball.forward (infer_model.py:370-468), eval mode: the Dynamic_volleyball trunk up to the box embeddings, then
+    [embedding | context encoding of the LAST backbone output + position embedding] (1024 + 512 channels) through DIN and the vgg16 head."""
+    b, t = images.shape[:2]
+    n = cfg.num_boxes
+    h, w = cfg.image_size
+    k = cfg.crop_size[0]
+    outs = vgg16_features(prep_images(images.reshape(b * t, 3, h, w)), p)
+    fm = multiscale_fuse(outs, *cfg.out_size)
+    idx = boxes_frame_index(b * t, n)
+    crops = roi_align(fm, boxes.reshape(b * t * n, 4), idx, k)
+    x = embed_boxes(crops.reshape(b, t, n, -1), p)                                        # [B,T,N,NFB]
+    context = outs[-1]
+    context = context + context_position_embedding(context.shape[2], context.shape[3], dtype=context.dtype)[None]   # :404-406
+    enc = tce_context_encoding(x.reshape(b * t * n, -1), context, p).reshape(b, t, n, -1)   # :408-409
+    xc = torch.cat((x, enc), dim=3)                                                       # :410
+    if cfg.hierarchical_inference:
+        graph, _ = din_hierarchical_inference(xc, p, "DPI.", cfg.ST_kernel_size, cfg.sampling_ratio, cfg.scale_factor, cfg.beta_factor)
+    else:
+        graph, _ = din_multi_inference(xc, p, "DPI.", cfg.ST_kernel_size, cfg.sampling_ratio, cfg.scale_factor, cfg.beta_factor)
+    scores = head(graph, xc, p, "vgg16")                                                  # :436-442, :452-466
+    if return_intermediates:
+        return {"activities": scores}, dict(x=x, enc=enc, context=context)
+    return {"activities": scores}
+
+
+# ----------------------------------------------------------------------------------------
 # Row C -- Dynamic_collective (infer_model.py:1226-1319), intended semantics
 # ----------------------------------------------------------------------------------------
 def dynamic_collective_forward(cfg: OracleCfg, p: Params, images: Tensor, boxes: Tensor,

@@ -541,3 +541,85 @@ def test_plain_and_parallel_modes_match_reference_golden(gpu, path):
     for k in z.files:
         if k.startswith("g."):
             assert rel(named[k[2:]].grad, z[k]) <= 2e-4, k
+
+
+# ---- Dynamic_TCE_volleyball ---------------------------------------------------------------------------------------------
+TCE_CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "tce_*.npz")))
+
+
+@pytest.mark.parametrize("path", TCE_CASES, ids=[os.path.basename(p)[:-4] for p in TCE_CASES])
+def test_tce_model_matches_reference_golden(gpu, path):
+    """the whole Dynamic_TCE_volleyball forward + backward against the reference's own run (fp32): logits, loss, the stored head's attention
+    map, the context encoding, every stored gradient"""
+    from tests.test_oracle_golden import load_tce_case
+    from din_amd.config import Config
+    from din_amd.infer_model import Dynamic_TCE_volleyball
+    z, ocfg, p, images, boxes, labels = load_tce_case(path)
+    cfg = Config("volleyball")
+    cfg.backbone, cfg.image_size, cfg.out_size, cfg.emb_features = "vgg16", ocfg.image_size, ocfg.out_size, ocfg.emb_features
+    cfg.num_boxes, cfg.num_frames = ocfg.num_boxes, ocfg.num_frames
+    cfg.num_features_boxes = cfg.num_features_gcn = ocfg.num_features_boxes
+    cfg.ST_kernel_size, cfg.sampling_ratio, cfg.num_DIM = ocfg.ST_kernel_size, ocfg.sampling_ratio, ocfg.num_DIM
+    cfg.beta_factor, cfg.lite_dim, cfg.hierarchical_inference = False, None, False
+    cfg.train_backbone, cfg.backbone_dtype = True, "fp32"
+    model = Dynamic_TCE_volleyball(cfg)
+    missing, unexpected = model.load_state_dict(p, strict=False)
+    assert not unexpected and all("num_batches_tracked" in k for k in missing), (missing, unexpected)
+    model = model.to(gpu).eval()
+    enc = {}
+    model.multilayer_head_embfeature_context_encoding.register_forward_hook(lambda m, i, o: enc.__setitem__("enc", o.detach()))
+    ret = model((images.to(gpu), boxes.to(gpu)))
+    loss = F.cross_entropy(ret["activities"], labels.to(gpu))
+    loss.backward()
+    assert rel(ret["activities"], z["logits"]) <= 1e-4
+    assert abs(loss.item() - float(z["loss"])) <= 1e-4 * max(1.0, abs(float(z["loss"])))
+    B, T, N = images.shape[0], images.shape[1], ocfg.num_boxes
+    assert rel(enc["enc"].reshape(B, T, N, -1), z["enc"]) <= 1e-4
+    att = model.multilayer_head_embfeature_context_encoding.CET[int(z["att_head"])].att_map
+    assert rel(att, z["att_map"]) <= 1e-4
+    named = dict(model.named_parameters())
+    for k in z.files:
+        if k.startswith("g."):
+            tol = 1e-3 if not k.startswith("g.backbone.") else 3e-2
+            assert rel(named[k[2:]].grad, z[k]) <= tol, (k, rel(named[k[2:]].grad, z[k]))
+        if k.startswith("gsum."):
+            name = k[5:]
+            got = named[name].grad.double()
+            assert abs(got.sum().item() - float(z[k])) <= 2e-3 * float(z["gabs." + name]) + 1e-6, name
+
+
+def test_tce_train_mode_runs_with_dropout_and_bf16(gpu):
+    """training mode (context dropout 0.1, FFN dropout, global dropout) on a bf16 trunk: finite loss, every parameter gets a gradient, and
+    the same step counter gives the same masks (two models with equal seeds and inputs agree bit for bit in the forward pass)"""
+    from din_amd.config import Config
+    from din_amd.infer_model import Dynamic_TCE_volleyball
+    cfg = Config("volleyball")
+    cfg.backbone, cfg.image_size, cfg.out_size, cfg.emb_features = "vgg16", (96, 160), (3, 5), 512
+    cfg.num_boxes, cfg.num_frames, cfg.num_features_boxes, cfg.num_features_gcn = 12, 3, 64, 64
+    cfg.ST_kernel_size, cfg.sampling_ratio, cfg.num_DIM, cfg.beta_factor = [(3, 3)], [1], 1, False
+    cfg.train_backbone, cfg.backbone_dtype = True, "bf16"
+    images, boxes, labels = O.synth_inputs(2, 3, 12, 96, 160, 3, 5, 8, seed=5)
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(3)
+        model = Dynamic_TCE_volleyball(cfg).to(gpu).train()
+        ret = model((images.to(gpu), boxes.to(gpu)))
+        loss = F.cross_entropy(ret["activities"], labels.to(gpu))
+        loss.backward()
+        assert torch.isfinite(loss)
+        missing = [k for k, v in model.named_parameters() if v.requires_grad and v.grad is None]
+        assert not missing, missing
+        outs.append((ret["activities"].detach().clone(), model.fc_emb_1.weight.grad.detach().clone()))
+    assert torch.equal(outs[0][0], outs[1][0]), "same seeds and step counter -> same dropout masks -> bit-identical forward"
+    assert rel(outs[0][1], outs[1][1]) <= 1e-4      # (the backward sums with fp32 atomics in places: order-dependent last bits)
+
+
+def test_train_net_runs_the_tce_model(gpu, tmp_path):
+    """cfg.inference_module_name = 'dynamic_tce_volleyball' (reference scripts/train_volleyball_stage2_dynamic_tce.py, registry at
+    train_net_dynamic.py:66-73) through the drop-in train_net: one epoch of train_volleyball + test_volleyball"""
+    from din_amd.train_net_dynamic import train_net
+    cfg = _trainer_cfg("volleyball", tmp_path)
+    cfg.inference_module_name, cfg.max_epoch, cfg.num_boxes = "dynamic_tce_volleyball", 1, 12
+    infos = train_net(cfg)
+    tr, te = infos[0]["train"], infos[0]["test"]
+    assert np.isfinite(tr["loss"]) and np.isfinite(te["loss"])

@@ -581,6 +581,55 @@ def test_roi_align_multiscale_equals_resize_cat_crop(env, dtype, k):
         assert bool(((wb == 0) == (fbd.grad.float().cpu().permute(0, 3, 1, 2) == 0)).all()), "footprint of the composed backward"
 
 
+@pytest.mark.parametrize("shape", [(3, 12, 15, 4, 128), (2, 12, 3600, 4, 128), (2, 5, 70, 2, 32), (1, 16, 257, 1, 256)],
+                         ids=["small", "vgg_720p_map", "odd", "n16_c256"])
+def test_context_attention_matches_torch(env, shape):
+    """ops.ContextAttentionFunction (scores, row softmax, weighted sum) against torch on the CPU: attention map, output and
+    both gradients"""
+    lib, L, nhwc, ops = env
+    bt, n, p, heads, c = shape
+    g = torch.Generator().manual_seed(bt * 100 + p)
+    q = torch.randn(bt, n, heads * c, generator=g) * 0.3
+    kf = torch.randn(bt, p, heads * c, generator=g) * 0.3
+    cot = torch.randn(bt, n, heads * c, generator=g)
+    qr, kr = q.clone().requires_grad_(True), kf.clone().requires_grad_(True)
+    qh = qr.reshape(bt, n, heads, c).permute(0, 2, 1, 3)                     # [bt,h,n,c]
+    kh = kr.reshape(bt, p, heads, c).permute(0, 2, 1, 3)                     # [bt,h,p,c]
+    att_ref = torch.softmax(qh @ kh.transpose(2, 3), dim=3)                  # [bt,h,n,p]
+    out_ref = (att_ref @ kh).permute(0, 2, 1, 3).reshape(bt, n, heads * c)
+    out_ref.backward(cot)
+    qd, kd = q.cuda().requires_grad_(True), kf.cuda().requires_grad_(True)
+    out, att = ops.ContextAttentionFunction.apply(qd, kd, heads)
+    out.backward(cot.cuda())
+    assert rel(att, att_ref) <= 2e-5 and rel(out, out_ref) <= 2e-5
+    assert abs(float(att.sum(-1).mean()) - 1.0) <= 1e-5
+    assert rel(qd.grad, qr.grad) <= 5e-5 and rel(kd.grad, kr.grad) <= 5e-5
+
+
+def test_add_position_and_act_dropout(env):
+    lib, L, nhwc, ops = env
+    g = torch.Generator().manual_seed(4)
+    pos = torch.randn(3, 5, 8, generator=g)
+    for tdt in (torch.float32, torch.bfloat16):
+        x = torch.randn(4, 3, 5, 8, generator=g).to(tdt)
+        xd = x.cuda().requires_grad_(True)
+        y = ops.AddPositionFunction.apply(xd, pos.cuda(), True)
+        assert y.dtype == torch.float32 and torch.equal(y.cpu(), x.float() + pos)
+        cot = torch.randn(4, 3, 5, 8, generator=g)
+        y.backward(cot.cuda())
+        assert xd.grad.dtype == tdt and torch.equal(xd.grad.cpu(), (cot * (x.float() > 0)).to(tdt))
+    x = torch.randn(64, 512, generator=g).cuda().requires_grad_(True)
+    y0 = ops.ActDropoutFunction.apply(x, True, 0.0, 1)
+    assert torch.equal(y0, torch.relu(x))
+    y = ops.ActDropoutFunction.apply(x, True, 0.25, 77)
+    kept = (y != 0) | (x <= 0)
+    frac = float(((y != 0).sum()) / (x > 0).sum())
+    assert 0.70 <= frac <= 0.80 and rel(y[y != 0], torch.relu(x)[y != 0] / 0.75) <= 1e-6
+    y.sum().backward()
+    assert torch.equal(x.grad != 0, y != 0)                       # the backward regenerates the same mask
+    assert torch.equal(ops.ActDropoutFunction.apply(x, True, 0.25, 77), y) and not torch.equal(ops.ActDropoutFunction.apply(x, True, 0.25, 78), y)
+
+
 def test_layernorm_variants(env):
     lib, L, nhwc, ops = env
     g = torch.Generator().manual_seed(11)

@@ -255,3 +255,58 @@ def test_plain_and_parallel_oracle_matches_reference(path):
     for k in z.files:
         if k.startswith("g."):
             assert _rel(po["DPI." + k[2:]].grad, z[k]) <= 1e-4, k
+
+
+TCE_CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "tce_*.npz")))
+
+
+def load_tce_case(path):
+    z = np.load(path)
+    B, T, N, H, W, OH, OW, D, NFB, num_dim = [int(v) for v in z["meta"]]
+    kernels = [tuple(int(x) for x in k) for k in z["kernels"]]
+    cfg = O.OracleCfg(backbone="vgg16", image_size=(H, W), out_size=(OH, OW), emb_features=D, num_boxes=N, num_frames=T,
+                      num_features_boxes=NFB, ST_kernel_size=kernels, sampling_ratio=[int(r) for r in z["ratios"]], num_DIM=num_dim)
+    seed = int(z["seed"])
+    p = O.tce_synth_params(cfg, seed)
+    images, boxes, labels = O.synth_inputs(B, T, N, H, W, OH, OW, 8, seed=seed)
+    return z, cfg, p, images, boxes, labels
+
+
+def test_tce_golden_present():
+    assert len(TCE_CASES) >= 2
+
+
+@pytest.mark.parametrize("path", TCE_CASES, ids=[os.path.basename(p)[:-4] for p in TCE_CASES])
+def test_tce_oracle_matches_reference(path):
+    """Dynamic_TCE_volleyball (reference infer_model.py:237-468) imported and run by tools/gen_golden.py::tce_case: logits, loss, one head's
+    attention map, the context encoding and every stored parameter gradient"""
+    z, cfg, p, images, boxes, labels = load_tce_case(path)
+    assert np.array_equal(labels.numpy(), z["labels"])
+    po = {k: v.clone().requires_grad_("running_" not in k) for k, v in p.items()}
+    out, inter = O.dynamic_tce_volleyball_forward(cfg, po, images.float(), boxes, return_intermediates=True)
+    loss = F.cross_entropy(out["activities"], labels)
+    loss.backward()
+    assert _rel(out["activities"].detach(), z["logits"]) <= 2e-4
+    assert abs(loss.item() - float(z["loss"])) <= 2e-4 * max(1.0, abs(float(z["loss"])))
+    assert _rel(inter["enc"].detach(), z["enc"]) <= 1e-4
+    b, t, n = images.shape[0], images.shape[1], cfg.num_boxes
+    _, atts = O.tce_context_encoding(inter["x"].reshape(b * t * n, -1), inter["context"], po, return_attention=True)
+    assert _rel(atts[int(z["att_head"])].detach(), z["att_map"]) <= 1e-4
+    for k in z.files:
+        if k.startswith("g."):
+            assert _rel(po[k[2:]].grad, z[k]) <= 1e-2, k
+        if k.startswith("gsum."):
+            name = k[5:]
+            assert abs(po[name].grad.double().sum().item() - float(z[k])) <= 2e-3 * float(z["gabs." + name]) + 1e-6, name
+
+
+def test_context_position_embedding_known_answers():
+    """positional_encoding.py:67-92 by hand: 1-based coordinates x 16, channel pairs (sin, cos) at T^(2i/256), y half then x half"""
+    pos = O.context_position_embedding(3, 5)
+    assert tuple(pos.shape) == (512, 3, 5)
+    import math
+    assert abs(float(pos[0, 0, 0]) - math.sin(16.0)) < 1e-6 and abs(float(pos[1, 0, 3]) - math.cos(16.0)) < 1e-6      # y = 1, any x
+    assert abs(float(pos[0, 2, 1]) - math.sin(48.0)) < 1e-5                                                            # y = 3
+    assert abs(float(pos[256, 1, 4]) - math.sin(80.0)) < 1e-5 and abs(float(pos[257, 1, 4]) - math.cos(80.0)) < 1e-5    # x = 5
+    t2 = 10000.0 ** (2.0 / 256.0)
+    assert abs(float(pos[2, 1, 0]) - math.sin(32.0 / t2)) < 1e-5 and abs(float(pos[259, 0, 1]) - math.cos(32.0 / t2)) < 1e-5

@@ -398,6 +398,64 @@ def model_case(name, refim, refcfg, out_dir, *, backbone, H, W, OH, OW, D, B, T,
     print(f"[model] {name}: logits rel err {e:.2e}, worst grad rel err {eg:.2e}, loss {loss.item():.6f}")
 
 
+def tce_case(name, refim, refcfg, out_dir, *, H, W, OH, OW, B, T, NFB, kernels, ratios, num_dim=1, seed=0, full_grads_upto=4096):
+    """Whole Dynamic_TCE_volleyball forward (+ backward of the CE loss) from the reference (infer_model.py:237-468), vgg16 trunk, eval mode
+    (dropout off).  N = 12 is asserted by the reference's transformer (TCE_STBiP_module.py:263)."""
+    N, D = 12, 512
+    cfg = refcfg.Config("volleyball")
+    cfg.log_path = None
+    cfg.backbone = "vgg16"
+    cfg.image_size, cfg.out_size, cfg.emb_features = (H, W), (OH, OW), D
+    cfg.num_boxes, cfg.num_frames, cfg.batch_size = N, T, B
+    cfg.num_features_boxes = cfg.num_features_gcn = NFB
+    cfg.ST_kernel_size, cfg.sampling_ratio, cfg.num_DIM = kernels, ratios, num_dim
+    cfg.dynamic_sampling, cfg.scale_factor, cfg.beta_factor = True, True, False
+    cfg.lite_dim, cfg.hierarchical_inference = None, False
+    cfg.train_backbone = True
+    cfg.train_dropout_prob = 0.3
+    torch.manual_seed(0)
+    model = refim.Dynamic_TCE_volleyball(cfg)
+    model.eval()
+    ocfg = O.OracleCfg(backbone="vgg16", image_size=(H, W), out_size=(OH, OW), emb_features=D, num_boxes=N, num_frames=T,
+                       num_features_boxes=NFB, ST_kernel_size=kernels, sampling_ratio=ratios, num_DIM=num_dim)
+    p = O.tce_synth_params(ocfg, seed)
+    missing, unexpected = model.load_state_dict(p, strict=False)
+    bad = [k for k in missing if "num_batches_tracked" not in k and "zero_padding" not in k]
+    assert not unexpected and not bad, (bad, unexpected)
+    images, boxes, labels = O.synth_inputs(B, T, N, H, W, OH, OW, 8, seed=seed)
+    ret = model((images.float(), boxes.float()))
+    loss = F.cross_entropy(ret["activities"], labels)
+    loss.backward()
+    ref_grads = {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}
+    po = {k: v.clone().requires_grad_("running_" not in k) for k, v in p.items()}
+    oret, inter = O.dynamic_tce_volleyball_forward(ocfg, po, images.float(), boxes.float(), return_intermediates=True)
+    oloss = F.cross_entropy(oret["activities"], labels)
+    oloss.backward()
+    e = close(oret["activities"], ret["activities"], 2e-4, name + ".logits")
+    eg = 0.0
+    for k, v in ref_grads.items():
+        if po[k].grad is None:
+            raise AssertionError("oracle produced no grad for " + k)
+        eg = max(eg, close(po[k].grad, v, 1e-2, name + ".grad." + k))
+    att = model.multilayer_head_embfeature_context_encoding.CET[TCE_PROBE_HEAD].att_map.detach()     # [BT,N,P] of one head
+    _, oatt = O.tce_context_encoding(inter["x"].reshape(B * T * N, -1), inter["context"], po, return_attention=True)
+    close(oatt[TCE_PROBE_HEAD], att, 1e-4, name + ".att_map")
+    rec = dict(meta=np.array([B, T, N, H, W, OH, OW, D, NFB, num_dim], dtype=np.int64), kernels=np.array(kernels, dtype=np.int64),
+               ratios=np.array(ratios, dtype=np.int64), seed=np.int64(seed), logits=ret["activities"].detach().numpy(),
+               loss=np.float64(loss.item()), labels=labels.numpy(), att_map=att.numpy(), att_head=np.int64(TCE_PROBE_HEAD),
+               enc=inter["enc"].detach().numpy())
+    for k, v in ref_grads.items():
+        rec["gsum." + k] = np.float64(v.double().sum().item())
+        rec["gabs." + k] = np.float64(v.double().abs().sum().item())
+        if v.numel() <= full_grads_upto or ("context_encoding" in k and v.numel() <= 20000):
+            rec["g." + k] = v.numpy()
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
+    print(f"[tce] {name}: logits rel err {e:.2e}, worst grad rel err {eg:.2e}, loss {loss.item():.6f}")
+
+
+TCE_PROBE_HEAD = 2
+
+
 class _First(nn.Module):
     """SURVEY 8c oracle recipe: the reference feeds DPI's (ft, MAD) tuple where a tensor is expected
     (dynamic_infer_module.py:492-493, infer_model.py:1294); wrap the sub-module so only `ft` flows on."""
@@ -507,6 +565,7 @@ def main():
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--skip-big", action="store_true")
+    ap.add_argument("--only", default="", help="'tce': only (re)generate the Dynamic_TCE_volleyball fixtures")
     a = ap.parse_args()
     sys.dont_write_bytecode = True
     install_stubs()
@@ -519,6 +578,14 @@ def main():
     refim = importlib.import_module("infer_model")
     refcfg = importlib.import_module("config")
 
+    def tce_cases():
+        # Dynamic_TCE_volleyball: OH x OW follows the VGG16 arithmetic (H/32, W/32), 15 and 24 context pixels per frame
+        tce_case("tce_vgg16_96x160_nfb64", refim, refcfg, a.out, H=96, W=160, OH=3, OW=5, B=2, T=3, NFB=64, kernels=[(3, 3)], ratios=[1], seed=300)
+        tce_case("tce_vgg16_128x192_nfb128_2dim", refim, refcfg, a.out, H=128, W=192, OH=4, OW=6, B=1, T=4, NFB=128, kernels=[(1, 3), (3, 1)],
+                 ratios=[1], num_dim=2, seed=301)
+    if a.only == "tce":
+        tce_cases()
+        return
     prep_case(refutils, a.out)
     f32, f64 = torch.float32, torch.float64
     # small, fully stored DIN cases (C=32) -- every structural variant that runs as shipped
@@ -569,6 +636,7 @@ def main():
     if not a.skip_big:
         hier_case("hier_k13_k31_t10_c1024", refdin, a.out)
     collective_case("collective_vgg16_96x160", refim, refcfg, a.out)
+    tce_cases()
     print("golden vectors written to", a.out)
 
 
