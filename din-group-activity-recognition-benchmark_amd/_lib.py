@@ -13,7 +13,7 @@ import subprocess
 from typing import Dict, List
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdin_hip.so")
+LIB_PATH = os.environ.get("DIN_LIB_PATH") or os.path.join(_HERE, "libdin_hip.so")     # (DIN_LIB_PATH: experiment builds, tools/ only)
 CSRC_DIR = os.path.join(_HERE, "csrc")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "din_hip.h")
 

@@ -2307,16 +2307,19 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
             const char* pe = getenv("DIN_WGRAD_PIPE");
             const int pipe_mode = pe ? atoi(pe) : 1;
             if (pipe_mode == 1) {
-                // every wide bank runs the pipelined kernel, rows padded to the next of {128, 192, 256}: measured against the round-1
-                // choice below (DIN_WGRAD_PIPE=3; profiles/r02_wgrad_ring_vs_pipe_vs_atomic.txt) it is 5-17 % faster on the 128 / 160 /
-                // 256-row banks the padding rule used to send to the two-workgroup kernels, and equal on the 320-row one
+                // wide banks run the pipelined kernel with rows padded to the next of {128, 192, 256} whatever their k-column padding:
+                // measured against the round-1 choice below (DIN_WGRAD_PIPE=3; profiles/r02_wgrad_ring_vs_pipe_vs_atomic.txt) it is
+                // 11-17 % faster on the 112 / 128 / 256-row banks the k-padding rule used to send to the two-workgroup kernels
                 int pb = 128, pt = (d->cout + 127) / 128, pp = pt * 128;
                 const int pc[2] = {192, 256};
                 for (int ci = 0; ci < 2; ++ci) {
                     int bc = pc[ci], tl = (d->cout + bc - 1) / bc, pad = tl * bc;
                     if (tl < pt || (tl == pt && pad < pp)) { pb = bc; pt = tl; pp = pad; }
                 }
-                w.bco = pb;
+                // (row padding above 15 % -- the 160-row banks as 192 -- measured +5 % only: those stay on the round-1 choice below)
+                if (pp * 100 <= d->cout * 115) w.bco = pb;
+                else if (best_pad * 100 <= d->cout * 105 && (best == 192 || kpad * 100 <= w.kcols * 112)) w.bco = best;
+                else w.ring = 0;
             } else if ((best_pad * 100 <= d->cout * 105 && (best == 192 || kpad * 100 <= w.kcols * 112)) || mode == 2) w.bco = best;
             else w.ring = 0;
         }

@@ -20,6 +20,9 @@
 //   * optionally (WgradK::atomic) the workgroups add their tiles into ONE fp32 tile buffer with native atomics, so the slice
 //     partials (25-80 MB per launch whatever the batch) are neither written nor read back.
 #include "conv_wgrad.h"
+#ifndef DIN_PIPE_KNOCK
+#define DIN_PIPE_KNOCK 0      // timing experiments only (results are wrong for != 0): 1 no stage barrier, 2 fragments read once, 3 no DMA after the prologue, 4 no MFMA
+#endif
 #include <unordered_map>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -174,6 +177,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_pipe_kernel(WgradK p) {
     }
 
     bf16x8 ga[2][TI], xb[2][XJ];                                   // two fragment sets
+#if DIN_PIPE_KNOCK == 2
+    bool knock_first = true;
+#endif
     auto frag = [&](uint32_t addr) {                               // one operand fragment: pixels 0..3 and 4..7 of the lane's octet
         const s16x4 lo = tr_read(addr), hi = tr_read(addr + 4 * ROWB);
         return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -182,11 +188,21 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_pipe_kernel(WgradK p) {
     auto load_frag = [&](auto slot_c, int set, int u, int q) {
         constexpr int SLOT = decltype(slot_c)::value;
         const uint32_t imm = (uint32_t)((SLOT & 1) * STAGE + u * 16 * ROWB);
+#if DIN_PIPE_KNOCK == 2
+        if (knock_first) {
+#endif
         if (q < TI) ga[set][q] = frag(colG[SLOT >> 1][q] + imm);
         else xb[set][q - TI] = frag(colX[SLOT >> 1][q - TI] + imm);
+#if DIN_PIPE_KNOCK == 2
+        }
+#endif
     };
     auto mma = [&](int set, int m) {                               // MFMA m of a half-stage: tile (m / XJ, m % XJ)
+#if DIN_PIPE_KNOCK == 4
+        asm volatile("" : "+v"(acc[m / XJ][m % XJ]) : "v"(ga[set][m / XJ]), "v"(xb[set][m % XJ]));
+#else
         acc[m / XJ][m % XJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[set][m / XJ], xb[set][m % XJ], acc[m / XJ][m % XJ], 0, 0, 0);
+#endif
     };
     // (inline asm on purpose: with the builtin the compiler merges the per-tile branches below into one indexed access of the fragment
     // array, which then lives in scratch memory -- and scratch traffic would also break the hand-counted vmcnt of the DMA ring)
@@ -229,7 +245,14 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_pipe_kernel(WgradK p) {
     auto stage = [&](auto slot_c, int s) {
         constexpr int SLOT = decltype(slot_c)::value;
         constexpr int NEXT = (SLOT + 1) & (NS - 1), FILL = (SLOT + NS - 1) & (NS - 1);
+#if DIN_PIPE_KNOCK == 3
+        const bool more = false;
+#else
         const bool more = s + NS - 1 < nst;
+#endif
+#if DIN_PIPE_KNOCK == 2
+        if (s > 0) knock_first = false;
+#endif
         if constexpr (SLOT == 0) pace(s);
         // ---- first half: request the second half's fragments (set 1), then the MFMAs of set 0 with the DMA issues of stage s+3
         //      between them (they go to the ring slot of stage s-1: every wave finished reading it before the last barrier)
@@ -255,7 +278,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_pipe_kernel(WgradK p) {
         if (s + 3 < nst) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * NDMA) : "memory");
         else if (s + 2 < nst) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#if DIN_PIPE_KNOCK != 1
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
         // ---- second half: MFMAs of set 1 with the requests for the next stage's first half (set 0) between them
         //      (unconditionally: behind the last stage they fetch stale ring contents that nobody uses)

@@ -21,6 +21,15 @@ run collective_vgg16_fp32_b4 --workload collective_fp32 --global-batch 4 --no-cp
 run inv3_fp32_b8 --workload inv3_fp32 --global-batch 8 --no-cpu-baseline
 run vgg16_bf16_b32 --workload vgg16_bf16 --no-cpu-baseline
 run vgg16_fp32_b8 --workload vgg16_fp32 --global-batch 8 --no-cpu-baseline
+run tce_vgg16_bf16_t10_b8 --workload vgg16_bf16 --tce --global-batch 8
+run vgg16_bf16_t10_b8 --workload vgg16_bf16 --frames 10 --global-batch 8 --no-cpu-baseline
+# gradient-bucket path in one process (world size 1, RCCL): hook + flat buckets + async all_reduce + views, no wire
+for c in 4 32; do
+  MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python bench.py --global-batch $c --steps 20 --warmup 5 \
+      --no-cpu-baseline --force-buckets 2>&1 | grep '"metric"' > $OUT/bench_inv3_bf16_b${c}_forced_buckets.json
+  timeout 600 python bench.py --global-batch $c --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_inv3_bf16_b${c}_20steps.json
+  cut -c75-170 $OUT/bench_inv3_bf16_b${c}_20steps.json $OUT/bench_inv3_bf16_b${c}_forced_buckets.json
+done
 # rocprofv3 kernel-trace summaries (same command as the default bench line, 5 timed + 2 warm-up steps)
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof_b32 -o x -- python $OLDPWD/bench.py --no-cpu-baseline > $OLDPWD/$OUT/prof_b32.log 2>&1)
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof_b4 -o x -- python $OLDPWD/bench.py --no-cpu-baseline --global-batch 4 > $OLDPWD/$OUT/prof_b4.log 2>&1)
