@@ -185,8 +185,11 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_pipe_kernel(WgradK p) {
         return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     // fragment q (G tiles first, then X tiles) of half-stage u of ring slot SLOT -> set
-    auto load_frag = [&](auto slot_c, int set, int u, int q) {
+    // request order = first use by the MFMA sequence (0,0) (0,1) (1,0) (1,1) ...: G tile 0, the X tiles, then the other G tiles -- the
+    // first MFMA of the next half-stage then waits for the 1st and 2nd request instead of the 1st and (TI+1)-th
+    auto load_frag = [&](auto slot_c, int set, int u, int q_req) {
         constexpr int SLOT = decltype(slot_c)::value;
+        const int q = q_req == 0 ? 0 : (q_req <= XJ ? TI + q_req - 1 : q_req - XJ);
         const uint32_t imm = (uint32_t)((SLOT & 1) * STAGE + u * 16 * ROWB);
 #if DIN_PIPE_KNOCK == 2
         if (knock_first) {
