@@ -18,7 +18,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "din_hip.h")
 
 DIN_F32, DIN_BF16 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 CONV_BIAS, CONV_RELU, CONV_ACCUM, CONV_MASK = 1, 2, 4, 8
 
 
@@ -29,7 +29,7 @@ class DinError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "nb", "h", "w", "cin", "oh", "ow", "cout", "kh", "kw", "sh", "sw", "ph", "pw", "dh", "dw",
-        "ldi", "cioff", "ldo", "cooff", "dtype")]
+        "ldi", "cioff", "ldo", "cooff", "dtype", "in_u8")]
 
 
 class PoolDesc(C.Structure):
@@ -63,6 +63,7 @@ SIGNATURES: Dict[str, tuple] = {
     "din_conv_kernel_tile": (_I, [_CD, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "din_conv_kernel_variant": (_I, [_CD, _I, C.POINTER(C.c_int32)]),
     "din_conv_workspace_bytes": (_L, [_CD, _I]),
+    "din_conv_accepts_u8": (_I, [_P]),
     "din_conv_fwd": (_I, [_CD, _P, _P, _P, _P, _I, _P, _L, _P]),
     "din_conv_fwd2": (_I, [_CD, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "din_conv_dgrad": (_I, [_CD, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P]),

@@ -32,6 +32,7 @@ struct ConvK {
     // offset cooff2 + (channel - csplit)); csplit == 0: single destination.  Staged (aligned) epilogue only, no mask / accumulate.
     void* out2; int ldo2, cooff2, csplit;
     int craw;                       // > 0: produced channels >= craw get neither bias nor ReLU (a sibling whose epilogue runs later, after its pool)
+    const unsigned char* u8;        // image layer only: raw uint8 frames [NB][3][H][W], normalised on load (din_conv_desc::in_u8)
 };
 
 __device__ __forceinline__ int64_t out_pixel(const ConvK& p, int m) {

@@ -584,6 +584,62 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
 #endif
 }
 
+// ---- image layer fed from raw uint8 frames (din_conv_desc::in_u8): the halo pixels of a tile are fetched as bytes from the three colour
+//      planes, normalised exactly like utils.prep_images ((x / 255 - 0.5) * 2: three separately rounded fp32 operations, utils.py:8-19),
+//      rounded to bf16 and written to the LDS position the LDS-DMA of a prepared NHWC tensor would have filled (16 bytes per pixel:
+//      r, g, b and five zero channels; pixels outside the image are zero).  Lane-linear: halo pixel id = (wave + 4 i) * 64 + lane.
+__device__ __forceinline__ float prep_u8(uint32_t v) {
+    float y = __fdiv_rn((float)v, 255.0f);
+    y = __fsub_rn(y, 0.5f);
+    return __fmul_rn(y, 2.0f);
+}
+__device__ __forceinline__ void u8_lut_init(bf16_t* lut, int tid) {          // NTHREADS == 256: one entry per thread
+    lut[tid] = (bf16_t)(pack_bf16x2(prep_u8((uint32_t)tid), 0.f) & 0xffffu);
+}
+template <int NTR>
+struct U8Halo {
+    // the three bytes of a pixel stay in separate registers until store(): nothing consumes them at load time, so the loads stay in flight
+    // under the tile's MFMAs instead of being waited for where they are issued
+    uint32_t r[NTR], g[NTR], b[NTR];
+    uint32_t valid;                                      // bit i: pixel i lies inside the image
+    // hyv / hxv: the lane's halo coordinates per transfer (the kernels' tile-independent DMA plans); inside[i]: the id is a halo pixel
+    template <int NSLOT>
+    __device__ __forceinline__ void load(const unsigned char* __restrict__ img, int n, int H, int W, int gy0, int gx0, int wid,
+                                         const short (&hyv)[NTR], const short (&hxv)[NTR], const int (&inside)[NTR]) {
+        const int64_t plane = (int64_t)H * W;
+        const unsigned char* base = img + (int64_t)n * 3 * plane + (int64_t)gy0 * W + gx0;
+        valid = 0u;
+#pragma unroll
+        for (int i = 0; i < NTR; ++i) {
+            r[i] = g[i] = b[i] = 0u;
+            if (wid + 4 * i < NSLOT) {
+                const int gy = gy0 + hyv[i], gx = gx0 + hxv[i];
+                if (inside[i] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    const unsigned char* q = base + (hyv[i] * W + hxv[i]);
+                    r[i] = q[0]; g[i] = q[plane]; b[i] = q[2 * plane];
+                    valid |= 1u << i;
+                }
+            }
+        }
+    }
+    // lut: the 256 normalised bf16 values (prep_u8 of every byte, built once per workgroup by u8_lut_init) -- three LDS reads per pixel
+    // instead of three fp32 divisions
+    template <int NSLOT>
+    __device__ __forceinline__ void store(unsigned char* lds_buf, const bf16_t* lut, int wid, int lane) const {   // lds_buf: the halo buffer
+#pragma unroll
+        for (int i = 0; i < NTR; ++i) {
+            if (wid + 4 * i < NSLOT) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if ((valid >> i) & 1u) {
+                    v[0] = (uint32_t)lut[r[i]] | ((uint32_t)lut[g[i]] << 16);
+                    v[1] = (uint32_t)lut[b[i]];
+                }
+                *reinterpret_cast<u32x4*>(lds_buf + ((wid + 4 * i) * 64 + lane) * 16) = v;
+            }
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // Small-channel 3x3 (stem) convolution: filters stationary in LDS + input HALO tiles, persistent workgroups.
 // For layers with 32/64 reduction channels and <= 64 produced channels over millions of pixels (Inception Conv2d_2a/2b, fwd and
@@ -597,8 +653,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
 //     usual fused bias / ReLU / ReLU-backward mask / accumulate.
 // bf16 only; stride 1, dilation 1; the gather geometry (ay = 1, by, cy = +-1) covers forward and (stride-1) dgrad.
 // ------------------------------------------------------------------------------------------------
-template <int CPP, int BN, int NBUF, int KH, int KW, int ST>
+template <int CPP, int BN, int NBUF, int KH, int KW, int ST, bool U8 = false>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_small_kernel(ConvK p) {
+    static_assert(!U8 || (CPP == 1 && NBUF == 2), "uint8 frames feed the image layer only");
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef bf16_t T;
     constexpr int TH = 8, TW = 32, NPX = TH * TW;
@@ -681,12 +738,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_small_kernel(ConvK p) {
         }
     };
 
+    // uint8 frames: the next tile's halo bytes are fetched into registers where the DMA would be issued and written to the other halo
+    // buffer after this tile's MFMAs (nobody reads that buffer between the two barriers around them)
+    U8Halo<NTR> u8h;
+    bf16_t* u8lut = reinterpret_cast<bf16_t*>(smem_raw + WBYTES + NBUF * HBYTES);       // 512 bytes behind the halo buffers (host adds them)
+    if (U8) { u8_lut_init(u8lut, tid); __syncthreads(); }
+    auto u8_load = [&](int tile) {
+        const int n = tile / tiles_img;
+        const int tr = tile - n * tiles_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        u8h.template load<NSLOT>(p.u8, n, p.H, p.W, ty * TH * ST + hy0, tx * TW * ST + hx0, wid, hyv, hxv, rel);
+    };
     const int frow = lane & 15, g4 = lane >> 4;
     int cur = 0;
     // persistent walk: round i covers tiles [i*G, (i+1)*G); inside a round every XCD takes a contiguous run (shared halo rows hit L2)
     int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     bool first = true;
-    if (tile < ntiles) issue_halo(0, tile);
+    if (U8) {
+        if (tile < ntiles) { u8_load(tile); u8h.template store<NSLOT>(smem_raw + WBYTES, u8lut, wid, lane); }
+    } else if (tile < ntiles) issue_halo(0, tile);
     __syncthreads();                                                                   // filters visible
     for (; tile < ntiles; tile += gridDim.x) {
         // in-order completion: the halo transfers of this tile are older than the (always NST) stores of the previous tile when
@@ -696,7 +766,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_small_kernel(ConvK p) {
         first = false;
         __builtin_amdgcn_s_barrier();                                                  // halo(tile) landed; everyone left the previous tile
         asm volatile("" ::: "memory");
-        if (NBUF == 2 && tile + (int)gridDim.x < ntiles) issue_halo(cur ^ 1, tile + gridDim.x);
+        const bool have_next = tile + (int)gridDim.x < ntiles;
+        if (U8) { if (have_next) u8_load(tile + gridDim.x); }
+        else if (NBUF == 2 && have_next) issue_halo(cur ^ 1, tile + gridDim.x);
         const u32x4* Hl = reinterpret_cast<const u32x4*>(smem_raw + WBYTES + cur * HBYTES);
 
         f32x4 acc[TI][TJ];
@@ -752,6 +824,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_small_kernel(ConvK p) {
                     for (int j = 0; j < TJ; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
             }
         }
+        if (U8 && have_next) u8h.template store<NSLOT>(smem_raw + WBYTES + (cur ^ 1) * HBYTES, u8lut, wid, lane);
         __syncthreads();                                                               // all waves done reading halo(cur)
         // ---- epilogue: stage through the consumed halo buffer, then 16-byte coalesced buffer stores (always NST per wave) -----
         const int n = tile / tiles_img;
@@ -1694,8 +1767,9 @@ __global__ __launch_bounds__(512, (4 * (((32 * (BCO / 8) + 511) / 512) * 8192 + 
 //   wave w owns the 16-column tiles w, w+4, ... of the (tap, ci) axis and all BN filter rows; wave 0 also forms the bias gradient
 //   (G^T x ones).  Result: one fp32 partial slab per workgroup in the layout conv_wgrad_reduce_kernel expects.
 // ------------------------------------------------------------------------------------------------
-template <int CPP, int BN, int ST>
+template <int CPP, int BN, int ST, bool U8 = false>
 __global__ __launch_bounds__(NTHREADS, (CPP == 4 && BN == 64) ? 1 : 2) void conv_wgrad_small_kernel(WgradK p) {
+    static_assert(!U8 || CPP == 1, "uint8 frames feed the image layer only");
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TH = 8, TW = 32, NPX = TH * TW, KH = 3, KW = 3;
     constexpr int HWW = (TW - 1) * ST + KW, HWH = (TH - 1) * ST + KH, HPX = HWW * HWH, HC = HPX * CPP;
@@ -1747,12 +1821,14 @@ __global__ __launch_bounds__(NTHREADS, (CPP == 4 && BN == 64) ? 1 : 2) void conv
         const int baseX = (gy0 * p.W + gx0) * p.ldi * 2 + p.cioff * 2;
         const int baseG = ((ty * TH) * p.OW + tx * TW) * p.ldo * 2 + p.cooff * 2;
         const uint32_t dH = ldsW + (uint32_t)(buf * STAGE), dG = dH + (uint32_t)HBYTES;
+        if (!U8) {
 #pragma unroll
-        for (int i = 0; i < NTR_H; ++i) {
-            if (wid + 4 * i < NSLOT_H) {
-                const int gy = gy0 + hyv[i], gx = gx0 + hxv[i];
-                const bool ok = relH[i] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-                lds_dma16(dH + (uint32_t)(i * 4096), rsX, ok ? baseX + relH[i] : (int)OOB, 0);
+            for (int i = 0; i < NTR_H; ++i) {
+                if (wid + 4 * i < NSLOT_H) {
+                    const int gy = gy0 + hyv[i], gx = gx0 + hxv[i];
+                    const bool ok = relH[i] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                    lds_dma16(dH + (uint32_t)(i * 4096), rsX, ok ? baseX + relH[i] : (int)OOB, 0);
+                }
             }
         }
 #pragma unroll
@@ -1788,14 +1864,31 @@ __global__ __launch_bounds__(NTHREADS, (CPP == 4 && BN == 64) ? 1 : 2) void conv
         unitX[jj] = j & 1;
     }
 
+    // uint8 frames (U8): the input halo is fetched as bytes into registers where the DMA is issued, and written (normalised, bf16) to the
+    // other stage's halo buffer after this tile's MFMAs; the G tile still arrives by LDS-DMA
+    U8Halo<NTR_H> u8h;
+    bf16_t* u8lut = reinterpret_cast<bf16_t*>(smem_raw + 2 * STAGE);                    // 512 bytes behind the two stages (host adds them)
+    if (U8) { u8_lut_init(u8lut, tid); __syncthreads(); }
+    auto u8_load = [&](int tile) {
+        const int n = tile / tiles_img;
+        const int tr = tile - n * tiles_img;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        u8h.template load<NSLOT_H>(p.u8, n, p.H, p.W, ty * TH * ST - p.ph, tx * TW * ST - p.pw, wid, hyv, hxv, relH);
+    };
     int cur = 0;
     int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    if (tile < ntiles) issue(0, tile);
+    if (tile < ntiles) {
+        issue(0, tile);
+        if (U8) { u8_load(tile); u8h.template store<NSLOT_H>(smem_raw, u8lut, wid, lane); }
+    }
     for (; tile < ntiles; tile += gridDim.x) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (U8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                   // stage(cur) landed; everyone finished reading stage(cur^1)
         asm volatile("" ::: "memory");
-        if (tile + (int)gridDim.x < ntiles) issue(cur ^ 1, tile + gridDim.x);
+        const bool have_next = tile + (int)gridDim.x < ntiles;
+        if (have_next) issue(cur ^ 1, tile + gridDim.x);
+        if (U8 && have_next) u8_load(tile + gridDim.x);
         const uint32_t Hb = lds_base + (uint32_t)(cur * STAGE), Gb = Hb + (uint32_t)HBYTES;
         // software pipeline: the transpose reads of k-step ks+1 are in flight while the MFMAs of k-step ks run
         u32x4 gf[2][TI], xf[2][TJ];
@@ -1845,6 +1938,7 @@ __global__ __launch_bounds__(NTHREADS, (CPP == 4 && BN == 64) ? 1 : 2) void conv
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (U8 && have_next) u8h.template store<NSLOT_H>(smem_raw + (cur ^ 1) * STAGE, u8lut, wid, lane);
         cur ^= 1;
     }
     // ---- this workgroup's partial slab: [BN][NCT * 16] fp32 ------------------------------------------------------------------
@@ -2383,6 +2477,7 @@ int check_desc(const din_conv_desc* d) {
     int eow = (d->w + 2 * d->pw - d->dw * (d->kw - 1) - 1) / d->sw + 1;
     DIN_REQUIRE(eoh == d->oh && eow == d->ow, "conv: output size %dx%d inconsistent (expected %dx%d)", d->oh, d->ow, eoh, eow);
     DIN_REQUIRE((int64_t)d->nb * d->h * d->w < (1ll << 31) && (int64_t)d->nb * d->oh * d->ow < (1ll << 31), "conv: too many pixels");
+    DIN_REQUIRE(d->in_u8 == 0 || d->in_u8 == 1, "conv: in_u8 must be 0 or 1");
     return DIN_OK;
 }
 
@@ -2608,13 +2703,14 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
             const int hpx = (7 * st_ + 3) * (31 * st_ + 3);
             const int hbytes = (hpx * g.cpt * 16 + 1023) / 1024 * 1024;
             const int nbuf = g.cpt == 8 ? 1 : 2;
-            const size_t lds = (size_t)(image ? 3 * bnS * 64 : 9 * bnS * g.cpt * 16) + (size_t)nbuf * hbytes;
+            const size_t lds = (size_t)(image ? 3 * bnS * 64 : 9 * bnS * g.cpt * 16) + (size_t)nbuf * hbytes + (k.u8 ? 512 : 0);   // (+ the uint8 -> bf16 table)
             dim3 grid(512);
             auto launch = [&](auto kern) {
                 if (lds > 65536) raise_lds_limit(kern, lds);
                 hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, k);
             };
-            if (image) launch(conv_small_kernel<1, 32, 2, 3, 3, 2>);
+            if (image && k.u8) launch(conv_small_kernel<1, 32, 2, 3, 3, 2, true>);
+            else if (image) launch(conv_small_kernel<1, 32, 2, 3, 3, 2>);
             else if (g.cpt == 4 && bnS == 32) launch(conv_small_kernel<4, 32, 2, 3, 3, 1>);
             else if (g.cpt == 4) launch(conv_small_kernel<4, 64, 2, 3, 3, 1>);
             else launch(conv_small_kernel<8, 32, 1, 3, 3, 1>);
@@ -2622,6 +2718,7 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
             return DIN_OK;
         }
     }
+    DIN_REQUIRE(!k.u8, "%s: in_u8 is only served by the image-layer kernel (see din_conv_accepts_u8)", what);
     if (fast && !k.remap && k.nsrc == 0 && want_gather_pipe(dtype, k.M, k.Cin, k.kh * k.kw, g.bn, g.splitk, (k.Cout + g.bn - 1) / g.bn) &&
         g.cpt % 4 == 0 && k.Cout % 8 == 0 && k.cooff % 8 == 0 && k.ldo % 8 == 0 &&
         (!(k.flags & DIN_CONV_MASK) || (k.ldm % 8 == 0 && k.moff % 8 == 0)) && (k.csplit == 0 || (k.csplit % 8 == 0 && k.ldo2 % 8 == 0 && k.cooff2 % 8 == 0))) {
@@ -2821,14 +2918,34 @@ int din_conv_fwd(const din_conv_desc* d, const void* in, const void* wpk, const 
     k.M = d->nb * d->oh * d->ow; k.flags = flags; k.ldm = 0; k.moff = 0;
     k.in_bytes = (long long)d->nb * d->h * d->w * d->ldi * (d->dtype == DIN_F32 ? 4 : 2);
     k.w_bytes = din_conv_packed_elems(d, 0) * (d->dtype == DIN_F32 ? 4 : 2);
+    if (d->in_u8) {                                   // raw uint8 frames: plan as the 8-channel prepared tensor the image layer would read
+        DIN_REQUIRE(din_conv_accepts_u8(d), "conv_fwd: in_u8 on a layer din_conv_accepts_u8() rejects");
+        k.u8 = reinterpret_cast<const unsigned char*>(in);
+        k.ldi = 8; k.cioff = 0; k.in_bytes = (long long)d->nb * d->h * d->w * 16;
+    }
     GatherPlan g = plan_gather(k.M, d->cin, d->cout, d->kh * d->kw, d->dtype);
     return run_gather(k, g, d->dtype, workspace, workspace_bytes, as_stream(stream), "conv_fwd");
+}
+
+int din_conv_accepts_u8(const din_conv_desc* d) {
+    if (!d || d->dtype != DIN_BF16 || d->kh != 3 || d->kw != 3 || d->sh != 2 || d->sw != 2 || d->dh != 1 || d->dw != 1) return 0;
+    if (d->cin != 3 || d->cout > 32 || d->cout % 8 != 0 || d->ldo % 8 != 0 || d->cooff % 8 != 0) return 0;
+    if ((int64_t)d->nb * d->oh * d->ow < 256 * 1024) return 0;
+    if ((long long)d->h * d->w * 16 >= 0x7fffffffll || (long long)d->oh * d->ow * d->ldo * 2 >= 0x7fffffffll) return 0;
+    const char* sv = getenv("DIN_CONV_SMALL");
+    if (sv && atoi(sv) == 0) return 0;
+    const char* uv = getenv("DIN_CONV_U8");
+    if (uv && atoi(uv) == 0) return 0;
+    din_conv_desc t = *d;
+    t.in_u8 = 0; t.ldi = 8; t.cioff = 0;             // the plan of the prepared-tensor form must pick the image-layer wgrad kernel
+    return plan_wgrad(&t).small == 3 ? 1 : 0;
 }
 
 int din_conv_fwd2(const din_conv_desc* d, const void* in, const void* wpk, const float* bias, void* out, void* out2, int ldo2, int cooff2,
                   int csplit, int craw, int flags, void* workspace, int64_t workspace_bytes, void* stream) {
     if (int e = check_desc(d)) return e;
     DIN_REQUIRE(in && wpk && out && out2, "conv_fwd2: null pointer");
+    DIN_REQUIRE(!d->in_u8, "conv_fwd2: in_u8 is a din_conv_fwd / din_conv_wgrad option");
     DIN_REQUIRE(!(flags & DIN_CONV_BIAS) || bias, "conv_fwd2: BIAS flag without bias");
     DIN_REQUIRE(!(flags & (DIN_CONV_ACCUM | DIN_CONV_MASK)), "conv_fwd2: ACCUM/MASK are dgrad-only flags");
     const int epc = epc_of(d->dtype);
@@ -2857,6 +2974,7 @@ int din_conv_dgrad(const din_conv_desc* d, const void* dout, const void* wpk_t, 
                    int moff, int flags, void* workspace, int64_t workspace_bytes, void* stream) {
     if (int e = check_desc(d)) return e;
     DIN_REQUIRE(dout && wpk_t && din_, "conv_dgrad: null pointer");
+    DIN_REQUIRE(!d->in_u8, "conv_dgrad: in_u8 is a din_conv_fwd / din_conv_wgrad option");
     DIN_REQUIRE(!(flags & (DIN_CONV_BIAS | DIN_CONV_RELU)), "conv_dgrad: BIAS/RELU are fwd-only flags");
     DIN_REQUIRE(!(flags & DIN_CONV_MASK) || mask, "conv_dgrad: MASK flag without mask");
     int epc = epc_of(d->dtype);
@@ -2956,6 +3074,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
     if (int e = check_desc(d)) return e;
     DIN_REQUIRE(in && dout && dw, "conv_wgrad: null pointer");
     DIN_REQUIRE(!wdot || w, "conv_wgrad: wdot needs w");
+    DIN_REQUIRE(!d->in_u8 || din_conv_accepts_u8(d), "conv_wgrad: in_u8 on a layer din_conv_accepts_u8() rejects");
     hipStream_t st = as_stream(stream);
     const bool prezeroed = (accumulate & 2) != 0;            // dbias / wdot were zeroed by the caller (one memset for a whole backbone)
     accumulate &= 1;
@@ -2986,13 +3105,14 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
             }
             const int st_ = wp.small == 3 ? 2 : 1, cpp = wp.small == 3 ? 1 : 4;
             const int hbytes = ((7 * st_ + 3) * (31 * st_ + 3) * cpp * 16 + 1023) / 1024 * 1024;
-            const size_t lds = 2 * ((size_t)hbytes + 256 * (size_t)wp.bco * 2);
+            const size_t lds = 2 * ((size_t)hbytes + 256 * (size_t)wp.bco * 2) + (d->in_u8 ? 512 : 0);
             auto launch = [&](auto kern) {
                 if (lds > 65536) raise_lds_limit(kern, lds);
                 hipLaunchKernelGGL(kern, dim3(WGRAD_SMALL_GRID), dim3(NTHREADS), lds, st, k);
             };
             if (wp.small == 1) launch(conv_wgrad_small_kernel<4, 32, 1>);
             else if (wp.small == 2) launch(conv_wgrad_small_kernel<4, 64, 1>);
+            else if (d->in_u8) { k.u8 = reinterpret_cast<const unsigned char*>(in); launch(conv_wgrad_small_kernel<1, 32, 2, true>); }
             else launch(conv_wgrad_small_kernel<1, 32, 2>);
         } else if (wp.pipe) {
             if (dbias) {

@@ -463,6 +463,8 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
         if op.kind == "conv":
             cin = g.cin_image if op.src.tid == g.input_tid else op.src.c
             d = _conv_desc(g, op, nb, dt, cin)
+            if op.src.tid == g.input_tid and src.dtype == torch.uint8:
+                d.in_u8, d.ldi, d.cioff = 1, 8, 0                      # raw uint8 frames [nb,3,h,w]: the image layer normalises on load
             w = next(it)
             scale = shift = None
             if op.bn:
@@ -710,6 +712,8 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
         if op.kind == "conv":
             cin = g.cin_image if op.src.tid == g.input_tid else op.src.c
             d = _conv_desc(g, op, nb, dt, cin)
+            if op.src.tid == g.input_tid and bufs[g.input_tid].dtype == torch.uint8:
+                d.in_u8, d.ldi, d.cioff = 1, 8, 0
             po = offsets[oi]
             w = params[po]
             scale = aux[oi][0]
@@ -872,6 +876,21 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
     return grads
 
 
+def _accepts_u8_frames(g: Graph, nb: int, dt: int) -> bool:
+    """True when the only reader of the graph input is a conv whose forward and weight-gradient launches take the image-layer kernels
+    that read uint8 frames directly (din_conv_accepts_u8): Inception's Conv2d_1a_3x3 at full frame size in bf16."""
+    readers = [op for op in g.ops if op.src.tid == g.input_tid]
+    if len(readers) != 1 or readers[0].kind != "conv" or readers[0].pooled is not None:
+        return False
+    key = (nb, dt)
+    cache = g.__dict__.setdefault("_u8_ok", {})
+    if key not in cache:
+        d = _conv_desc(g, readers[0], nb, dt, g.cin_image)
+        d.ldi, d.cioff = 8, 0
+        cache[key] = bool(L.load().din_conv_accepts_u8(C.byref(d)))
+    return cache[key]
+
+
 class NHWCGraphFunction(torch.autograd.Function):
     """images (uint8|fp32 NCHW, 0..255) -> output NHWC buffers.  One autograd node for the whole conv stack."""
 
@@ -882,14 +901,18 @@ class NHWCGraphFunction(torch.autograd.Function):
         nb, _, h, w = images.shape
         ti = graph.tensors[graph.input_tid]
         assert (h, w) == (ti.h, ti.w), f"image {h}x{w} does not match the graph ({ti.h}x{ti.w})"
-        img = torch.empty((nb, h, w, ti.c), dtype=torch_dtype(dt), device=images.device)
         st = _stream()
-        if prenormalised:
+        if not prenormalised and images.dtype == torch.uint8 and _accepts_u8_frames(graph, nb, dt):
+            # the image layer (forward and weight gradient) reads the uint8 frames itself: no prepared NHWC copy of the clip batch
+            img = images.contiguous()
+        elif prenormalised:
+            img = torch.empty((nb, h, w, ti.c), dtype=torch_dtype(dt), device=images.device)
             if ti.c > 3:
                 img.zero_()
             L.check(lib.din_nchw_f32_to_nhwc(_ptr(images.float().contiguous()), nb, h, w, 3, _ptr(img), dt, ti.c, 0, st),
                     "nchw_to_nhwc")
         else:
+            img = torch.empty((nb, h, w, ti.c), dtype=torch_dtype(dt), device=images.device)
             if images.dtype == torch.uint8:
                 L.check(lib.din_prep_images_nhwc(_ptr(images), 1, _ptr(img), dt, nb, h, w, ti.c, st), "prep_nhwc")
             else:

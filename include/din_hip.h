@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DIN_ABI_VERSION 3   /* 2: din_walk_* take plain / clamp / n_per_clip; + bn, mask_actors.  3: din_roi_align_* take the box grid and a crop channel range */
+#define DIN_ABI_VERSION 4   /* 2: din_walk_* take plain / clamp / n_per_clip; + bn, mask_actors.  3: din_roi_align_* take the box grid and a crop channel range.  4: din_conv_desc.in_u8, context-encoding entry points */
 
 enum { DIN_F32 = 0, DIN_BF16 = 1 };
 
@@ -69,6 +69,10 @@ typedef struct din_conv_desc {
     int32_t kh, kw, sh, sw, ph, pw, dh, dw;
     int32_t ldi, cioff, ldo, cooff;
     int32_t dtype;                  /* DIN_F32 / DIN_BF16 : storage type of in, out and packed weights       */
+    int32_t in_u8;                  /* 1: `in` is the raw uint8 clip batch [nb][3][h][w] (volleyball.py:223-275 frames before
+                                       utils.prep_images) and the image layer normalises on load -- (x/255 - 0.5)*2 in the reference's
+                                       three fp32 roundings, utils.py:8-19 -- instead of reading a prepared NHWC tensor; ldi / cioff are
+                                       ignored.  Only din_conv_fwd / din_conv_wgrad, only where din_conv_accepts_u8() says so. */
 } din_conv_desc;
 
 enum {
@@ -115,6 +119,11 @@ int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t
 int din_conv_kernel_variant(const din_conv_desc* d, int which, int32_t* flags);
 /* workspace bytes needed by fwd / dgrad / wgrad for this descriptor (split-K partial sums) */
 int64_t din_conv_workspace_bytes(const din_conv_desc* d, int which /*0 fwd,1 dgrad,2 wgrad*/);
+
+/* 1 when both the forward and the weight-gradient launch of this layer run the image-layer kernels that can read uint8 frames directly
+ * (bf16, 3x3 stride 2, <= 8 input channels, <= 32 filters, >= 256 Ki output pixels); 0 otherwise (prepare the input with
+ * din_prep_images_nhwc).  Host-only planning call. */
+int din_conv_accepts_u8(const din_conv_desc* d);
 
 int din_conv_fwd(const din_conv_desc* d, const void* in, const void* wpk, const float* bias, void* out,
                  int flags, void* workspace, int64_t workspace_bytes, void* stream);

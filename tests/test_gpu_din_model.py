@@ -623,3 +623,33 @@ def test_train_net_runs_the_tce_model(gpu, tmp_path):
     infos = train_net(cfg)
     tr, te = infos[0]["train"], infos[0]["test"]
     assert np.isfinite(tr["loss"]) and np.isfinite(te["loss"])
+
+
+def test_materialised_multiscale_fuse_still_matches_golden(gpu, monkeypatch):
+    """DIN_ROI_COMPOSE=0: the round-1 graph (Mixed_5d written into the fused [5d | resize(6e)] tensor, din_bilinear_fwd / _bwd, one plain
+    RoIAlign) gives the reference's logits and the same gradients as the composed default"""
+    from din_amd.config import Config
+    from din_amd.infer_model import Dynamic_volleyball
+    path = [p for p in MODEL_CASES if "inv3_139x203_nfb64" in p][0]
+    z, ocfg, p, images, boxes, labels = load_model_case(path)
+    grads = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DIN_ROI_COMPOSE", mode)
+        cfg = Config("volleyball")
+        cfg.backbone, cfg.image_size, cfg.out_size, cfg.emb_features = ocfg.backbone, ocfg.image_size, ocfg.out_size, ocfg.emb_features
+        cfg.num_boxes, cfg.num_frames = ocfg.num_boxes, ocfg.num_frames
+        cfg.num_features_boxes = cfg.num_features_gcn = ocfg.num_features_boxes
+        cfg.ST_kernel_size, cfg.sampling_ratio, cfg.num_DIM = ocfg.ST_kernel_size, ocfg.sampling_ratio, ocfg.num_DIM
+        cfg.beta_factor, cfg.lite_dim, cfg.hierarchical_inference = ocfg.beta_factor, ocfg.lite_dim, ocfg.hierarchical_inference
+        cfg.train_backbone, cfg.backbone_dtype = True, "fp32"
+        model = Dynamic_volleyball(cfg)
+        assert model.backbone.materialise_fuse == (mode == "0")
+        model.load_state_dict(p, strict=False)
+        model = model.to(gpu).eval()
+        ret = model((images.to(gpu), boxes.to(gpu)))
+        F.cross_entropy(ret["activities"], labels.to(gpu)).backward()
+        assert rel(ret["activities"], z["logits"]) <= 1e-4
+        grads.append({k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None})
+    for k in ("backbone.Mixed_6e.branch1x1.conv.weight", "backbone.Mixed_5d.branch1x1.conv.weight", "backbone.Conv2d_4a_3x3.conv.weight",
+              "fc_emb_1.weight"):
+        assert rel(grads[0][k], grads[1][k]) <= 2e-3, k

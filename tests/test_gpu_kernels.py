@@ -459,6 +459,60 @@ def test_avgpool_strip_kernel_is_bit_identical(env, shape, monkeypatch):
         assert torch.equal(res[0], res[1])
 
 
+def test_image_layer_reads_uint8_frames_bit_identically(env):
+    """din_conv_desc.in_u8: Inception's Conv2d_1a (3 -> 32, 3x3 stride 2) fed with the raw uint8 clip batch [nb,3,h,w] -- forward and weight /
+    bias gradient -- equals din_prep_images_nhwc + the same launches on the prepared tensor BIT FOR BIT (the loader writes the same bf16
+    halo image the LDS-DMA would have); ragged tile edges; and the planner refuses layers the image-layer kernels do not serve"""
+    lib, L, nhwc, ops = env
+    nb, h, w, cout = 2, 727, 1283, 32
+    oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+    g = torch.Generator().manual_seed(12)
+    img = torch.randint(0, 256, (nb, 3, h, w), dtype=torch.uint8, generator=g).cuda()
+    wt = (torch.randn(cout, 3, 3, 3, generator=g) * 0.3).cuda()
+    bias = (torch.randn(cout, generator=g) * 0.1).cuda()
+    gz = torch.randn(nb, oh, ow, cout, generator=g).bfloat16().cuda()
+    d = L.ConvDesc()
+    d.nb, d.h, d.w, d.cin, d.oh, d.ow, d.cout = nb, h, w, 3, oh, ow, cout
+    d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.dh, d.dw = 3, 3, 2, 2, 0, 0, 1, 1
+    d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = 8, 0, cout, 0, L.DIN_BF16
+    assert lib.din_conv_accepts_u8(C.byref(d)) == 1
+    wpk = torch.empty(lib.din_conv_packed_elems(C.byref(d), 0), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.din_conv_pack_weights(C.byref(d), wt.data_ptr(), None, wpk.data_ptr(), 0, None))
+    prepared = torch.empty(nb, h, w, 8, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.din_prep_images_nhwc(img.data_ptr(), 1, prepared.data_ptr(), L.DIN_BF16, nb, h, w, 8, None))
+    res = []
+    for u8 in (0, 1):
+        d.in_u8 = u8
+        src = img if u8 else prepared
+        out = torch.full((nb, oh, ow, cout), 7.0, dtype=torch.bfloat16, device="cuda")
+        wsb = lib.din_conv_workspace_bytes(C.byref(d), 0)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
+        L.check(lib.din_conv_fwd(C.byref(d), src.data_ptr(), wpk.data_ptr(), bias.data_ptr(), out.data_ptr(), L.CONV_BIAS | L.CONV_RELU,
+                                 ws.data_ptr(), wsb, None))
+        dw, db = torch.empty_like(wt), torch.empty(cout, device="cuda")
+        wsb = lib.din_conv_workspace_bytes(C.byref(d), 2)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
+        L.check(lib.din_conv_wgrad(C.byref(d), src.data_ptr(), gz.data_ptr(), dw.data_ptr(), db.data_ptr(), None, None, None, 0,
+                                   ws.data_ptr(), wsb, None))
+        torch.cuda.synchronize()
+        res.append((out, dw, db))
+    assert torch.equal(res[0][0], res[1][0]), "forward differs"
+    assert torch.equal(res[0][1], res[1][1]), "weight gradient differs"
+    assert rel(res[0][2], res[1][2]) <= 1e-4, "bias gradient differs"          # (summed with fp32 atomics across workgroups: order-dependent last bits)
+    # against torch on the normalised image (what the layer computes at all)
+    x = O.prep_images(img.cpu().float()).bfloat16().float()
+    y = F.relu(F.conv2d(x, wt.cpu().bfloat16().float(), bias.cpu(), stride=2))
+    assert rel(res[1][0].float().cpu().permute(0, 3, 1, 2), y) <= 1.5e-2
+    # layers the image-layer kernels do not serve: small frames, stride 1, fp32
+    d.in_u8 = 0
+    d.nb = 1; d.h, d.w, d.oh, d.ow = 139, 203, 69, 101
+    assert lib.din_conv_accepts_u8(C.byref(d)) == 0
+    d.in_u8 = 1
+    small = torch.zeros(1, 3, 139, 203, dtype=torch.uint8, device="cuda")
+    out = torch.empty(1, 69, 101, cout, dtype=torch.bfloat16, device="cuda")
+    assert lib.din_conv_fwd(C.byref(d), small.data_ptr(), wpk.data_ptr(), None, out.data_ptr(), 0, None, 0, None) != 0
+
+
 def test_prep_images_bit_exact(env):
     lib, L, nhwc, ops = env
     x = torch.arange(0, 256, dtype=torch.float32)
