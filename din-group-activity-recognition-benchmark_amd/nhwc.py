@@ -479,6 +479,7 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
                 # conv -> raw [nb,oh,ow,cout] (-> commuted pool: also linear, so avgpool(conv(x)) == conv(avgpool(x)) holds before the
                 # normalisation) -> batch statistics -> normalise + ReLU into dst's view
                 dR = _conv_desc(g, op, nb, dt, cin)
+                dR.in_u8, dR.ldi, dR.cioff = d.in_u8, d.ldi, d.cioff      # (uint8 frames feed the image layer in this mode too)
                 dR.ldo, dR.cooff = op.dst.c, 0
                 raw = torch.empty((nb, g.tensors[op.src.tid].h if op.pooled is not None else td.h,
                                    g.tensors[op.src.tid].w if op.pooled is not None else td.w, op.dst.c), dtype=tdt, device=dev)

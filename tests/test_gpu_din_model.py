@@ -653,3 +653,34 @@ def test_materialised_multiscale_fuse_still_matches_golden(gpu, monkeypatch):
     for k in ("backbone.Mixed_6e.branch1x1.conv.weight", "backbone.Mixed_5d.branch1x1.conv.weight", "backbone.Conv2d_4a_3x3.conv.weight",
               "fc_emb_1.weight"):
         assert rel(grads[0][k], grads[1][k]) <= 2e-3, k
+
+
+@pytest.mark.parametrize("bn_train", [False, True], ids=["bn_eval", "bn_batch_stats"])
+def test_uint8_frames_through_the_image_layer_match_the_prepared_tensor(gpu, monkeypatch, bn_train):
+    """Inception bf16 on full-size uint8 frames: the image layer reading the frames itself (din_conv_desc.in_u8, default) gives bit-identical
+    backbone outputs and the same Conv2d_1a / BatchNorm gradients as DIN_CONV_U8=0 (din_prep_images_nhwc + prepared tensor), with folded and
+    with batch-statistics BatchNorm"""
+    from din_amd.backbone.backbone import MyInception_v3
+    g = torch.Generator().manual_seed(8)
+    images = torch.randint(0, 256, (3, 3, 720, 1280), dtype=torch.uint8, generator=g).to(gpu)
+    res = []
+    for mode in (("1", "0", "0") if bn_train else ("1", "0")):      # batch statistics: the prepared-tensor path twice = the run-to-run yardstick
+        monkeypatch.setenv("DIN_CONV_U8", mode)
+        torch.manual_seed(4)
+        net = MyInception_v3(compute_dtype="bf16").to(gpu)
+        net.train(bn_train)
+        bufs, graph = net.forward_nhwc(images)
+        from din_amd import nhwc
+        assert nhwc._accepts_u8_frames(graph, 3, 1) == (mode == "1")
+        (bufs[0].float().mean() + bufs[1].float().mean()).backward()
+        res.append((bufs[0].detach().clone(), bufs[1].detach().clone(), net.Conv2d_1a_3x3.conv.weight.grad.clone(),
+                    net.Conv2d_1a_3x3.bn.weight.grad.clone()))
+        graph.__dict__.pop("_u8_ok", None)
+    if not bn_train:
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        assert rel(res[0][2], res[1][2]) <= 1e-4 and rel(res[0][3], res[1][3]) <= 1e-4
+    else:       # batch statistics are summed with atomics: order-dependent last bits, then bf16 roundings and ReLU decisions downstream --
+        # the same path run twice differs; the uint8 path must not differ from it by more than that
+        for i in range(4):
+            yard = rel(res[1][i], res[2][i])
+            assert rel(res[0][i], res[1][i]) <= max(3.0 * yard, 1e-3), (i, rel(res[0][i], res[1][i]), yard)
