@@ -20,6 +20,7 @@
 #include "din_common.h"
 #include "conv_wgrad.h"
 #include "conv_gather.h"
+#include <atomic>
 #include <unordered_map>
 #include <mutex>
 #include <stdlib.h>
@@ -1194,6 +1195,41 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, const float* __res
     }
 }
 
+// 1x1 filter banks (the 26400 x 1024 embedding filter is re-packed twice per step: 108 MB in, 54 MB out per orientation): 64 x 64 tiles
+// through LDS, reads coalesced along the filter's contiguous axis (ci), writes coalesced along the packed row -- instead of one element
+// per thread with two 64-bit divisions (106 -> ~35 us per orientation).  out[row][k]: row = co (k = ci) or, transposed, row = ci (k = co).
+template <typename T>
+__global__ __launch_bounds__(256) void conv_pack_1x1_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ out,
+                                                            int cout, int cin, int rows_pad, int kelems, int transposed) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, k0 = blockIdx.x * 64;                  // tile of the packed matrix
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;                // 64 x 4
+    if (!transposed) {
+#pragma unroll 4
+        for (int rr = ty; rr < 64; rr += 4) {
+            const int co = r0 + rr, ci = k0 + tx;
+            float v = 0.f;
+            if (co < cout && ci < cin) { v = w[(int64_t)co * cin + ci]; if (scale) v *= scale[co]; }
+            if (co < rows_pad && ci < kelems) Elem<T>::st(out + (int64_t)co * kelems + ci, v);
+        }
+        return;
+    }
+    // transposed: packed row = ci, packed column = co; read w[co][ci] with ci fastest
+#pragma unroll 4
+    for (int cc = ty; cc < 64; cc += 4) {
+        const int co = k0 + cc, ci = r0 + tx;
+        float v = 0.f;
+        if (co < cout && ci < cin) { v = w[(int64_t)co * cin + ci]; if (scale) v *= scale[co]; }
+        tile[cc][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int rr = ty; rr < 64; rr += 4) {
+        const int ci = r0 + rr, co = k0 + tx;
+        if (ci < rows_pad && co < kelems) Elem<T>::st(out + (int64_t)ci * kelems + co, tile[tx][rr]);
+    }
+}
+
 // every filter bank of a backbone (both orientations) in one launch: workgroup b packs elements [chunk_index[b] * chunk, +chunk) of
 // bank layer_of[b]; the table lives on the device and is built once (weights, scales and packed buffers keep their addresses)
 __global__ __launch_bounds__(256) void conv_pack_multi_kernel(const din_pack_desc* __restrict__ table, const int32_t* __restrict__ layer_of,
@@ -1206,14 +1242,18 @@ __global__ __launch_bounds__(256) void conv_pack_multi_kernel(const din_pack_des
     int64_t i1 = i0 + chunk;
     if (i1 > total) i1 = total;
     const int taps = d.kh * d.kw;
+    // (banks below 2^31 elements -- every backbone bank -- take 32-bit index arithmetic: the 64-bit divisions cost more than the traffic)
+    const bool small = total < (1ll << 31);
     for (int64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        const int row = (int)(i / d.kelems), k = (int)(i - (int64_t)row * d.kelems);
+        int row, k;
+        if (small) { row = (int)((uint32_t)i / (uint32_t)d.kelems); k = (int)((uint32_t)i - (uint32_t)row * (uint32_t)d.kelems); }
+        else { row = (int)(i / d.kelems); k = (int)(i - (int64_t)row * d.kelems); }
         const int tap = k / d.inner_pad, c = k - tap * d.inner_pad;
         float v = 0.f;
         if (row < d.rows && tap < taps && c < d.inner) {
             const int r = tap / d.kw, s2 = tap - r * d.kw;
             const int co = d.transposed ? c : row, ci = d.transposed ? row : c;
-            v = w[(((int64_t)co * d.cin + ci) * d.kh + r) * d.kw + s2];
+            v = small ? w[(uint32_t)(((co * d.cin + ci) * d.kh + r) * d.kw + s2)] : w[(((int64_t)co * d.cin + ci) * d.kh + r) * d.kw + s2];
             if (scale) v *= scale[co];
         }
         if (d.dtype == DIN_F32) reinterpret_cast<float*>(d.out)[i] = v;
@@ -2789,6 +2829,14 @@ int din_conv_pack_weights(const din_conv_desc* d, const float* w, const float* s
     int rows_pad = pad_to(cprod, 256);
     int64_t total = (int64_t)rows_pad * kelems;
     hipStream_t st = as_stream(stream);
+    if (d->kh == 1 && d->kw == 1 && total >= (1 << 20) && !(getenv("DIN_PACK_TILES") && atoi(getenv("DIN_PACK_TILES")) == 0)) {
+        // (tap-major k = channel index for a single tap; the padded tail of every row / the padded rows are written as zeros)
+        dim3 grid((kelems + 63) / 64, (rows_pad + 63) / 64);
+        if (d->dtype == DIN_F32) hipLaunchKernelGGL(conv_pack_1x1_kernel<float>, grid, dim3(256), 0, st, w, scale, (float*)wpk, d->cout, d->cin, rows_pad, kelems, transposed);
+        else hipLaunchKernelGGL(conv_pack_1x1_kernel<bf16_t>, grid, dim3(256), 0, st, w, scale, (bf16_t*)wpk, d->cout, d->cin, rows_pad, kelems, transposed);
+        DIN_CHECK_LAUNCH("conv_pack(1x1)");
+        return DIN_OK;
+    }
     if (d->dtype == DIN_F32)
         hipLaunchKernelGGL(conv_pack_kernel<float>, dim3(grid_1d(total, 256)), dim3(256), 0, st, w, scale, (float*)wpk,
                            d->cout, d->cin, d->kh, d->kw, cprod, rows_pad, cred, inner_pad, kelems, transposed);
@@ -3129,9 +3177,13 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
                 const size_t words = (size_t)wp.slices * wp.n_co_tiles * 8;                 // rows of 8 words (one s_load_dwordx8)
                 // measured (tools/pace_experiment.sh, profiles/r02_wgrad_pacing.txt): Conv2d_4a (3 k tiles) 6.67 -> 3.12 GB fetched per launch at
                 // unchanged time; with 6+ siblings the naps cost 4-10 % and the L2 hit rate was 74 % anyway -> default: up to 3 siblings
-                if (want && wp.n_k_tiles >= 2 && wp.n_k_tiles <= (want >= 2 ? 8 : 3) && !wp.atomic) {
+                if (want && wp.n_k_tiles >= 2 && wp.n_k_tiles <= (want >= 2 ? 8 : 3) && !wp.atomic && wp.m_per_slice / 32 < (1 << 20) - 1) {
                     k.pace = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + (((size_t)wp.slices * wp.cout_pad * wp.kcols_pad * 4 + 31) & ~(size_t)31));
-                    if (hipMemsetAsync(k.pace, 0, words * sizeof(int), st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
+                    // no memset: every launch tags its words (1..1023 << 20, never 0); words of older launches or stale workspace contents
+                    // are out of range for this tag (an alias once in 1023 launches costs one bounded spin, never correctness)
+                    static std::atomic<unsigned> pace_epoch{0};
+                    k.pace_base = (int)(((pace_epoch.fetch_add(1) % 1023u) + 1u) << 20);
+                    (void)words;
                 }
             }
             if (int e = din_wgrad::launch_wgrad_pipe(k, wp.bco, wp.bk, grid, st)) return e;

@@ -233,13 +233,16 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_pipe_kernel(WgradK p) {
     int* pace_row = p.pace ? p.pace + (int64_t)(slice * p.n_co_tiles + co_tile) * PACE_ROW : nullptr;
     auto pace = [&](int s) {
         if (pace_row == nullptr || wid != 0 || (s & (PACE_EVERY - 1)) != 0) return;      // scalar conditions
-        if (lane == 0) __hip_atomic_store(pace_row + k_tile, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(pace_row + k_tile, p.pace_base + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int spin = 0; spin < PACE_SPINS; ++spin) {
             i32x8 v;
             asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(pace_row) : "memory");
             int behind = 0x7fffffff;
 #pragma unroll
-            for (int e = 0; e < PACE_ROW; ++e) behind = (v[e] != 0 && v[e] < behind) ? v[e] : behind;   // 0: not started / no such sibling
+            for (int e = 0; e < PACE_ROW; ++e) {        // words outside this launch's tag range: not started / no such sibling / an older launch
+                const unsigned rel = (unsigned)(v[e] - p.pace_base - 1);
+                behind = (rel < (1u << 20) && (int)rel + 1 < behind) ? (int)rel + 1 : behind;
+            }
             if (s + 1 - behind <= PACE_SLACK) break;                 // (own word included: behind <= s + 1 once the store landed)
             __builtin_amdgcn_s_sleep(4);
         }

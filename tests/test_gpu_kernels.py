@@ -513,6 +513,33 @@ def test_image_layer_reads_uint8_frames_bit_identically(env):
     assert lib.din_conv_fwd(C.byref(d), small.data_ptr(), wpk.data_ptr(), None, out.data_ptr(), 0, None, 0, None) != 0
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_tiled_1x1_filter_pack_is_bit_identical(env, dtype, monkeypatch):
+    """the 64 x 64-tile pack of large 1x1 filter banks (fc_emb_1: 26400 x 1024, both orientations, every step) writes exactly what the
+    element-per-thread pack writes, padded rows / columns included, with and without the folded scale"""
+    lib, L, nhwc, ops = env
+    cout, cin = 300, 5003 if dtype == "fp32" else 5000
+    tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(cout, cin, 1, 1, generator=g).cuda()
+    scale = (torch.rand(cout, generator=g) + 0.5).cuda()
+    d = L.ConvDesc()
+    d.nb, d.h, d.w, d.cin, d.oh, d.ow, d.cout = 1, 1, 64, cin, 1, 64, cout
+    d.kh = d.kw = d.sh = d.sw = d.dh = d.dw = 1
+    epc = 4 if dtype == "fp32" else 8
+    d.ldi, d.ldo, d.dtype = (cin + epc - 1) // epc * epc, (cout + 7) // 8 * 8, L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
+    for transposed in (0, 1):
+        for sc in (None, scale):
+            outs = []
+            for mode in ("0", "1"):
+                monkeypatch.setenv("DIN_PACK_TILES", mode)
+                out = torch.full((lib.din_conv_packed_elems(C.byref(d), transposed),), 3.0, dtype=tdt, device="cuda")
+                L.check(lib.din_conv_pack_weights(C.byref(d), w.data_ptr(), sc.data_ptr() if sc is not None else None, out.data_ptr(), transposed, None))
+                torch.cuda.synchronize()
+                outs.append(out)
+            assert torch.equal(outs[0], outs[1]), (transposed, sc is not None)
+
+
 def test_prep_images_bit_exact(env):
     lib, L, nhwc, ops = env
     x = torch.arange(0, 256, dtype=torch.float32)
