@@ -325,6 +325,7 @@ def main():
         if it == a.steps - 1:
             profiling.PROFILE, profiling.PROFILE_ONLY = [], dom_survey
         loss = step()
+    host_enqueue_s = time.perf_counter() - t0                # host time to ENQUEUE the timed steps (nothing waits on the GPU inside a step)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -398,6 +399,7 @@ def main():
                                   if backbone == "inv3" else "n/a"},
             "roofline": roofline,
             "conv_time_frac_sampled_step": round(conv_time / (elapsed / a.steps), 4),
+            "host_enqueue_ms_per_step": round(host_enqueue_s / a.steps * 1e3, 3),
             "final_loss": round(float(loss.item()), 5),
         }
         if world == 1 and not a.no_cpu_baseline:
