@@ -684,3 +684,38 @@ def test_uint8_frames_through_the_image_layer_match_the_prepared_tensor(gpu, mon
         for i in range(4):
             yard = rel(res[1][i], res[2][i])
             assert rel(res[0][i], res[1][i]) <= max(3.0 * yard, 1e-3), (i, rel(res[0][i], res[1][i]), yard)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, (3, 3), [1]), (1, 1, 5, (3, 3), [1, 3]), (3, 2, 1, (1, 3), [1]), (1, 4, 13, (5, 5), [2]), (2, 1, 12, (3, 1), [1])],
+                         ids=["b1_t1_n1", "t1_n5_ratios13", "b3_t2_n1_k13", "t4_n13_k55_r2", "b2_t1_n12_k31"])
+def test_model_edge_shapes_match_oracle(gpu, shape):
+    """degenerate actor grids through the whole model (VGG16 trunk, fp32) against the CPU oracle: one frame, one actor, more actors than the
+    12 of the volleyball setup, kernels wider than the grid (every lattice point but the centre falls on zero padding), beta-weighted ratios --
+    logits and the DIN / embedding gradients"""
+    from din_amd.config import Config
+    from din_amd.infer_model import Dynamic_volleyball
+    B, T, N, kernel, ratios = shape
+    beta = len(ratios) > 1
+    ocfg = O.OracleCfg(image_size=(64, 96), out_size=(2, 3), num_boxes=N, num_frames=T, num_features_boxes=32, ST_kernel_size=[kernel],
+                       sampling_ratio=ratios, beta_factor=beta)
+    p = O.synth_params(O.model_param_shapes(ocfg), seed=15 + N, din_std=0.05)
+    images, boxes, labels = O.synth_inputs(B, T, N, 64, 96, 2, 3, 8, seed=20 + T)
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    out = O.dynamic_volleyball_forward(ocfg, po, images.float(), boxes)
+    F.cross_entropy(out["activities"], labels).backward()
+    cfg = Config("volleyball")
+    cfg.backbone, cfg.image_size, cfg.out_size, cfg.emb_features = "vgg16", (64, 96), (2, 3), 512
+    cfg.num_boxes, cfg.num_frames, cfg.num_features_boxes, cfg.num_features_gcn = N, T, 32, 32
+    cfg.ST_kernel_size, cfg.sampling_ratio, cfg.beta_factor, cfg.train_backbone = [kernel], ratios, beta, True
+    model = Dynamic_volleyball(cfg)
+    model.load_state_dict(p)
+    model = model.to(gpu).eval()
+    ret = model((images.to(gpu), boxes.to(gpu)))
+    F.cross_entropy(ret["activities"], labels.to(gpu)).backward()
+    assert rel(ret["activities"], out["activities"]) <= 1e-4
+    named = dict(model.named_parameters())
+    for k in po:
+        if k.startswith(("DPI.", "fc_emb_1.", "nl_emb_1.", "dpi_nl.", "fc_activities.")) and po[k].grad is not None:
+            assert named[k].grad is not None, k
+            if float(po[k].grad.abs().max()) > 0:
+                assert rel(named[k].grad, po[k].grad) <= 2e-3, (k, rel(named[k].grad, po[k].grad))
