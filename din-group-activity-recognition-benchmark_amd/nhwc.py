@@ -155,6 +155,7 @@ class Graph:
     input_tid: int = 0
     output_tids: List[int] = field(default_factory=list)
     cin_image: int = 3
+    u8_ok: Dict[Tuple[int, int], bool] = field(default_factory=dict)   # (frames, dtype) -> the image layer takes uint8 frames (_accepts_u8_frames)
     fwd_groups: List[Tuple[int, ...]] = field(default_factory=list)   # consecutive sibling conv ops (same source view, same 1x1 geometry) whose
                                                                       # forward runs as ONE launch: first member -> its own view, the rest -> adjacent views of one tensor
 
@@ -884,7 +885,7 @@ def _accepts_u8_frames(g: Graph, nb: int, dt: int) -> bool:
     if len(readers) != 1 or readers[0].kind != "conv" or readers[0].pooled is not None:
         return False
     key = (nb, dt)
-    cache = g.__dict__.setdefault("_u8_ok", {})
+    cache = g.u8_ok
     if key not in cache:
         d = _conv_desc(g, readers[0], nb, dt, g.cin_image)
         d.ldi, d.cioff = 8, 0

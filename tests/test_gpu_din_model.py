@@ -675,7 +675,7 @@ def test_uint8_frames_through_the_image_layer_match_the_prepared_tensor(gpu, mon
         (bufs[0].float().mean() + bufs[1].float().mean()).backward()
         res.append((bufs[0].detach().clone(), bufs[1].detach().clone(), net.Conv2d_1a_3x3.conv.weight.grad.clone(),
                     net.Conv2d_1a_3x3.bn.weight.grad.clone()))
-        graph.__dict__.pop("_u8_ok", None)
+        graph.u8_ok.clear()
     if not bn_train:
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
         assert rel(res[0][2], res[1][2]) <= 1e-4 and rel(res[0][3], res[1][3]) <= 1e-4
