@@ -42,22 +42,25 @@ __device__ __forceinline__ s16x4 tr_read(uint32_t byte_addr) {
 
 template <int V> struct IC { static constexpr int value = V; };
 
-template <int BCO, int BK, bool WIDE>
-__global__ __launch_bounds__(512, 1) void conv_wgrad_pipe_kernel(WgradK p) {
+// WN: waves along the k columns (WM = 2 along the filter rows): 4 -> 8 waves with (BCO/2) x 64 wave tiles; 2 -> 4 waves with (BCO/2) x 128
+// wave tiles (one wave per SIMD, 7 instead of 10 fragment reads per 12 MFMAs: the LDS-read experiment of profiles/r02_wgrad_pipe_knockout.txt)
+template <int BCO, int BK, bool WIDE, int WN = 4>
+__global__ __launch_bounds__(128 * WN, 1) void conv_wgrad_pipe_kernel(WgradK p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int PK = 32, NS = 4, NWV = 8;
+    constexpr int PK = 32, NS = 4, NWV = 2 * WN;
+    constexpr int TR = 16 / NWV;                                   // wave-level transfers per operand and stage (2 tile rows each)
     constexpr int ROWB = 512;                                      // LDS row pitch of both operand tiles (bytes)
     static_assert(BK == 256 && BCO % 64 == 0 && BCO <= 256, "tile");
     constexpr int CG = BCO / 8;                                    // real 16-byte chunks of a G row (of 32 slots)
     constexpr int OPG = PK * ROWB, STAGE = 2 * OPG;                // 16 KiB per operand, 32 KiB per stage
-    constexpr int TI = BCO / 64, XJ = BK / 128;                    // 32x32 MFMA tiles per wave (wave tile = BCO/2 x BK/4)
+    constexpr int TI = BCO / 64, XJ = BK / (32 * WN);              // 32x32 MFMA tiles per wave (wave tile = BCO/2 x BK/WN)
     constexpr int NM = TI * XJ;                                    // MFMAs per half-stage
-    constexpr int NDMA = 4;                                        // wave-level DMAs per stage per wave: 2 G + 2 X
+    constexpr int NDMA = 2 * TR;                                   // wave-level DMAs per stage per wave: TR for G + TR for X
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: lives in an SGPR, branches on it are scalar
-    const int wm = wid >> 2, wn = wid & 3;
+    const int wm = wid / WN, wn = wid % WN;
     int bx_, by_;
     xcd_block(bx_, by_);
     const int k_tile = bx_ % p.n_k_tiles, co_tile = bx_ / p.n_k_tiles;
@@ -81,16 +84,16 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_pipe_kernel(WgradK p) {
         const_cast<char*>(reinterpret_cast<const char*>(p.g)) + g_off, 0, (int)g_rem, 0x00020000);
 
     // ---- DMA plan.  A wave-level transfer is 1 KiB lane-linear = 2 tile rows x 32 slots of 16 B; transfer t of wave w covers rows
-    //      2 (w + 8 t) + (lane >> 5).  Slot s of row r holds the row's logical chunk (s - 4 (r & 3)) mod 32: the rotation is applied on
+    //      2 (w + NWV t) + (lane >> 5).  Slot s of row r holds the row's logical chunk (s - 4 (r & 3)) mod 32: the rotation is applied on
     //      the source side (the lane fetches the chunk that belongs at its slot) and again in the transpose-read addresses.
-    const int drow = 2 * wid + (lane >> 5);                       // rows drow, drow + 16 ((row & 3) is the same for both)
+    const int drow = 2 * wid + (lane >> 5);                       // rows drow + 2 NWV t ((row & 3) is the same for all t)
     const int lchunk = ((lane & 31) - 4 * (drow & 3)) & 31;       // logical chunk at this lane's slot
-    unsigned voffG[2];
+    unsigned voffG[TR];
     {
         const int gco = co_tile * BCO + lchunk * 8;
         const bool ok = lchunk < CG && gco + 7 < p.Cout;          // Cout % 8 == 0 enforced by the host
 #pragma unroll
-        for (int t = 0; t < 2; ++t) voffG[t] = ok ? (unsigned)(((drow + 16 * t) * p.ldo + p.cooff + gco) * 2) : OOB;
+        for (int t = 0; t < TR; ++t) voffG[t] = ok ? (unsigned)(((drow + 2 * NWV * t) * p.ldo + p.cooff + gco) * 2) : OOB;
     }
     const int kcol = k_tile * BK + lchunk * 8;
     const bool kok = kcol < p.kcols;
@@ -106,10 +109,10 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_pipe_kernel(WgradK p) {
     const int wrap_ix = p.OW * p.sw;
     const int img_off = (p.H - p.OH * p.sh) * p.W * p.ldi * 2;     // extra when wrapping to the next image
     const int img_iy = p.OH * p.sh;
-    int px[2], py[2], ix[2], iy[2], off[2], left[2];
+    int px[TR], py[TR], ix[TR], iy[TR], off[TR], left[TR];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int m = m_begin + drow + 16 * t;
+    for (int t = 0; t < TR; ++t) {
+        const int m = m_begin + drow + 2 * NWV * t;
         const int n = m / ohw, rem = m - n * ohw;
         py[t] = rem / p.OW; px[t] = rem - py[t] * p.OW;
         iy[t] = py[t] * p.sh + dy0; ix[t] = px[t] * p.sw + dx0;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_pipe_kernel(WgradK p) {
         const uint32_t Gd = ldsW + (uint32_t)(slot * STAGE);
         const int soffG = st * PK * p.ldo * 2;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) lds_dma16(Gd + (uint32_t)(t * 1024 * NWV), rsG, (int)voffG[t], soffG);   // rows past M: out of range -> zeros
+        for (int t = 0; t < TR; ++t) lds_dma16(Gd + (uint32_t)(t * 1024 * NWV), rsG, (int)voffG[t], soffG);   // rows past M: out of range -> zeros
     };
     auto issue_x = [&](int slot, int t) {                           // called once per stage and t, stages in order (the cursor advances)
         const uint32_t Xd = ldsW + (uint32_t)(slot * STAGE + OPG + t * 1024 * NWV);
@@ -153,9 +156,11 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_pipe_kernel(WgradK p) {
         for (int j = 0; j < XJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    // bias gradient: wave wn of a k_tile == 0 workgroup sums G-tile wn of its filter half (tiles beyond TI: none)
+    // bias gradient: wave wn of a k_tile == 0 workgroup sums the G tiles wn, wn + WN, ... (< TI) of its filter half
     const bool do_bias = p.dbias != nullptr && k_tile == 0 && wn < TI;        // wave-uniform
-    float bsum = 0.f;
+    float bsum[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) bsum[i] = 0.f;
 
     // ---- transpose-read addressing for the 32x32x16 operand layout (A: row l & 31, B: column l & 31; k = 8 (l >> 5) .. +7).  Lane
     //      l = 16 q + i RECEIVES channel 16 (q & 1) + i of a 32-channel tile for the 8 pixels 8 (q >> 1) .. +7 of the half-stage and
@@ -209,17 +214,17 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_pipe_kernel(WgradK p) {
     };
     // (inline asm on purpose: with the builtin the compiler merges the per-tile branches below into one indexed access of the fragment
     // array, which then lives in scratch memory -- and scratch traffic would also break the hand-counted vmcnt of the DMA ring)
-    auto ones_dot = [&](const bf16x8& f) {
+    auto ones_dot = [&](const bf16x8& f, float& sum) {
         const u32x4 v = __builtin_bit_cast(u32x4, f);
         asm volatile("v_dot2c_f32_bf16 %0, %1, %2\n\tv_dot2c_f32_bf16 %0, %1, %3\n\tv_dot2c_f32_bf16 %0, %1, %4\n\tv_dot2c_f32_bf16 %0, %1, %5"
-                     : "+v"(bsum) : "s"(0x3f803f80u), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                     : "+v"(sum) : "s"(0x3f803f80u), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
     };
     auto bias = [&](int set) {                                     // scalar branches: wn lives in an SGPR
         if (do_bias) {
-            if (wn == 0) ones_dot(ga[set][0]);
-            if constexpr (TI > 1) { if (wn == 1) ones_dot(ga[set][1]); }
-            if constexpr (TI > 2) { if (wn == 2) ones_dot(ga[set][2]); }
-            if constexpr (TI > 3) { if (wn == 3) ones_dot(ga[set][3]); }
+            if (wn == 0 % WN) ones_dot(ga[set][0], bsum[0]);
+            if constexpr (TI > 1) { if (wn == 1 % WN) ones_dot(ga[set][1], bsum[1]); }
+            if constexpr (TI > 2) { if (wn == 2 % WN) ones_dot(ga[set][2], bsum[2]); }
+            if constexpr (TI > 3) { if (wn == 3 % WN) ones_dot(ga[set][3], bsum[3]); }
         }
     };
 
@@ -268,12 +273,17 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_pipe_kernel(WgradK p) {
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             mma(0, m);
-            if (m == 1 || m == NM / 2 || m == NM - 2) {
+            // DMA issues of stage s+3 behind MFMAs 1 (G) and, per X transfer, NM/2 and NM-2 (8 waves) / 3, 5, 7, 9 (4 waves)
+            bool slot_here = m == 1;
+#pragma unroll
+            for (int t = 0; t < TR; ++t) slot_here = slot_here || m == (WN == 4 ? (t == 0 ? NM / 2 : NM - 2) : 3 + 2 * t);
+            if (slot_here) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (more) {
                     if (m == 1) issue_g(FILL, s + NS - 1);
-                    if (m == NM / 2) issue_x(FILL, 0);
-                    if (m == NM - 2) issue_x(FILL, 1);
+#pragma unroll
+                    for (int t = 0; t < TR; ++t)
+                        if (m == (WN == 4 ? (t == 0 ? NM / 2 : NM - 2) : 3 + 2 * t)) issue_x(FILL, t);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -305,7 +315,11 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_pipe_kernel(WgradK p) {
     if (nst > 0) {
 #pragma unroll
         for (int s0 = 0; s0 < NS - 1; ++s0)
-            if (s0 < nst) { issue_g(s0, s0); issue_x(s0, 0); issue_x(s0, 1); }
+            if (s0 < nst) {
+                issue_g(s0, s0);
+#pragma unroll
+                for (int t = 0; t < TR; ++t) issue_x(s0, t);
+            }
         if (nst >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NDMA) : "memory");
         else if (nst == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -324,7 +338,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_pipe_kernel(WgradK p) {
     // ---- epilogue.  32x32 accumulator layout: element e of lane l is row 8 (e >> 2) + 4 (l >> 5) + (e & 3), column l & 31
     float* dst = p.partial + (p.atomic ? (int64_t)0 : (int64_t)slice * p.cout_pad * p.kcols_pad);
     const int co0 = co_tile * BCO + wm * (BCO / 2) + 4 * (lane >> 5);
-    const int kc0 = k_tile * BK + wn * (BK / 4) + (lane & 31);
+    const int kc0 = k_tile * BK + wn * (BK / WN) + (lane & 31);
     if (p.atomic) {
         if (nst > 0) {
 #pragma unroll
@@ -346,9 +360,13 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_pipe_kernel(WgradK p) {
     }
     if (do_bias) {
         // lanes l and l ^ 32 hold the two pixel-octets' sums of the same channel
-        bsum += __shfl_xor(bsum, 32, 64);
-        const int co = co_tile * BCO + wm * (BCO / 2) + 32 * wn + (lane & 31);
-        if (lane < 32 && co < p.Cout) atomicAdd(p.dbias + co, bsum);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            if (i % WN != wn) continue;
+            const float tsum = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+            const int co = co_tile * BCO + wm * (BCO / 2) + 32 * i + (lane & 31);
+            if (lane < 32 && co < p.Cout) atomicAdd(p.dbias + co, tsum);
+        }
     }
 #endif
 }
@@ -370,14 +388,22 @@ size_t wgrad_pipe_lds_bytes(int, int) { return 4 * 2 * 32 * 512; }
 int launch_wgrad_pipe(const WgradK& k, int bco, int bk, dim3 grid, hipStream_t st) {
     DIN_REQUIRE(bk == 256 && (bco == 128 || bco == 192 || bco == 256), "wgrad pipe kernel: tile %dx%d not instantiated", bco, bk);
     const size_t lds = wgrad_pipe_lds_bytes(bco, bk);
-    auto launch = [&](auto kern) {
+    const char* wv = getenv("DIN_WGRAD_PIPE_WAVES");              // experiment: 4 = (BCO/2) x 128 wave tiles on four waves
+    const bool four = wv && atoi(wv) == 4;
+    auto launch = [&](auto kern, int threads) {
         raise_lds(kern, lds);
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, k);
+        hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, k);
     };
     const bool wide = k.OW >= 32;                                  // a feature-map row holds at least one 32-pixel stage
-    if (bco == 128) { if (wide) launch(conv_wgrad_pipe_kernel<128, 256, true>); else launch(conv_wgrad_pipe_kernel<128, 256, false>); }
-    else if (bco == 192) { if (wide) launch(conv_wgrad_pipe_kernel<192, 256, true>); else launch(conv_wgrad_pipe_kernel<192, 256, false>); }
-    else { if (wide) launch(conv_wgrad_pipe_kernel<256, 256, true>); else launch(conv_wgrad_pipe_kernel<256, 256, false>); }
+    if (four) {
+        if (bco == 128) { if (wide) launch(conv_wgrad_pipe_kernel<128, 256, true, 2>, 256); else launch(conv_wgrad_pipe_kernel<128, 256, false, 2>, 256); }
+        else if (bco == 192) { if (wide) launch(conv_wgrad_pipe_kernel<192, 256, true, 2>, 256); else launch(conv_wgrad_pipe_kernel<192, 256, false, 2>, 256); }
+        else { if (wide) launch(conv_wgrad_pipe_kernel<256, 256, true, 2>, 256); else launch(conv_wgrad_pipe_kernel<256, 256, false, 2>, 256); }
+        return DIN_OK;
+    }
+    if (bco == 128) { if (wide) launch(conv_wgrad_pipe_kernel<128, 256, true>, 512); else launch(conv_wgrad_pipe_kernel<128, 256, false>, 512); }
+    else if (bco == 192) { if (wide) launch(conv_wgrad_pipe_kernel<192, 256, true>, 512); else launch(conv_wgrad_pipe_kernel<192, 256, false>, 512); }
+    else { if (wide) launch(conv_wgrad_pipe_kernel<256, 256, true>, 512); else launch(conv_wgrad_pipe_kernel<256, 256, false>, 512); }
     return DIN_OK;
 }
 
