@@ -42,8 +42,9 @@ __device__ __forceinline__ s16x4 tr_read(uint32_t byte_addr) {
 
 template <int V> struct IC { static constexpr int value = V; };
 
-// WN: waves along the k columns (WM = 2 along the filter rows): 4 -> 8 waves with (BCO/2) x 64 wave tiles; 2 -> 4 waves with (BCO/2) x 128
-// wave tiles (one wave per SIMD, 7 instead of 10 fragment reads per 12 MFMAs: the LDS-read experiment of profiles/r02_wgrad_pipe_knockout.txt)
+// WN: waves along the k columns (WM = 2 along the filter rows): 8 -> 16 waves with (BCO/2) x 32 wave tiles (shipped: four waves per SIMD);
+// 4 -> 8 waves with (BCO/2) x 64 wave tiles; 2 -> 4 waves with (BCO/2) x 128 wave tiles (one wave per SIMD, 7 instead of 10 fragment reads
+// per 12 MFMAs).  Measured (profiles/r02_wgrad_pipe_knockout.txt): more waves win although they read more fragments.
 template <int BCO, int BK, bool WIDE, int WN = 4>
 __global__ __launch_bounds__(128 * WN, 1) void conv_wgrad_pipe_kernel(WgradK p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -252,6 +253,8 @@ __global__ __launch_bounds__(128 * WN, 1) void conv_wgrad_pipe_kernel(WgradK p) 
             __builtin_amdgcn_s_sleep(4);
         }
     };
+    // MFMA of the first half behind which X transfer t of stage s+3 is issued (G: behind MFMA 1)
+    auto xslot = [](int t) { return WN == 4 ? (t == 0 ? NM / 2 : NM - 2) : WN == 2 ? 3 + 2 * t : NM - 1; };
     // One stage (ring slot SLOT).  On entry its first half-stage's fragments (set 0) are already requested.
     auto stage = [&](auto slot_c, int s) {
         constexpr int SLOT = decltype(slot_c)::value;
@@ -276,14 +279,14 @@ __global__ __launch_bounds__(128 * WN, 1) void conv_wgrad_pipe_kernel(WgradK p) 
             // DMA issues of stage s+3 behind MFMAs 1 (G) and, per X transfer, NM/2 and NM-2 (8 waves) / 3, 5, 7, 9 (4 waves)
             bool slot_here = m == 1;
 #pragma unroll
-            for (int t = 0; t < TR; ++t) slot_here = slot_here || m == (WN == 4 ? (t == 0 ? NM / 2 : NM - 2) : 3 + 2 * t);
+            for (int t = 0; t < TR; ++t) slot_here = slot_here || m == xslot(t);
             if (slot_here) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (more) {
                     if (m == 1) issue_g(FILL, s + NS - 1);
 #pragma unroll
                     for (int t = 0; t < TR; ++t)
-                        if (m == (WN == 4 ? (t == 0 ? NM / 2 : NM - 2) : 3 + 2 * t)) issue_x(FILL, t);
+                        if (m == xslot(t)) issue_x(FILL, t);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -309,7 +312,10 @@ __global__ __launch_bounds__(128 * WN, 1) void conv_wgrad_pipe_kernel(WgradK p) 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        static_assert(NM >= TI + XJ, "one fragment request behind each MFMA");
+        if constexpr (NM < TI + XJ) {                               // (16 waves: 3 MFMAs, 4 fragments) the rest behind the last MFMA
+#pragma unroll
+            for (int q = NM; q < TI + XJ; ++q) load_frag(IC<NEXT>{}, 0, 0, q);
+        }
         bias(1);
     };
     if (nst > 0) {
@@ -388,13 +394,22 @@ size_t wgrad_pipe_lds_bytes(int, int) { return 4 * 2 * 32 * 512; }
 int launch_wgrad_pipe(const WgradK& k, int bco, int bk, dim3 grid, hipStream_t st) {
     DIN_REQUIRE(bk == 256 && (bco == 128 || bco == 192 || bco == 256), "wgrad pipe kernel: tile %dx%d not instantiated", bco, bk);
     const size_t lds = wgrad_pipe_lds_bytes(bco, bk);
-    const char* wv = getenv("DIN_WGRAD_PIPE_WAVES");              // experiment: 4 = (BCO/2) x 128 wave tiles on four waves
-    const bool four = wv && atoi(wv) == 4;
+    // wave grid of the workgroup: 2 x 8 (sixteen waves, four per SIMD, (BCO/2) x 32 wave tiles; default: +6 % on the dominant kernel inside
+    // the training step over 2 x 4, whose 60 % fewer fragment reads do not matter), DIN_WGRAD_PIPE_WAVES=8: 2 x 4, =4: 2 x 2 (-13 %)
+    const char* wv = getenv("DIN_WGRAD_PIPE_WAVES");
+    const int waves = wv ? atoi(wv) : 16;
+    const bool four = waves == 4 && bco <= 192, sixteen = waves == 16;   // (the four-wave 256-row tile spills: scratch traffic would break the vmcnt count)
     auto launch = [&](auto kern, int threads) {
         raise_lds(kern, lds);
         hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, k);
     };
     const bool wide = k.OW >= 32;                                  // a feature-map row holds at least one 32-pixel stage
+    if (sixteen) {
+        if (bco == 128) { if (wide) launch(conv_wgrad_pipe_kernel<128, 256, true, 8>, 1024); else launch(conv_wgrad_pipe_kernel<128, 256, false, 8>, 1024); }
+        else if (bco == 192) { if (wide) launch(conv_wgrad_pipe_kernel<192, 256, true, 8>, 1024); else launch(conv_wgrad_pipe_kernel<192, 256, false, 8>, 1024); }
+        else { if (wide) launch(conv_wgrad_pipe_kernel<256, 256, true, 8>, 1024); else launch(conv_wgrad_pipe_kernel<256, 256, false, 8>, 1024); }
+        return DIN_OK;
+    }
     if (four) {
         if (bco == 128) { if (wide) launch(conv_wgrad_pipe_kernel<128, 256, true, 2>, 256); else launch(conv_wgrad_pipe_kernel<128, 256, false, 2>, 256); }
         else if (bco == 192) { if (wide) launch(conv_wgrad_pipe_kernel<192, 256, true, 2>, 256); else launch(conv_wgrad_pipe_kernel<192, 256, false, 2>, 256); }

@@ -844,15 +844,17 @@ PIPE_CASES = [
 ]
 
 
+@pytest.mark.parametrize("waves", ["16", "8", "4"], ids=["w16", "w8", "w4"])
 @pytest.mark.parametrize("atomic", ["0", "1"], ids=["slices", "atomic"])
 @pytest.mark.parametrize("case", PIPE_CASES, ids=[c[0] for c in PIPE_CASES])
-def test_wgrad_pipe_kernel(env, case, atomic, monkeypatch):
-    """The software-pipelined 32x32x16 weight-gradient kernel (conv_wgrad_pipe.hip), both epilogues (slice partials + reduce, fp32 atomics
+def test_wgrad_pipe_kernel(env, case, atomic, waves, monkeypatch):
+    """The software-pipelined 32x32x16 weight-gradient kernel (conv_wgrad_pipe.hip), every wave grid it is instantiated for, both epilogues (slice partials + reduce, fp32 atomics
     into one tile buffer), against autograd of F.conv2d on bf16-rounded operands; bias gradient (packed dot-product path) included."""
     lib, L, nhwc, ops = env
     name, nb, cin, h, w, cout, k, s, p = case
     monkeypatch.setenv("DIN_WGRAD_PIPE", "1")
     monkeypatch.setenv("DIN_WGRAD_ATOMIC", atomic)
+    monkeypatch.setenv("DIN_WGRAD_PIPE_WAVES", waves)        # wave grids 2 x 8 (default), 2 x 4, 2 x 2 of the same tile
     g = torch.Generator().manual_seed(sum(map(ord, name)))
     x = torch.randn(nb, cin, h, w, generator=g).relu().bfloat16().float()
     wt = torch.randn(cout, cin, *k, generator=g).requires_grad_(True)
