@@ -1807,16 +1807,18 @@ __global__ __launch_bounds__(512, (4 * (((32 * (BCO / 8) + 511) / 512) * 8192 + 
 //   wave w owns the 16-column tiles w, w+4, ... of the (tap, ci) axis and all BN filter rows; wave 0 also forms the bias gradient
 //   (G^T x ones).  Result: one fp32 partial slab per workgroup in the layout conv_wgrad_reduce_kernel expects.
 // ------------------------------------------------------------------------------------------------
-template <int CPP, int BN, int ST, bool U8 = false>
-__global__ __launch_bounds__(NTHREADS, (CPP == 4 && BN == 64) ? 1 : 2) void conv_wgrad_small_kernel(WgradK p) {
+// NW: waves per workgroup.  The 32 -> 64 layer (Conv2d_2b) needs 108 KiB of LDS, i.e. one workgroup per CU: with four waves that is ONE wave
+// per SIMD (3.1 TB/s); eight waves split the 18 column tiles 3 / 2 per wave instead of 5 / 4 and give every SIMD two waves.
+template <int CPP, int BN, int ST, bool U8 = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (CPP == 4 && BN == 64) ? 1 : 2) void conv_wgrad_small_kernel(WgradK p) {
     static_assert(!U8 || CPP == 1, "uint8 frames feed the image layer only");
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TH = 8, TW = 32, NPX = TH * TW, KH = 3, KW = 3;
     constexpr int HWW = (TW - 1) * ST + KW, HWH = (TH - 1) * ST + KH, HPX = HWW * HWH, HC = HPX * CPP;
-    constexpr int HBYTES = (HC * 16 + 1023) / 1024 * 1024, NSLOT_H = HBYTES / 1024, NTR_H = (NSLOT_H + 3) / 4;
-    constexpr int CG = BN / 8, GBYTES = NPX * CG * 16, NTR_G = GBYTES / 4096;
+    constexpr int HBYTES = (HC * 16 + 1023) / 1024 * 1024, NSLOT_H = HBYTES / 1024, NTR_H = (NSLOT_H + NW - 1) / NW;
+    constexpr int CG = BN / 8, GBYTES = NPX * CG * 16, NTR_G = GBYTES / (1024 * NW);
     constexpr int STAGE = HBYTES + GBYTES;
-    constexpr int NCT = CPP == 4 ? 18 : 5, TI = BN / 16, TJ = (NCT + 3) / 4;
+    constexpr int NCT = CPP == 4 ? 18 : 5, TI = BN / 16, TJ = (NCT + NW - 1) / NW;
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1827,7 +1829,7 @@ __global__ __launch_bounds__(NTHREADS, (CPP == 4 && BN == 64) ? 1 : 2) void conv
     int relH[NTR_H]; short hyv[NTR_H], hxv[NTR_H];
 #pragma unroll
     for (int i = 0; i < NTR_H; ++i) {
-        const int id = (wid + 4 * i) * 64 + lane;
+        const int id = (wid + NW * i) * 64 + lane;
         const int hp = id / CPP, slot = id - hp * CPP;
         const int cc = slot ^ swzX(hp);
         const int hy = hp / HWW, hx = hp - hy * HWW;
@@ -1837,7 +1839,7 @@ __global__ __launch_bounds__(NTHREADS, (CPP == 4 && BN == 64) ? 1 : 2) void conv
     int relG[NTR_G]; short gyv[NTR_G], gxv[NTR_G];
 #pragma unroll
     for (int i = 0; i < NTR_G; ++i) {
-        const int id = (wid + 4 * i) * 64 + lane;
+        const int id = (wid + NW * i) * 64 + lane;
         const int t = id / CG, slot = id - t * CG;
         const int cc = slot ^ swzG(t);
         gyv[i] = (short)(t >> 5); gxv[i] = (short)(t & 31);
@@ -1864,17 +1866,17 @@ __global__ __launch_bounds__(NTHREADS, (CPP == 4 && BN == 64) ? 1 : 2) void conv
         if (!U8) {
 #pragma unroll
             for (int i = 0; i < NTR_H; ++i) {
-                if (wid + 4 * i < NSLOT_H) {
+                if (wid + NW * i < NSLOT_H) {
                     const int gy = gy0 + hyv[i], gx = gx0 + hxv[i];
                     const bool ok = relH[i] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-                    lds_dma16(dH + (uint32_t)(i * 4096), rsX, ok ? baseX + relH[i] : (int)OOB, 0);
+                    lds_dma16(dH + (uint32_t)(i * 1024 * NW), rsX, ok ? baseX + relH[i] : (int)OOB, 0);
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < NTR_G; ++i) {
             const bool ok = relG[i] >= 0 && ty * TH + gyv[i] < p.OH && tx * TW + gxv[i] < p.OW;
-            lds_dma16(dG + (uint32_t)(i * 4096), rsG, ok ? baseG + relG[i] : (int)OOB, 0);
+            lds_dma16(dG + (uint32_t)(i * 1024 * NW), rsG, ok ? baseG + relG[i] : (int)OOB, 0);
         }
     };
 
@@ -1897,7 +1899,7 @@ __global__ __launch_bounds__(NTHREADS, (CPP == 4 && BN == 64) ? 1 : 2) void conv
     int unitX[TJ];
 #pragma unroll
     for (int jj = 0; jj < TJ; ++jj) {
-        const int j = min(wid + 4 * jj, NCT - 1);
+        const int j = min(wid + NW * jj, NCT - 1);
         const int tap = CPP == 4 ? (j >> 1) : min(2 * j + csel, KH * KW - 1);
         const int r = tap / KW, s2 = tap - r * KW;
         tapoff[jj] = r * HWW + s2;
@@ -1987,7 +1989,7 @@ __global__ __launch_bounds__(NTHREADS, (CPP == 4 && BN == 64) ? 1 : 2) void conv
     for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int jj = 0; jj < TJ; ++jj) {
-            const int j = wid + 4 * jj;
+            const int j = wid + NW * jj;
             if (j < NCT) {
                 const int co = i * 16 + g4 * 4, kc = j * 16 + i16;
 #pragma unroll
@@ -3159,6 +3161,10 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
                 hipLaunchKernelGGL(kern, dim3(WGRAD_SMALL_GRID), dim3(NTHREADS), lds, st, k);
             };
             if (wp.small == 1) launch(conv_wgrad_small_kernel<4, 32, 1>);
+            else if (wp.small == 2 && !(getenv("DIN_WGRAD_SMALL_WAVES") && atoi(getenv("DIN_WGRAD_SMALL_WAVES")) == 4)) {
+                if (lds > 65536) raise_lds_limit(conv_wgrad_small_kernel<4, 64, 1, false, 8>, lds);
+                hipLaunchKernelGGL((conv_wgrad_small_kernel<4, 64, 1, false, 8>), dim3(WGRAD_SMALL_GRID), dim3(512), lds, st, k);
+            }
             else if (wp.small == 2) launch(conv_wgrad_small_kernel<4, 64, 1>);
             else if (d->in_u8) { k.u8 = reinterpret_cast<const unsigned char*>(in); launch(conv_wgrad_small_kernel<1, 32, 2, true>); }
             else launch(conv_wgrad_small_kernel<1, 32, 2>);
