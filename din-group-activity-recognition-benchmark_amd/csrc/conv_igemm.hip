@@ -654,13 +654,17 @@ struct U8Halo {
 //     usual fused bias / ReLU / ReLU-backward mask / accumulate.
 // bf16 only; stride 1, dilation 1; the gather geometry (ay = 1, by, cy = +-1) covers forward and (stride-1) dgrad.
 // ------------------------------------------------------------------------------------------------
-template <int CPP, int BN, int NBUF, int KH, int KW, int ST, bool U8 = false>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_small_kernel(ConvK p) {
+// NW: waves per workgroup (4, or 8 for the two variants whose 80 KiB of LDS allow ONE workgroup per CU -- the 64-filter forward and the
+// 64-channel dgrad of Conv2d_2b: eight waves give every SIMD two waves; each wave then owns two instead of four 16-pixel segments)
+template <int CPP, int BN, int NBUF, int KH, int KW, int ST, bool U8 = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv_small_kernel(ConvK p) {
+    constexpr int NTHREADS = 64 * NW;                                  // (shadows the file-level 256)
+    static_assert(!U8 || NW == 4, "the uint8 halo loader is written for four waves");
     static_assert(!U8 || (CPP == 1 && NBUF == 2), "uint8 frames feed the image layer only");
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef bf16_t T;
     constexpr int TH = 8, TW = 32, NPX = TH * TW;
-    constexpr int TI = BN / 16, TJ = 4, NTAPS = KH * KW;
+    constexpr int TI = BN / 16, TJ = 16 / NW, NTAPS = KH * KW;
     // MFMA k-slices (32 channels-of-taps each): CPP >= 4: SL slices per tap; CPP == 1 (image layer, 8 padded channels per pixel):
     // four taps share one slice, lane group g4 carries tap 4*slice + g4 (taps >= NTAPS hit zero filter chunks of the packed bank)
     constexpr int SL = CPP >= 4 ? CPP / 4 : 1, NSL = CPP >= 4 ? NTAPS * SL : (NTAPS + 3) / 4;
@@ -668,7 +672,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_small_kernel(ConvK p) {
     constexpr int HWW = (TW - 1) * ST + KW, HWH = (TH - 1) * ST + KH, HPX = HWW * HWH, HC = HPX * CPP;  // halo geometry (pixels, chunks)
     constexpr int WBYTES = NSL * BN * 4 * 16;
     constexpr int HBYTES = (HC * 16 + 1023) / 1024 * 1024;                                // whole 1-KiB DMA slots
-    constexpr int NSLOT = HBYTES / 1024, NTR = (NSLOT + 3) / 4;
+    constexpr int NSLOT = HBYTES / 1024, NTR = (NSLOT + NW - 1) / NW;
     constexpr int NPASS = HBYTES / CPITCH >= NPX ? 1 : 2;                                  // epilogue passes through the staging buffer
     static_assert(HBYTES / CPITCH >= NPX / NPASS, "staging does not fit the halo buffer");
     constexpr int JN = TJ / NPASS;                                                         // pixel segments per wave per pass
@@ -704,7 +708,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_small_kernel(ConvK p) {
     short hyv[NTR], hxv[NTR];
 #pragma unroll
     for (int i = 0; i < NTR; ++i) {
-        const int id = (wid + 4 * i) * 64 + lane;
+        const int id = (wid + NW * i) * 64 + lane;
         const int hp = id / CPP, slot = id - hp * CPP;
         const int cc = slot ^ swz(hp);
         const int hy = hp / HWW, hx = hp - hy * HWW;
@@ -731,10 +735,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_small_kernel(ConvK p) {
         const uint32_t dst = ldsH0 + (uint32_t)(buf * HBYTES);
 #pragma unroll
         for (int i = 0; i < NTR; ++i) {
-            if (wid + 4 * i < NSLOT) {                                                  // uniform: slot inside the halo buffer
+            if (wid + NW * i < NSLOT) {                                                  // uniform: slot inside the halo buffer
                 const int gy = gy0 + hyv[i], gx = gx0 + hxv[i];
                 const bool ok = rel[i] >= 0 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-                lds_dma16(dst + (uint32_t)(i * 4096), rs, ok ? base + rel[i] : (int)OOB, 0);
+                lds_dma16(dst + (uint32_t)(i * 1024 * NW), rs, ok ? base + rel[i] : (int)OOB, 0);
             }
         }
     };
@@ -795,7 +799,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_small_kernel(ConvK p) {
                     }
 #pragma unroll
                     for (int j = 0; j < TJ; ++j) {
-                        const int q = wid * 4 + j;                                     // 16-pixel segment of the tile
+                        const int q = wid * TJ + j;                                     // 16-pixel segment of the tile
                         const int hp = ((q >> 1) * ST + dy) * HWW + ((q & 1) * 16 + frow) * ST + dx;
                         xf[j] = Hl[hp * CPP + (chunk ^ swz(hp))];
                     }
@@ -816,7 +820,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_small_kernel(ConvK p) {
                 for (int i = 0; i < TI; ++i) wf[i] = Wl[(sl * BN + i * 16 + frow) * 4 + g4];
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
-                    const int q = wid * 4 + j;
+                    const int q = wid * TJ + j;
                     xf[j] = Hl[((q >> 1) * ST + dy) * HWW + ((q & 1) * 16 + frow) * ST + dx];
                 }
 #pragma unroll
@@ -860,7 +864,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_small_kernel(ConvK p) {
                 const int idx = it * NTHREADS + tid;
                 const int srow = idx / CPR, c = idx - srow * CPR;
                 const int w_ = srow / (JN * 16), rem = srow - w_ * (JN * 16);
-                const int q = w_ * 4 + ps * JN + rem / 16;                                // segment of the tile
+                const int q = w_ * TJ + ps * JN + rem / 16;                                // segment of the tile
                 const int gy = ty * TH + (q >> 1), gx = tx * TW + (q & 1) * 16 + (rem & 15);
                 const int co = c * 8;
                 const bool ok = gy < p.OH && gx < p.OW && co < p.Cout;
@@ -2754,8 +2758,16 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
             if (image && k.u8) launch(conv_small_kernel<1, 32, 2, 3, 3, 2, true>);
             else if (image) launch(conv_small_kernel<1, 32, 2, 3, 3, 2>);
             else if (g.cpt == 4 && bnS == 32) launch(conv_small_kernel<4, 32, 2, 3, 3, 1>);
-            else if (g.cpt == 4) launch(conv_small_kernel<4, 64, 2, 3, 3, 1>);
-            else launch(conv_small_kernel<8, 32, 1, 3, 3, 1>);
+            else {
+                // the two 80 KiB variants (one workgroup per CU) run on eight waves; DIN_CONV_SMALL_WAVES=4 restores four
+                const bool w8 = !(getenv("DIN_CONV_SMALL_WAVES") && atoi(getenv("DIN_CONV_SMALL_WAVES")) == 4);
+                auto launch8 = [&](auto kern) {
+                    if (lds > 65536) raise_lds_limit(kern, lds);
+                    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, k);
+                };
+                if (g.cpt == 4) { if (w8) launch8(conv_small_kernel<4, 64, 2, 3, 3, 1, false, 8>); else launch(conv_small_kernel<4, 64, 2, 3, 3, 1>); }
+                else { if (w8) launch8(conv_small_kernel<8, 32, 1, 3, 3, 1, false, 8>); else launch(conv_small_kernel<8, 32, 1, 3, 3, 1>); }
+            }
             DIN_CHECK_LAUNCH(what);
             return DIN_OK;
         }
