@@ -7,6 +7,7 @@ dominant kernel's launch times pays for ~20 event pairs instead of ~190."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -39,7 +40,9 @@ class LaunchTimer:
             if bm.value == 0:
                 return f"conv_wgrad_small_kernel<..., {bn.value}, ...>"
             if bn.value >= 2000:
-                return f"conv_wgrad_pipe_kernel<{bm.value}, {bn.value - 2000}, {'true' if d.ow >= 32 else 'false'}>"
+                waves = int(os.environ.get("DIN_WGRAD_PIPE_WAVES", "16"))      # wave grid 2 x WN (conv_wgrad_pipe.hip launch_wgrad_pipe)
+                wn = 8 if waves == 16 else (2 if waves == 4 and bm.value <= 192 else 4)
+                return f"conv_wgrad_pipe_kernel<{bm.value}, {bn.value - 2000}, {'true' if d.ow >= 32 else 'false'}, {wn}>"
             if bn.value >= 1000:
                 return f"conv_wgrad_ring_kernel<{bm.value}, {bn.value - 1000}>"
             return f"conv_wgrad_bf16_kernel<{bm.value}>" if d.dtype == L.DIN_BF16 else "conv_wgrad_f32_kernel"
