@@ -913,13 +913,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv_small_kernel(Co
 // (every wave issues the same number of transfers; surplus ones fetch nothing into pad space).  Epilogue straight from the
 // accumulators as always-issued buffer stores (bias / ReLU / ReLU-backward mask / accumulate).
 // ------------------------------------------------------------------------------------------------
-template <int BN, int KH, int KW, int TH, int TW, int NSW>
-__global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvK p) {
+template <int BN, int KH, int KW, int TH, int TW, int NSW, int NWV_ = 8>
+__global__ __launch_bounds__(64 * NWV_, 1) void conv_halo_kernel(ConvK p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef bf16_t T;
     // 8 waves: wave = (pixel group wp of 64 pixels, filter half wc): two waves per SIMD, so one wave's waits (barrier, vmcnt, LDS
     // latency) hide behind the other's MFMAs -- with 4 waves (one per SIMD) the kernel ran at 20 % MFMA utilisation
-    constexpr int NWV = 8, NTAPS = KH * KW, TI = BN / 32, TJ = 4;
+    // NWV_ = 16: pixel groups of 32 instead of 64 pixels (four waves per SIMD; the LDS budget then allows a 2-slot filter ring only)
+    constexpr int NWV = NWV_, NTAPS = KH * KW, TI = BN / 32, TJ = 32 / NWV;
     constexpr int HWW = TW + KW - 1, HWH = TH + KH - 1, HPX = HWW * HWH;
     constexpr int PCH = 10, PB = PCH * 16;                            // row pitch: 10 chunks = 160 bytes
     constexpr int NTR_H = (HPX * PCH + 64 * NWV - 1) / (64 * NWV), HBYTES = NTR_H * 1024 * NWV;
@@ -930,7 +931,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvK p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int frow = lane & 15, g4 = lane >> 4;
-    const int wp = wid & 3, wc = wid >> 2;
+    const int wp = wid & (NWV / 2 - 1), wc = wid / (NWV / 2);
     const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw;
     const uint32_t ldsWv = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(wid * 1024));
 
@@ -1000,7 +1001,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvK p) {
     uint32_t xbase[TJ];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
-        const int q = wp * 4 + j;
+        const int q = wp * TJ + j;
         const int qy = TW == 32 ? (q >> 1) : q, qx = TW == 32 ? (q & 1) * 16 : 0;
         xbase[j] = (uint32_t)(((qy + yb) * HWW + qx + frow + xb) * PB + g4 * 16);
     }
@@ -1106,7 +1107,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(ConvK p) {
             }
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
-                const int q = wp * 4 + j;
+                const int q = wp * TJ + j;
                 const int qy = TW == 32 ? (q >> 1) : q, qx = TW == 32 ? (q & 1) * 16 : 0;
                 const int gy = cur.ty * TH + qy, gx = cur.tx * TW + qx + frow;
                 const bool pok = gy < p.OH && gx < p.OW;
@@ -2540,7 +2541,7 @@ static void raise_lds_limit(K kern, size_t lds) {
     granted[fn] = lds;
 }
 
-struct HaloPlan { int bn, th, tw, nsw, n_co_tiles; size_t lds; };
+struct HaloPlan { int bn, th, tw, nsw, nwv, n_co_tiles; size_t lds; };
 static bool plan_halo(int dtype, int kh, int kw, int cred, int cprod, int oh, int ow, int64_t M, HaloPlan& hp) {
     const char* hv = getenv("DIN_CONV_HALO");
     if (hv && atoi(hv) == 0) return false;
@@ -2556,6 +2557,7 @@ static bool plan_halo(int dtype, int kh, int kw, int cred, int cprod, int oh, in
     // loses against the 128x192 / 128x160 gather tiles on the wide 192-filter and 7-tap layers.  DIN_CONV_HALO=2 forces it everywhere.
     if (!(hv && atoi(hv) == 2) && !(k33 && hp.n_co_tiles == 1)) return false;
     hp.th = k33 ? 8 : 16; hp.tw = k33 ? 32 : 16;
+    hp.nwv = 8;
     // padded-area waste of the tile grid must stay moderate
     const int64_t padded = (int64_t)((oh + hp.th - 1) / hp.th * hp.th) * ((ow + hp.tw - 1) / hp.tw * hp.tw);
     if (padded * 100 > (int64_t)oh * ow * 118) return false;
@@ -2563,6 +2565,12 @@ static bool plan_halo(int dtype, int kh, int kw, int cred, int cprod, int oh, in
     const size_t hbytes = (size_t)((hpx * 10 + 511) / 512) * 8192, wbytes = (size_t)((hp.bn * 10 + 511) / 512) * 8192;
     hp.nsw = 3;
     hp.lds = 2 * hbytes + 3 * wbytes;
+    {   // sixteen waves (3x3 tiles only): transfers cover 16 KiB, the filter ring shrinks to two slots to stay inside 160 KiB
+        const char* wv = getenv("DIN_HALO_WAVES");
+        const int want = wv ? atoi(wv) : 16;
+        const size_t hb16 = (size_t)((hpx * 10 + 1023) / 1024) * 16384, wb16 = (size_t)((hp.bn * 10 + 1023) / 1024) * 16384;
+        if (want == 16 && k33 && 2 * hb16 + 2 * wb16 <= 160 * 1024) { hp.nwv = 16; hp.nsw = 2; hp.lds = 2 * hb16 + 2 * wb16; }
+    }
     return hp.lds <= 160 * 1024;
 }
 
@@ -2721,7 +2729,14 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
                 hipLaunchKernelGGL(kern, grid, dim3(512), hp.lds, st, k);
             };
             bool done = true;
-            if (k.kh == 3 && k.kw == 3) { if (hp.bn == 64) launch(conv_halo_kernel<64, 3, 3, 8, 32, 3>); else launch(conv_halo_kernel<96, 3, 3, 8, 32, 3>); }
+            if (k.kh == 3 && k.kw == 3 && hp.nwv == 16) {
+                auto launch16 = [&](auto kern) {
+                    raise_lds_limit(kern, hp.lds);
+                    hipLaunchKernelGGL(kern, grid, dim3(1024), hp.lds, st, k);
+                };
+                if (hp.bn == 64) launch16(conv_halo_kernel<64, 3, 3, 8, 32, 2, 16>); else launch16(conv_halo_kernel<96, 3, 3, 8, 32, 2, 16>);
+            }
+            else if (k.kh == 3 && k.kw == 3) { if (hp.bn == 64) launch(conv_halo_kernel<64, 3, 3, 8, 32, 3>); else launch(conv_halo_kernel<96, 3, 3, 8, 32, 3>); }
             else if (k.kh == 1 && k.kw == 7) { if (hp.bn == 64) launch(conv_halo_kernel<64, 1, 7, 16, 16, 3>); else launch(conv_halo_kernel<96, 1, 7, 16, 16, 3>); }
             else if (k.kh == 7 && k.kw == 1) { if (hp.bn == 64) launch(conv_halo_kernel<64, 7, 1, 16, 16, 3>); else launch(conv_halo_kernel<96, 7, 1, 16, 16, 3>); }
             else done = false;
