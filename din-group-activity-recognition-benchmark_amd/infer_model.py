@@ -13,6 +13,8 @@ Deliberate differences from the reference (all documented in DESIGN.md):
 """
 from __future__ import annotations
 
+import collections
+
 import torch
 import torch.nn as nn
 
@@ -65,6 +67,20 @@ class _DynamicBase(nn.Module):
         self.backbone.load_state_dict(state["backbone_state_dict"])
         self.fc_emb_1.load_state_dict(state["fc_emb_state_dict"])
         print("Load model states from: ", filepath)
+
+    def loadpart(self, pretrained_state_dict, model, prefix):
+        """reference infer_model.py:358-368 (Dynamic_TCE_volleyball.loadpart): copy every entry of `pretrained_state_dict` whose key, with
+        `prefix` removed, exists in `model` -- partial initialisation from another checkpoint"""
+        num = 0
+        model_state_dict = model.state_dict()
+        picked = collections.OrderedDict()
+        for k, v in pretrained_state_dict.items():
+            if k.replace(prefix, "") in model_state_dict:
+                picked[k.replace(prefix, "")] = v
+                num += 1
+        model_state_dict.update(picked)
+        model.load_state_dict(model_state_dict)
+        print(str(num) + " parameters loaded for " + prefix)
 
     # ---- shared front: images -> per-box embeddings [B,T,N,NFB] ------------------------------------------
     def _embed(self, images_in, boxes_in, N, return_context: bool = False):

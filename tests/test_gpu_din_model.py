@@ -719,3 +719,39 @@ def test_model_edge_shapes_match_oracle(gpu, shape):
             assert named[k].grad is not None, k
             if float(po[k].grad.abs().max()) > 0:
                 assert rel(named[k].grad, po[k].grad) <= 2e-3, (k, rel(named[k].grad, po[k].grad))
+
+
+def test_tce_hierarchical_variant_matches_oracle(gpu):
+    """Dynamic_TCE_volleyball with hierarchical_inference=True (reference infer_model.py:321-333: DPI_1 -> LN -> ReLU -> dropout -> DPI_2 over the
+    NFB + 512 context channels; T = 10, N = 12 as the reference's hier_LN requires) against the oracle restatement, dropout neutralised on
+    both sides (cfg.hier_dropout_p = 0 / eval mode): logits and the transformer / DIN gradients"""
+    from din_amd.config import Config
+    from din_amd.infer_model import Dynamic_TCE_volleyball
+    T, N, NFB = 10, 12, 32
+    ocfg = O.OracleCfg(backbone="vgg16", image_size=(64, 96), out_size=(2, 3), num_boxes=N, num_frames=T, num_features_boxes=NFB,
+                       ST_kernel_size=[(1, 3), (3, 1)], sampling_ratio=[1], hierarchical_inference=True)
+    p = O.tce_synth_params(ocfg, seed=41)
+    g_ = torch.Generator().manual_seed(52)
+    p["DPI.hier_LN.weight"] = 0.75 + 0.5 * torch.rand(p["DPI.hier_LN.weight"].shape, generator=g_)
+    p["DPI.hier_LN.bias"] = 0.1 * torch.randn(p["DPI.hier_LN.bias"].shape, generator=g_)
+    images, boxes, labels = O.synth_inputs(1, T, N, 64, 96, 2, 3, 8, seed=33)
+    po = {k: v.clone().requires_grad_("running_" not in k) for k, v in p.items()}
+    out = O.dynamic_tce_volleyball_forward(ocfg, po, images.float(), boxes)
+    F.cross_entropy(out["activities"], labels).backward()
+    cfg = Config("volleyball")
+    cfg.backbone, cfg.image_size, cfg.out_size, cfg.emb_features = "vgg16", (64, 96), (2, 3), 512
+    cfg.num_boxes, cfg.num_frames, cfg.num_features_boxes, cfg.num_features_gcn = N, T, NFB, NFB
+    cfg.ST_kernel_size, cfg.sampling_ratio, cfg.beta_factor, cfg.hierarchical_inference = [(1, 3), (3, 1)], [1], False, True
+    cfg.train_backbone, cfg.backbone_dtype, cfg.hier_dropout_p = True, "fp32", 0.0
+    model = Dynamic_TCE_volleyball(cfg)
+    missing, unexpected = model.load_state_dict(p, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    model = model.to(gpu).eval()
+    ret = model((images.to(gpu), boxes.to(gpu)))
+    F.cross_entropy(ret["activities"], labels.to(gpu)).backward()
+    assert rel(ret["activities"], out["activities"]) <= 1e-4
+    named = dict(model.named_parameters())
+    for k in po:
+        if ("context_encoding" in k or k.startswith("DPI.") or k.startswith("fc_activities")) and po[k].grad is not None:
+            if float(po[k].grad.abs().max()) > 0:
+                assert rel(named[k].grad, po[k].grad) <= 2e-3, (k, rel(named[k].grad, po[k].grad))

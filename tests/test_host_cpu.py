@@ -296,3 +296,31 @@ def test_grad_bucket_order_is_rank_independent_and_late_hooks_do_not_deadlock():
     b._on_grad(b.params[0], torch.zeros_like(b.params[0]))
     b.allreduce()
     assert not b._inflight and not b._got
+
+
+def test_tce_model_keys_and_loadpart():
+    """Dynamic_TCE_volleyball on the CPU: constructor limits of the reference model, state_dict key inventory of the oracle's
+    shape table, and loadpart() (reference infer_model.py:358-368) copying a prefixed sub-dictionary into one sub-module"""
+    from din_amd.config import Config
+    from din_amd.infer_model import Dynamic_TCE_volleyball
+    cfg = Config("volleyball")
+    cfg.backbone, cfg.image_size, cfg.out_size, cfg.emb_features = "vgg16", (96, 160), (3, 5), 512
+    cfg.num_features_boxes = cfg.num_features_gcn = 64
+    cfg.ST_kernel_size, cfg.sampling_ratio, cfg.beta_factor = [(3, 3)], [1], False
+    m = Dynamic_TCE_volleyball(cfg)
+    shapes = O.tce_model_param_shapes(O.OracleCfg(backbone="vgg16", image_size=(96, 160), out_size=(3, 5), num_features_boxes=64))
+    sd = m.state_dict()
+    assert set(shapes) == set(sd.keys())
+    for k, shp in shapes.items():
+        assert tuple(sd[k].shape) == tuple(shp), k
+    assert tuple(m.fc_activities.weight.shape) == (cfg.num_activities, 64 + 4 * 128)         # context_dim = NFB + heads * 128
+    src = {"module.fc_emb_1.weight": torch.full_like(m.fc_emb_1.weight, 0.25), "module.fc_emb_1.bias": torch.full_like(m.fc_emb_1.bias, -1.0),
+           "module.unrelated.weight": torch.zeros(3)}
+    m.loadpart(src, m.fc_emb_1, "module.fc_emb_1.")
+    assert float(m.fc_emb_1.weight.min()) == 0.25 and float(m.fc_emb_1.bias.max()) == -1.0
+    cfg.backbone = "inv3"
+    with pytest.raises(NotImplementedError):
+        Dynamic_TCE_volleyball(cfg)
+    cfg.backbone, cfg.lite_dim = "vgg16", 128
+    with pytest.raises(NotImplementedError):
+        Dynamic_TCE_volleyball(cfg)
