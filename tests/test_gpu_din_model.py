@@ -560,8 +560,9 @@ def test_tce_model_matches_reference_golden(gpu, path):
     cfg.num_boxes, cfg.num_frames = ocfg.num_boxes, ocfg.num_frames
     cfg.num_features_boxes = cfg.num_features_gcn = ocfg.num_features_boxes
     cfg.ST_kernel_size, cfg.sampling_ratio, cfg.num_DIM = ocfg.ST_kernel_size, ocfg.sampling_ratio, ocfg.num_DIM
-    cfg.beta_factor, cfg.lite_dim, cfg.hierarchical_inference = False, None, False
+    cfg.beta_factor, cfg.lite_dim, cfg.hierarchical_inference = False, None, ocfg.hierarchical_inference
     cfg.train_backbone, cfg.backbone_dtype = True, "fp32"
+    cfg.hier_dropout_p = 0.0                     # hierarchical fixture: the reference's always-on functional dropout neutralised
     model = Dynamic_TCE_volleyball(cfg)
     missing, unexpected = model.load_state_dict(p, strict=False)
     assert not unexpected and all("num_batches_tracked" in k for k in missing), (missing, unexpected)

@@ -262,18 +262,23 @@ TCE_CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "
 
 def load_tce_case(path):
     z = np.load(path)
-    B, T, N, H, W, OH, OW, D, NFB, num_dim = [int(v) for v in z["meta"]]
+    B, T, N, H, W, OH, OW, D, NFB, num_dim, hier = [int(v) for v in z["meta"]]
     kernels = [tuple(int(x) for x in k) for k in z["kernels"]]
     cfg = O.OracleCfg(backbone="vgg16", image_size=(H, W), out_size=(OH, OW), emb_features=D, num_boxes=N, num_frames=T,
-                      num_features_boxes=NFB, ST_kernel_size=kernels, sampling_ratio=[int(r) for r in z["ratios"]], num_DIM=num_dim)
+                      num_features_boxes=NFB, ST_kernel_size=kernels, sampling_ratio=[int(r) for r in z["ratios"]], num_DIM=num_dim,
+                      hierarchical_inference=bool(hier))
     seed = int(z["seed"])
     p = O.tce_synth_params(cfg, seed)
+    if hier:                                     # same recipe as tools/gen_golden.py::tce_case
+        g_ = torch.Generator().manual_seed(seed + 11)
+        p["DPI.hier_LN.weight"] = 0.75 + 0.5 * torch.rand(p["DPI.hier_LN.weight"].shape, generator=g_)
+        p["DPI.hier_LN.bias"] = 0.1 * torch.randn(p["DPI.hier_LN.bias"].shape, generator=g_)
     images, boxes, labels = O.synth_inputs(B, T, N, H, W, OH, OW, 8, seed=seed)
     return z, cfg, p, images, boxes, labels
 
 
 def test_tce_golden_present():
-    assert len(TCE_CASES) >= 2
+    assert len(TCE_CASES) >= 3
 
 
 @pytest.mark.parametrize("path", TCE_CASES, ids=[os.path.basename(p)[:-4] for p in TCE_CASES])

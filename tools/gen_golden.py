@@ -398,7 +398,8 @@ def model_case(name, refim, refcfg, out_dir, *, backbone, H, W, OH, OW, D, B, T,
     print(f"[model] {name}: logits rel err {e:.2e}, worst grad rel err {eg:.2e}, loss {loss.item():.6f}")
 
 
-def tce_case(name, refim, refcfg, out_dir, *, H, W, OH, OW, B, T, NFB, kernels, ratios, num_dim=1, seed=0, full_grads_upto=4096):
+def tce_case(name, refim, refcfg, out_dir, *, H, W, OH, OW, B, T, NFB, kernels, ratios, num_dim=1, seed=0, full_grads_upto=4096, hier=False,
+             refdin=None):
     """Whole Dynamic_TCE_volleyball forward (+ backward of the CE loss) from the reference (infer_model.py:237-468), vgg16 trunk, eval mode
     (dropout off).  N = 12 is asserted by the reference's transformer (TCE_STBiP_module.py:263)."""
     N, D = 12, 512
@@ -410,23 +411,38 @@ def tce_case(name, refim, refcfg, out_dir, *, H, W, OH, OW, B, T, NFB, kernels, 
     cfg.num_features_boxes = cfg.num_features_gcn = NFB
     cfg.ST_kernel_size, cfg.sampling_ratio, cfg.num_DIM = kernels, ratios, num_dim
     cfg.dynamic_sampling, cfg.scale_factor, cfg.beta_factor = True, True, False
-    cfg.lite_dim, cfg.hierarchical_inference = None, False
+    cfg.lite_dim, cfg.hierarchical_inference = None, hier
     cfg.train_backbone = True
     cfg.train_dropout_prob = 0.3
     torch.manual_seed(0)
     model = refim.Dynamic_TCE_volleyball(cfg)
     model.eval()
     ocfg = O.OracleCfg(backbone="vgg16", image_size=(H, W), out_size=(OH, OW), emb_features=D, num_boxes=N, num_frames=T,
-                       num_features_boxes=NFB, ST_kernel_size=kernels, sampling_ratio=ratios, num_DIM=num_dim)
+                       num_features_boxes=NFB, ST_kernel_size=kernels, sampling_ratio=ratios, num_DIM=num_dim, hierarchical_inference=hier)
     p = O.tce_synth_params(ocfg, seed)
+    if hier:
+        g_ = torch.Generator().manual_seed(seed + 11)
+        p["DPI.hier_LN.weight"] = 0.75 + 0.5 * torch.rand(p["DPI.hier_LN.weight"].shape, generator=g_)
+        p["DPI.hier_LN.bias"] = 0.1 * torch.randn(p["DPI.hier_LN.bias"].shape, generator=g_)
     missing, unexpected = model.load_state_dict(p, strict=False)
     bad = [k for k in missing if "num_batches_tracked" not in k and "zero_padding" not in k]
     assert not unexpected and not bad, (bad, unexpected)
     images, boxes, labels = O.synth_inputs(B, T, N, H, W, OH, OW, 8, seed=seed)
-    ret = model((images.float(), boxes.float()))
-    loss = F.cross_entropy(ret["activities"], labels)
-    loss.backward()
-    ref_grads = {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}
+    realF = None
+    if hier:                                             # the no-source-patch recipe of hier_case / model_case (reference bug 2, always-on dropout)
+        model.DPI.DPI_1 = _First(model.DPI.DPI_1)
+        realF = refdin.F
+        shim = types.SimpleNamespace(**{k: getattr(realF, k) for k in dir(realF) if not k.startswith("__")})
+        shim.dropout = lambda x, *a, **k: x
+        refdin.F = shim
+    try:
+        ret = model((images.float(), boxes.float()))
+        loss = F.cross_entropy(ret["activities"], labels)
+        loss.backward()
+    finally:
+        if realF is not None:
+            refdin.F = realF
+    ref_grads = {k.replace("DPI_1.m.", "DPI_1."): v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}
     po = {k: v.clone().requires_grad_("running_" not in k) for k, v in p.items()}
     oret, inter = O.dynamic_tce_volleyball_forward(ocfg, po, images.float(), boxes.float(), return_intermediates=True)
     oloss = F.cross_entropy(oret["activities"], labels)
@@ -440,7 +456,7 @@ def tce_case(name, refim, refcfg, out_dir, *, H, W, OH, OW, B, T, NFB, kernels, 
     att = model.multilayer_head_embfeature_context_encoding.CET[TCE_PROBE_HEAD].att_map.detach()     # [BT,N,P] of one head
     _, oatt = O.tce_context_encoding(inter["x"].reshape(B * T * N, -1), inter["context"], po, return_attention=True)
     close(oatt[TCE_PROBE_HEAD], att, 1e-4, name + ".att_map")
-    rec = dict(meta=np.array([B, T, N, H, W, OH, OW, D, NFB, num_dim], dtype=np.int64), kernels=np.array(kernels, dtype=np.int64),
+    rec = dict(meta=np.array([B, T, N, H, W, OH, OW, D, NFB, num_dim, int(hier)], dtype=np.int64), kernels=np.array(kernels, dtype=np.int64),
                ratios=np.array(ratios, dtype=np.int64), seed=np.int64(seed), logits=ret["activities"].detach().numpy(),
                loss=np.float64(loss.item()), labels=labels.numpy(), att_map=att.numpy(), att_head=np.int64(TCE_PROBE_HEAD),
                enc=inter["enc"].detach().numpy())
@@ -583,6 +599,9 @@ def main():
         tce_case("tce_vgg16_96x160_nfb64", refim, refcfg, a.out, H=96, W=160, OH=3, OW=5, B=2, T=3, NFB=64, kernels=[(3, 3)], ratios=[1], seed=300)
         tce_case("tce_vgg16_128x192_nfb128_2dim", refim, refcfg, a.out, H=128, W=192, OH=4, OW=6, B=1, T=4, NFB=128, kernels=[(1, 3), (3, 1)],
                  ratios=[1], num_dim=2, seed=301)
+        # (the reference hard-wires hier_LN to 1024 channels, dynamic_infer_module.py:483: NFB + 4 * 128 = 1024 -> NFB = 512 is its only shape)
+        tce_case("tce_vgg16_64x96_hier_t10", refim, refcfg, a.out, H=64, W=96, OH=2, OW=3, B=1, T=10, NFB=512, kernels=[(1, 3), (3, 1)],
+                 ratios=[1], seed=302, hier=True, refdin=refdin)
     if a.only == "tce":
         tce_cases()
         return
