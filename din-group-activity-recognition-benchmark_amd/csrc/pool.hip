@@ -517,6 +517,66 @@ __global__ __launch_bounds__(256) void avgpool3_strip_kernel(int nb, int h, int 
     }
 }
 
+// ---- 3x3 / stride 2 max pool, column strips (the three max-pools of Inception-v3) ------------------------------------------------------------
+// One thread owns R consecutive OUTPUT rows of one (frame, output column, channel group): consecutive windows share a row, so the strip
+// needs 2R + 1 input rows x 3 columns = 6.75 loads per output at R = 4 instead of 9, all issued before the first comparison.  Scan order per
+// window = the one-thread-per-output kernel's (rows top-to-bottom, taps left-to-right, first maximum wins): bit-identical values and arg-max bytes.
+template <int R>
+__global__ __launch_bounds__(256) void maxpool3s2_strip_kernel(din_pool_desc d, Dec3 dd, const void* __restrict__ in, void* __restrict__ out,
+                                                               uint8_t* __restrict__ amax) {
+    constexpr int V = 8;
+    const int strips = (d.oh + R - 1) / R, cgroups = d.c / V;
+    const int64_t total = (int64_t)d.nb * strips * d.ow * cgroups;
+    DIN_GRID_STRIDE(i, total) {
+        int cg, ox, sy, n; int64_t p;
+        decode(dd, i, cg, ox, sy, n, p);                                // dd built with (cgroups, ow, strips)
+        const int oy0 = sy * R;
+        const int y0 = oy0 * 2 - d.pad, x0 = ox * 2 - d.pad;
+        RawTap<V> t[2 * R + 1][3];
+#pragma unroll
+        for (int r = 0; r < 2 * R + 1; ++r) {
+            const int iy = min(max(y0 + r, 0), d.h - 1);
+            const int64_t rowp = ((int64_t)n * d.h + iy) * d.w;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int ix = min(max(x0 + c, 0), d.w - 1);
+                t[r][c].load(in, d.dtype, (rowp + ix) * d.ldi + d.cioff + cg * V);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int oy = oy0 + q;
+            if (oy >= d.oh) break;
+            float m[V]; int am[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) { m[e] = -INFINITY; am[e] = 0; }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int iy = y0 + 2 * q + r, ix = x0 + c;
+                    const bool ok = iy >= 0 && iy < d.h && ix >= 0 && ix < d.w;
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        const float v = t[2 * q + r][c].get(e);
+                        if (ok && v > m[e]) { m[e] = v; am[e] = r * 3 + c; }
+                    }
+                }
+            Vec<V> mv;
+#pragma unroll
+            for (int e = 0; e < V; ++e) mv.v[e] = m[e];
+            const int64_t po = ((int64_t)n * d.oh + oy) * d.ow + ox;
+            vstore<V>(out, d.dtype, po * d.ldo + d.cooff + cg * V, mv);
+            if (amax) {
+                uint32_t pk[2] = {0u, 0u};
+#pragma unroll
+                for (int e = 0; e < V; ++e) pk[e >> 2] |= (uint32_t)(m[e] > 0.f ? am[e] : 255) << (8 * (e & 3));
+                *reinterpret_cast<uint2*>(amax + po * d.c + cg * V) = uint2{pk[0], pk[1]};
+            }
+        }
+    }
+}
+
 // ---- bilinear resize, align_corners=True (infer_model.py:169): src = dst*(in-1)/(out-1) -----------------------------------------
 __device__ __forceinline__ void bil_coord(int o, int in, int out, int& i0, int& i1, float& l) {
     float sc = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
@@ -712,6 +772,19 @@ int din_maxpool_fwd(const din_pool_desc* d, const void* in, void* out, uint8_t* 
     const int v = wide8(d) ? 8 : 4;
     const int64_t total = (int64_t)d->nb * d->oh * d->ow * (d->c / v);
     const Dec3 dd = make_dec(d->c / v, d->ow, d->oh, total);
+    // column strips for the wide maps (measured, tools/pool_bench.py: 192 ch 570 -> 537 us, 288 ch 285 -> 201 us; 64 ch 864 -> 1027 us: not there);
+    // DIN_MAXPOOL_STRIP=0 / 2: never / always
+    const char* ms = getenv("DIN_MAXPOOL_STRIP");
+    const int strip_mode = ms ? atoi(ms) : 1;
+    if (v == 8 && d->k == 3 && d->stride == 2 && strip_mode != 0 && (d->c >= 128 || strip_mode == 2)) {
+        constexpr int R = 4;
+        const int strips = (d->oh + R - 1) / R;
+        const int64_t tot = (int64_t)d->nb * strips * d->ow * (d->c / v);
+        const Dec3 ds = make_dec(d->c / v, d->ow, strips, tot);
+        POOL_LAUNCH((maxpool3s2_strip_kernel<R>), tot, *d, ds, in, out, argmax);
+        DIN_CHECK_LAUNCH("maxpool_fwd");
+        return DIN_OK;
+    }
     if (v == 8) {
         if (d->k == 3) POOL_LAUNCH((maxpool_fwd_kernel<8, 3>), total, *d, dd, in, out, argmax);
         else if (d->k == 2) POOL_LAUNCH((maxpool_fwd_kernel<8, 2>), total, *d, dd, in, out, argmax);

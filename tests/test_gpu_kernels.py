@@ -540,6 +540,30 @@ def test_tiled_1x1_filter_pack_is_bit_identical(env, dtype, monkeypatch):
             assert torch.equal(outs[0], outs[1]), (transposed, sc is not None)
 
 
+@pytest.mark.parametrize("shape", [(2, 35, 47, 64), (3, 16, 9, 192), (1, 3, 3, 8)], ids=["ragged", "wide", "one_window"])
+def test_maxpool_strip_kernel_is_bit_identical(env, shape, monkeypatch):
+    """the column-strip 3x3 / stride-2 max pool (2R + 1 input rows in registers per R outputs) returns the values AND the arg-max bytes of the
+    one-thread-per-output kernel (same scan order, first maximum wins, 255 for non-positive winners)"""
+    lib, L, nhwc, ops = env
+    nb, h, w, c = shape
+    oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(nb, h, w, c, generator=g).relu().bfloat16().cuda()          # post-ReLU: many ties at zero
+    d = L.PoolDesc()
+    d.nb, d.h, d.w, d.c, d.oh, d.ow = nb, h, w, c, oh, ow
+    d.k, d.stride, d.pad, d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = 3, 2, 0, c, 0, c, 0, L.DIN_BF16
+    res = []
+    for mode in ("0", "2"):                                                       # never / always (the default picks by channel count)
+        monkeypatch.setenv("DIN_MAXPOOL_STRIP", mode)
+        out = torch.full((nb, oh, ow, c), float("nan"), dtype=torch.bfloat16, device="cuda")
+        am = torch.full((nb, oh, ow, c), 77, dtype=torch.uint8, device="cuda")
+        L.check(lib.din_maxpool_fwd(C.byref(d), x.data_ptr(), out.data_ptr(), am.data_ptr(), None))
+        torch.cuda.synchronize()
+        res.append((out, am))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[1][0].float().cpu().permute(0, 3, 1, 2), F.max_pool2d(x.float().cpu().permute(0, 3, 1, 2), 3, 2))
+
+
 def test_prep_images_bit_exact(env):
     lib, L, nhwc, ops = env
     x = torch.arange(0, 256, dtype=torch.float32)
