@@ -2666,7 +2666,9 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
         else if (pipe != 4 && sizeof(T) == 2) launch_wave8<T, 64>(k, grid, st);
         else launch_fast<T, 128, 64, 2, 2, 8, 2>(k, grid, st);
     }
-    else if (bn == 96) { if (pipe == 8 && sizeof(T) == 2) launch_fast<T, 128, 96, 4, 2, 8, 2>(k, grid, st); else launch_fast<T, 128, 96, 2, 2, 8, 2>(k, grid, st); }   // 8 waves measured 5 % slower here
+    // 128 x 96: four waves (eight measured 5-14 % slower on Conv2d_3b) -- except the parity classes of a strided dgrad, whose scattered,
+    // epilogue-bound tiles gain 5 % from eight waves (Mixed_6a.branch3x3 dgrad 1379 -> 1312 us)
+    else if (bn == 96) { if ((pipe == 8 || (k.remap && pipe != 4)) && sizeof(T) == 2) launch_fast<T, 128, 96, 4, 2, 8, 2>(k, grid, st); else launch_fast<T, 128, 96, 2, 2, 8, 2>(k, grid, st); }
     else if (bn == 160) { if (pipe != 4 && sizeof(T) == 2) launch_wave8<T, 160>(k, grid, st); else launch_fast<T, 128, 160, 2, 2, 8, 2>(k, grid, st); }
     // 128 x {128,160,192}: 8 waves (4 x 2, four per SIMD at two workgroups per CU) -- same LDS ring, more waves to hide the stage waits:
     // +8..12 % on the 7-tap layers, +24 % on thin-K dgrads (bf16 only; DIN_CONV_PIPE=4 restores the 4-wave form)
@@ -2943,9 +2945,10 @@ int din_conv_kernel_variant(const din_conv_desc* d, int which, int32_t* flags) {
     if (bm != 128 || d->dtype != DIN_BF16) return DIN_OK;          // the 8-wave / FASTK instantiations exist for bf16 128 x BN tiles only
     const char* pv = getenv("DIN_CONV_PIPE");
     const int pipe = pv ? atoi(pv) : -1;
-    const bool wave8 = (bn == 64 || bn == 128 || bn == 160 || bn == 192) && pipe != 4 && pipe != 1;
-    if (wave8) *flags |= 2;
     const bool strided = which == 1 && (d->sh > 1 || d->sw > 1);
+    const bool wave8 = ((bn == 64 || bn == 128 || bn == 160 || bn == 192) && pipe != 4 && pipe != 1) ||
+                       (bn == 96 && (pipe == 8 || (strided && pipe != 4)));       // (the parity classes of a strided dgrad: launch_gather)
+    if (wave8) *flags |= 2;
     const int ntaps = d->kh * d->kw, cred = which == 0 ? d->cin : d->cout;
     const int cpt = pad_to(cred, 8) / 8;
     GatherPlan g = which == 0 ? plan_gather(d->nb * d->oh * d->ow, d->cin, d->cout, ntaps, d->dtype)

@@ -63,7 +63,7 @@ class LaunchTimer:
         elif multi:
             geo = "4, 2, 8, 2" if (BN % 64 == 0 and d.dtype == L.DIN_BF16) else "2, 2, 8, 2"
         else:
-            geo = "4, 2, 8, 2" if fl.value & 2 else "2, 2, 8, 2"
+            geo = "4, 2, 8, 2" if fl.value & 2 else "2, 2, 8, 2"     # (bit 1: the 8-wave instantiation, incl. 128 x 96 for strided dgrads)
         return (f"conv_gather_fast_kernel<{tn}, {BM}, {BN}, {geo}, {'true' if multi else 'false'}, "
                 f"{'true' if fl.value & 1 else 'false'}>")
 
