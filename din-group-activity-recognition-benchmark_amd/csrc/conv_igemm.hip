@@ -2770,13 +2770,16 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
             const int nbuf = g.cpt == 8 ? 1 : 2;
             const size_t lds = (size_t)(image ? 3 * bnS * 64 : 9 * bnS * g.cpt * 16) + (size_t)nbuf * hbytes + (k.u8 ? 512 : 0);   // (+ the uint8 -> bf16 table)
             dim3 grid(512);
+            // the image layer's 42 KiB workgroups fit three to a CU: 768 persistent workgroups measured 690 -> 618 us on the 96 frames
+            // (1024: no better, four do not fit); DIN_CONV_IMAGE_GRID overrides
+            if (image) { const char* gv = getenv("DIN_CONV_IMAGE_GRID"); grid.x = gv && atoi(gv) > 0 ? atoi(gv) : 768; }
             auto launch = [&](auto kern) {
                 if (lds > 65536) raise_lds_limit(kern, lds);
                 hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, k);
             };
             if (image && k.u8) launch(conv_small_kernel<1, 32, 2, 3, 3, 2, true>);
             else if (image) launch(conv_small_kernel<1, 32, 2, 3, 3, 2>);
-            else if (g.cpt == 4 && bnS == 32) launch(conv_small_kernel<4, 32, 2, 3, 3, 1>);
+            else if (g.cpt == 4 && bnS == 32) launch(conv_small_kernel<4, 32, 2, 3, 3, 1>);     // (eight waves measured slower here: 706 -> 765 us)
             else {
                 // the two 80 KiB variants (one workgroup per CU) run on eight waves; DIN_CONV_SMALL_WAVES=4 restores four
                 const bool w8 = !(getenv("DIN_CONV_SMALL_WAVES") && atoi(getenv("DIN_CONV_SMALL_WAVES")) == 4);

@@ -27,6 +27,7 @@ struct WalkK {
                                       // dynamic_infer_module.py:154-181,285-298); offsets are ignored and get no gradient
     int ihy, ihx, phy, phx;           // clamp maxima of the corner indices / of the sampling position; -1 = the padded grid's (hp-1, wpc-1), which
                                       // is what dynamic_infer_ratio uses (:216-226); parallel_infer clamps with person_mat_shape instead (:307-317)
+    int ngroups;                      // backward only: position groups per (clip, channel chunk); a wave serves positions grp*W + w, + ngroups*W, ...
     const int32_t* n_per_clip;        // optional [b]: clip i is a T x n_per_clip[i] grid stored in the first columns of its T x n slab
                                       // (Dynamic_collective, infer_model.py:1286-1293); columns beyond it are zero padding
 };
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(WALK_BWD_WAVES * 64) void din_walk_bwd_kernel(WalkK
     float* off_s = dtile + (GLOBAL_DX ? 0 : cells * CH);        // t*n*2*k2 offsets
     float* a_s = off_s + p.t * p.n * 2 * p.k2; // t*n*k2 saved relation weights
     const int nchunks = (p.c + CH - 1) / CH;
-    const int ngroups = (p.t * p.n + WALK_BWD_WAVES - 1) / WALK_BWD_WAVES;
+    const int ngroups = p.ngroups;
     const int grp = blockIdx.x % ngroups, bc = blockIdx.x / ngroups;
     const int b = bc / nchunks, chunk = bc % nchunks, c0 = chunk * CH;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -199,13 +200,13 @@ __global__ __launch_bounds__(WALK_BWD_WAVES * 64) void din_walk_bwd_kernel(WalkK
     // din_walk_bwd_finish_kernel adds the chunks in a fixed order
     float* d_off = p.scratch + (int64_t)chunk * p.b * p.t * p.n * 3 * p.k2;
     float* d_a = d_off + (int64_t)p.b * p.t * p.n * 2 * p.k2;
-    const int pos = grp * WALK_BWD_WAVES + w;
-    if (pos < p.t * p.n && pos % p.n >= nb) {             // padding actor: no gradient (the finish kernel sums every chunk's slot)
+    for (int pos = grp * WALK_BWD_WAVES + w; pos < p.t * p.n; pos += ngroups * WALK_BWD_WAVES)
+    if (pos % p.n >= nb) {                                // padding actor: no gradient (the finish kernel sums every chunk's slot)
         const int64_t gpos = (int64_t)b * p.t * p.n + pos;
         for (int j = lane; j < 3 * p.k2; j += 64) {
             if (j < 2 * p.k2) d_off[gpos * 2 * p.k2 + j] = 0.f; else d_a[gpos * p.k2 + (j - 2 * p.k2)] = 0.f;
         }
-    } else if (pos < p.t * p.n) {
+    } else {
         int tt = pos / p.n, nn = pos - tt * p.n;
         const int64_t gpos = (int64_t)b * p.t * p.n + pos;
         const float* pr = off_s + pos * 2 * p.k2;
@@ -344,7 +345,10 @@ int din_walk_bwd(const float* x, const float* pred, int cp, const float* a, cons
     hipStream_t st = as_stream(stream);
     int64_t positions = (int64_t)b * t * n;
     const size_t tile_b = (size_t)p.hp * p.wp * CH * sizeof(float), tab_b = (size_t)t * n * 3 * p.k2 * sizeof(float);
-    const bool global_dx = 2 * tile_b + tab_b > 160 * 1024;        // the dP tile does not fit: scatter into dx directly
+    // feature gradient scattered straight into dx (fp32 L2 atomics): measured 320 -> 118 us on 32 clips x 36 positions against the LDS dP tile,
+    // whose ds_add_f32 traffic alone cost 230 us (a knock-out of the LDS atomics: 95 us).  DIN_WALK_BWD_GLOBAL=0 keeps the LDS tile when it fits.
+    const char* gx = getenv("DIN_WALK_BWD_GLOBAL");
+    const bool global_dx = 2 * tile_b + tab_b > 160 * 1024 || !(gx && atoi(gx) == 0);
     const size_t lds = (global_dx ? 1 : 2) * tile_b + tab_b;
     DIN_REQUIRE(lds <= 160 * 1024, "din_walk_bwd: T x N grid too large for one LDS tile (%zu bytes)", lds);
     auto raise = [&](const void* fn) -> int {
@@ -355,7 +359,13 @@ int din_walk_bwd(const float* x, const float* pred, int cp, const float* a, cons
     if (int e = raise(global_dx ? reinterpret_cast<const void*>(din_walk_bwd_kernel<true>) : reinterpret_cast<const void*>(din_walk_bwd_kernel<false>))) return e;
     if (hipMemsetAsync(dx, 0, sizeof(float) * positions * c, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "din_walk_bwd: memset");
     int nchunks = (c + CH - 1) / CH;
-    const int ngroups = (t * n + WALK_BWD_WAVES - 1) / WALK_BWD_WAVES;
+    // every workgroup stages the clip's whole padded tile: as few position groups as still fill the chip (~4 workgroups per CU); one wave per
+    // position (the round-1 launch) cost 298 us on 32 clips x 36 positions, almost all of it re-staging.  DIN_WALK_BWD_GROUPS overrides.
+    const int full = (t * n + WALK_BWD_WAVES - 1) / WALK_BWD_WAVES;
+    int ngroups = (1024 + b * nchunks - 1) / (b * nchunks);
+    { const char* gv = getenv("DIN_WALK_BWD_GROUPS"); if (gv && atoi(gv) > 0) ngroups = atoi(gv); }
+    if (ngroups > full) ngroups = full;
+    p.ngroups = ngroups;
     if (global_dx) hipLaunchKernelGGL(din_walk_bwd_kernel<true>, dim3(b * nchunks * ngroups), dim3(WALK_BWD_WAVES * 64), lds, st, p);
     else hipLaunchKernelGGL(din_walk_bwd_kernel<false>, dim3(b * nchunks * ngroups), dim3(WALK_BWD_WAVES * 64), lds, st, p);
     DIN_CHECK_LAUNCH("din_walk_bwd");
