@@ -656,7 +656,10 @@ struct U8Halo {
 // ------------------------------------------------------------------------------------------------
 // NW: waves per workgroup (4, or 8 for the two variants whose 80 KiB of LDS allow ONE workgroup per CU -- the 64-filter forward and the
 // 64-channel dgrad of Conv2d_2b: eight waves give every SIMD two waves; each wave then owns two instead of four 16-pixel segments)
-template <int CPP, int BN, int NBUF, int KH, int KW, int ST, bool U8 = false, int NW = 4>
+// EPI (dgrad launches: the host picks it when DIN_CONV_MASK / DIN_CONV_ACCUM is set): the epilogue's extra operands are requested at the top
+// of the tile and held in registers through the MFMA phase; without it they are fetched inside the store loop (and cost no registers --
+// compiled into the forward variants the prefetch registers slowed Conv2d_2b's forward by a third).
+template <int CPP, int BN, int NBUF, int KH, int KW, int ST, bool U8 = false, int NW = 4, bool EPI = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv_small_kernel(ConvK p) {
     constexpr int NTHREADS = 64 * NW;                                  // (shadows the file-level 256)
     static_assert(!U8 || NW == 4, "the uint8 halo loader is written for four waves");
@@ -775,6 +778,42 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv_small_kernel(Co
         if (U8) { if (have_next) u8_load(tile + gridDim.x); }
         else if (NBUF == 2 && have_next) issue_halo(cur ^ 1, tile + gridDim.x);
         const u32x4* Hl = reinterpret_cast<const u32x4*>(smem_raw + WBYTES + cur * HBYTES);
+        // ---- dgrad epilogue operands (ReLU mask of the produced pixels, accumulate input): requested HERE, a whole MFMA phase before the
+        //      epilogue uses them.  Fetched inside the store loop their HBM latency (~2 us) was exposed once per tile: the Conv2d_2a dgrad
+        //      ran 1083 us inside the training step, 871 us with the early request (and 680 us with no mask at all).
+        constexpr int NIT = (NPX / NPASS) * CPR / NTHREADS;
+        const int n = tile / tiles_img;
+        const int trm = tile - n * tiles_img;
+        const int ty = trm / tiles_x, tx = trm - ty * tiles_x;
+        __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + (long long)n * oimg_bytes, 0, (int)oimg_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>((p.flags & DIN_CONV_MASK) ? p.mask : p.out)) + (long long)n * mimg_bytes, 0,
+            (p.flags & DIN_CONV_MASK) ? (int)mimg_bytes : 0, 0x00020000);
+        auto out_pixel = [&](int ps, int it, int& opx, int& co) -> bool {              // pixel / channel chunk of store `it` of pass `ps`
+            const int idx = it * NTHREADS + tid;
+            const int srow = idx / CPR, c = idx - srow * CPR;
+            const int w_ = srow / (JN * 16), rem = srow - w_ * (JN * 16);
+            const int q = w_ * TJ + ps * JN + rem / 16;                                // segment of the tile
+            const int gy = ty * TH + (q >> 1), gx = tx * TW + (q & 1) * 16 + (rem & 15);
+            co = c * 8;
+            opx = gy * p.OW + gx;
+            return gy < p.OH && gx < p.OW && co < p.Cout;
+        };
+        u32x4 mkP[EPI ? NPASS : 1][EPI ? NIT : 1], oldP[EPI ? NPASS : 1][EPI ? NIT : 1];
+        if (EPI && (p.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM))) {
+#pragma unroll
+            for (int ps = 0; ps < (EPI ? NPASS : 1); ++ps)
+#pragma unroll
+                for (int it = 0; it < (EPI ? NIT : 1); ++it) {
+                    int opx, co;
+                    const bool ok = out_pixel(ps, it, opx, co);
+                    mkP[ps][it] = u32x4{0u, 0u, 0u, 0u}; oldP[ps][it] = u32x4{0u, 0u, 0u, 0u};
+                    if (p.flags & DIN_CONV_MASK)
+                        mkP[ps][it] = __builtin_amdgcn_raw_buffer_load_b128(rsM, ok ? (opx * p.ldm + p.moff + co) * 2 : (int)OOB, 0, 0);
+                    if (p.flags & DIN_CONV_ACCUM)
+                        oldP[ps][it] = __builtin_amdgcn_raw_buffer_load_b128(rsO, ok ? (opx * p.ldo + p.cooff + co) * 2 : (int)OOB, 0, 0);
+                }
+        }
 
         f32x4 acc[TI][TJ];
 #pragma unroll
@@ -832,14 +871,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv_small_kernel(Co
         if (U8 && have_next) u8h.template store<NSLOT>(smem_raw + WBYTES + (cur ^ 1) * HBYTES, u8lut, wid, lane);
         __syncthreads();                                                               // all waves done reading halo(cur)
         // ---- epilogue: stage through the consumed halo buffer, then 16-byte coalesced buffer stores (always NST per wave) -----
-        const int n = tile / tiles_img;
-        const int trm = tile - n * tiles_img;
-        const int ty = trm / tiles_x, tx = trm - ty * tiles_x;
         unsigned char* stg = smem_raw + WBYTES + cur * HBYTES;
-        __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + (long long)n * oimg_bytes, 0, (int)oimg_bytes, 0x00020000);
-        __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(reinterpret_cast<const char*>((p.flags & DIN_CONV_MASK) ? p.mask : p.out)) + (long long)n * mimg_bytes, 0,
-            (p.flags & DIN_CONV_MASK) ? (int)mimg_bytes : 0, 0x00020000);
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
@@ -860,21 +892,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv_small_kernel(Co
             }
             __syncthreads();
 #pragma unroll
-            for (int it = 0; it < (NPX / NPASS) * CPR / NTHREADS; ++it) {
+            for (int it = 0; it < NIT; ++it) {
+                int opx, co;
+                const bool ok = out_pixel(ps, it, opx, co);
                 const int idx = it * NTHREADS + tid;
                 const int srow = idx / CPR, c = idx - srow * CPR;
-                const int w_ = srow / (JN * 16), rem = srow - w_ * (JN * 16);
-                const int q = w_ * TJ + ps * JN + rem / 16;                                // segment of the tile
-                const int gy = ty * TH + (q >> 1), gx = tx * TW + (q & 1) * 16 + (rem & 15);
-                const int co = c * 8;
-                const bool ok = gy < p.OH && gx < p.OW && co < p.Cout;
                 u32x4 v = *reinterpret_cast<const u32x4*>(stg + srow * CPITCH + c * 16);
-                const int opx = gy * p.OW + gx;
                 const int o = ok ? (opx * p.ldo + p.cooff + co) * 2 : (int)OOB;
                 if (p.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM)) {
                     u32x4 mk = {0u, 0u, 0u, 0u}, old = {0u, 0u, 0u, 0u};
-                    if (p.flags & DIN_CONV_MASK) mk = __builtin_amdgcn_raw_buffer_load_b128(rsM, ok ? (opx * p.ldm + p.moff + co) * 2 : (int)OOB, 0, 0);
-                    if (p.flags & DIN_CONV_ACCUM) old = __builtin_amdgcn_raw_buffer_load_b128(rsO, o, 0, 0);
+                    if (EPI) { mk = mkP[EPI ? ps : 0][EPI ? it : 0]; old = oldP[EPI ? ps : 0][EPI ? it : 0]; }
+                    else {
+                        if (p.flags & DIN_CONV_MASK) mk = __builtin_amdgcn_raw_buffer_load_b128(rsM, ok ? (opx * p.ldm + p.moff + co) * 2 : (int)OOB, 0, 0);
+                        if (p.flags & DIN_CONV_ACCUM) old = __builtin_amdgcn_raw_buffer_load_b128(rsO, o, 0, 0);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
@@ -2770,6 +2801,8 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
             const int nbuf = g.cpt == 8 ? 1 : 2;
             const size_t lds = (size_t)(image ? 3 * bnS * 64 : 9 * bnS * g.cpt * 16) + (size_t)nbuf * hbytes + (k.u8 ? 512 : 0);   // (+ the uint8 -> bf16 table)
             dim3 grid(512);
+            // dgrad launches with a mask / accumulate operand: the variant that requests them a tile phase early (DIN_CONV_SMALL_EPI=0: in the store loop)
+            const bool epi = (k.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM)) && !(getenv("DIN_CONV_SMALL_EPI") && atoi(getenv("DIN_CONV_SMALL_EPI")) == 0);
             // the image layer's 42 KiB workgroups fit three to a CU: 768 persistent workgroups measured 690 -> 618 us on the 96 frames
             // (1024: no better, four do not fit); DIN_CONV_IMAGE_GRID overrides
             if (image) { const char* gv = getenv("DIN_CONV_IMAGE_GRID"); grid.x = gv && atoi(gv) > 0 ? atoi(gv) : 768; }
@@ -2779,7 +2812,9 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
             };
             if (image && k.u8) launch(conv_small_kernel<1, 32, 2, 3, 3, 2, true>);
             else if (image) launch(conv_small_kernel<1, 32, 2, 3, 3, 2>);
-            else if (g.cpt == 4 && bnS == 32) launch(conv_small_kernel<4, 32, 2, 3, 3, 1>);     // (eight waves measured slower here: 706 -> 765 us)
+            else if (g.cpt == 4 && bnS == 32) {                                                // (eight waves measured slower here: 706 -> 765 us)
+                if (epi) launch(conv_small_kernel<4, 32, 2, 3, 3, 1, false, 4, true>); else launch(conv_small_kernel<4, 32, 2, 3, 3, 1>);
+            }
             else {
                 // the two 80 KiB variants (one workgroup per CU) run on eight waves; DIN_CONV_SMALL_WAVES=4 restores four
                 const bool w8 = !(getenv("DIN_CONV_SMALL_WAVES") && atoi(getenv("DIN_CONV_SMALL_WAVES")) == 4);
@@ -2788,6 +2823,7 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, k);
                 };
                 if (g.cpt == 4) { if (w8) launch8(conv_small_kernel<4, 64, 2, 3, 3, 1, false, 8>); else launch(conv_small_kernel<4, 64, 2, 3, 3, 1>); }
+                else if (epi && w8) launch8(conv_small_kernel<8, 32, 1, 3, 3, 1, false, 8, true>);
                 else { if (w8) launch8(conv_small_kernel<8, 32, 1, 3, 3, 1, false, 8>); else launch(conv_small_kernel<8, 32, 1, 3, 3, 1>); }
             }
             DIN_CHECK_LAUNCH(what);
