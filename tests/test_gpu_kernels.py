@@ -170,6 +170,37 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
         assert rel(from_nhwc(dx, cin), want) <= 2 * tolg
 
 
+@pytest.mark.parametrize("cout", [32, 64], ids=["dY32_conv_small_4", "dY64_conv_small_8"])
+def test_stem_dgrad_early_operand_request_is_bit_identical(env, monkeypatch, cout):
+    """conv_small_kernel<..., EPI = true> (dgrad launches: ReLU mask / accumulate operands requested at the top of the tile) against the
+    in-loop fetch (DIN_CONV_SMALL_EPI=0) on the two stem dgrad geometries, mask + accumulate, ragged right / bottom tile edges."""
+    lib, L, nhwc, ops = env
+    g = torch.Generator().manual_seed(41)
+    nb, h, w, bf = 2, 365, 645, torch.bfloat16                   # 363 x 643 outputs: not multiples of the 8 x 32 tile
+    d = L.ConvDesc()
+    d.nb, d.h, d.w, d.cin, d.oh, d.ow, d.cout = nb, h, w, 32, h - 2, w - 2, cout
+    d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.dh, d.dw = 3, 3, 1, 1, 0, 0, 1, 1
+    d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = 32, 0, cout, 0, L.DIN_BF16
+    xin = torch.randn(nb, h, w, 32, generator=g).to(bf).cuda()
+    gy = torch.randn(nb, h - 2, w - 2, cout, generator=g).to(bf).cuda()
+    wt = (torch.randn(cout, 32, 3, 3, generator=g) * 0.1).cuda()
+    wpt = torch.empty(lib.din_conv_packed_elems(C.byref(d), 1), dtype=bf, device="cuda")
+    L.check(lib.din_conv_pack_weights(C.byref(d), wt.data_ptr(), None, wpt.data_ptr(), 1, None))
+    base = torch.randn(nb, h, w, 32, generator=g).to(bf).cuda()
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DIN_CONV_SMALL_EPI", mode)
+        dx = base.clone()
+        L.check(lib.din_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), dx.data_ptr(), xin.data_ptr(), 32, 0,
+                                   L.CONV_MASK | L.CONV_ACCUM, None, 0, None))
+        torch.cuda.synchronize()
+        outs.append(dx)
+    assert torch.equal(outs[0], outs[1])
+    changed = outs[0] != base
+    assert 0.3 < float(changed.float().mean()) < 0.7                      # about half of the positions pass the ReLU mask
+    assert not bool((changed & ~(xin > 0)).any())                         # nothing was added where the mask is off
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_pipe"])
 def test_conv_fwd_two_destinations(env, dtype, monkeypatch):
     """din_conv_fwd2: sibling 1x1 convs of one input as ONE launch -- channels [0, csplit) into the first tensor's view, the rest into a second
