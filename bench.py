@@ -12,8 +12,9 @@ A step = forward + cross-entropy + backward + gradient all-reduce (N>1) + fused 
 HBM-resident uint8 clips (inputs are on the device before the timed region starts).
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (implicit-GEMM gather conv, fwd+dgrad launches of the 128-filter tile variant): algorithmic
-                FLOPs per launch / live HIP-event launch time, against the dense MFMA peak of the compute dtype
+  roofline      dominant kernel (the conv kernel with the largest summed launch time of a surveyed step; Inception bf16: the pipelined
+                weight-gradient kernel conv_wgrad_pipe_kernel<192, 256, true, 8>): algorithmic FLOPs per launch / live HIP-event launch
+                time, against the dense MFMA peak of the compute dtype
   cpu_baseline  the CPU oracle (oracle/din_oracle.py, torch-CPU fp32 "port") timed on this box's host cores on a bounded
                 sample of the same workload (rank 0, N=1 only)
 """
@@ -26,6 +27,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL otherwise fails with hipIpcGetMemHandle: invalid argument);
+# the launch environment normally exports it already -- must be in place before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch
 import torch.distributed as dist
