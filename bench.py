@@ -48,6 +48,8 @@ WORKLOADS = {
 }
 COLLECTIVE = {"H": 480, "W": 720, "N": 13, "T": 10, "activities": 4, "global_batch": 8, "dropout": 0.5}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0                               # HBM3E spec peak, MI355X_MICROARCH.md (6.3 TB/s is what a plain copy achieves)
+TRAFFIC_FILE = "r03_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) else "r02_pmc_traffic.json"
 
 
 def make_cfg(workload, T=3, N=12, H=720, W=1280, lite=None, hierarchical=False):
@@ -94,8 +96,8 @@ def synth_boxes_labels(b, t, n, oh, ow, num_classes=8, seed=0):
     return torch.from_numpy(boxes.astype(np.float32)), torch.from_numpy(labels)
 
 
-def cpu_baseline(workload, T, N, H, W, budget_s=25.0, lite=None, hierarchical=False):
-    """Oracle fwd+bwd on the host cores for a bounded sample (B=1 clip per step).
+def cpu_baseline(workload, T, N, H, W, budget_s=25.0, lite=None, hierarchical=False, B=1):
+    """Oracle fwd+bwd on the host cores for a bounded sample (B clips per step; default 1).
 
     torch-CPU does not scale to every SMT thread of a 2-socket host (256 threads measured 40x SLOWER than 64 on the
     2 x EPC 9575F box), so the baseline gets its best shot: one step at each of a few thread counts, then the remaining
@@ -110,7 +112,6 @@ def cpu_baseline(workload, T, N, H, W, budget_s=25.0, lite=None, hierarchical=Fa
                        collective=collective, num_activities=COLLECTIVE["activities"] if collective else 8)
     p = O.synth_params(O.model_param_shapes(ocfg), seed=3, din_std=0.02)
     p = {k: v.requires_grad_("running_" not in k) for k, v in p.items()}
-    B = 1
     images, boxes, labels = O.synth_inputs(B, T, N, H, W, OH, OW, ocfg.num_activities, seed=0)
     images = images.float()
     counts = torch.full((B, T), max(1, N // 2), dtype=torch.int32)
@@ -143,13 +144,56 @@ def cpu_baseline(workload, T, N, H, W, budget_s=25.0, lite=None, hierarchical=Fa
     t0 = time.time()
     for _ in range(n):
         step()
-    dt = (time.time() - t0) / n
-    dt = min(dt, best_t)
+    dt = (time.time() - t0) / n                              # mean of the timed steps (the probe steps only chose the thread count)
     return {"value": B / dt, "unit": "clips/sec", "cores": best_th, "kind": "port", "host_logical_cpus": ncpu,
-            "sample": f"{n} timed fwd+bwd step(s) of B={B} clip (T={T}, {H}x{W}, {backbone}" + (f", lite_dim={lite}" if lite else "") +
+            "sample": f"{n} timed fwd+bwd step(s) (mean) of B={B} clip(s) (T={T}, {H}x{W}, {backbone}" + (f", lite_dim={lite}" if lite else "") +
                       (", hierarchical" if hierarchical else "") + (f", collective with {max(1, N // 2)} of {N} actors" if collective else "") +
                       ", fp32 torch-CPU oracle) at the fastest of "
                       f"threads={cands} (1 probe step each)"}
+
+
+def parity_mode_sample(a, dev, T, N, H, W, clips=4, steps=2):
+    """clips/sec of the SAME workload in the fp32 parity mode (fp32 storage, exact-fp32 MFMA): the only mode that meets north_star's
+    1e-4 logits bar (tests/test_gpu_din_model.py::test_full_size_fp32_model_matches_reference_golden).  Bounded sample: `clips` clips,
+    one warm-up + `steps` timed steps of fwd + CE + bwd + fused Adam, HBM-resident uint8 clips."""
+    from din_amd.infer_model import Dynamic_volleyball
+    from din_amd.optim import FusedAdam
+    from din_amd.train_net_dynamic import set_bn_eval
+    wl = a.workload.replace("bf16", "fp32")
+    backbone, dtype, (OH, OW), D = WORKLOADS[wl]
+    cfg = make_cfg(wl, T, N, H, W, lite=a.lite_dim, hierarchical=a.hierarchical)
+    torch.manual_seed(0)
+    model = Dynamic_volleyball(cfg)
+    synth_weights(model)
+    model = model.to(dev).train()
+    model.apply(set_bn_eval)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = FusedAdam(params, lr=1e-4, weight_decay=0.0)
+    g = torch.Generator().manual_seed(2000)
+    images = torch.randint(0, 256, (clips, T, 3, H, W), dtype=torch.uint8, generator=g).to(dev)
+    boxes, labels = synth_boxes_labels(clips, T, N, OH, OW, cfg.num_activities, seed=0)
+    boxes, labels = boxes.to(dev), labels.to(dev)
+
+    def step():
+        opt.zero_grad()
+        loss = F.cross_entropy(model((images, boxes))["activities"], labels)
+        loss.backward()
+        opt.step()
+        return loss
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"value": round(clips / dt, 2), "unit": "clips/sec", "dtype": "fp32", "clips_per_step": clips, "steps": steps,
+           "ms_per_step": round(dt * 1e3, 2), "final_loss": round(float(loss.item()), 5),
+           "note": "same workload in the fp32 parity mode (logits within 1e-4 of the reference: tests/golden/full_*.npz), "
+                   "fwd + CE + bwd + fused Adam, 1 warm-up step"}
+    del model, opt, images
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -165,6 +209,7 @@ def main():
     ap.add_argument("--tce", action="store_true", help="Dynamic_TCE_volleyball (SURVEY 8(f)-4; scripts/train_volleyball_stage2_dynamic_tce.py: "
                     "vgg16 trunk, T defaults to 10): DIN behind the 4-head context-encoding transformer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32 parity-mode sample, the HBM-group survey and the config-1 CPU baseline")
     ap.add_argument("--no-adam", action="store_true")
     ap.add_argument("--host-images", action="store_true", help="clips start in pinned host memory every step (uint8): the PCIe-inclusive rate, never the headline value")
     ap.add_argument("--forward-only", action="store_true", help="evaluation path (SURVEY 8f-3): model.eval(), torch.no_grad(), forward + loss only")
@@ -270,14 +315,19 @@ def main():
     # The LAST warm-up step is run with every conv launch bracketed by HIP events: it names the dominant kernel (largest summed launch
     # time) and fills the per-kernel survey.  The timed region then brackets ONLY that kernel's launches (in its last step), so the
     # headline number pays for ~20 event pairs instead of ~190 (a fully bracketed step costs ~10 % of its own duration).
-    survey = None
+    survey, hbm = None, None
     for wi in range(a.warmup):
         if wi == a.warmup - 1:
             profiling.PROFILE = []
+            if not a.no_extras:
+                hbm = profiling.hbm_survey()
+                hbm.__enter__()
         step()
         if wi == a.warmup - 1:
             torch.cuda.synchronize()
             survey, profiling.PROFILE = profiling.PROFILE, None
+            if hbm is not None:
+                hbm.__exit__(None, None, None)
     if os.environ.get("DIN_BENCH_TORCH_PROFILE"):          # tuning aid: which host-side torch ops launch the small fill / copy kernels
         from torch.profiler import profile, ProfilerActivity
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
@@ -368,7 +418,7 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process; they come from the separate rocprofv3
     # --pmc passes over this same command whose per-kernel result is committed under profiles/ (tools/pmc_traffic.py)
     try:
-        tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")))
+        tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", TRAFFIC_FILE)))
         if tr.get("workload") == a.workload and tr.get("global_batch") == a.global_batch and world == 1:
             prefix = dom.split(", ...>")[0]
             hits = [v for k, v in tr["kernels"].items() if k.startswith(prefix)]
@@ -378,7 +428,8 @@ def main():
                 wr = sum((h["write_bytes_per_launch"] or 0.0) * h["launches"] for h in hits) / n
                 roofline["traffic"] = round(rd + wr)
                 roofline["traffic_detail"] = {"unit": "HBM bytes per launch", "read": round(rd), "write": round(wr),
-                                              "source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"}
+                                              "source": f"profiles/{TRAFFIC_FILE} (committed result of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                        "passes over this command, tools/pmc_traffic.py; not measured in this run)"}
     except (OSError, ValueError, KeyError):
         pass
     conv_time = sum(v[1] for v in agg.values())
@@ -397,7 +448,8 @@ def main():
                                     (f", lite_dim={a.lite_dim}" if a.lite_dim else "") + f", N=12, {H}x{W}, {dtype}"),
                        "global_batch": a.global_batch, "clips_per_gpu": B, "frames": T, "parallelism": f"dp{world}",
                        "includes": "fwd + cross-entropy (eval mode, no_grad)" if a.forward_only else
-                                   "fwd + cross-entropy + bwd" + (" + RCCL grad all-reduce" if world > 1 else "")
+                                   "fwd + cross-entropy + bwd" + (f" + grad all-reduce ({'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()})"
+                                                                  if (world > 1 or buckets is not None) else "")
                                    + ("" if a.no_adam else " + fused Adam"),
                        "bn_mode": ("running statistics (set_bn_eval)" if cfg.set_bn_eval else "batch statistics (reference stage-2 default)")
                                   if backbone == "inv3" else "n/a"},
@@ -406,9 +458,19 @@ def main():
             "host_enqueue_ms_per_step": round(host_enqueue_s / a.steps * 1e3, 3),
             "final_loss": round(float(loss.item()), 5),
         }
+        if hbm is not None:
+            # HBM-bound kernel groups of the surveyed (last warm-up) step: ALGORITHMIC bytes / HIP-event time vs 8 TB/s
+            out["roofline_hbm"] = dict(hbm.summary(event_overhead_ms, PEAK_HBM_GBS),
+                                       source="algorithmic bytes per launch / HIP-event launch time, last warm-up step (din_amd/profiling.py::hbm_survey)")
+        plain = world == 1 and not (a.forward_only or a.tce or collective or a.no_extras or a.host_images or a.force_buckets)
+        if plain and dtype == "bf16":
+            out["parity_mode"] = parity_mode_sample(a, dev, T, N, H, W)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.workload, T, N, H, W, lite=a.lite_dim, hierarchical=a.hierarchical)
             out["vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            if plain and not (a.workload.startswith("vgg16") or a.lite_dim or a.hierarchical):
+                # the CPU reference path's own configuration -- configs[0], VGG16, T=3, B=2 (one probe + timed steps)
+                out["cpu_baseline_config1"] = cpu_baseline("vgg16_fp32", 3, 12, 720, 1280, budget_s=30.0, B=2)
         print(json.dumps(out))
     if world > 1 or (a.force_buckets and dist.is_initialized()):
         dist.destroy_process_group()

@@ -16,10 +16,110 @@ from . import nhwc
 
 PROFILE = None
 PROFILE_ONLY = None      # str: while PROFILE is a list, bracket only the launches of this kernel (as named below) with events
+HBM = None               # list while the HBM-bound launch groups are surveyed: (group, kernel entry point, algorithmic bytes, start event, end event)
 
 
 def _conv_flops(d) -> float:
     return 2.0 * d.nb * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
+
+
+def _esz(dt: int) -> int:
+    return 4 if dt == L.DIN_F32 else 2
+
+
+def _stem_bytes(kind: str, d) -> float:
+    """algorithmic HBM bytes of one launch of the halo-tiled stem kernels (input once + output once; the dgrad also reads
+    the ReLU mask = the layer's stored input, the weight gradient reads input + output gradient)"""
+    e = _esz(d.dtype)
+    x = d.nb * d.h * d.w * (3 if d.in_u8 else d.cin * e)               # uint8 frames: 3 bytes per pixel
+    y = d.nb * d.oh * d.ow * d.cout * e
+    if kind == "fwd":
+        return float(x + y)
+    if kind == "dgrad":
+        return float(y + 2 * x)                                        # gradient in, ReLU mask in, gradient out
+    return float(x + y)
+
+
+def _pool_bytes(name: str, args) -> float:
+    d = args[0]._obj
+    e = _esz(d.dtype)
+    big, small = d.nb * d.h * d.w * d.c, d.nb * d.oh * d.ow * d.c
+    if name == "din_maxpool_fwd":                                      # (d, in, out, argmax, stream)
+        return float(e * (big + small) + (small if args[3] else 0))
+    # din_maxpool_bwd(d, in, argmax, dout, din, relu_mask, accumulate, stream): with the arg-max map the input is not read
+    return float(e * (small + big) + (small if args[2] else e * big) + (e * big if args[6] else 0))
+
+
+def _roi_bytes(name: str, args) -> float:
+    if name == "din_roi_align_fwd":                                    # (fm, dt, nb, hf, wf, c, ldf, gh, gw, boxes, ind, m, k, out, ...)
+        _fm, dt, nb, hf, wf, c, _ldf, _gh, _gw, _b, _i, m, k = args[:13]
+        return float(nb * hf * wf * c * _esz(dt) + m * c * k * k * 4)   # the stored map at most once + the crops
+    if name == "din_roi_crop_grad_transpose":                          # (dout, m, c, k, out, stream)
+        _d, m, c, k = args[:4]
+        return float(2 * m * c * k * k * 4)
+    # din_roi_align_bwd_nhwc(dout, dout_c, dout_coff, transposed, nb, hf, wf, c, gh, gw, boxes, ind, m, k, fm_mask, dtype, ldf, gfm, ldg, st)
+    nb, hf, wf, c = args[4:8]
+    m, k, mask, dt = args[12], args[13], args[14], args[15]
+    return float(nb * hf * wf * c * _esz(dt) * (2 if mask else 1) + m * c * k * k * 4)
+
+
+def _walk_bytes(name: str, args) -> float:
+    if name == "din_walk_fwd":                                         # (x, pred, cp, b, t, n, c, kh, kw, ...)
+        cp, b, t, n, c, kh, kw = args[2:9]
+        return float(4 * b * t * n * (2 * c + cp + 5 * kh * kw))       # x in, z out, predictions in, relation weights + corner indices out
+    cp = args[2]
+    b, t, n, c = args[5:9]
+    return float(4 * b * t * n * (3 * c + 2 * cp))                     # x, gz in; dx out; predictions in, their gradient out
+
+
+_HBM_CALLS = {"din_maxpool_fwd": ("max-pools", _pool_bytes), "din_maxpool_bwd": ("max-pools", _pool_bytes),
+              "din_roi_align_fwd": ("RoIAlign", _roi_bytes), "din_roi_crop_grad_transpose": ("RoIAlign", _roi_bytes),
+              "din_roi_align_bwd_nhwc": ("RoIAlign", _roi_bytes),
+              "din_walk_fwd": ("DIN walk", _walk_bytes), "din_walk_bwd": ("DIN walk", _walk_bytes)}
+
+
+class hbm_survey:
+    """`with hbm_survey() as rec:` -- every launch of the HBM-bound groups (stem halo kernels through the conv timer, max-pools, RoIAlign,
+    DIN walk through wrapped library entry points) is bracketed with HIP events on the launch stream and recorded with its ALGORITHMIC
+    bytes.  Measurement side only: the wrappers are removed on exit."""
+    def __enter__(self):
+        global HBM
+        HBM = []
+        lib = L.load()
+        self.saved = {}
+        for name, (group, fbytes) in _HBM_CALLS.items():
+            fn = getattr(lib, name)
+            self.saved[name] = fn
+
+            def wrapped(*args, _fn=fn, _name=name, _group=group, _fb=fbytes):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream())
+                rc = _fn(*args)
+                e1.record(torch.cuda.current_stream())
+                vals = [a.value if isinstance(a, (C.c_void_p, C.c_int, C.c_int64)) else a for a in args]
+                HBM.append((_group, _name, _fb(_name, vals), e0, e1))
+                return rc
+            setattr(lib, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        global HBM
+        lib = L.load()
+        for name, fn in self.saved.items():
+            setattr(lib, name, fn)
+        self.records, HBM = HBM, None
+        return False
+
+    def summary(self, event_overhead_ms: float = 0.0, peak_gbs: float = 8000.0):
+        out = {}
+        for group, _name, nbytes, e0, e1 in self.records:
+            rec = out.setdefault(group, [0.0, 0.0, 0])
+            rec[0] += nbytes
+            rec[1] += max(e0.elapsed_time(e1) - event_overhead_ms, 1e-4) * 1e-3
+            rec[2] += 1
+        return {g: {"bound": "hbm", "achieved": round(v[0] / v[1] / 1e9, 1), "peak": peak_gbs, "unit": "GB/s",
+                    "frac": round(v[0] / v[1] / 1e9 / peak_gbs, 4), "launches": v[2], "time_ms": round(v[1] * 1e3, 3),
+                    "algorithmic_bytes": round(v[0])} for g, v in out.items()}
 
 
 class LaunchTimer:
@@ -81,6 +181,8 @@ class LaunchTimer:
         if self.rec:
             self.e1.record(torch.cuda.current_stream())
             PROFILE.append((self.kind, self.variant, _conv_flops(self.d), int(self.d.dtype), self.e0, self.e1, self.name))
+            if HBM is not None and self.variant.startswith(("conv_small_kernel", "conv_wgrad_small_kernel")):
+                HBM.append(("stem (Conv2d_1a-2b halo kernels)", self.variant, _stem_bytes(self.kind, self.d), self.e0, self.e1))
         return False
 
 

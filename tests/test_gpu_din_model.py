@@ -756,3 +756,145 @@ def test_tce_hierarchical_variant_matches_oracle(gpu):
         if ("context_encoding" in k or k.startswith("DPI.") or k.startswith("fc_activities")) and po[k].grad is not None:
             if float(po[k].grad.abs().max()) > 0:
                 assert rel(named[k].grad, po[k].grad) <= 2e-3, (k, rel(named[k].grad, po[k].grad))
+
+
+# ---- the two full-size 720x1280 fixtures (tools/gen_golden.py::full_case) --------------------------------------------
+# Inputs and the 29 M weights are regenerated from the seed recipe on both sides; the fixture holds the reference's logits, loss,
+# per-stage feature probes (backbone outputs, RoIAlign crops, embedding, DIN output) and gradients.  At this size the planner takes the
+# kernels no reduced fixture sees together: stem halo tiles, the mid-network halo kernel, pipelined wgrad with sibling pacing.
+FULL_CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "full_*.npz")))
+
+
+def _probe_idx(numel, count=8192):
+    count = min(count, numel)
+    return torch.arange(count, dtype=torch.int64) * (numel // count)
+
+
+def _run_full_case(gpu, path, backbone_dtype):
+    """one fwd + bwd of the full-size fixture through the HIP path; returns (fixture, logits, loss, named grads, captured stage tensors)"""
+    from din_amd import ops
+    from din_amd.config import Config
+    from din_amd.infer_model import Dynamic_volleyball
+    z, ocfg, p, images, boxes, labels = load_model_case(path)
+    cfg = Config("volleyball")
+    cfg.backbone, cfg.image_size, cfg.out_size, cfg.emb_features = ocfg.backbone, ocfg.image_size, ocfg.out_size, ocfg.emb_features
+    cfg.num_boxes, cfg.num_frames = ocfg.num_boxes, ocfg.num_frames
+    cfg.num_features_boxes = cfg.num_features_gcn = ocfg.num_features_boxes
+    cfg.ST_kernel_size, cfg.sampling_ratio, cfg.num_DIM = ocfg.ST_kernel_size, ocfg.sampling_ratio, ocfg.num_DIM
+    cfg.beta_factor, cfg.lite_dim, cfg.hierarchical_inference = False, None, False
+    cfg.train_backbone, cfg.backbone_dtype = True, backbone_dtype
+    model = Dynamic_volleyball(cfg)
+    missing, unexpected = model.load_state_dict(p, strict=False)
+    assert not unexpected and all("num_batches_tracked" in k for k in missing), (missing, unexpected)
+    model = model.to(gpu).eval()
+    cap = {}
+    # stage taps: the backbone's NHWC buffers, the RoIAlign crops, the first LayerNorm(+ReLU) = the embedding, the DIN output
+    real_fwd = model.backbone.forward_nhwc
+
+    def tap_backbone(images_flat, prenormalised=False):
+        bufs, graph = real_fwd(images_flat, prenormalised)
+        for j, (buf, (tid, coff, c)) in enumerate(zip(bufs, model.backbone.output_views(graph))):
+            cap[f"fm{j}"] = buf[..., coff:coff + c].detach().permute(0, 3, 1, 2).float()      # NCHW like the reference
+        return bufs, graph
+    model.backbone.forward_nhwc = tap_backbone
+    if hasattr(model.roi_align, "forward_multiscale"):
+        real_ms = model.roi_align.forward_multiscale
+
+        def tap_ms(*a, **k):
+            out = real_ms(*a, **k)
+            cap["crops"] = out.detach()
+            return out
+        model.roi_align.forward_multiscale = tap_ms
+    hooks = [model.roi_align.register_forward_hook(lambda m, i, o: cap.__setitem__("crops", o.detach())),
+             model.DPI.register_forward_hook(lambda m, i, o: cap.__setitem__("graph", o[0].detach()))]
+    real_ln = ops.layer_norm
+
+    def tap_ln(x, *a, **k):
+        out = real_ln(x, *a, **k)
+        cap.setdefault("x_emb", out.detach())
+        return out
+    ops.layer_norm = tap_ln
+    try:
+        ret = model((images.to(gpu), boxes.to(gpu)))
+        loss = F.cross_entropy(ret["activities"], labels.to(gpu))
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.layer_norm = real_ln
+        for h in hooks:
+            h.remove()
+    return z, ret["activities"].detach(), loss.item(), dict(model.named_parameters()), cap
+
+
+def _probe_err(z, key, got):
+    """max abs error of the captured stage tensor at the fixture's 8192 sample positions, relative to the reference tensor's max"""
+    got = got.reshape(-1).double().cpu()
+    assert got.numel() == int(np.prod(z[f"feat.{key}.shape"])), (key, got.numel(), z[f"feat.{key}.shape"])
+    ref = torch.as_tensor(z[f"feat.{key}.sample"]).double()
+    return ((got[_probe_idx(got.numel())] - ref).abs().max() / float(z[f"feat.{key}.max"])).item()
+
+
+def _cos(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu().flatten(), torch.as_tensor(b).detach().double().cpu().flatten()
+    return float(a @ b / (a.norm() * b.norm() + 1e-300))
+
+
+@pytest.mark.parametrize("path", FULL_CASES, ids=[os.path.basename(p)[:-4] for p in FULL_CASES])
+def test_full_size_fp32_model_matches_reference_golden(gpu, path):
+    """fp32 parity mode at 720x1280 (BASELINE configs[0] VGG16 B=2, configs[1] Inception-v3 B=1): logits, loss and every stage probe within
+    1e-4 of the reference's own CPU run (reference infer_model.py:141-234)."""
+    z, logits, loss, named, cap = _run_full_case(gpu, path, "fp32")
+    assert rel(logits, z["logits"]) <= 1e-4
+    assert abs(loss - float(z["loss"])) <= 1e-4 * max(1.0, abs(float(z["loss"])))
+    for key in ("fm0", "fm1", "crops", "x_emb", "graph"):
+        if f"feat.{key}.sample" not in z.files:
+            continue
+        assert _probe_err(z, key, cap[key]) <= 1e-4, (key, _probe_err(z, key, cap[key]))
+        s = cap[key].double().sum().item()
+        assert abs(s - float(z[f"feat.{key}.sum"])) <= 1e-4 * float(z[f"feat.{key}.abs"]) + 1e-6, key
+    for k in z.files:
+        if k.startswith("g."):               # small tensors stored whole: same tolerances as the reduced-size fixtures (see above)
+            tol = 1e-3 if not k.startswith("g.backbone.") else 3e-2
+            assert rel(named[k[2:]].grad, z[k]) <= tol, (k, rel(named[k[2:]].grad, z[k]))
+            assert _cos(named[k[2:]].grad, z[k]) >= 0.9999, k
+        if k.startswith("gs."):              # 8192 strided samples of the big tensors
+            gfl = named[k[3:]].grad.reshape(-1).cpu()
+            got = gfl[_probe_idx(gfl.numel())]
+            tol = 1e-3 if not k.startswith("gs.backbone.") else 3e-2
+            assert rel(got, z[k]) <= tol, (k, rel(got, z[k]))
+            assert _cos(got, z[k]) >= 0.9999, k
+        if k.startswith("gsum."):
+            got = named[k[5:]].grad.double()
+            assert abs(got.sum().item() - float(z[k])) <= 2e-3 * float(z["gabs." + k[5:]]) + 1e-6, k
+
+
+BF16_FULL = [p for p in FULL_CASES if "inv3" in p]
+
+
+@pytest.mark.parametrize("path", BF16_FULL, ids=[os.path.basename(p)[:-4] for p in BF16_FULL])
+def test_full_size_bf16_model_tracks_reference_golden(gpu, path):
+    """The BENCHMARKED mode (Inception-v3, bf16 storage, fp32 accumulation) against the REFERENCE's fp32 run at full size -- not against
+    this repo's own fp32 mode.  bf16 cannot meet north_star's 1e-4 and does not claim to; the stated tolerances are: logits 5e-2 of
+    the largest logit, loss 5e-2, backbone maps 2e-2 of their maximum at the probe positions (8 mantissa bits through 47 layers), the
+    embedding / DIN output 5e-2, head gradients cosine >= 0.99, sampled fc_emb_1 / backbone gradients cosine >= 0.95 / 0.90."""
+    z, logits, loss, named, cap = _run_full_case(gpu, path, "bf16")
+    errs = {"logits": rel(logits, z["logits"]), "loss": abs(loss - float(z["loss"]))}
+    for key in ("fm0", "fm1", "crops", "x_emb", "graph"):
+        errs[key] = _probe_err(z, key, cap[key])
+    cosv = {}
+    for k in z.files:
+        if k.startswith("g.") and z[k].size >= 8:
+            cosv[k[2:]] = _cos(named[k[2:]].grad, z[k])
+        if k.startswith("gs."):
+            gfl = named[k[3:]].grad.reshape(-1).cpu()
+            cosv[k[3:]] = _cos(gfl[_probe_idx(gfl.numel())], z[k])
+    head = {k: v for k, v in cosv.items() if not k.startswith("backbone.")}
+    body = {k: v for k, v in cosv.items() if k.startswith("backbone.") and k.endswith("conv.weight")}
+    print("bf16 vs reference fp32 @720x1280:", {k: f"{v:.2e}" for k, v in errs.items()}, "min head cosine", min(head.values()),
+          "min backbone conv-weight cosine", min(body.values()), min(body, key=body.get))
+    assert errs["logits"] <= 5e-2 and errs["loss"] <= 5e-2 * max(1.0, abs(float(z["loss"]))), errs
+    assert errs["fm0"] <= 2e-2 and errs["fm1"] <= 2e-2 and errs["crops"] <= 2e-2, errs
+    assert errs["x_emb"] <= 5e-2 and errs["graph"] <= 5e-2, errs
+    assert min(v for k, v in head.items() if k.startswith(("fc_activities", "dpi_nl", "nl_emb_1"))) >= 0.99, head
+    assert cosv["fc_emb_1.weight"] >= 0.95, cosv["fc_emb_1.weight"]
+    assert min(body.values()) >= 0.90, sorted(body.items(), key=lambda kv: kv[1])[:5]

@@ -124,6 +124,25 @@ def test_model_oracle_matches_reference(path):
             assert _rel(po[k[2:]].grad, z[k]) <= 1e-2, k
 
 
+FULL_CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "full_*.npz")))
+
+
+def test_full_size_fixtures_are_present_and_seed_reproducible():
+    """the two 720x1280 fixtures (tools/gen_golden.py::full_case; the oracle was held against the reference when they were written --
+    re-running it here would take minutes): both backbones present, the seed recipe still regenerates the stored labels, every stage
+    probe and gradient record is there"""
+    assert {os.path.basename(p) for p in FULL_CASES} == {"full_inv3_720x1280_b1.npz", "full_vgg16_720x1280_cfg1_b2.npz"}
+    for path in FULL_CASES:
+        z = np.load(path)
+        B, T, N, H, W, OH, OW = [int(v) for v in z["meta"][:7]]
+        assert (H, W, T, N) == (720, 1280, 3, 12)
+        r2 = np.random.default_rng(int(z["seed"]) + 2)
+        assert np.array_equal(r2.integers(0, 8, size=(B,)).astype(np.int64), z["labels"])
+        for key in ("fm0", "crops", "x_emb", "graph"):
+            assert z[f"feat.{key}.sample"].shape == (8192,) and np.isfinite(z[f"feat.{key}.sample"]).all()
+        assert z["logits"].shape == (B, 8) and "gs.fc_emb_1.weight" in z.files and "g.fc_activities.weight" in z.files
+
+
 def test_roi_align_known_answers():
     """RoIAlign oracle (third-party algorithm, parity unpinned by the reference): hand-checked identities."""
     fm = torch.arange(2 * 3 * 6 * 8, dtype=torch.float32).reshape(2, 3, 6, 8)

@@ -17,6 +17,7 @@ usage: python tools/gen_golden.py [--ref /root/reference] [--out tests/golden]
 import argparse
 import os
 import sys
+import time
 import types
 
 import numpy as np
@@ -398,6 +399,100 @@ def model_case(name, refim, refcfg, out_dir, *, backbone, H, W, OH, OW, D, B, T,
     print(f"[model] {name}: logits rel err {e:.2e}, worst grad rel err {eg:.2e}, loss {loss.item():.6f}")
 
 
+def _probe_idx(numel, count=8192):
+    """deterministic sample positions of a flat tensor (same recipe in tests/test_gpu_din_model.py)"""
+    count = min(count, numel)
+    return (torch.arange(count, dtype=torch.int64) * (numel // count))
+
+
+def full_case(name, refim, refcfg, out_dir, *, backbone, OH, OW, D, B, seed, H=720, W=1280, T=3, N=12, NFB=1024):
+    """ONE full-size 720x1280 run of the reference's Dynamic_volleyball (infer_model.py:141-234), fwd + backward of the
+    CE loss, eval mode.  Inputs and the 29 M weights are NOT stored: both sides regenerate them from the seed recipe of
+    oracle.din_oracle.synth_inputs / synth_params.  Stored: logits, loss, per-stage feature probes taken with forward hooks on the
+    reference's own modules (backbone outputs, RoIAlign crops, embedding after LN+ReLU, DIN output: sums + 8192 strided samples each),
+    every parameter gradient's sum / abs-sum, small gradients whole and 8192 strided samples of the big ones."""
+    cfg = refcfg.Config("volleyball")
+    cfg.log_path = None
+    cfg.backbone = backbone
+    cfg.image_size, cfg.out_size, cfg.emb_features = (H, W), (OH, OW), D
+    cfg.num_boxes, cfg.num_frames, cfg.batch_size = N, T, B
+    cfg.num_features_boxes = cfg.num_features_gcn = NFB
+    cfg.ST_kernel_size, cfg.sampling_ratio, cfg.num_DIM = [(3, 3)], [1], 1
+    cfg.dynamic_sampling, cfg.scale_factor, cfg.beta_factor = True, True, False
+    cfg.lite_dim, cfg.hierarchical_inference = None, False
+    cfg.train_backbone = True
+    cfg.train_dropout_prob = 0.3
+    torch.manual_seed(0)
+    model = refim.Dynamic_volleyball(cfg)
+    model.eval()
+    if backbone == "inv3":
+        model.cfg.backbone = "vgg16"               # same recipe as model_case: the reference has no inv3 head branch
+    ocfg = O.OracleCfg(backbone=backbone, image_size=(H, W), out_size=(OH, OW), emb_features=D, num_boxes=N, num_frames=T,
+                       num_features_boxes=NFB, ST_kernel_size=[(3, 3)], sampling_ratio=[1], num_DIM=1)
+    p = O.synth_params(O.model_param_shapes(ocfg), seed=seed + 3, din_std=0.02)
+    missing, unexpected = model.load_state_dict(p, strict=False)
+    bad = [k for k in missing if "num_batches_tracked" not in k and "zero_padding" not in k]
+    assert not unexpected and not bad, (bad, unexpected)
+    images, boxes, labels = O.synth_inputs(B, T, N, H, W, OH, OW, 8, seed=seed)
+    probes = {}
+
+    def probe(key, t):
+        t = t.detach()
+        flat = t.reshape(-1)
+        probes["feat." + key + ".shape"] = np.array(t.shape, dtype=np.int64)
+        probes["feat." + key + ".sum"] = np.float64(flat.double().sum().item())
+        probes["feat." + key + ".abs"] = np.float64(flat.double().abs().sum().item())
+        probes["feat." + key + ".max"] = np.float64(flat.abs().max().item())
+        probes["feat." + key + ".sample"] = flat[_probe_idx(flat.numel())].clone().numpy()
+
+    def hook(fn):
+        def run(_m, _i, o):
+            fn(o)                                   # (a forward hook's return value would replace the module output: return None)
+        return run
+
+    hooks = [model.backbone.register_forward_hook(hook(lambda o: [probe(f"fm{j}", t) for j, t in enumerate(o)])),
+             model.roi_align.register_forward_hook(hook(lambda o: probe("crops", o))),
+             model.nl_emb_1.register_forward_hook(hook(lambda o: probe("x_emb", torch.relu(o)))),     # (:185-186; the ReLU is in place)
+             model.DPI.register_forward_hook(hook(lambda o: probe("graph", o[0])))]
+    t0 = time.time()
+    ret = model((images.float(), boxes))
+    loss = F.cross_entropy(ret["activities"], labels)
+    loss.backward()
+    for h_ in hooks:
+        h_.remove()
+    t_ref = time.time() - t0
+    ref_grads = {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}
+    ref_logits = ret["activities"].detach().clone()
+    del model, ret
+    # the oracle restatement on the same seeds must agree before the fixture is written
+    po = {k: v.clone().requires_grad_("running_" not in k) for k, v in p.items()}
+    oret, inter = O.dynamic_volleyball_forward(ocfg, po, images.float(), boxes, return_intermediates=True)
+    oloss = F.cross_entropy(oret["activities"], labels)
+    oloss.backward()
+    e = close(oret["activities"], ref_logits, 2e-4, name + ".logits")
+    for key, t in (("crops", inter["crops"]), ("x_emb", inter["x"]), ("graph", inter["graph"])):
+        got = t.detach().reshape(-1)[_probe_idx(t.numel())]
+        close(got, torch.from_numpy(probes["feat." + key + ".sample"]), 2e-4, name + ".feat." + key)
+    eg = 0.0
+    for k, v in ref_grads.items():
+        eg = max(eg, close(po[k].grad, v, 1e-2, name + ".grad." + k))
+    rec = dict(meta=np.array([B, T, N, H, W, OH, OW, D, NFB, 1, 0, 0, 0], dtype=np.int64), backbone=np.array(backbone),
+               kernels=np.array([(3, 3)], dtype=np.int64), ratios=np.array([1], dtype=np.int64), seed=np.int64(seed),
+               dtype=np.array("float32"), logits=ref_logits.numpy(), loss=np.float64(loss.item()), labels=labels.numpy(),
+               ref_seconds_fwd_bwd=np.float64(t_ref), ref_threads=np.int64(torch.get_num_threads()))
+    rec.update(probes)
+    for k, v in ref_grads.items():
+        rec["gsum." + k] = np.float64(v.double().sum().item())
+        rec["gabs." + k] = np.float64(v.double().abs().sum().item())
+        if v.numel() <= 9216:
+            rec["g." + k] = v.numpy()
+        else:
+            rec["gs." + k] = v.reshape(-1)[_probe_idx(v.numel())].clone().numpy()
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
+    print(f"[full] {name}: reference fwd+bwd {t_ref:.1f} s on {torch.get_num_threads()} threads; oracle logits rel err {e:.2e}, "
+          f"worst grad rel err {eg:.2e}, loss {loss.item():.6f}")
+
+
 def tce_case(name, refim, refcfg, out_dir, *, H, W, OH, OW, B, T, NFB, kernels, ratios, num_dim=1, seed=0, full_grads_upto=4096, hier=False,
              refdin=None):
     """Whole Dynamic_TCE_volleyball forward (+ backward of the CE loss) from the reference (infer_model.py:237-468), vgg16 trunk, eval mode
@@ -581,7 +676,7 @@ def main():
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--skip-big", action="store_true")
-    ap.add_argument("--only", default="", help="'tce': only (re)generate the Dynamic_TCE_volleyball fixtures")
+    ap.add_argument("--only", default="", help="'tce': only (re)generate the Dynamic_TCE_volleyball fixtures; 'full': only the two full-size 720x1280 fixtures")
     a = ap.parse_args()
     sys.dont_write_bytecode = True
     install_stubs()
@@ -602,8 +697,16 @@ def main():
         # (the reference hard-wires hier_LN to 1024 channels, dynamic_infer_module.py:483: NFB + 4 * 128 = 1024 -> NFB = 512 is its only shape)
         tce_case("tce_vgg16_64x96_hier_t10", refim, refcfg, a.out, H=64, W=96, OH=2, OW=3, B=1, T=10, NFB=512, kernels=[(1, 3), (3, 1)],
                  ratios=[1], seed=302, hier=True, refdin=refdin)
+    def full_cases():
+        # SURVEY 8(c)-(v) / BASELINE configs[1] and configs[0] at their real frame size (720x1280): the planner picks kernels here that
+        # no reduced-size fixture sees together (stem halo tiles, mid-network halo, pipelined wgrad, sibling pacing)
+        full_case("full_inv3_720x1280_b1", refim, refcfg, a.out, backbone="inv3", OH=87, OW=157, D=1056, B=1, seed=400)
+        full_case("full_vgg16_720x1280_cfg1_b2", refim, refcfg, a.out, backbone="vgg16", OH=22, OW=40, D=512, B=2, seed=401)
     if a.only == "tce":
         tce_cases()
+        return
+    if a.only == "full":
+        full_cases()
         return
     prep_case(refutils, a.out)
     f32, f64 = torch.float32, torch.float64
@@ -656,6 +759,8 @@ def main():
         hier_case("hier_k13_k31_t10_c1024", refdin, a.out)
     collective_case("collective_vgg16_96x160", refim, refcfg, a.out)
     tce_cases()
+    if not a.skip_big:
+        full_cases()
     print("golden vectors written to", a.out)
 
 
