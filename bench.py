@@ -217,6 +217,9 @@ def main():
     ap.add_argument("--force-buckets", action="store_true",
                     help="single process: run the gradient-bucket path anyway (hook bookkeeping, one concatenation per bucket, a 1-rank all-reduce) "
                          "to measure what it costs on the host and in copy kernels -- compare ms_per_step with and without")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step's forward + loss + backward from a captured HIP graph (din_amd.graph_step; the all-reduce and the "
+                         "optimizer stay eager calls).  auto: on for a single process whose share is <= 8 clips (the host-bound regime), off otherwise")
     ap.add_argument("--bn-mode", default="eval", choices=["eval", "batch"],
                     help="Inception BatchNorm: 'eval' = cfg.set_bn_eval (running statistics, folded; results independent of the GPU count), "
                          "'batch' = the reference's stage-2 default (batch statistics of the rank's frames + running-stat update)")
@@ -287,8 +290,17 @@ def main():
                 yield images_host
         feed = iter(DeviceFeed(_forever(), dev))
 
-    def step():
+    cap = None                                             # graph_step.CapturedStep once the warm-up steps are done
+
+    def step(eager=False):
         nonlocal images
+        if cap is not None and not eager:
+            loss = cap.replay()                            # hipGraphLaunch: forward + cross-entropy + backward
+            if buckets is not None:
+                buckets.allreduce(scale_in_optimizer=not a.no_adam)
+            if not a.no_adam:
+                opt.step(grad_scale=buckets.grad_scale if buckets is not None else 1.0)
+            return loss
         if feed is not None:
             images = next(feed)
         if a.forward_only:
@@ -328,6 +340,18 @@ def main():
             survey, profiling.PROFILE = profiling.PROFILE, None
             if hbm is not None:
                 hbm.__exit__(None, None, None)
+    use_graph = a.graph == "on" or (a.graph == "auto" and world == 1 and B <= 8)
+    if use_graph and not (a.forward_only or a.host_images or a.bn_mode == "batch") and a.warmup >= 2:
+        from din_amd import graph_step
+        try:
+            cap = graph_step.CapturedStep(lambda: F.cross_entropy(model(batch(images))["activities"], labels), params,
+                                          graph_step.dropout_counters(model))
+            step()                                         # one untimed replay: the capture itself executed nothing
+            torch.cuda.synchronize()
+        except Exception as e:                             # stay on the eager path (and say so)
+            print(f"HIP graph capture failed, running eagerly: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            cap = None
+            opt.zero_grad()
     if os.environ.get("DIN_BENCH_TORCH_PROFILE"):          # tuning aid: which host-side torch ops launch the small fill / copy kernels
         from torch.profiler import profile, ProfilerActivity
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
@@ -376,9 +400,12 @@ def main():
     # during the LAST step only and only around the dominant kernel's launches (every conv launch when there was no warm-up survey).
     t0 = time.perf_counter()
     for it in range(a.steps):
-        if it == a.steps - 1:
+        last = it == a.steps - 1
+        if last:
             profiling.PROFILE, profiling.PROFILE_ONLY = [], dom_survey
-        loss = step()
+            if cap is not None:
+                opt.zero_grad()                            # the bracketed step runs eagerly (HIP events cannot time nodes of a replayed graph)
+        loss = step(eager=last)
     host_enqueue_s = time.perf_counter() - t0                # host time to ENQUEUE the timed steps (nothing waits on the GPU inside a step)
     if world > 1:
         dist.barrier()
@@ -451,6 +478,8 @@ def main():
                                    "fwd + cross-entropy + bwd" + (f" + grad all-reduce ({'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()})"
                                                                   if (world > 1 or buckets is not None) else "")
                                    + ("" if a.no_adam else " + fused Adam"),
+                       "launch_mode": ("HIP graph replay of fwd + loss + bwd (din_amd.graph_step), eager all-reduce / optimizer; the last timed "
+                                       "step runs eagerly for the per-launch HIP events" if cap is not None else "eager launches"),
                        "bn_mode": ("running statistics (set_bn_eval)" if cfg.set_bn_eval else "batch statistics (reference stage-2 default)")
                                   if backbone == "inv3" else "n/a"},
             "roofline": roofline,

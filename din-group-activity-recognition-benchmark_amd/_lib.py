@@ -18,7 +18,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "din_hip.h")
 
 DIN_F32, DIN_BF16 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 CONV_BIAS, CONV_RELU, CONV_ACCUM, CONV_MASK = 1, 2, 4, 8
 
 
@@ -91,8 +91,9 @@ SIGNATURES: Dict[str, tuple] = {
     "din_roi_align_bwd_nhwc": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P, _I, _P]),
     "din_grad_cast_mask": (_I, [_P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _I, _P]),
     "din_boxes_frame_index": (_I, [_P, _I, _I, _P]),
-    "din_layernorm_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _L, _L, _I, _F, _U64, _P]),
-    "din_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _F, _U64, _P]),
+    "din_layernorm_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _L, _L, _I, _F, _U64, _P, _P]),
+    "din_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _F, _U64, _P, _P]),
+    "din_counter_add": (_I, [_P, _U64, _P]),
     "din_walk_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "din_walk_bwd": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "din_head_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
@@ -111,8 +112,8 @@ SIGNATURES: Dict[str, tuple] = {
     "din_ctx_keys_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "din_add_position": (_I, [_P, _I, _P, _P, _L, _L, _P]),
     "din_add_position_bwd": (_I, [_P, _P, _I, _P, _L, _I, _P]),
-    "din_act_dropout_fwd": (_I, [_P, _P, _L, _I, _F, _U64, _P]),
-    "din_act_dropout_bwd": (_I, [_P, _P, _P, _L, _I, _F, _U64, _P]),
+    "din_act_dropout_fwd": (_I, [_P, _P, _L, _I, _F, _U64, _P, _P]),
+    "din_act_dropout_bwd": (_I, [_P, _P, _P, _L, _I, _F, _U64, _P, _P]),
     "din_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
     "din_adam_step_multi": (_I, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _I, _F, _P]),
 }
@@ -146,6 +147,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise DinError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        f"(or `make -C {CSRC_DIR}`); the DIN hot path has no fallback implementation")
+    # torch first: its wheel bundles its own libamdhip64; if this library pulled in /opt/rocm's copy before torch loaded its own, the
+    # process would hold two HIP runtimes and the second one finds no device ("no ROCm-capable device is detected")
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:

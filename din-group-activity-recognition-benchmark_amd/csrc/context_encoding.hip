@@ -198,7 +198,9 @@ __global__ void add_position_bwd_kernel(const float* __restrict__ gy, const void
 }
 
 // ---- y = dropout(relu?(x)) and its backward (nn.ReLU + nn.Dropout inside the transformer's FFN, nn.Dropout on the attended context) --
-__global__ void act_dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int relu, float p, uint64_t seed) {
+__global__ void act_dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int relu, float p, uint64_t seed,
+                                   const uint64_t* __restrict__ seed_off) {
+    seed = fold_seed(seed, seed_off);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float v = x[i];
         if (relu) v = fmaxf(v, 0.f);
@@ -206,7 +208,8 @@ __global__ void act_dropout_kernel(const float* __restrict__ x, float* __restric
     }
 }
 __global__ void act_dropout_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ gx, int64_t n, int relu,
-                                       float p, uint64_t seed) {
+                                       float p, uint64_t seed, const uint64_t* __restrict__ seed_off) {
+    seed = fold_seed(seed, seed_off);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float g = gy[i] * keep_scale(seed, i, p);
         if (relu && !(x[i] > 0.f)) g = 0.f;
@@ -286,18 +289,19 @@ int din_add_position_bwd(const float* gy, const void* x, int dtype, void* gx, in
     return DIN_OK;
 }
 
-int din_act_dropout_fwd(const float* x, float* y, int64_t n, int relu, float drop_p, uint64_t seed, void* stream) {
+int din_act_dropout_fwd(const float* x, float* y, int64_t n, int relu, float drop_p, uint64_t seed, const uint64_t* seed_offset, void* stream) {
     DIN_REQUIRE(x && y && n >= 0 && drop_p >= 0.f && drop_p < 1.f, "act_dropout_fwd: bad argument");
     if (n == 0) return DIN_OK;
-    hipLaunchKernelGGL(act_dropout_kernel, dim3(grid_1d(n, 256)), dim3(256), 0, as_stream(stream), x, y, n, relu, drop_p, seed);
+    hipLaunchKernelGGL(act_dropout_kernel, dim3(grid_1d(n, 256)), dim3(256), 0, as_stream(stream), x, y, n, relu, drop_p, seed, seed_offset);
     DIN_CHECK_LAUNCH("act_dropout_fwd");
     return DIN_OK;
 }
 
-int din_act_dropout_bwd(const float* gy, const float* x, float* gx, int64_t n, int relu, float drop_p, uint64_t seed, void* stream) {
+int din_act_dropout_bwd(const float* gy, const float* x, float* gx, int64_t n, int relu, float drop_p, uint64_t seed,
+                        const uint64_t* seed_offset, void* stream) {
     DIN_REQUIRE(gy && x && gx && n >= 0 && drop_p >= 0.f && drop_p < 1.f, "act_dropout_bwd: bad argument");
     if (n == 0) return DIN_OK;
-    hipLaunchKernelGGL(act_dropout_bwd_kernel, dim3(grid_1d(n, 256)), dim3(256), 0, as_stream(stream), gy, x, gx, n, relu, drop_p, seed);
+    hipLaunchKernelGGL(act_dropout_bwd_kernel, dim3(grid_1d(n, 256)), dim3(256), 0, as_stream(stream), gy, x, gx, n, relu, drop_p, seed, seed_offset);
     DIN_CHECK_LAUNCH("act_dropout_bwd");
     return DIN_OK;
 }

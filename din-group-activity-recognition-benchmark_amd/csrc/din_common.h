@@ -89,6 +89,10 @@ __device__ __forceinline__ uint32_t mix32(uint64_t x) {
     x = x ^ (x >> 31);
     return (uint32_t)(x >> 32);
 }
+// mask seed of a launch: the by-value seed plus the optional device-side per-step offset (graph-captured steps), mod 2^63
+__device__ __forceinline__ uint64_t fold_seed(uint64_t seed, const uint64_t* off) {
+    return off ? ((seed + *off) & 0x7FFFFFFFFFFFFFFFull) : seed;
+}
 __device__ __forceinline__ float keep_scale(uint64_t seed, int64_t idx, float p) {
     if (p <= 0.f) return 1.f;
     float u = (float)(mix32(seed ^ ((uint64_t)idx * 0xD1342543DE82EF95ull)) >> 8) * (1.0f / 16777216.0f);

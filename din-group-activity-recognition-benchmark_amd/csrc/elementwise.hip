@@ -186,6 +186,8 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const uint64_t* __restr
     }
 }
 
+__global__ void counter_add_kernel(uint64_t* counter, uint64_t delta) { *counter = (*counter + delta) & 0x7FFFFFFFFFFFFFFFull; }
+
 }  // namespace
 
 extern "C" {
@@ -220,6 +222,12 @@ int din_boxes_frame_index(int32_t* out, int bt, int n, void* stream) {
     DIN_REQUIRE(out && bt > 0 && n > 0, "boxes_frame_index: bad argument");
     hipLaunchKernelGGL(frame_index_kernel, dim3((bt * n + 255) / 256), dim3(256), 0, as_stream(stream), out, bt, n);
     DIN_CHECK_LAUNCH("boxes_frame_index");
+    return DIN_OK;
+}
+int din_counter_add(uint64_t* counter, uint64_t delta, void* stream) {
+    DIN_REQUIRE(counter, "counter_add: null pointer");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, as_stream(stream), counter, delta);
+    DIN_CHECK_LAUNCH("counter_add");
     return DIN_OK;
 }
 int din_axpby(const float* x, const float* y, float* out, float alpha, float beta, int64_t n, void* stream) {

@@ -27,8 +27,9 @@ constexpr int LN_WAVES = LN_THREADS / 64;
 
 __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float eps, float* __restrict__ y, float* __restrict__ stats, int64_t len, int relu, float drop_p, uint64_t seed) {
+    float eps, float* __restrict__ y, float* __restrict__ stats, int64_t len, int relu, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_off) {
     __shared__ float red[LN_WAVES];
+    seed = fold_seed(seed, seed_off);
     const int64_t row = blockIdx.x;
     const float* xr = x + row * len;
     const float* rr = res ? res + row * len : nullptr;
@@ -99,7 +100,8 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
 __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
     const float* __restrict__ y, const float* __restrict__ stats, float* __restrict__ dx, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, int64_t len, int relu, float drop_p, uint64_t seed, int atomic_params) {
+    float* __restrict__ dbeta, int64_t len, int relu, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_off, int atomic_params) {
+    seed = fold_seed(seed, seed_off);
     __shared__ float red[LN_WAVES];
     const int64_t row = blockIdx.x;
     const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
@@ -179,7 +181,8 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
 __global__ void layernorm_param_grad_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ res,
                                             const float* __restrict__ y, const float* __restrict__ stats, float* __restrict__ dgamma,
                                             float* __restrict__ dbeta, int64_t rows, int64_t len, int relu, float drop_p,
-                                            uint64_t seed, int64_t rows_per_block) {
+                                            uint64_t seed, const uint64_t* __restrict__ seed_off, int64_t rows_per_block) {
+    seed = fold_seed(seed, seed_off);
     const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= len) return;
     int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block;
@@ -202,19 +205,19 @@ __global__ void layernorm_param_grad_kernel(const float* __restrict__ dy, const 
 extern "C" {
 
 int din_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps, float* y,
-                      float* stats, int64_t rows, int64_t len, int relu, float drop_p, uint64_t seed, void* stream) {
+                      float* stats, int64_t rows, int64_t len, int relu, float drop_p, uint64_t seed, const uint64_t* seed_offset, void* stream) {
     DIN_REQUIRE(x && gamma && beta && y && stats, "layernorm_fwd: null pointer");
     DIN_REQUIRE(rows >= 0 && len > 0 && drop_p >= 0.f && drop_p < 1.f, "layernorm_fwd: bad argument");
     if (rows == 0) return DIN_OK;
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)rows), dim3(LN_THREADS), 0, as_stream(stream), x, res, gamma, beta, eps, y,
-                       stats, len, relu, drop_p, seed);
+                       stats, len, relu, drop_p, seed, seed_offset);
     DIN_CHECK_LAUNCH("layernorm_fwd");
     return DIN_OK;
 }
 
 int din_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma, const float* y,
                       const float* stats, float* dx, float* dgamma, float* dbeta, int64_t rows, int64_t len, int relu,
-                      float drop_p, uint64_t seed, void* stream) {
+                      float drop_p, uint64_t seed, const uint64_t* seed_offset, void* stream) {
     DIN_REQUIRE(dy && x && gamma && y && stats && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
     DIN_REQUIRE(rows >= 0 && len > 0, "layernorm_bwd: bad argument");
     if (rows == 0) return DIN_OK;
@@ -222,13 +225,13 @@ int din_layernorm_bwd(const float* dy, const float* x, const float* res, const f
     // many short rows (nl_emb_1): dedicated column-reduction kernel
     const int atomic_params = rows <= 8 ? 1 : 0;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)rows), dim3(LN_THREADS), 0, as_stream(stream), dy, x, res, gamma, y, stats, dx,
-                       dgamma, dbeta, len, relu, drop_p, seed, atomic_params);
+                       dgamma, dbeta, len, relu, drop_p, seed, seed_offset, atomic_params);
     DIN_CHECK_LAUNCH("layernorm_bwd");
     if (!atomic_params) {
         int64_t rpb = 32;
         dim3 grid((unsigned)ceil_div64(len, 256), (unsigned)ceil_div64(rows, rpb));
         hipLaunchKernelGGL(layernorm_param_grad_kernel, grid, dim3(256), 0, as_stream(stream), dy, x, res, y, stats, dgamma, dbeta, rows, len,
-                           relu, drop_p, seed, rpb);
+                           relu, drop_p, seed, seed_offset, rpb);
         DIN_CHECK_LAUNCH("layernorm_param_grad");
     }
     return DIN_OK;

@@ -68,6 +68,10 @@ GRAD_HOOK = None
 # Called as GRAD_BUFFER(weight) before a conv layer's weight gradient is computed; may return the fp32 tensor (weight's shape) the kernel
 # should write into -- parallel.GradBuckets hands out the weight's slot of its flat all-reduce bucket, so no packing copy is needed.
 GRAD_BUFFER = None
+# Called as GRAD_ASSIGN(weight, dweight) for every parameter gradient when the backward pass returns; True = the callee installed the
+# tensor as weight.grad itself (a gradient that was written in place into its all-reduce bucket slot), autograd then gets None for it:
+# handing autograd a tensor that somebody else still references makes AccumulateGrad clone it -- one copy launch per parameter per step.
+GRAD_ASSIGN = None
 
 
 def _dw_buffer(w: torch.Tensor) -> torch.Tensor:
@@ -940,4 +944,6 @@ class NHWCGraphFunction(torch.autograd.Function):
             grads = graph_backward(graph, ctx.bufs, ctx.aux, ctx.params, ctx.dt, og, ctx.need, ctx.bn_train)
         ctx.bufs = ctx.aux = None
         grads = [gr if need else None for gr, need in zip(grads, ctx.need)]
+        if GRAD_ASSIGN is not None:
+            grads = [None if (gr is not None and GRAD_ASSIGN(p_, gr)) else gr for p_, gr in zip(ctx.params, grads)]
         return (None, None, None, None, None, *grads)

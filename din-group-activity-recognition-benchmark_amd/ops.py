@@ -14,6 +14,11 @@ from . import _lib as L
 from .nhwc import _ptr, _stream, din_dtype, require_gpu, workspace
 
 
+# Device-side per-step part of every dropout seed (int64 [1]) or None.  A training step captured in a HIP graph (din_amd.graph_step) bakes
+# the host-computed seeds into the launches; the kernels add *SEED_OFFSET, which the captured step advances once per replay.
+SEED_OFFSET: Optional[torch.Tensor] = None
+
+
 # ------------------------------------------------------------------------------------------------
 # Row P (API-parity form)
 # ------------------------------------------------------------------------------------------------
@@ -224,7 +229,8 @@ class LayerNormFunction(torch.autograd.Function):
         y = torch.empty_like(x)
         stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
         L.check(lib.din_layernorm_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), 1e-5, _ptr(y), _ptr(stats), rows, length,
-                                      int(relu), float(drop_p), int(seed), _stream()), "layernorm_fwd")
+                                      int(relu), float(drop_p), int(seed), _ptr(SEED_OFFSET), _stream()), "layernorm_fwd")
+        ctx.seed_offset = SEED_OFFSET
         ctx.save_for_backward(x, res if res is not None else x.new_empty(0), gamma, y, stats)
         ctx.has_res, ctx.relu, ctx.drop_p, ctx.seed, ctx.rows, ctx.length = res is not None, relu, drop_p, seed, rows, length
         return y
@@ -239,7 +245,7 @@ class LayerNormFunction(torch.autograd.Function):
         dbeta = torch.zeros_like(gamma)
         L.check(lib.din_layernorm_bwd(_ptr(gy), _ptr(x), _ptr(res) if ctx.has_res else None, _ptr(gamma), _ptr(y), _ptr(stats),
                                       _ptr(dx), _ptr(dgamma), _ptr(dbeta), ctx.rows, ctx.length, int(ctx.relu), float(ctx.drop_p),
-                                      int(ctx.seed), _stream()), "layernorm_bwd")
+                                      int(ctx.seed), _ptr(ctx.seed_offset), _stream()), "layernorm_bwd")
         return dx, (dx if ctx.has_res else None), dgamma, dbeta, None, None, None, None
 
 
@@ -434,9 +440,11 @@ class ActDropoutFunction(torch.autograd.Function):
         x = x.contiguous()
         require_gpu(x)
         y = torch.empty_like(x)
-        L.check(lib.din_act_dropout_fwd(_ptr(x), _ptr(y), x.numel(), int(relu), float(drop_p), int(seed), _stream()), "act_dropout_fwd")
+        L.check(lib.din_act_dropout_fwd(_ptr(x), _ptr(y), x.numel(), int(relu), float(drop_p), int(seed), _ptr(SEED_OFFSET), _stream()),
+                "act_dropout_fwd")
         ctx.save_for_backward(x)
         ctx.args = (relu, drop_p, seed)
+        ctx.seed_offset = SEED_OFFSET
         return y
 
     @staticmethod
@@ -446,8 +454,8 @@ class ActDropoutFunction(torch.autograd.Function):
         relu, drop_p, seed = ctx.args
         gy = gy.contiguous()
         gx = torch.empty_like(x)
-        L.check(lib.din_act_dropout_bwd(_ptr(gy), _ptr(x), _ptr(gx), x.numel(), int(relu), float(drop_p), int(seed), _stream()),
-                "act_dropout_bwd")
+        L.check(lib.din_act_dropout_bwd(_ptr(gy), _ptr(x), _ptr(gx), x.numel(), int(relu), float(drop_p), int(seed), _ptr(ctx.seed_offset),
+                                        _stream()), "act_dropout_bwd")
         return gx, None, None, None
 
 

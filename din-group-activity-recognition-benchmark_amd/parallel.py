@@ -74,6 +74,7 @@ class GradBuckets:
                 from . import nhwc
                 nhwc.GRAD_HOOK = self._on_grad
                 nhwc.GRAD_BUFFER = self._grad_buffer
+                nhwc.GRAD_ASSIGN = self._grad_assign
             except Exception:                                    # host-only use (CPU tests): no conv executor
                 pass
 
@@ -120,6 +121,19 @@ class GradBuckets:
         if p is None or p.data_ptr() not in self._slot or p.grad is not None:
             return None                                          # a live .grad would be ACCUMULATED into by autograd: it must not alias the kernel's output
         return self._view_of(p)
+
+    def _grad_assign(self, param: torch.Tensor, grad: torch.Tensor) -> bool:
+        """a gradient the conv executor wrote into the parameter's bucket slot becomes `.grad` here (autograd is handed None for it): the
+        cached view is referenced from this object too, so AccumulateGrad would otherwise clone it -- one copy launch per conv weight per step,
+        reading the flat buffer while its asynchronous all-reduce may already be running"""
+        p = self._by_ptr.get(param.data_ptr())
+        if p is None or p.grad is not None:
+            return False
+        v = self._views.get(p.data_ptr())
+        if v is None or v.data_ptr() != grad.data_ptr():
+            return False
+        p.grad = v
+        return True
 
     def _flat_of(self, bi: int) -> torch.Tensor:
         bucket = self.buckets[bi]

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DIN_ABI_VERSION 4   /* 2: din_walk_* take plain / clamp / n_per_clip; + bn, mask_actors.  3: din_roi_align_* take the box grid and a crop channel range.  4: din_conv_desc.in_u8, context-encoding entry points */
+#define DIN_ABI_VERSION 5   /* 5: dropout seeds take an optional device-side offset (din_layernorm_*, din_act_dropout_*), din_counter_add.   2: din_walk_* take plain / clamp / n_per_clip; + bn, mask_actors.  3: din_roi_align_* take the box grid and a crop channel range.  4: din_conv_desc.in_u8, context-encoding entry points */
 
 enum { DIN_F32 = 0, DIN_BF16 = 1 };
 
@@ -280,22 +280,28 @@ int din_add_position(const void* x, int dtype, const float* pos, float* y, int64
 int din_add_position_bwd(const float* gy, const void* x, int dtype, void* gx, int64_t elems, int use_mask, void* stream);
 /* y = dropout(relu?(x)) (nn.ReLU + nn.Dropout of the FFN, TCE_STBiP_module.py:243-247; nn.Dropout on the attended context :277) with the
  * counter-based keep mask of din_layernorm_* (same seed + element index -> same mask in the backward) */
-int din_act_dropout_fwd(const float* x, float* y, int64_t n, int relu, float drop_p, uint64_t seed, void* stream);
-int din_act_dropout_bwd(const float* gy, const float* x, float* gx, int64_t n, int relu, float drop_p, uint64_t seed, void* stream);
+int din_act_dropout_fwd(const float* x, float* y, int64_t n, int relu, float drop_p, uint64_t seed, const uint64_t* seed_offset, void* stream);
+int din_act_dropout_bwd(const float* gy, const float* x, float* gx, int64_t n, int relu, float drop_p, uint64_t seed,
+                        const uint64_t* seed_offset, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (+residual, +ReLU, +dropout): nl_emb_1 (infer_model.py:185), point_ln (:192), dpi_nl (:214),
  * hier_LN (dynamic_infer_module.py:493).  x, res: [rows][len]; gamma/beta [len]; eps 1e-5.
  * y = dropout(relu?(LN(x + res?)*gamma + beta)).  stats: [rows][2] = (mean, rstd) saved for backward.
  * dropout: keep-mask from a counter-based hash of (seed, element index), scale 1/(1-p); p=0 disables.
+ * seed_offset (nullable, device memory): the mask seed is (seed + *seed_offset) mod 2^63, read by the kernel -- a training step captured
+ * in a HIP graph bakes `seed` into the launch, so the part that changes per step lives in device memory (din_counter_add advances it
+ * inside the graph); forward and backward of one step see the same value.
  * ---------------------------------------------------------------------------------------------- */
 int din_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps,
                       float* y, float* stats, int64_t rows, int64_t len, int relu, float drop_p,
-                      uint64_t seed, void* stream);
+                      uint64_t seed, const uint64_t* seed_offset, void* stream);
 /* dx [rows][len] (also the gradient of res); dgamma/dbeta [len] are ACCUMULATED atomically (caller zeroes) */
 int din_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma,
                       const float* y, const float* stats, float* dx, float* dgamma, float* dbeta,
-                      int64_t rows, int64_t len, int relu, float drop_p, uint64_t seed, void* stream);
+                      int64_t rows, int64_t len, int relu, float drop_p, uint64_t seed, const uint64_t* seed_offset, void* stream);
+/* *counter += delta (one thread; stream-ordered): the per-step part of the dropout seeds of a graph-captured training step */
+int din_counter_add(uint64_t* counter, uint64_t delta, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Rows D2-D4  Dynamic Relation + Dynamic Walk (dynamic_infer_module.py:184-282, 344-404), one module,

@@ -852,20 +852,37 @@ def test_full_size_fp32_model_matches_reference_golden(gpu, path):
         assert _probe_err(z, key, cap[key]) <= 1e-4, (key, _probe_err(z, key, cap[key]))
         s = cap[key].double().sum().item()
         assert abs(s - float(z[f"feat.{key}.sum"])) <= 1e-4 * float(z[f"feat.{key}.abs"]) + 1e-6, key
+    # Gradients.  Below the max-pools a 1e-7 perturbation re-routes single gradient elements (near-tied pool windows, pre-activations at
+    # zero), so two correct fp32 runs differ there by up to a few 1e-2.  The fixture therefore also carries the SAME model's gradients in
+    # float64 (`g64.*` / `gs64.*`) and, per tensor, how far the reference's own fp32 run is from them (`yard.*`).  Bars:
+    #   HIP fp32 vs float64            <= max(3 x the reference's own distance, 1e-3 head / 2e-3 backbone)   -- as exact as the reference
+    #   HIP fp32 vs the reference fp32 <= that bound + the reference's distance (triangle), and cosine >= 0.999
+    def tol_of(name):
+        return max(3.0 * float(z["yard." + name]), 2e-3 if name.startswith("backbone.") else 1e-3)
+
+    def maxrel(got, ref):
+        ref = torch.as_tensor(ref).double()
+        return float((got.double().cpu() - ref).abs().max() / (ref.abs().max() + 1e-30))
+    worst = []
     for k in z.files:
-        if k.startswith("g."):               # small tensors stored whole: same tolerances as the reduced-size fixtures (see above)
-            tol = 1e-3 if not k.startswith("g.backbone.") else 3e-2
-            assert rel(named[k[2:]].grad, z[k]) <= tol, (k, rel(named[k[2:]].grad, z[k]))
-            assert _cos(named[k[2:]].grad, z[k]) >= 0.9999, k
-        if k.startswith("gs."):              # 8192 strided samples of the big tensors
-            gfl = named[k[3:]].grad.reshape(-1).cpu()
-            got = gfl[_probe_idx(gfl.numel())]
-            tol = 1e-3 if not k.startswith("gs.backbone.") else 3e-2
-            assert rel(got, z[k]) <= tol, (k, rel(got, z[k]))
-            assert _cos(got, z[k]) >= 0.9999, k
+        if k.startswith("g.") or k.startswith("gs."):
+            name = k.split(".", 1)[1]
+            got = named[name].grad.detach()
+            if k.startswith("gs."):          # 8192 strided samples of the big tensors (relative to the sample's own maximum)
+                gfl = got.reshape(-1).cpu()
+                got = gfl[_probe_idx(gfl.numel())]
+            k64 = k.replace("g.", "g64.", 1) if k.startswith("g.") else k.replace("gs.", "gs64.", 1)
+            e64, eref = maxrel(got, z[k64]), maxrel(got, z[k])
+            slack = 2.0 if k.startswith("gs.") else 1.0
+            worst.append((e64 / tol_of(name), name, e64, eref, float(z["yard." + name])))
+            assert e64 <= slack * tol_of(name), (k, "vs float64", e64, "vs reference", eref, "yardstick", float(z["yard." + name]))
+            assert eref <= slack * (tol_of(name) + float(z["yard." + name])), (k, "vs reference", eref, "vs float64", e64)
+            assert _cos(got, z[k]) >= 0.999, k
         if k.startswith("gsum."):
             got = named[k[5:]].grad.double()
             assert abs(got.sum().item() - float(z[k])) <= 2e-3 * float(z["gabs." + k[5:]]) + 1e-6, k
+    worst.sort(reverse=True)
+    print("full-size fp32 gradients, worst 3 (fraction of bound, tensor, vs float64, vs reference fp32, reference's own distance):", worst[:3])
 
 
 BF16_FULL = [p for p in FULL_CASES if "inv3" in p]
@@ -898,3 +915,66 @@ def test_full_size_bf16_model_tracks_reference_golden(gpu, path):
     assert min(v for k, v in head.items() if k.startswith(("fc_activities", "dpi_nl", "nl_emb_1"))) >= 0.99, head
     assert cosv["fc_emb_1.weight"] >= 0.95, cosv["fc_emb_1.weight"]
     assert min(body.values()) >= 0.90, sorted(body.items(), key=lambda kv: kv[1])[:5]
+
+
+def test_captured_step_matches_eager(gpu):
+    """din_amd.graph_step: forward + loss + backward replayed from ONE captured HIP graph reproduce the eager step (same kernels, same
+    seeds), the device-side seed offset gives every replay a fresh dropout mask, and the host-side dropout counters keep counting."""
+    from din_amd import graph_step, ops
+    from din_amd.config import Config
+    from din_amd.infer_model import Dynamic_volleyball
+    from din_amd.train_net_dynamic import set_bn_eval
+    H, W, OH, OW, N, T, NFB = 139, 203, 15, 23, 6, 3, 64
+    ocfg = O.OracleCfg(backbone="inv3", image_size=(H, W), out_size=(OH, OW), emb_features=1056, num_boxes=N, num_frames=T,
+                       num_features_boxes=NFB)
+    p = O.synth_params(O.model_param_shapes(ocfg), seed=7, din_std=0.05)
+    images, boxes, labels = O.synth_inputs(2, T, N, H, W, OH, OW, 8, seed=8)
+    cfg = Config("volleyball")
+    cfg.backbone, cfg.image_size, cfg.out_size, cfg.emb_features = "inv3", (H, W), (OH, OW), 1056
+    cfg.num_boxes, cfg.num_frames, cfg.num_features_boxes, cfg.num_features_gcn = N, T, NFB, NFB
+    cfg.ST_kernel_size, cfg.sampling_ratio, cfg.beta_factor, cfg.train_backbone = [(3, 3)], [1], False, True
+    cfg.backbone_dtype, cfg.train_dropout_prob = "bf16", 0.3
+    model = Dynamic_volleyball(cfg)
+    model.load_state_dict(p, strict=False)
+    model = model.to(gpu).train()
+    model.apply(set_bn_eval)
+    params = [q for q in model.parameters() if q.requires_grad]
+    images, boxes, labels = images.to(gpu), boxes.to(gpu), labels.to(gpu)
+    counters = graph_step.dropout_counters(model)
+    assert model in counters
+
+    def loss_fn():
+        return F.cross_entropy(model((images, boxes))["activities"], labels)
+
+    def eager(offset=None):
+        for c in counters:
+            c._step = 0
+        for q in params:
+            q.grad = None
+        prev, ops.SEED_OFFSET = ops.SEED_OFFSET, offset
+        try:
+            loss = loss_fn()
+            loss.backward()
+        finally:
+            ops.SEED_OFFSET = prev
+        torch.cuda.synchronize()
+        return loss.item(), [q.grad.detach().clone() for q in params]
+
+    l1, g1 = eager()
+    off = torch.full((1,), graph_step.SEED_STRIDE, dtype=torch.int64, device=gpu)
+    l2, g2 = eager(off)
+    assert abs(l1 - l2) > 1e-6, "a non-zero seed offset must draw another dropout mask"
+    for c in counters:
+        c._step = 0
+    cap = graph_step.CapturedStep(loss_fn, params, counters)
+    steps_per_pass = [c._step for c in counters]
+    r1 = cap.replay().item()
+    gr1 = [q.grad.detach().clone() for q in params]
+    r2 = cap.replay().item()
+    gr2 = [q.grad.detach().clone() for q in params]
+    torch.cuda.synchronize()
+    assert abs(r1 - l1) <= 1e-5 * max(1.0, abs(l1)) and abs(r2 - l2) <= 1e-5 * max(1.0, abs(l2)), (l1, r1, l2, r2)
+    for a_, b_ in zip(g1 + g2, gr1 + gr2):
+        assert rel(b_, a_) <= 1e-4                      # (fp32 atomics in the DIN walk / LayerNorm backward: not bitwise)
+    assert [c._step for c in counters] == [2 * s for s in steps_per_pass]
+    assert int(cap.seed_offset.item()) == (2 * graph_step.SEED_STRIDE) & 0x7FFFFFFFFFFFFFFF

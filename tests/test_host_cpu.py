@@ -23,7 +23,7 @@ def test_library_exports_every_header_symbol():
         assert hasattr(lib, n), f"{n} declared in include/din_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes table out of sync with include/din_hip.h"
     loaded = _lib.load()
-    assert loaded.din_abi_version() == _lib.ABI_VERSION == 4 and loaded.din_build_arch() == b"gfx950"
+    assert loaded.din_abi_version() == _lib.ABI_VERSION == 5 and loaded.din_build_arch() == b"gfx950"
 
 
 def test_conv_planning_is_callable_without_gpu():
