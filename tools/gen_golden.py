@@ -429,11 +429,31 @@ def full_case(name, refim, refcfg, out_dir, *, backbone, OH, OW, D, B, seed, H=7
         model.cfg.backbone = "vgg16"               # same recipe as model_case: the reference has no inv3 head branch
     ocfg = O.OracleCfg(backbone=backbone, image_size=(H, W), out_size=(OH, OW), emb_features=D, num_boxes=N, num_frames=T,
                        num_features_boxes=NFB, ST_kernel_size=[(3, 3)], sampling_ratio=[1], num_DIM=1)
-    p = O.synth_params(O.model_param_shapes(ocfg), seed=seed + 3, din_std=0.02)
+    # Seed choice: the head takes the maximum over the 12 actors per (clip, frame, channel) (infer_model.py:224).  With thousands of such
+    # windows a random draw usually holds a few whose two largest entries agree to ~1e-6 of the activation scale; a 1e-6 forward
+    # difference (any other fp32 summation order) then hands the whole gradient of that window to the other actor and every upstream
+    # gradient moves by ~1e-2 -- a property of the draw, not of the implementation under test.  Take the first seed (seed, seed + 1000, ...)
+    # whose smallest relative top-2 gap is >= 5e-6; the fixture records it.
+    min_gap = 0.0
+    for _try in range(64):
+        p = O.synth_params(O.model_param_shapes(ocfg), seed=seed + 3, din_std=0.02)
+        images, boxes, labels = O.synth_inputs(B, T, N, H, W, OH, OW, 8, seed=seed)
+        with torch.no_grad():
+            _o, inter0 = O.dynamic_volleyball_forward(ocfg, p, images.float(), boxes, return_intermediates=True)
+            lw, lb = p["dpi_nl.weight"], p["dpi_nl.bias"]
+            s_ = F.relu(F.layer_norm(inter0["graph"] + inter0["x"], lw.shape, lw, lb, 1e-5))
+            top2 = s_.topk(2, dim=2).values
+            live = top2[:, :, 0] > 0
+            min_gap = float(((top2[:, :, 0] - top2[:, :, 1])[live] / s_.abs().max()).min())
+        print(f"[full] {name}: seed {seed}: smallest relative top-2 gap of the actor max {min_gap:.2e}")
+        if min_gap >= 5e-6:
+            break
+        seed += 1000
+    assert min_gap >= 5e-6
+    del inter0, s_, top2
     missing, unexpected = model.load_state_dict(p, strict=False)
     bad = [k for k in missing if "num_batches_tracked" not in k and "zero_padding" not in k]
     assert not unexpected and not bad, (bad, unexpected)
-    images, boxes, labels = O.synth_inputs(B, T, N, H, W, OH, OW, 8, seed=seed)
     probes = {}
 
     def probe(key, t):
@@ -498,7 +518,7 @@ def full_case(name, refim, refcfg, out_dir, *, backbone, OH, OW, D, B, seed, H=7
                kernels=np.array([(3, 3)], dtype=np.int64), ratios=np.array([1], dtype=np.int64), seed=np.int64(seed),
                dtype=np.array("float32"), logits=ref_logits.numpy(), loss=np.float64(loss.item()), labels=labels.numpy(),
                ref_seconds_fwd_bwd=np.float64(t_ref), ref_threads=np.int64(torch.get_num_threads()),
-               yard_logits=np.float64(yard_logits))
+               yard_logits=np.float64(yard_logits), min_actor_gap=np.float64(min_gap))
     for k, v in yard.items():
         rec["yard." + k] = np.float64(v)
     rec.update(g64)
