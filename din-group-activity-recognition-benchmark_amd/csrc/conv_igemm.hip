@@ -2413,6 +2413,7 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype, bool str
 
 struct WgradPlan { int cin_pad, kcols, kcols_pad, cout_pad, n_co_tiles, n_k_tiles, slices, m_per_slice, bco, v2, small, ring, bk, pipe, atomic; int64_t ws_bytes; };
 constexpr int WGRAD_SMALL_GRID = 512;
+constexpr int WGRAD_HALO_GRID = 128;       // persistent workgroups per filter-row class of conv_wgrad_halo_kernel (2 classes x 128 = one per CU)
 WgradPlan plan_wgrad(const din_conv_desc* d) {
     WgradPlan w;
     w.pipe = w.atomic = 0;
@@ -2446,6 +2447,26 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
                             (long long)d->h * d->w * d->ldi * 2 < 0x7fffffffll && (long long)d->oh * d->ow * d->ldo * 2 < 0x7fffffffll;
         if (common && d->sh == 1 && d->sw == 1 && d->cin == 32 && d->cout <= 64) w.small = d->cout <= 32 ? 1 : 2;
         else if (common && d->sh == 2 && d->sw == 2 && d->cin <= 8 && d->ldi >= d->cioff + 8 && d->cout <= 32) w.small = 3;
+    }
+    // narrow mid-network layers (conv_wgrad_halo.hip): small = 4 -- dW stationary in registers, halo tiles, two filter-row classes
+    if (!w.small) {
+        const char* hv = getenv("DIN_WGRAD_HALO");
+        const int64_t M = (int64_t)d->nb * d->oh * d->ow;
+        int bnt = 0;
+        const int hmode = hv ? atoi(hv) : 1;                      // 0: off, 1: launches of >= 256K pixels, 2: any size (tests)
+        if (hmode && d->dtype == DIN_BF16 && d->sh == 1 && d->sw == 1 && d->dh == 1 && d->dw == 1 &&
+            din_wgrad::wgrad_halo_shape(d->cin, d->cout, d->kh, d->kw, &bnt) && d->ldi % 8 == 0 && d->cioff % 8 == 0 && d->ldo % 8 == 0 &&
+            d->cooff % 8 == 0 && (M >= 256 * 1024 || hmode == 2) && d->ow >= 32 && (long long)d->h * d->w * d->ldi * 2 < 0x7fffffffll &&
+            (long long)d->oh * d->ow * d->ldo * 2 < 0x7fffffffll) {
+            w.small = 4; w.v2 = 0; w.bco = bnt;
+            w.cin_pad = d->cin;
+            w.kcols = w.kcols_pad = d->kh * d->kw * d->cin;
+            w.cout_pad = d->cout; w.n_co_tiles = 2; w.n_k_tiles = 1;
+            w.slices = WGRAD_HALO_GRID; w.m_per_slice = 0;
+            w.ring = 0; w.bk = 0;
+            w.ws_bytes = (int64_t)w.slices * w.cout_pad * w.kcols_pad * 4;
+            return w;
+        }
     }
     if (w.small) {
         w.v2 = 0; w.bco = w.small == 2 ? 64 : 32;
@@ -2943,7 +2964,7 @@ int din_conv_pack_multi(const din_pack_desc* table, const int32_t* layer_of, con
 
 int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t* bn) {
     DIN_REQUIRE(d && bm && bn && which >= 0 && which <= 2, "conv_kernel_tile: bad argument");
-    if (which == 2) { WgradPlan wp = plan_wgrad(d); *bm = wp.small ? 0 : wp.bco; *bn = wp.small ? wp.bco : (wp.pipe ? 2000 + wp.bk : wp.ring ? 1000 + wp.bk : WG_TILE); return DIN_OK; }
+    if (which == 2) { WgradPlan wp = plan_wgrad(d); if (wp.small == 4) { *bm = 3; *bn = wp.bco; return DIN_OK; } *bm = wp.small ? 0 : wp.bco; *bn = wp.small ? wp.bco : (wp.pipe ? 2000 + wp.bk : wp.ring ? 1000 + wp.bk : WG_TILE); return DIN_OK; }
     const bool strided = which == 1 && (d->sh > 1 || d->sw > 1);
     GatherPlan g = which == 0 ? plan_gather(d->nb * d->oh * d->ow, d->cin, d->cout, d->kh * d->kw, d->dtype)
                               : plan_gather(d->nb * (strided ? (d->h + d->sh - 1) / d->sh * ((d->w + d->sw - 1) / d->sw) : d->h * d->w),
@@ -3218,7 +3239,14 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
     } else {
         int epc = 8;
         DIN_REQUIRE(d->ldo % epc == 0 && d->cooff % epc == 0, "conv_wgrad: bf16 dout stride/offset must be multiples of 8");
-        if (wp.small) {
+        if (wp.small == 4) {
+            if (dbias) {
+                if (!prezeroed && hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
+                k.dbias = dbias;
+                bias_fused = true;
+            }
+            if (int e = din_wgrad::launch_wgrad_halo(k, WGRAD_HALO_GRID, st)) return e;
+        } else if (wp.small) {
             if (dbias) {
                 if (!prezeroed && hipMemsetAsync(dbias, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
                 k.dbias = dbias;

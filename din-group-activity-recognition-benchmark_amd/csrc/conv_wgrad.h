@@ -35,5 +35,8 @@ __device__ __forceinline__ void lds_dma16(uint32_t lds_addr, __amdgpu_buffer_rsr
 // host entry of conv_wgrad_pipe.hip: launches the software-pipelined 32x32x16 ring kernel for a plan with pipe != 0
 int launch_wgrad_pipe(const WgradK& k, int bco, int bk, dim3 grid, hipStream_t st);
 size_t wgrad_pipe_lds_bytes(int bco, int bk);
+// host entries of conv_wgrad_halo.hip: the halo-tiled weight gradient of the narrow mid-network layers (dW block stationary in registers)
+bool wgrad_halo_shape(int cin, int cout, int kh, int kw, int* bnt);
+int launch_wgrad_halo(const WgradK& k, int nwg, hipStream_t st);
 
 }  // namespace din_wgrad

@@ -137,6 +137,8 @@ class LaunchTimer:
         L.load().din_conv_kernel_tile(C.byref(d), which, C.byref(bm), C.byref(bn))
         tn = "unsigned short" if d.dtype == L.DIN_BF16 else "float"
         if self.kind == "wgrad":
+            if bm.value == 3:
+                return f"conv_wgrad_halo_kernel<..., {bn.value}, ...>"
             if bm.value == 0:
                 return f"conv_wgrad_small_kernel<..., {bn.value}, ...>"
             if bn.value >= 2000:

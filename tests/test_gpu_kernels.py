@@ -67,6 +67,7 @@ CONV_CASES = [
     ("halo_3x3_64_96", 6, 64, 87, 157, 96, (3, 3), (1, 1), (1, 1), 1),
     ("halo_3x3_80_192_p0", 2, 80, 181, 321, 192, (3, 3), (1, 1), (0, 0), 1),
     ("halo_5x5_48_64", 6, 48, 87, 157, 64, (5, 5), (1, 1), (2, 2), 1),
+    ("halo_3x3_96_96", 6, 96, 87, 157, 96, (3, 3), (1, 1), (1, 1), 1),        # (+ the three shapes of conv_wgrad_halo_kernel: dW stationary)
     ("halo_1x7_128_160", 20, 128, 43, 78, 160, (1, 7), (1, 1), (0, 3), 1),
     ("halo_7x1_160_192", 20, 160, 43, 78, 192, (7, 1), (1, 1), (3, 0), 1),
     # 256-pixel software-pipelined tiles (conv_gather_pipe_kernel<128 | 192 | 256>, bf16; forced on these small shapes with DIN_GATHER_PIPE=2):
@@ -88,6 +89,7 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
     name, nb, cin, h, w, cout, k, s, p, dil = case
     if name.startswith("halo_"):
         monkeypatch.setenv("DIN_CONV_HALO", "2")        # the planner only picks the halo kernel where it wins; cover every instantiation
+        monkeypatch.setenv("DIN_WGRAD_HALO", "2")       # ... and the halo weight-gradient kernel only on launches of >= 256K pixels
     if name.startswith("gp"):
         monkeypatch.setenv("DIN_GATHER_PIPE", "2")      # ... and the 256-pixel pipelined tiles only on launches that fill the chip
         monkeypatch.setenv("DIN_CONV_HALO", "0")
@@ -141,6 +143,10 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
     assert float(out[..., :coff].float().min()) == 7.0 and float(out[..., coff + cout:].float().min()) == 7.0, "wrote outside its channel range"
 
     # ---- wgrad + bias grad
+    if name in ("halo_3x3_64_96", "halo_5x5_48_64", "halo_3x3_96_96") and dtype == "bf16":
+        bm, bn = C.c_int32(0), C.c_int32(0)
+        lib.din_conv_kernel_tile(C.byref(d), 2, C.byref(bm), C.byref(bn))
+        assert bm.value == 3, f"{name}: weight gradient not on conv_wgrad_halo_kernel (code {bm.value}, {bn.value})"
     gz = to_nhwc(gz_ref, tdt, ldo, coff)
     dw = torch.empty_like(wdev)
     db = torch.empty(cout, device="cuda")
