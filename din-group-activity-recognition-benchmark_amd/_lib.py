@@ -46,6 +46,11 @@ class ConvSrc(C.Structure):
     _fields_ = [("dout", C.c_void_p), ("wpk_t", C.c_void_p), ("cout", C.c_int32), ("ldo", C.c_int32), ("cooff", C.c_int32)]
 
 
+class ConvWSrc(C.Structure):
+    _fields_ = [("dout", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p), ("scale", C.c_void_p), ("w", C.c_void_p), ("wdot", C.c_void_p),
+                ("cout", C.c_int32), ("ldo", C.c_int32), ("cooff", C.c_int32)]
+
+
 _P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 _CD, _PD = C.POINTER(ConvDesc), C.POINTER(PoolDesc)
 
@@ -68,6 +73,8 @@ SIGNATURES: Dict[str, tuple] = {
     "din_conv_fwd2": (_I, [_CD, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "din_conv_dgrad": (_I, [_CD, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P]),
     "din_conv1x1_dgrad_multi": (_I, [_I, C.POINTER(ConvSrc), _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
+    "din_conv1x1_wgrad_multi_workspace": (_L, [_I, C.POINTER(ConvWSrc), _I, _L, _I]),
+    "din_conv1x1_wgrad_multi": (_I, [_I, C.POINTER(ConvWSrc), _I, _L, _I, _I, _I, _P, _I, _P, _L, _P]),
     "din_conv_wgrad": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P]),
     "din_colsum": (_I, [_P, _I, _L, _I, _I, _I, _P, _P]),
     "din_bn_fold": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),

@@ -2453,10 +2453,10 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
         const char* hv = getenv("DIN_WGRAD_HALO");
         const int64_t M = (int64_t)d->nb * d->oh * d->ow;
         int bnt = 0;
-        const int hmode = hv ? atoi(hv) : 1;                      // 0: off, 1: launches of >= 256K pixels, 2: any size (tests)
+        const int hmode = hv ? atoi(hv) : 1;                      // 0: off, 1: launches of >= 128K pixels (12 frames of 87x157 measured +3..34 %), 2: any size (tests)
         if (hmode && d->dtype == DIN_BF16 && d->sh == 1 && d->sw == 1 && d->dh == 1 && d->dw == 1 &&
             din_wgrad::wgrad_halo_shape(d->cin, d->cout, d->kh, d->kw, &bnt) && d->ldi % 8 == 0 && d->cioff % 8 == 0 && d->ldo % 8 == 0 &&
-            d->cooff % 8 == 0 && (M >= 256 * 1024 || hmode == 2) && d->ow >= 32 && (long long)d->h * d->w * d->ldi * 2 < 0x7fffffffll &&
+            d->cooff % 8 == 0 && (M >= 128 * 1024 || hmode == 2) && d->ow >= 32 && (long long)d->h * d->w * d->ldi * 2 < 0x7fffffffll &&
             (long long)d->oh * d->ow * d->ldo * 2 < 0x7fffffffll) {
             w.small = 4; w.v2 = 0; w.bco = bnt;
             w.cin_pad = d->cin;
@@ -3345,6 +3345,58 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
     }
     if (dbias && !bias_fused) {
         if (int e = launch_colsum(d->dtype, dout, dbias, k.M, d->cout, d->ldo, d->cooff, st)) return e;
+    }
+    return DIN_OK;
+}
+
+static bool wgrad_multi_plan(int nsrc, const din_conv_wsrc* srcs, int dtype, int64_t pixels, int cin, din_wgrad::Wg1x1K* k) {
+    const char* ev = getenv("DIN_WGRAD_1X1_MULTI");
+    const int mode = ev ? atoi(ev) : 1;                        // 0: off, 1: launches of >= 128K pixels, 2: any size (tests)
+    if (!mode || dtype != DIN_BF16 || !srcs || nsrc < 2 || nsrc > 4 || (pixels < 128 * 1024 && mode != 2) || pixels <= 0) return false;
+    int couts[4];
+    for (int s = 0; s < nsrc; ++s) {
+        couts[s] = srcs[s].cout;
+        if (srcs[s].ldo % 8 != 0 || srcs[s].cooff % 8 != 0 || srcs[s].ldo < srcs[s].cooff + srcs[s].cout ||
+            pixels * srcs[s].ldo * 2 >= 0x7fffffffll) return false;
+    }
+    return din_wgrad::plan_wgrad_1x1_multi(nsrc, couts, cin, k);
+}
+
+int64_t din_conv1x1_wgrad_multi_workspace(int nsrc, const din_conv_wsrc* srcs, int dtype, int64_t pixels, int cin) {
+    din_wgrad::Wg1x1K k{};
+    if (!wgrad_multi_plan(nsrc, srcs, dtype, pixels, cin, &k)) return 0;
+    return (int64_t)WGRAD_HALO_GRID * k.rows_pad * cin * 4;
+}
+
+int din_conv1x1_wgrad_multi(int nsrc, const din_conv_wsrc* srcs, int dtype, int64_t pixels, int cin, int ldi, int cioff, const void* in,
+                            int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+    din_wgrad::Wg1x1K k{};
+    DIN_REQUIRE(in && workspace, "conv1x1_wgrad_multi: null pointer");
+    DIN_REQUIRE(wgrad_multi_plan(nsrc, srcs, dtype, pixels, cin, &k), "conv1x1_wgrad_multi: this group does not fit the kernel "
+                "(din_conv1x1_wgrad_multi_workspace returns 0 for it: run din_conv_wgrad per layer)");
+    DIN_REQUIRE(ldi % 8 == 0 && cioff % 8 == 0 && ldi >= cioff + cin && pixels * ldi * 2 < 0x7fffffffll, "conv1x1_wgrad_multi: bad input view");
+    const int64_t need = (int64_t)WGRAD_HALO_GRID * k.rows_pad * cin * 4;
+    if (workspace_bytes < need) DIN_FAIL(DIN_E_WORKSPACE, "conv1x1_wgrad_multi: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+    hipStream_t st = as_stream(stream);
+    const bool prezeroed = (accumulate & 2) != 0;
+    accumulate &= 1;
+    k.x = in; k.partial = reinterpret_cast<float*>(workspace);
+    k.M = (int)pixels; k.Cin = cin; k.ldi = ldi; k.cioff = cioff; k.nsrc = nsrc;
+    for (int s = 0; s < nsrc; ++s) {
+        DIN_REQUIRE(srcs[s].dout && srcs[s].dw && (!srcs[s].wdot || srcs[s].w), "conv1x1_wgrad_multi: null pointer in source %d", s);
+        k.src[s].g = srcs[s].dout; k.src[s].dbias = srcs[s].dbias; k.src[s].cout = srcs[s].cout; k.src[s].ld = srcs[s].ldo; k.src[s].coff = srcs[s].cooff;
+        if (!prezeroed) {
+            if (srcs[s].dbias && hipMemsetAsync(srcs[s].dbias, 0, sizeof(float) * srcs[s].cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv1x1_wgrad_multi: memset");
+            if (srcs[s].wdot && hipMemsetAsync(srcs[s].wdot, 0, sizeof(float) * srcs[s].cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv1x1_wgrad_multi: memset");
+        }
+    }
+    if (int e = din_wgrad::launch_wgrad_1x1_multi(k, WGRAD_HALO_GRID, st)) return e;
+    DIN_CHECK_LAUNCH("conv1x1_wgrad_multi");
+    for (int s = 0; s < nsrc; ++s) {
+        dim3 rgrid(srcs[s].cout, (cin + 255) / 256);
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, rgrid, dim3(64, 16), 0, st, k.partial + (int64_t)k.src[s].row0 * cin, srcs[s].dw, srcs[s].scale,
+                           srcs[s].w, srcs[s].wdot, srcs[s].cout, cin, 1, 1, cin, k.rows_pad, cin, WGRAD_HALO_GRID, accumulate);
+        DIN_CHECK_LAUNCH("conv1x1_wgrad_multi reduce");
     }
     return DIN_OK;
 }

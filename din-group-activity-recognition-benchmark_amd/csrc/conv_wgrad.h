@@ -22,6 +22,16 @@ struct WgradK {
                     // XCD's L2 holds and dY comes from HBM once.  Speed only: no sibling is ever waited for indefinitely.
 };
 
+// conv_wgrad_1x1.hip: weight gradients of up to four 1x1 convs that read one tensor, in one launch (dW stationary in registers)
+struct Wg1x1K {
+    const void* x; float* partial;
+    int M, Cin, ldi, cioff;                     // pixels, input channels (192 | 256 | 288), pixel stride, channel offset
+    int nsrc, rows_pad;                         // sources; rows of a slab = sum of their couts
+    struct Src { const void* g; float* dbias; int cout, ld, coff, row0; } src[4];   // gradient operand [M][ld] at channel coff; first slab row
+    int cls_src[2][2];                          // the (<= 2) sources of each workgroup class, -1 = none
+    int cls_gbytes[2], gbytes_max;              // bytes of a stage's G image per class
+};
+
 // One wave-level LDS-DMA: 64 lanes x 16 B land at LDS byte address `lds_addr` + lane*16 (lane-linear; out-of-range lanes write
 // zeros -- measured, profiles/r01_probe_lds_dma.txt).  Issued through inline asm on purpose: with the builtin, hipcc tracks the LDS
 // write, cannot tell the ring stages apart and drains vmcnt(0) before the next barrier/ds_read, which serialises the pipeline.
@@ -38,5 +48,8 @@ size_t wgrad_pipe_lds_bytes(int bco, int bk);
 // host entries of conv_wgrad_halo.hip: the halo-tiled weight gradient of the narrow mid-network layers (dW block stationary in registers)
 bool wgrad_halo_shape(int cin, int cout, int kh, int kw, int* bnt);
 int launch_wgrad_halo(const WgradK& k, int nwg, hipStream_t st);
+// host entries of conv_wgrad_1x1.hip
+bool plan_wgrad_1x1_multi(int nsrc, const int* couts, int cin, Wg1x1K* k);
+int launch_wgrad_1x1_multi(const Wg1x1K& k, int nwg, hipStream_t st);
 
 }  // namespace din_wgrad

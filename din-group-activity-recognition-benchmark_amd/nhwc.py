@@ -84,6 +84,7 @@ import os as _os
 FUSE_1X1_DGRAD = _os.environ.get("DIN_FUSE_1X1", "1") != "0"     # fuse the dgrads of 1x1 convs that read the same tensor
 FUSE_FWD_SIBLINGS = _os.environ.get("DIN_FUSE_FWD", "1") != "0"   # run Graph.fwd_groups (sibling 1x1 convs) as one two-destination launch
 FUSE_WGRAD_SIBLINGS = _os.environ.get("DIN_FUSE_WGRAD", "1") != "0"  # ... and the wgrads of the members that share the second tensor as one launch
+FUSE_WGRAD_1X1 = _os.environ.get("DIN_FUSE_WGRAD_1X1", "1") != "0"   # weight gradients of ALL 1x1 convs reading one view in one launch (din_conv1x1_wgrad_multi)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -669,16 +670,60 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
     remaining = {key: len(v) for key, v in groups.items()}
     pending: Dict[Tuple[int, int, int], list] = {key: [] for key in groups}
 
+    def flush_wgrad_multi(key, items):
+        """the deferred weight gradients of a 1x1 group (multi_w): ONE launch reads the block input once and produces every member's dW"""
+        nonlocal bn_touched
+        by_oi = {it[0]: it for it in items}
+        op0 = g.ops[items[0][0]]
+        ts0 = g.tensors[op0.src.tid]
+        plan, wsb_need = multi_w[key]
+        srcs = (L.ConvWSrc * len(plan))()
+        keep, outs = [], []
+        for j, mem in enumerate(plan):
+            if any(i not in by_oi for i in mem):
+                raise L.DinError("1x1 weight-gradient group: a member received no gradient")      # (cannot happen in the backbones here)
+            _oi, gout_, _w, _scale, ldj, coffj, pre = by_oi[mem[0]]
+            o0, o1 = bn.off_list[bn_index[mem[0]]], bn.off_list[bn_index[mem[-1]] + 1]
+            if len(mem) == 1:
+                wj = params[offsets[mem[0]]]
+                dwj = _dw_buffer(wj)
+            else:
+                wj = torch.cat([params[offsets[i]] for i in mem])
+                dwj = torch.empty_like(wj)
+            keep += [wj, dwj, gout_]
+            srcs[j].dout, srcs[j].dw = gout_.data_ptr(), dwj.data_ptr()
+            srcs[j].dbias = 0 if pre else bn_dshift[o0:o1].data_ptr()
+            srcs[j].scale, srcs[j].w, srcs[j].wdot = pcache.bn_scale[o0:o1].data_ptr(), wj.data_ptr(), bn_wdot[o0:o1].data_ptr()
+            srcs[j].cout, srcs[j].ldo, srcs[j].cooff = o1 - o0, ldj, coffj
+            outs.append((mem, dwj))
+        bn_touched = True
+        ws, wsb = workspace(wsb_need, dev, wtag)
+        dM = _conv_desc(g, op0, nb, dt)
+        dM.cout = sum(s_.cout for s_ in srcs)                    # FLOP accounting of the fused launch
+        with _timed("wgrad", dM, "1x1multi:" + "+".join(g.ops[i].name for mem in plan for i in mem)):
+            L.check(lib.din_conv1x1_wgrad_multi(len(plan), srcs, dt, nb * ts0.h * ts0.w, op0.src.c, ts0.c, op0.src.coff, _ptr(bufs[op0.src.tid]), 2,
+                                                _ptr(ws), wsb, st), "conv1x1_wgrad_multi")
+        for mem, dwj in outs:
+            r0 = 0
+            for i in mem:
+                c = g.ops[i].dst.c
+                grads[offsets[i]] = dwj if len(mem) == 1 else dwj[r0:r0 + c]
+                r0 += c
+                if GRAD_HOOK is not None:
+                    GRAD_HOOK(params[offsets[i]], grads[offsets[i]])
+
     def flush_group(key):
         items = pending[key]
         if not items:
             return
+        if key in multi_w:
+            flush_wgrad_multi(key, items)
         op0 = g.ops[items[0][0]]
         ts0 = g.tensors[op0.src.tid]
         gsrc, acc = grad_target(op0.src)
         srcs = (L.ConvSrc * len(items))()
         keep = []
-        for j, (oi_, gout_, w_, scale_, ldj, coffj) in enumerate(items):
+        for j, (oi_, gout_, w_, scale_, ldj, coffj, _pre) in enumerate(items):
             opj = g.ops[oi_]
             dj = _conv_desc(g, opj, nb, dt)
             wpt = pcache.wpt[oi_]
@@ -704,6 +749,32 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
             if len(mem) >= 2:                                               #  operand is the un-pooled map, a separate buffer)
                 wgrad_group[mem[-1]] = mem
     wgrad_done = set()
+    # 1x1 groups whose weight gradients run as ONE launch (din_conv1x1_wgrad_multi): sources = the members, sibling pairs that share a
+    # tensor (wgrad_group) counted as one source; the library says whether the group fits its kernel (0 bytes of workspace: it does not)
+    multi_w: Dict[Tuple[int, int, int], tuple] = {}
+    if FUSE_WGRAD_1X1 and bn is not None and not bn_train and side is None and dt == L.DIN_BF16:
+        pair_of = {i: mem for mem in wgrad_group.values() for i in mem}
+        for key, members in groups.items():
+            if not all(g.ops[i].bn for i in members):
+                continue
+            plan, seen = [], set()
+            for i in members:
+                if i in seen:
+                    continue
+                mem = pair_of.get(i, (i,))
+                if not all(j in members for j in mem):
+                    mem = (i,)
+                plan.append(tuple(mem))
+                seen.update(mem)
+            probe = (L.ConvWSrc * len(plan))()
+            for j, mem in enumerate(plan):
+                o = g.ops[mem[0]]
+                probe[j].cout = sum(g.ops[i].dst.c for i in mem)
+                probe[j].ldo, probe[j].cooff = (o.dst.c, 0) if o.pooled is not None else (g.tensors[o.dst.tid].c, o.dst.coff)
+            ts_ = g.tensors[g.ops[members[0]].src.tid]
+            need = lib.din_conv1x1_wgrad_multi_workspace(len(plan), probe, dt, nb * ts_.h * ts_.w, g.ops[members[0]].src.c) if 2 <= len(plan) <= 4 else 0
+            if need > 0:
+                multi_w[key] = (plan, need)
     for oi in range(len(g.ops) - 1, -1, -1):
         op = g.ops[oi]
         if op.dst.tid not in gbufs:
@@ -761,7 +832,8 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 L.check(lib.din_avgpool_bwd(C.byref(pd), _ptr(gout), _ptr(gtmp), None, 0, st), "avgpool_bwd(epilogue)")
                 gout, g_ld, g_coff = gtmp, pd.c, 0
             # ---- wgrad (+ bias / BN parameter gradients): on the side stream when enabled
-            if oi in wgrad_done:
+            defer_w = oi in member_of and member_of[oi] in multi_w and src_needs_grad      # produced when its 1x1 group is flushed (flush_wgrad_multi)
+            if defer_w or oi in wgrad_done:
                 pass                                              # produced by the group launch of a sibling (below)
             elif oi in wgrad_group and op.bn and side is None:
                 # the members of a forward group that share the second tensor: their output gradients are adjacent channel views of ONE
@@ -789,7 +861,9 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                     if GRAD_HOOK is not None:
                         GRAD_HOOK(params[offsets[i]], grads[offsets[i]])
                 wgrad_done.update(mem)
-            if oi in wgrad_done:
+            if defer_w:
+                dw = None
+            elif oi in wgrad_done:
                 dw = grads[po]
             elif bn_live:
                 dw = _dw_buffer(w)
@@ -834,12 +908,12 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 grads[po] = dw
                 if op.bias:
                     grads[po + 1] = db
-            if GRAD_HOOK is not None and side is None and oi not in wgrad_done:
+            if GRAD_HOOK is not None and side is None and oi not in wgrad_done and not defer_w:
                 GRAD_HOOK(w, dw)
             # ---- dgrad
             if src_needs_grad and oi in member_of:
                 key = member_of[oi]
-                pending[key].append((oi, gout, w, scale, g_ld, g_coff))
+                pending[key].append((oi, gout, w, scale, g_ld, g_coff, dshift_pre is not None))
                 remaining[key] -= 1
                 if remaining[key] == 0:
                     flush_group(key)

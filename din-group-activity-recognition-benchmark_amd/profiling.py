@@ -137,6 +137,8 @@ class LaunchTimer:
         L.load().din_conv_kernel_tile(C.byref(d), which, C.byref(bm), C.byref(bn))
         tn = "unsigned short" if d.dtype == L.DIN_BF16 else "float"
         if self.kind == "wgrad":
+            if self.name.startswith("1x1multi:"):
+                return f"conv_wgrad_1x1_multi_kernel<{d.cin // 8}>"
             if bm.value == 3:
                 return f"conv_wgrad_halo_kernel<..., {bn.value}, ...>"
             if bm.value == 0:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DIN_ABI_VERSION 5   /* 5: dropout seeds take an optional device-side offset (din_layernorm_*, din_act_dropout_*), din_counter_add.   2: din_walk_* take plain / clamp / n_per_clip; + bn, mask_actors.  3: din_roi_align_* take the box grid and a crop channel range.  4: din_conv_desc.in_u8, context-encoding entry points */
+#define DIN_ABI_VERSION 5   /* 5: dropout seeds take an optional device-side offset (din_layernorm_*, din_act_dropout_*), din_counter_add, din_conv1x1_wgrad_multi.   2: din_walk_* take plain / clamp / n_per_clip; + bn, mask_actors.  3: din_roi_align_* take the box grid and a crop channel range.  4: din_conv_desc.in_u8, context-encoding entry points */
 
 enum { DIN_F32 = 0, DIN_BF16 = 1 };
 
@@ -150,6 +150,26 @@ int din_conv1x1_dgrad_multi(int nsrc, const din_conv_src* srcs, int dtype, int n
 int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, float* dw, float* dbias,
                    const float* scale, const float* w, float* wdot, int accumulate,
                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Weight gradients of 2..4 1x1 / stride-1 convs that read the SAME tensor view (the block-entry convs of an InceptionA block, reference
+ * backbone/backbone.py:44-58 through torchvision: branch1x1, branch5x5_1 + branch3x3dbl_1, branch_pool) in ONE launch: the input is read
+ * once instead of once per layer, every layer's dW block stays in registers of persistent workgroups (csrc/conv_wgrad_1x1.hip).
+ * Source b: dout_b [pixels][ldo] at channel cooff (its gradient operand), dw_b [cout_b][cin] fp32, and din_conv_wgrad's optional
+ * dbias / scale / w / wdot of that layer.  din_conv1x1_wgrad_multi_workspace returns the workspace bytes, or 0 when the group does not
+ * fit the kernel (bf16, cin in {192, 256, 288}, couts multiples of 16 that can be dealt to two classes of <= 128 rows, >= 128K pixels):
+ * the caller then runs din_conv_wgrad per layer.  accumulate as in din_conv_wgrad.                                              */
+typedef struct din_conv_wsrc {
+    const void* dout;
+    float* dw;
+    float* dbias;
+    const float* scale;
+    const float* w;
+    float* wdot;
+    int32_t cout, ldo, cooff;
+} din_conv_wsrc;
+int64_t din_conv1x1_wgrad_multi_workspace(int nsrc, const din_conv_wsrc* srcs, int dtype, int64_t pixels, int cin);
+int din_conv1x1_wgrad_multi(int nsrc, const din_conv_wsrc* srcs, int dtype, int64_t pixels, int cin, int ldi, int cioff, const void* in,
+                            int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* out[c] = sum over rows of g[row*ld + coff + c] (fp32 result; BatchNorm shift gradient of a conv whose epilogue ran in the pool) */
 int din_colsum(const void* g, int dtype, int64_t rows, int c, int ld, int coff, float* out, void* stream);

@@ -987,3 +987,44 @@ def test_captured_step_matches_eager(gpu):
         assert rel(b_, a_) <= 1e-4                      # (fp32 atomics in the DIN walk / LayerNorm backward: not bitwise)
     assert [c._step for c in counters] == [2 * s for s in steps_per_pass]
     assert int(cap.seed_offset.item()) == (2 * graph_step.SEED_STRIDE) & 0x7FFFFFFFFFFFFFFF
+
+
+def test_inception_bf16_stationary_wgrad_kernels_match_general_kernels(gpu, monkeypatch):
+    """bf16 backbone backward with the dW-stationary weight-gradient kernels forced on at a small frame (conv_wgrad_halo_kernel for the
+    narrow 3x3 / 5x5 layers, din_conv1x1_wgrad_multi for the block-entry 1x1 groups: normally >= 128K pixels) against the same backbone on
+    the general kernels: same bf16 operands, fp32 accumulation either way -> parameter gradients equal to summation order (<= 2e-4)."""
+    from din_amd import nhwc
+    from din_amd.backbone.backbone import MyInception_v3
+    g = torch.Generator().manual_seed(43)
+    images = torch.randint(0, 256, (2, 3, 331, 395), generator=g, dtype=torch.uint8)      # Mixed_5 grid 38 x 46: ragged 8 x 32 / 64-pixel tiles
+    ref = MyInception_v3(compute_dtype="bf16")
+    sd = {}
+    for k, v in ref.state_dict().items():
+        if not v.dtype.is_floating_point:
+            sd[k] = v
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(v.shape, generator=g) + 0.5
+        elif k.endswith("conv.weight"):
+            sd[k] = torch.randn(v.shape, generator=g) * (2.0 / (v.shape[1] * v.shape[2] * v.shape[3])) ** 0.5
+        else:
+            sd[k] = torch.randn(v.shape, generator=g) * 0.1 + (1.0 if k.endswith("bn.weight") else 0.0)
+    outs = []
+    for mode in ("2", "0"):
+        monkeypatch.setenv("DIN_WGRAD_HALO", mode)
+        monkeypatch.setenv("DIN_WGRAD_1X1_MULTI", mode)
+        m = MyInception_v3(compute_dtype="bf16")
+        m.load_state_dict(sd)
+        m = m.to(gpu).eval()
+        calls = []
+        lib = nhwc.L.load()
+        real = lib.din_conv1x1_wgrad_multi
+        monkeypatch.setattr(lib, "din_conv1x1_wgrad_multi", lambda *a, _r=real: (calls.append(a[0]), _r(*a))[1])
+        feats = m(images.to(gpu))
+        sum((f.float() ** 2).mean() for f in feats).backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(lib, "din_conv1x1_wgrad_multi", real)
+        outs.append({k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+        assert (len(calls) == 3 and calls == [3, 3, 3]) if mode == "2" else not calls, calls      # Mixed_5b / 5c / 5d: three sources each
+    assert outs[0].keys() == outs[1].keys()
+    for k, gb_ in outs[1].items():
+        assert rel(outs[0][k], gb_) <= 2e-4, (k, rel(outs[0][k], gb_))

@@ -1100,3 +1100,48 @@ def test_din_walk_bwd_large_kernel_uses_global_scatter(env):
     assert rel(xd.grad, ins[0].grad) <= 2e-4
     assert rel(wd.grad, torch.cat([ins[1].grad, ins[3].grad], 0)) <= 2e-4
     assert rel(bd.grad, torch.cat([ins[2].grad, ins[4].grad], 0)) <= 2e-4
+
+
+@pytest.mark.parametrize("cin,couts", [(192, (64, 112, 32)), (256, (64, 112, 64)), (288, (64, 112, 64)), (288, (112, 16, 96, 32))],
+                         ids=["5b_192", "5c_256", "5d_288", "four_sources"])
+def test_conv1x1_wgrad_multi_source(env, monkeypatch, cin, couts):
+    """din_conv1x1_wgrad_multi (conv_wgrad_1x1_multi_kernel: the weight gradients of every 1x1 conv reading one tensor view in one launch,
+    dW stationary in registers) against fp32 einsums on the bf16-rounded operands: dW with the BatchNorm scale folded, the <W, dW> dot, the
+    bias gradient; gradient operands at channel offsets of wider tensors, a pixel count that is not a multiple of the 64-pixel stage."""
+    lib, L, nhwc, ops = env
+    monkeypatch.setenv("DIN_WGRAD_1X1_MULTI", "2")
+    g = torch.Generator().manual_seed(cin + len(couts))
+    nb, h, w = 3, 37, 41                                              # 4551 pixels = 71 stages + 7 pixels
+    M, ldi, cioff = nb * h * w, cin + 16, 8
+    xb = torch.randn(M, ldi, generator=g).bfloat16()
+    x = xb[:, cioff:cioff + cin].float()
+    srcs = (L.ConvWSrc * len(couts))()
+    keep, refs = [], []
+    for j, co in enumerate(couts):
+        ld, coff = co + 24, 16 if j % 2 == 0 else 0
+        gb = torch.randn(M, ld, generator=g).bfloat16()
+        gsl = gb[:, coff:coff + co].float()
+        wj = torch.randn(co, cin, 1, 1, generator=g) * 0.05
+        scale = torch.rand(co, generator=g) + 0.5
+        dw_raw = gsl.t() @ x                                          # [co, cin]
+        refs.append((dw_raw * scale[:, None], (dw_raw * wj.reshape(co, cin)).sum(1), gsl.sum(0)))
+        dev = dict(g=gb.cuda(), w=wj.cuda(), scale=scale.cuda(), dw=torch.full((co, cin, 1, 1), 7.0, device="cuda"),
+                   db=torch.zeros(co, device="cuda"), wdot=torch.zeros(co, device="cuda"))
+        keep.append(dev)
+        srcs[j].dout, srcs[j].dw, srcs[j].dbias = dev["g"].data_ptr(), dev["dw"].data_ptr(), dev["db"].data_ptr() if j != 1 else None
+        srcs[j].scale, srcs[j].w, srcs[j].wdot = dev["scale"].data_ptr(), dev["w"].data_ptr(), dev["wdot"].data_ptr()
+        srcs[j].cout, srcs[j].ldo, srcs[j].cooff = co, ld, coff
+    wsb = lib.din_conv1x1_wgrad_multi_workspace(len(couts), srcs, L.DIN_BF16, M, cin)
+    assert wsb > 0
+    assert lib.din_conv1x1_wgrad_multi_workspace(len(couts), srcs, L.DIN_F32, M, cin) == 0          # bf16 only
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    xd = xb.cuda()
+    L.check(lib.din_conv1x1_wgrad_multi(len(couts), srcs, L.DIN_BF16, M, cin, ldi, cioff, xd.data_ptr(), 2, ws.data_ptr(), wsb, None))
+    torch.cuda.synchronize()
+    for j, (dev, (dw_ref, wdot_ref, db_ref)) in enumerate(zip(keep, refs)):
+        assert rel(dev["dw"].reshape(dw_ref.shape), dw_ref) <= 2e-5, j
+        assert rel(dev["wdot"], wdot_ref) <= 2e-5, j
+        if j != 1:
+            assert rel(dev["db"], db_ref) <= 2e-5, j
+        else:
+            assert float(dev["db"].abs().max()) == 0.0
