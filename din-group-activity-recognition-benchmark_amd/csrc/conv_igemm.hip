@@ -2650,7 +2650,18 @@ void launch_wave8(const ConvK& k, dim3 grid, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         const char* fv = getenv("DIN_CONV_FASTK");
         const bool want = fv ? atoi(fv) != 0 : true;
-        if (want && !k.remap && k.nsrc == 0 && (k.cpt % 8) == 0 && (k.korder || k.kh * k.kw == 1)) {
+        const bool fastk = want && !k.remap && k.nsrc == 0 && (k.cpt % 8) == 0 && (k.korder || k.kh * k.kw == 1);
+        if constexpr (BN == 192) {
+            // wave grid 2 x 4 (64 pixels x 48 filters per wave: 4 + 3 fragments per 12 MFMAs) instead of 4 x 2 (32 x 96: 2 + 6): an eighth
+            // fewer LDS fragment reads for the same tile (experiment switch DIN_CONV_WAVEGRID=24)
+            static const bool grid24 = getenv("DIN_CONV_WAVEGRID") && atoi(getenv("DIN_CONV_WAVEGRID")) == 24;
+            if (grid24) {
+                if (fastk) launch_fast<T, 128, BN, 2, 4, 8, 2, true>(k, grid, st);
+                else launch_fast<T, 128, BN, 2, 4, 8, 2>(k, grid, st);
+                return;
+            }
+        }
+        if (fastk) {
             launch_fast<T, 128, BN, 4, 2, 8, 2, true>(k, grid, st);
             return;
         }

@@ -10,7 +10,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 run() { name=$1; shift; timeout 600 python bench.py "$@" > $OUT/bench_$name.log 2>&1; tail -1 $OUT/bench_$name.log > $OUT/bench_$name.json; cut -c1-160 $OUT/bench_$name.json; }
 run inv3_bf16_b32 --per-layer $OUT/inv3_bf16_per_layer.txt
-run inv3_bf16_b4 --global-batch 4 --no-cpu-baseline --per-layer $OUT/inv3_bf16_b4_per_layer.txt
+run inv3_bf16_b4 --global-batch 4 --no-cpu-baseline --no-extras --per-layer $OUT/inv3_bf16_b4_per_layer.txt
 run inv3_bf16_b32_host_images --host-images --no-cpu-baseline
 run inv3_bf16_b32_bn_batch --bn-mode batch --no-cpu-baseline
 run inv3_bf16_b32_forward_only --forward-only --no-cpu-baseline
