@@ -3367,8 +3367,7 @@ static bool wgrad_multi_plan(int nsrc, const din_conv_wsrc* srcs, int dtype, int
     int couts[4];
     for (int s = 0; s < nsrc; ++s) {
         couts[s] = srcs[s].cout;
-        if (srcs[s].ldo % 8 != 0 || srcs[s].cooff % 8 != 0 || srcs[s].ldo < srcs[s].cooff + srcs[s].cout ||
-            pixels * srcs[s].ldo * 2 >= 0x7fffffffll) return false;
+        if (srcs[s].ldo % 8 != 0 || srcs[s].cooff % 8 != 0 || srcs[s].ldo < srcs[s].cooff + srcs[s].cout || pixels >= 0x7fffffffll / 64) return false;
     }
     return din_wgrad::plan_wgrad_1x1_multi(nsrc, couts, cin, k);
 }
@@ -3385,7 +3384,7 @@ int din_conv1x1_wgrad_multi(int nsrc, const din_conv_wsrc* srcs, int dtype, int6
     DIN_REQUIRE(in && workspace, "conv1x1_wgrad_multi: null pointer");
     DIN_REQUIRE(wgrad_multi_plan(nsrc, srcs, dtype, pixels, cin, &k), "conv1x1_wgrad_multi: this group does not fit the kernel "
                 "(din_conv1x1_wgrad_multi_workspace returns 0 for it: run din_conv_wgrad per layer)");
-    DIN_REQUIRE(ldi % 8 == 0 && cioff % 8 == 0 && ldi >= cioff + cin && pixels * ldi * 2 < 0x7fffffffll, "conv1x1_wgrad_multi: bad input view");
+    DIN_REQUIRE(ldi % 8 == 0 && cioff % 8 == 0 && ldi >= cioff + cin, "conv1x1_wgrad_multi: bad input view");
     const int64_t need = (int64_t)WGRAD_HALO_GRID * k.rows_pad * cin * 4;
     if (workspace_bytes < need) DIN_FAIL(DIN_E_WORKSPACE, "conv1x1_wgrad_multi: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
     hipStream_t st = as_stream(stream);

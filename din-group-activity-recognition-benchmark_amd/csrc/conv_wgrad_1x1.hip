@@ -90,19 +90,27 @@ __global__ __launch_bounds__(1024, 1) void conv_wgrad_1x1_multi_kernel(Wg1x1K p)
     const int ntiles = (p.M + SPX - 1) / SPX;
     const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw;
     const uint32_t ldsW = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(wid * 1024));
-    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) + p.cioff * 2, 0,
-                                                                   (int)((long long)p.M * p.ldi * 2 - p.cioff * 2), 0x00020000);
-    __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src[gsrc].g), 0, (int)((long long)p.M * p.src[gsrc].ld * 2), 0x00020000);
+    // buffer resources are rebuilt per stage with the stage's first pixel as base (64-bit scalar arithmetic): tensors beyond 2 GiB
+    // (T = 10 clips: 320 frames) stay addressable with 32-bit lane offsets, and rows beyond M fall outside num_records -> zeros
+    const char* xbase = reinterpret_cast<const char*>(p.x) + p.cioff * 2;
+    const char* gbase = reinterpret_cast<const char*>(p.src[gsrc].g);
+    const long long xrow = (long long)p.ldi * 2, grow_b = (long long)p.src[gsrc].ld * 2;
 
     auto issue = [&](int buf, int tile) {
         const uint32_t dX = ldsW + (uint32_t)(buf * stage), dG = dX + (uint32_t)XBYTES;
-        const int m0 = tile * SPX;
+        const long long m0 = (long long)tile * SPX;
+        long long left = (long long)p.M - m0;
+        if (left > SPX) left = SPX;
+        __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xbase + m0 * xrow), 0, (int)(left * xrow - p.cioff * 2), 0x00020000);
 #pragma unroll
         for (int i = 0; i < NTR_X; ++i) {
-            if (wid + NW * i < NSLOT_X)                                // (wave-uniform; rows beyond M are out of the resource's range -> zeros)
-                lds_dma16(dX + (uint32_t)(i * 1024 * NW), rsX, relX[i] >= 0 ? m0 * p.ldi * 2 + relX[i] : (int)OOB, 0);
+            if (wid + NW * i < NSLOT_X)                                // (wave-uniform)
+                lds_dma16(dX + (uint32_t)(i * 1024 * NW), rsX, relX[i] >= 0 ? relX[i] : (int)OOB, 0);
         }
-        if (wid < nslot_g) lds_dma16(dG, rsG, relG >= 0 ? m0 * p.src[gsrc].ld * 2 + relG : (int)OOB, 0);
+        if (wid < nslot_g) {
+            __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(gbase + m0 * grow_b), 0, (int)(left * grow_b), 0x00020000);
+            lds_dma16(dG, rsG, relG >= 0 ? relG : (int)OOB, 0);
+        }
     };
     // transfers THIS wave issues per stage (wave-uniform): its share of the X image + at most one of the G image
     int ndma = wid < nslot_g ? 1 : 0;
