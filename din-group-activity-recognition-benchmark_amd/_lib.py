@@ -81,8 +81,8 @@ SIGNATURES: Dict[str, tuple] = {
     "din_bn_fold_bwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "din_bn_fold_multi": (_I, [_P, _P, _I, _I, _F, _P, _P, _P]),
     "din_bn_fold_bwd_multi": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P, _P]),
-    "din_bn_stats": (_I, [_P, _I, _L, _I, _I, _I, _P, _P]),
-    "din_bn_finalize": (_I, [_P, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "din_bn_stats": (_I, [_P, _I, _L, _I, _I, _I, _P, _P, _P]),
+    "din_bn_finalize": (_I, [_P, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "din_bn_apply": (_I, [_P, _I, _L, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P]),
     "din_bn_bwd_stats": (_I, [_P, _I, _I, _P, _I, _I, _I, _L, _I, _P, _P, _P, _P]),
     "din_bn_bwd_apply": (_I, [_P, _I, _I, _P, _I, _I, _I, _L, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),

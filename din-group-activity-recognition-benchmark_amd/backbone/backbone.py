@@ -66,15 +66,16 @@ class _GraphBackbone(nn.Module):
         graph, dt = self.graph_for(images.shape[2], images.shape[3])
         # BatchNorm mode as in torch: a BatchNorm2d module in training mode normalises with batch statistics and updates its running
         # statistics; `model.apply(set_bn_eval)` (train_net_dynamic.py:17-20) puts the modules in eval mode -> running statistics, folded
-        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        bns = getattr(self, "_bn_modules", None)
+        if bns is None:                                           # (cached: walking ~300 modules per step is host time on the small-batch step)
+            bns = self._bn_modules = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
         bn_train = any(m.training for m in bns)
         if bn_train and not all(m.training for m in bns):
             raise L.DinError("BatchNorm modules of one backbone must all be in the same mode (all train or all eval)")
         outs = NHWCGraphFunction.apply(graph, dt, images, prenormalised, bn_train, *self._ordered_params(graph))
         if bn_train:
-            with torch.no_grad():
-                for m in bns:
-                    m.num_batches_tracked += 1
+            with torch.no_grad():                                 # one launch for all ~94 counters instead of one each
+                torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
         if not isinstance(outs, tuple):
             outs = (outs,)
         return list(outs), graph

@@ -62,6 +62,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
         if (BWD) {
 #pragma unroll
             for (int e = 0; e < V; ++e) { mu[e] = mean[ch * V + e]; rs[e] = rstd[ch * V + e]; }
+        } else if (mean) {                                          // forward: sums of (x - shift), shift = the running mean before its update:
+#pragma unroll                                                      // E[(x-s)^2] - E[x-s]^2 does not cancel when |mean| >> std
+            for (int e = 0; e < V; ++e) mu[e] = mean[ch * V + e];
         }
         for (int64_t r = r0 + rl; r < r1; r += rpp) {
             float xv[V];
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
                 for (int e = 0; e < V; ++e) { s1[e] += gv[e]; s2[e] += gv[e] * ((xv[e] - mu[e]) * rs[e]); }
             } else {
 #pragma unroll
-                for (int e = 0; e < V; ++e) { s1[e] += xv[e]; s2[e] += xv[e] * xv[e]; }
+                for (int e = 0; e < V; ++e) { const float dv = xv[e] - mu[e]; s1[e] += dv; s2[e] += dv * dv; }
             }
         }
 #pragma unroll
@@ -86,11 +89,12 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t M, int C, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float* __restrict__ a, float* __restrict__ b, float* __restrict__ mean,
-                                   float* __restrict__ rstd) {
+                                   float* __restrict__ rstd, const float* __restrict__ shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double mu = sums[c] / (double)M;
-    double var = sums[C + c] / (double)M - mu * mu;                 // biased (normalisation) variance
+    const double ms = sums[c] / (double)M;                          // mean of (x - shift)
+    const double mu = ms + (shift ? (double)shift[c] : 0.0);
+    double var = sums[C + c] / (double)M - ms * ms;                 // biased (normalisation) variance
     if (var < 0.0) var = 0.0;
     const float r = (float)(1.0 / sqrt(var + (double)eps));
     mean[c] = (float)mu; rstd[c] = r;
@@ -164,27 +168,27 @@ int check_view(int dtype, int64_t rows, int c, int ld, int coff, const char* wha
 
 extern "C" {
 
-int din_bn_stats(const void* x, int dtype, int64_t rows, int c, int ld, int coff, double* sums, void* stream) {
+int din_bn_stats(const void* x, int dtype, int64_t rows, int c, int ld, int coff, const float* shift, double* sums, void* stream) {
     DIN_REQUIRE(x && sums, "bn_stats: null pointer");
     if (int e = check_view(dtype, rows, c, ld, coff, "bn_stats")) return e;
     const int blocks = (int)ceil_div64(rows, BN_ROWS_PER_BLOCK);
     const size_t lds = 2 * (size_t)c * sizeof(float);
     if (dtype == DIN_F32)
         hipLaunchKernelGGL((bn_stats_kernel<float, false>), dim3(blocks), dim3(256), lds, as_stream(stream), (const float*)x, ld, coff,
-                           (const float*)nullptr, 0, 0, (const float*)nullptr, (const float*)nullptr, rows, c, sums);
+                           (const float*)nullptr, 0, 0, shift, (const float*)nullptr, rows, c, sums);
     else
         hipLaunchKernelGGL((bn_stats_kernel<bf16_t, false>), dim3(blocks), dim3(256), lds, as_stream(stream), (const bf16_t*)x, ld, coff,
-                           (const bf16_t*)nullptr, 0, 0, (const float*)nullptr, (const float*)nullptr, rows, c, sums);
+                           (const bf16_t*)nullptr, 0, 0, shift, (const float*)nullptr, rows, c, sums);
     DIN_CHECK_LAUNCH("bn_stats");
     return DIN_OK;
 }
 
 int din_bn_finalize(const double* sums, int64_t rows, int c, const float* gamma, const float* beta, float eps, float momentum,
-                    float* running_mean, float* running_var, float* a, float* b, float* mean, float* rstd, void* stream) {
+                    float* running_mean, float* running_var, float* a, float* b, float* mean, float* rstd, const float* shift, void* stream) {
     DIN_REQUIRE(sums && gamma && beta && a && b && mean && rstd && rows > 0 && c > 0, "bn_finalize: bad argument");
     DIN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running_mean and running_var go together");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), sums, rows, c, gamma, beta, eps, momentum,
-                       running_mean, running_var, a, b, mean, rstd);
+                       running_mean, running_var, a, b, mean, rstd, shift);
     DIN_CHECK_LAUNCH("bn_finalize");
     return DIN_OK;
 }

@@ -423,9 +423,12 @@ def _bn_train_forward(lib, raw: torch.Tensor, dt: int, rows: int, cout: int, gam
     sums = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
     ab = torch.empty(4 * cout, dtype=torch.float32, device=dev)
     a, b, bmean, rstd = ab[:cout], ab[cout:2 * cout], ab[2 * cout:3 * cout], ab[3 * cout:]
-    L.check(lib.din_bn_stats(_ptr(raw), dt, rows, cout, cout, 0, _ptr(sums), st), "bn_stats")
+    # sums of (x - shift) with shift = the running mean before this step's update: no cancellation in E[x^2] - mean^2 (fp32 partial sums).
+    # The shift is a COPY: din_bn_finalize overwrites the running mean it also reads the shift from
+    shift = mean.clone()
+    L.check(lib.din_bn_stats(_ptr(raw), dt, rows, cout, cout, 0, _ptr(shift), _ptr(sums), st), "bn_stats")
     L.check(lib.din_bn_finalize(_ptr(sums), rows, cout, _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(var), _ptr(a), _ptr(b),
-                                _ptr(bmean), _ptr(rstd), st), "bn_finalize")
+                                _ptr(bmean), _ptr(rstd), _ptr(shift), st), "bn_finalize")
     L.check(lib.din_bn_apply(_ptr(raw), dt, rows, cout, cout, 0, _ptr(a), _ptr(b), int(relu), _ptr(dst), ldd, coffd, st), "bn_apply")
     return bmean, rstd
 

@@ -64,9 +64,11 @@ class FusedAdam:
     def _launch(self, live, step, g, grad_scale):
         dev = live[0].device
         key = tuple(id(p) for p in live)
-        slot = len(live)                                         # table cache slot: keyed by the group's size (stable across steps)
-        tb = self._tables.get(slot)
-        if tb is None or tb[0] != key:
+        slot = key                                               # table cache slot: the group's identity (two step-count groups of equal size
+        tb = self._tables.get(slot)                              # must not evict each other every step)
+        if tb is None:
+            if len(self._tables) > 8:                            # (groups change only when a parameter's first gradient arrives late)
+                self._tables.clear()
             sizes = torch.tensor([p.numel() for p in live], dtype=torch.int64)
             ct, ci = [], []
             for t, p in enumerate(live):

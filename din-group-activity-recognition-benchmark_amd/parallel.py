@@ -178,6 +178,11 @@ class GradBuckets:
         self._hook_order.append(key)
         if self._learned is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not self.force):
             return                                               # first step: only learn the order (single process: nothing to send)
+        if self._by_ptr[key].grad is not None and self._by_ptr[key].grad.data_ptr() != grad.data_ptr():
+            # a live .grad means the caller accumulates over micro-batches: the early all-reduce would send only THIS micro-batch's
+            # gradient and allreduce() would then replace the accumulated .grad with it
+            raise RuntimeError("parallel.GradBuckets: gradient accumulation (p.grad kept between backward passes) is not supported with the "
+                               "overlapped all-reduce; call optimizer.zero_grad() before every backward pass")
         self._got[key] = grad
         bi, _ = self._slot[key]
         if bi < self._early and bi not in self._inflight and all(q.data_ptr() in self._got for q in self.buckets[bi]):

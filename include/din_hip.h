@@ -192,16 +192,19 @@ int din_bn_fold_bwd_multi(const uint64_t* ptrs, const int32_t* offs, int n, int 
 /* BatchNorm with BATCH statistics: the reference's default for the Inception-v3 backbone in stage 2 -- model.train() without
  * set_bn_eval (train_net_dynamic.py:98-100,170-172; config.py:80) -> torch.nn.functional.batch_norm(training=True) inside torchvision's
  * BasicConv2d.  Views are [rows][c] with pixel stride ld and channel offset coff (elements; multiples of 4 fp32 / 8 bf16).
- *   din_bn_stats     : sums[0..c) += sum_rows x, sums[c..2c) += sum_rows x^2           (fp64 accumulators, zeroed by the caller)
+ *   din_bn_stats     : sums[0..c) += sum_rows (x - shift), sums[c..2c) += sum_rows (x - shift)^2   (fp64 accumulators, zeroed by the
+ *                      caller; shift [c] nullable = 0: pass the running mean -- the per-workgroup partial sums are fp32, and
+ *                      E[x^2] - mean^2 cancels when |mean| >> std; din_bn_finalize must get the SAME shift)
  *   din_bn_finalize  : mean, rstd = 1/sqrt(biased var + eps); a = gamma*rstd, b = beta - mean*a; running_mean/var (may be NULL) updated
  *                      in place with `momentum` and the unbiased variance, as torch does
  *   din_bn_apply     : y = a*x + b (relu != 0: max(.,0)) -- x and y may be views of different tensors
  *   din_bn_bwd_stats : sums[0..c) += sum gz, sums[c..2c) += sum gz*xhat, xhat = (x - mean)*rstd   (gz: gradient at the BN output,
  *                      already masked by the ReLU that follows)
  *   din_bn_bwd_apply : dy = gamma*rstd*(gz - s1/rows - xhat*s2/rows); dgamma = s2, dbeta = s1                                   */
-int din_bn_stats(const void* x, int dtype, int64_t rows, int c, int ld, int coff, double* sums, void* stream);
+int din_bn_stats(const void* x, int dtype, int64_t rows, int c, int ld, int coff, const float* shift, double* sums, void* stream);
 int din_bn_finalize(const double* sums, int64_t rows, int c, const float* gamma, const float* beta, float eps, float momentum,
-                    float* running_mean, float* running_var, float* a, float* b, float* mean, float* rstd, void* stream);
+                    float* running_mean, float* running_var, float* a, float* b, float* mean, float* rstd, const float* shift,
+                    void* stream);
 int din_bn_apply(const void* x, int dtype, int64_t rows, int c, int ldx, int cxoff, const float* a, const float* b, int relu,
                  void* y, int ldy, int cyoff, void* stream);
 int din_bn_bwd_stats(const void* gz, int ldg, int cgoff, const void* x, int ldx, int cxoff, int dtype, int64_t rows, int c,

@@ -947,8 +947,9 @@ def test_wgrad_pipe_kernel(env, case, atomic, waves, monkeypatch):
         assert rel(db, br.grad) <= 2e-3
 
 
+@pytest.mark.parametrize("offset", [0.4, 300.0], ids=["mean0.4", "mean300"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_batch_stat_bn_kernels(env, dtype):
+def test_batch_stat_bn_kernels(env, dtype, offset):
     """din_bn_stats / din_bn_finalize / din_bn_apply / din_bn_bwd_stats / din_bn_bwd_apply on channel views against torch's
     F.batch_norm(training=True) + ReLU in float64 (on the storage-rounded input): output, batch mean / rstd, running statistics
     (momentum 0.1, unbiased variance), dy, dgamma, dbeta."""
@@ -957,9 +958,11 @@ def test_batch_stat_bn_kernels(env, dtype):
     tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
     g = torch.Generator().manual_seed(7)
     rows, c, ldx, cxoff, ldy, cyoff = 4 * 37 * 53 + 5, 96, 112, 8, 160, 32
-    x = (torch.randn(rows, c, generator=g) * 1.7 + 0.4).to(tdt)
+    # offset 300: |mean| >> std -- the statistics are sums of (x - running mean), so E[.^2] - E[.]^2 does not cancel in the fp32 partial sums
+    # (without the shift the variance of this case is off by ~1e-3)
+    x = (torch.randn(rows, c, generator=g) * 1.7 + offset).to(tdt)
     gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2
-    rmean, rvar = torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5
+    rmean, rvar = torch.randn(c, generator=g) * 0.1 + (offset if offset > 1 else 0.0), torch.rand(c, generator=g) + 0.5
     cot = torch.randn(rows, c, generator=g).to(tdt)
     # reference in float64
     x64 = x.double().requires_grad_(True)
@@ -975,9 +978,10 @@ def test_batch_stat_bn_kernels(env, dtype):
     sums = torch.zeros(2 * c, dtype=torch.float64, device="cuda")
     a, b, mean, rstd = (torch.empty(c, device="cuda") for _ in range(4))
     gd, bd, rmd, rvd = gamma.cuda(), beta.cuda(), rmean.cuda(), rvar.cuda()
-    L.check(lib.din_bn_stats(xb.data_ptr(), dt, rows, c, ldx, cxoff, sums.data_ptr(), None))
+    shift = rmd.clone()
+    L.check(lib.din_bn_stats(xb.data_ptr(), dt, rows, c, ldx, cxoff, shift.data_ptr(), sums.data_ptr(), None))
     L.check(lib.din_bn_finalize(sums.data_ptr(), rows, c, gd.data_ptr(), bd.data_ptr(), 1e-3, 0.1, rmd.data_ptr(), rvd.data_ptr(), a.data_ptr(),
-                                b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None))
+                                b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), shift.data_ptr(), None))
     L.check(lib.din_bn_apply(xb.data_ptr(), dt, rows, c, ldx, cxoff, a.data_ptr(), b.data_ptr(), 1, yb.data_ptr(), ldy, cyoff, None))
     torch.cuda.synchronize()
     tol = 1e-5 if dtype == "fp32" else 6e-3                            # bf16: output rounding only (statistics are exact sums of bf16 values)
