@@ -505,10 +505,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
         for (int i = 0; i < PA; ++i) pixq[i] = (unsigned)(pixoff[i] + cq * 16);
         unsigned va[PA];
         int soffA = 0, soffB = 0;
+        const bool knockA = (p.flags & 0x200) != 0;
+        if (p.flags & 0x400) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) voffB[i] = (int)OOB;
+        }
         auto prepare = [&]() {                                     // offsets of the transfer for the walk's current step, then advance it
             const unsigned bit = 1u << tap;
 #pragma unroll
-            for (int i = 0; i < PA; ++i) va[i] = (vmask[i] & bit) ? pixq[i] + (unsigned)td : OOB;
+            for (int i = 0; i < PA; ++i) va[i] = ((vmask[i] & bit) && !knockA) ? pixq[i] + (unsigned)td : OOB;
             soffA = fa; soffB = fb;
             ++tap; ++tc; td += dB; fb += cpt16;
             if (tc == p.kw) { tc = 0; td += tap_row_wrap; }
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 if (ks + 1 < ks_end) lds_dma_stage<PA, PB, LR * KC * 16>(ldsA0 + (uint32_t)((cur ^ 1) * BUF * 16), rsA, va, soffA, rsB, voffB, soffB);
-                compute(cur);
+                if (!(p.flags & 0x800)) compute(cur);
                 prepare();
                 cur ^= 1;
             }
@@ -2768,6 +2773,9 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
     }
     k.splitk = g.splitk; k.ks_per_split = g.ks_per_split; k.n_co_tiles = g.n_co_tiles;
     if (const char* eb = getenv("DIN_CONV_EPI_BATCH")) { if (atoi(eb) == 0) k.flags |= 0x100; }
+    // timing experiments only (results are WRONG): DIN_GATHER_KNOCK bit 0 = the pixel-tile transfers of the scalar-walk loop fetch nothing
+    // (all lanes out of range: issued, landed as zeros, no cache / HBM access), bit 1 = the same for the filter tile, bit 2 = no MFMA
+    if (const char* kn = getenv("DIN_GATHER_KNOCK")) k.flags |= (atoi(kn) & 7) << 9;
     if (getenv("DIN_DEBUG_PLAN"))
         fprintf(stderr, "[din] %s M=%d NB=%d HxW=%dx%d Cin=%d Cout=%d k=%dx%d ay=%d cy=%d tile=%dx%d splitk=%d korder=%d remap=%d flags=%d dtype=%d\n", what,
                 k.M, k.NB, k.H, k.W, k.Cin, k.Cout, k.kh, k.kw, k.ay, k.cy, g.bm, g.bn, g.splitk, k.korder, k.remap, k.flags, dtype);
