@@ -2725,7 +2725,16 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
         if constexpr (sizeof(T) == 2) {
             if (bn == 96) launch_fast<T, 256, 96, 2, 2, 8, 2>(k, grid, st);
             else if (bn == 160) launch_fast<T, 256, 160, 2, 2, 8, 2>(k, grid, st);
-            else if (bn == 192) launch_fast<T, 256, 192, 4, 2, 8, 2>(k, grid, st);
+            else if (bn == 192) {
+                // experiment (DIN_CONV_W16=1 with DIN_CONV_TILE=256): sixteen waves as 8 x 2 on the 256 x 192 tile -- the 128 x 192 kernel's wave
+                // tile and four waves per SIMD, but ONE filter stage per 256 pixels: 64 instead of 80 LDS-DMA transfers per 256-pixel k-step
+                static const bool w16 = getenv("DIN_CONV_W16") && atoi(getenv("DIN_CONV_W16")) == 1;
+                const char* fv = getenv("DIN_CONV_FASTK");
+                const bool fastk = (fv ? atoi(fv) != 0 : true) && !k.remap && k.nsrc == 0 && (k.cpt % 8) == 0 && (k.korder || k.kh * k.kw == 1);
+                if (w16 && fastk) launch_fast<T, 256, 192, 8, 2, 8, 2, true>(k, grid, st);
+                else if (w16) launch_fast<T, 256, 192, 8, 2, 8, 2>(k, grid, st);
+                else launch_fast<T, 256, 192, 4, 2, 8, 2>(k, grid, st);
+            }
             else { if (pipe == 1) launch_fast<T, 256, 128, 4, 2, 4, 4>(k, grid, st); else launch_fast<T, 256, 128, 4, 2, 8, 2>(k, grid, st); }
         }
     }
