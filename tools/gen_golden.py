@@ -395,6 +395,16 @@ def model_case(name, refim, refcfg, out_dir, *, backbone, H, W, OH, OW, D, B, T,
     for k, v in ref_grads.items():
         if v.numel() <= full_grads_upto and "g." + k not in rec:
             rec["g." + k] = v.numpy()
+    if full_grads_upto and dtype == torch.float32 and not hier:
+        # yardstick for the stored gradients (as in full_case): the same model in float64, and how far the reference's fp32 run is from it
+        p64 = {k: v.double().requires_grad_("running_" not in k) for k, v in p.items()}
+        o64 = O.dynamic_volleyball_forward(ocfg, p64, images.double(), boxes.double())
+        F.cross_entropy(o64["activities"], labels).backward()
+        for k in list(rec):
+            if k.startswith("g.") and k[2:] in p64 and p64[k[2:]].grad is not None:
+                g64 = p64[k[2:]].grad
+                rec["g64." + k[2:]] = g64.float().numpy().copy()
+                rec["yard." + k[2:]] = np.float64(float((ref_grads[k[2:]].double() - g64).abs().max() / (g64.abs().max() + 1e-300)))
     np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
     print(f"[model] {name}: logits rel err {e:.2e}, worst grad rel err {eg:.2e}, loss {loss.item():.6f}")
 
@@ -719,7 +729,7 @@ def main():
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--skip-big", action="store_true")
-    ap.add_argument("--only", default="", help="'tce': only (re)generate the Dynamic_TCE_volleyball fixtures; 'full': only the two full-size 720x1280 fixtures")
+    ap.add_argument("--only", default="", help="'inv3': only the two reduced-size Inception fixtures; 'tce': only (re)generate the Dynamic_TCE_volleyball fixtures; 'full': only the two full-size 720x1280 fixtures")
     a = ap.parse_args()
     sys.dont_write_bytecode = True
     install_stubs()
@@ -745,6 +755,13 @@ def main():
         # no reduced-size fixture sees together (stem halo tiles, mid-network halo, pipelined wgrad, sibling pacing)
         full_case("full_inv3_720x1280_b1", refim, refcfg, a.out, backbone="inv3", OH=87, OW=157, D=1056, B=1, seed=400)
         full_case("full_vgg16_720x1280_cfg1_b2", refim, refcfg, a.out, backbone="vgg16", OH=22, OW=40, D=512, B=2, seed=401)
+    if a.only == "inv3":
+        f32 = torch.float32
+        model_case("model_inv3_139x203_nfb64", refim, refcfg, a.out, backbone="inv3", H=139, W=203, OH=15, OW=23,
+                   D=1056, B=1, T=3, N=6, NFB=64, kernels=[(3, 3)], ratios=[1], seed=104, full_grads_upto=9216)
+        model_case("model_inv3_139x203_lite128", refim, refcfg, a.out, backbone="inv3", H=139, W=203, OH=15, OW=23,
+                   D=1056, B=1, T=3, N=6, NFB=256, kernels=[(3, 3)], ratios=[1], lite=128, seed=105, full_grads_upto=9216)
+        return
     if a.only == "tce":
         tce_cases()
         return
