@@ -219,7 +219,7 @@ def main():
                          "to measure what it costs on the host and in copy kernels -- compare ms_per_step with and without")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step's forward + loss + backward from a captured HIP graph (din_amd.graph_step; the all-reduce and the "
-                         "optimizer stay eager calls).  auto: on for a single process whose share is <= 8 clips (the host-bound regime), off otherwise")
+                         "optimizer stay eager calls).  auto = off (measured: no gain at 4 clips, a loss on 80-frame VGG16 steps); on: opt in")
     ap.add_argument("--bn-mode", default="eval", choices=["eval", "batch"],
                     help="Inception BatchNorm: 'eval' = cfg.set_bn_eval (running statistics, folded; results independent of the GPU count), "
                          "'batch' = the reference's stage-2 default (batch statistics of the rank's frames + running-stat update)")
@@ -340,7 +340,9 @@ def main():
             survey, profiling.PROFILE = profiling.PROFILE, None
             if hbm is not None:
                 hbm.__exit__(None, None, None)
-    use_graph = a.graph == "on" or (a.graph == "auto" and world == 1 and B <= 8)
+    # auto = off: measured no gain where it was expected (4 clips: 10.27 -> 10.24 ms; the step is GPU-bound) and a 3x LOSS on the 80-frame VGG16
+    # workloads (T = 10, 8 clips: 172 -> 514 ms per step when replayed; profiles/r03_wgrad_stationary.txt) -- opt-in only
+    use_graph = a.graph == "on"
     if use_graph and not (a.forward_only or a.host_images or a.bn_mode == "batch") and a.warmup >= 2:
         from din_amd import graph_step
         try:
