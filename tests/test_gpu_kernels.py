@@ -601,6 +601,53 @@ def test_maxpool_strip_kernel_is_bit_identical(env, shape, monkeypatch):
     assert torch.equal(res[1][0].float().cpu().permute(0, 3, 1, 2), F.max_pool2d(x.float().cpu().permute(0, 3, 1, 2), 3, 2))
 
 
+@pytest.mark.parametrize("shape,ldi,cioff,ldo,cooff", [((2, 35, 47, 64), 64, 0, 64, 0), ((3, 16, 9, 192), 200, 8, 208, 16), ((1, 3, 3, 8), 8, 0, 8, 0),
+                                                       ((2, 36, 48, 32), 40, 8, 32, 0), ((1, 7, 600, 16), 16, 0, 16, 0)],
+                         ids=["ragged", "wide_views", "one_window", "even_uncovered_edge", "long_row"])
+def test_maxpool_row_kernels_are_bit_identical(env, shape, ldi, cioff, ldo, cooff, monkeypatch):
+    """the one-workgroup-per-row 3x3 / stride-2 max pool (forward: v_max3_f32 on (bf16 << 16) | (15 - tap) words; backward: scalar row bases)
+    returns the values, the arg-max bytes and the input gradients of the element-per-thread kernels (bytes and gradients bit for bit), on strided channel views, with
+    and without accumulation, and the forward matches F.max_pool2d"""
+    lib, L, nhwc, ops = env
+    nb, h, w, c = shape
+    oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+    g = torch.Generator().manual_seed(17)
+    xf = torch.randn(nb, h, w, c, generator=g)
+    xf[0, : h // 2] = xf[0, : h // 2].relu()                                     # ties at zero in one half, negative winners in the other
+    xf[-1, :, : w // 2] = -xf[-1, :, : w // 2].abs()
+    xbuf = torch.zeros(nb, h, w, ldi, dtype=torch.bfloat16, device="cuda")
+    xbuf[..., cioff:cioff + c] = xf.bfloat16().cuda()
+    gout = torch.zeros(nb, oh, ow, ldo, dtype=torch.bfloat16, device="cuda")
+    gout[..., cooff:cooff + c] = torch.randn(nb, oh, ow, c, generator=g).bfloat16().cuda()
+    base = torch.randn(nb, h, w, ldi, generator=g).bfloat16().cuda()
+    d = L.PoolDesc()
+    d.nb, d.h, d.w, d.c, d.oh, d.ow = nb, h, w, c, oh, ow
+    d.k, d.stride, d.pad, d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = 3, 2, 0, ldi, cioff, ldo, cooff, L.DIN_BF16
+    res = []
+    for mode in ("0", "2"):                                                       # never / always (the default leaves the wide maps' forward to the strip kernel)
+        monkeypatch.setenv("DIN_MAXPOOL_ROWS", mode)
+        monkeypatch.setenv("DIN_MAXPOOL_STRIP", "0")
+        out = torch.full((nb, oh, ow, ldo), 5.0, dtype=torch.bfloat16, device="cuda")
+        am = torch.full((nb, oh, ow, c), 77, dtype=torch.uint8, device="cuda")
+        L.check(lib.din_maxpool_fwd(C.byref(d), xbuf.data_ptr(), out.data_ptr(), am.data_ptr(), None))
+        dx0 = torch.full_like(xbuf, 3.0)
+        L.check(lib.din_maxpool_bwd(C.byref(d), None, am.data_ptr(), gout.data_ptr(), dx0.data_ptr(), 1, 0, None))
+        dx1 = base.clone()
+        L.check(lib.din_maxpool_bwd(C.byref(d), None, am.data_ptr(), gout.data_ptr(), dx1.data_ptr(), 1, 1, None))
+        torch.cuda.synchronize()
+        res.append((out, am, dx0, dx1))
+    # values: equal as numbers -- a window holding both -0.0 and +0.0 and nothing positive pools to whichever zero comes first in the scan
+    # kernels and to +0.0 in the max3 kernel (its arg-max byte is 255 either way); everything else: the same bits
+    assert torch.equal(res[0][0].float(), res[1][0].float()), "values"
+    for a, b, what in zip(res[0][1:], res[1][1:], ("arg-max bytes", "gradient", "accumulated gradient")):
+        assert torch.equal(a.view(torch.uint8) if a.dtype != torch.uint8 else a, b.view(torch.uint8) if b.dtype != torch.uint8 else b), what
+    want = F.max_pool2d(xf.bfloat16().float().permute(0, 3, 1, 2), 3, 2).permute(0, 2, 3, 1)
+    assert torch.equal(res[1][0][..., cooff:cooff + c].float().cpu(), want)
+    assert float((res[1][0][..., :cooff].float() - 5.0).abs().sum()) == 0.0      # channels outside the view untouched
+    if res[1][1].numel() > 64:
+        assert int((res[1][1] != 255).sum()) > 0 and int((res[1][1] == 255).sum()) > 0
+
+
 def test_prep_images_bit_exact(env):
     lib, L, nhwc, ops = env
     x = torch.arange(0, 256, dtype=torch.float32)

@@ -49,11 +49,15 @@ def main():
         yo = torch.empty(nb, oh, ow, c, device="cuda", dtype=bf)
         am = torch.empty(nb, oh, ow, c, device="cuda", dtype=torch.uint8)
         gi = torch.empty_like(xi)
-        ms = bench(lambda: L.check(lib.din_maxpool_fwd(C.byref(p), xi.data_ptr(), yo.data_ptr(), am.data_ptr(), None)))
         b1 = xi.numel() * 2 + yo.numel() * 3
-        print(f"maxpool fwd {c:3d}ch {h}x{w}: {ms * 1e3:8.1f} us  {b1 / ms / 1e9:6.2f} TB/s")
-        ms = bench(lambda: L.check(lib.din_maxpool_bwd(C.byref(p), xi.data_ptr(), am.data_ptr(), yo.data_ptr(), gi.data_ptr(), 1, 0, None)))
-        print(f"maxpool bwd {c:3d}ch {h}x{w}: {ms * 1e3:8.1f} us  {b1 / ms / 1e9:6.2f} TB/s")
+        for rows, nt, blk in (("0", "0", "256"), ("2", "0", "256"), ("2", "0", "1024")):
+            os.environ["DIN_MAXPOOL_ROWS"], os.environ["DIN_MAXPOOL_NT"], os.environ["DIN_MAXPOOL_BLOCK"] = rows, nt, blk
+            rows = f"{rows} nt={nt} block={blk:4s}"
+            ms = bench(lambda: L.check(lib.din_maxpool_fwd(C.byref(p), xi.data_ptr(), yo.data_ptr(), am.data_ptr(), None)))
+            print(f"maxpool fwd rows={rows} {c:3d}ch {h}x{w}: {ms * 1e3:8.1f} us  {b1 / ms / 1e9:6.2f} TB/s")
+            ms = bench(lambda: L.check(lib.din_maxpool_bwd(C.byref(p), xi.data_ptr(), am.data_ptr(), yo.data_ptr(), gi.data_ptr(), 1, 0, None)))
+            print(f"maxpool bwd rows={rows} {c:3d}ch {h}x{w}: {ms * 1e3:8.1f} us  {b1 / ms / 1e9:6.2f} TB/s")
+        os.environ.pop("DIN_MAXPOOL_ROWS")
     # 3x3 / 1 / pad 1 average pools behind the commuted branch_pool 1x1 convs: (channels, h, w, pixel stride of the destination view)
     for (c, h, w, ldo) in ((32, 87, 157, 256), (64, 87, 157, 288), (64, 87, 157, 1056), (192, 43, 78, 768)):
         p = L.PoolDesc()
