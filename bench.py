@@ -356,11 +356,22 @@ def main():
             opt.zero_grad()
     if os.environ.get("DIN_BENCH_TORCH_PROFILE"):          # tuning aid: which host-side torch ops launch the small fill / copy kernels
         from torch.profiler import profile, ProfilerActivity
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
             step()
             torch.cuda.synchronize()
         with open(os.environ["DIN_BENCH_TORCH_PROFILE"], "w") as f:
             f.write(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=200, max_shapes_column_width=90))
+            f.write("\n\n==== ATen ops that launch something, by call site ====\n")
+            sites = {}
+            for ev in prof.events():
+                if ev.device_type.name != "CPU" or not ev.name.startswith("aten::") or ev.self_device_time_total <= 0:
+                    continue
+                frames = [fr for fr in (ev.stack or []) if "din_amd" in fr or "din-group" in fr or "bench.py" in fr][:3]
+                key = (ev.name, str(ev.input_shapes)[:80], " <- ".join(fr.split("/")[-1] for fr in frames))
+                c = sites.setdefault(key, [0, 0.0])
+                c[0] += 1; c[1] += ev.self_device_time_total
+            for key, (n, us) in sorted(sites.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{n:4d} x {us:9.1f} us  {key[0]:28s} {key[1]:80s} {key[2]}\n")
 
     # calibrate what a HIP event pair adds around ONE launch (two marker packets; kernels otherwise run back to back):
     # per-launch cost of a trivial kernel bracketed individually minus its cost inside one long bracket

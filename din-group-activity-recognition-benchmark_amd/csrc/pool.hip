@@ -577,12 +577,12 @@ __global__ __launch_bounds__(256) void maxpool3s2_strip_kernel(din_pool_desc d, 
     }
 }
 
-// ---- 3x3 / stride 2 / pad 0 max pool, bf16, one workgroup per row ------------------------------------------------------------------------
+// ---- 3x3 / stride 2 / pad 0 max pool, bf16, workgroups inside rows ------------------------------------------------------------------------
 // The element-per-thread kernels above are VALU-bound, not HBM-bound, on the stem's big maps (measured: 3.7 - 5 TB/s where a plain
 // streaming kernel reaches 6.2): a three-level index decode plus 64-bit address arithmetic per tap (quarter-rate integer multiplies), and
 // compare + two selects per element and tap.  These two kernels take both away:
-//   * one workgroup = one output row (forward) / one pair of input rows (backward): every row base is a scalar, a thread only derives
-//     (x, channel group) from its position in the row -- one multiply-shift;
+//   * one workgroup = 256 items of one output row (forward) / of one pair of input rows (backward): every row base is a scalar, a thread
+//     only derives (x, channel group) from its position in the row -- one multiply-shift; one item per thread, no loop;
 //   * forward: a tap's bf16 becomes the fp32 word (bf16 << 16) | (15 - tap), so ONE v_max3_f32 folds two taps into the running maximum
 //     and carries the arg-max with it: among equal bf16 values the larger payload = the earlier tap wins (PyTorch's first-maximum rule);
 //     for winners <= 0 the payload is not used (the map stores 255 there), and the pooled value is the word's upper half either way.
@@ -599,16 +599,19 @@ __device__ __forceinline__ uint32_t max3_f32_bits(uint32_t a, uint32_t b, uint32
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void maxpool3s2_row_fwd_kernel(din_pool_desc d, FastDiv cgd, const bf16_t* __restrict__ in,
                                                                    bf16_t* __restrict__ out, uint8_t* __restrict__ amax) {
-    const int row = xcd_remap((int)blockIdx.x, (int)gridDim.x);           // (n, oy)
+    // one item per thread, no loop: a wave that loops waits for its previous stores before its next loads return (gfx9 counts both in vmcnt)
+    const int cgs = d.c >> 3, items = d.ow * cgs, chunks = (items + BLOCK - 1) / BLOCK;
+    const int lin = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int row = lin / chunks, chunk = lin - row * chunks;             // row = (n, oy)
     const int n = row / d.oh, oy = row - n * d.oh;
-    const int cgs = d.c >> 3, items = d.ow * cgs;
     const char* rp[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) rp[r] = (const char*)(in + ((int64_t)(n * d.h + 2 * oy + r) * d.w) * d.ldi + d.cioff);
     char* orow = (char*)(out + (int64_t)row * d.ow * d.ldo + d.cooff);
     uint8_t* arow = amax ? amax + (int64_t)row * d.ow * d.c : nullptr;
     const uint32_t pix = (uint32_t)d.ldi * 2u;                             // bytes per input pixel
-    for (int j = threadIdx.x; j < items; j += BLOCK) {
+    const int j = chunk * BLOCK + (int)threadIdx.x;
+    if (j < items) {
         const uint32_t ox = fdiv((uint32_t)j, cgd), cg = (uint32_t)j - ox * (uint32_t)cgs;
         const uint32_t off = ox * 2u * pix + cg * 16u;
         uint4 t[3][3];
@@ -650,13 +653,19 @@ __global__ __launch_bounds__(BLOCK) void maxpool3s2_row_fwd_kernel(din_pool_desc
 
 // Backward from the arg-max map: a workgroup owns input rows (2 by, 2 by + 1) of one frame; a thread a 2x2 pixel block x 8 channels, as in
 // maxpool_bwd_amax_k3s2_kernel (same window visit order: the fp32 sums round identically).
+// One item per thread, no loop (grid = rows x chunks of BLOCK items).  Measured alternatives (tools/pool_bench.py, 64-channel map): a row walk per
+// workgroup 814 us, the same walk with the next item's windows requested before the current item's arithmetic and stores (ping-pong registers,
+// 98 VGPRs) 869 us, one item per thread 769 us.  Knock-outs of this kernel: stores only 438 us, loads only 344 us, arithmetic only 390 us.
+typedef uint32_t pool_u32x4 __attribute__((ext_vector_type(4)));
+template <bool ACC> struct PoolWin { uint2 am[4]; uint4 go[4]; uint4 prev[ACC ? 4 : 1]; };
 template <int BLOCK, bool ACC>
 __global__ __launch_bounds__(BLOCK, ACC ? 5 : 8) void maxpool3s2_row_bwd_kernel(din_pool_desc d, FastDiv cgd, const uint8_t* __restrict__ amax,
                                                                       const bf16_t* __restrict__ dout, bf16_t* __restrict__ din_) {
     const int hb = (d.h + 1) >> 1, wb = (d.w + 1) >> 1;
-    const int row = xcd_remap((int)blockIdx.x, (int)gridDim.x);           // (n, by)
+    const int cgs = d.c >> 3, items = wb * cgs, chunks = (items + BLOCK - 1) / BLOCK;
+    const int lin = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int row = lin / chunks, chunk = lin - row * chunks;             // row = (n, by)
     const int n = row / hb, by = row - n * hb;
-    const int cgs = d.c >> 3, items = wb * cgs;
     const uint8_t* arow[2]; const char* grow[2]; bool rok[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -666,54 +675,57 @@ __global__ __launch_bounds__(BLOCK, ACC ? 5 : 8) void maxpool3s2_row_bwd_kernel(
         arow[a] = amax + po * d.c;
         grow[a] = (const char*)(dout + po * d.ldo + d.cooff);
     }
-    char* irow[2]; bool iok[2];
+    // the gradient rows as buffer resources: a pixel beyond the row (odd widths) or a row beyond the image (odd heights) is an out-of-range
+    // offset / an empty resource, and the hardware drops the store -- every thread issues the same four stores, no branch around them
+    char* irow[2]; __amdgpu_buffer_rsrc_t irs[2];
+    const int row_bytes = d.w * d.ldi * 2 - d.cioff * 2;
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
         const int iy = 2 * by + dy;
-        iok[dy] = iy < d.h;
         irow[dy] = (char*)(din_ + ((int64_t)(n * d.h + min(iy, d.h - 1)) * d.w) * d.ldi + d.cioff);
+        irs[dy] = __builtin_amdgcn_make_buffer_rsrc(irow[dy], 0, iy < d.h ? row_bytes : 0, 0x00020000);
     }
     const uint32_t ipix = (uint32_t)d.ldi * 2u, opix = (uint32_t)d.ldo * 2u;
-    for (int j = threadIdx.x; j < items; j += BLOCK) {
+    auto fetch = [&](int j, PoolWin<ACC>& w) {                                         // raw loads only: nothing here waits for them
         const uint32_t bx = fdiv((uint32_t)j, cgd), cg = (uint32_t)j - bx * (uint32_t)cgs;
-        uint32_t pk[4][2]; uint4 go[4];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const uint32_t oxc = (uint32_t)min(max((int)bx - 1 + b, 0), d.ow - 1);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                w.am[a * 2 + b] = *reinterpret_cast<const uint2*>(arow[a] + (oxc * (uint32_t)d.c + cg * 8u));
+                w.go[a * 2 + b] = *reinterpret_cast<const uint4*>(grow[a] + (oxc * opix + cg * 16u));
+            }
+        }
+        if (ACC) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                w.prev[p] = *reinterpret_cast<const uint4*>(irow[p >> 1] + (min(2u * bx + (uint32_t)(p & 1), (uint32_t)d.w - 1u) * ipix + cg * 16u));
+        }
+    };
+    auto finish = [&](int j, const PoolWin<ACC>& w) {
+        const uint32_t bx = fdiv((uint32_t)j, cgd), cg = (uint32_t)j - bx * (uint32_t)cgs;
+        uint32_t pk[4][2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int ox = (int)bx - 1 + b;
             const bool cok = ox >= 0 && ox < d.ow;
-            const uint32_t oxc = (uint32_t)min(max(ox, 0), d.ow - 1);
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                const uint2 am = *reinterpret_cast<const uint2*>(arow[a] + (oxc * (uint32_t)d.c + cg * 8u));
-                go[a * 2 + b] = *reinterpret_cast<const uint4*>(grow[a] + (oxc * opix + cg * 16u));
                 const bool ok = cok && rok[a];
-                pk[a * 2 + b][0] = ok ? am.x : 0xfefefefeu;                // 254: a tap no window records
-                pk[a * 2 + b][1] = ok ? am.y : 0xfefefefeu;
+                pk[a * 2 + b][0] = ok ? w.am[a * 2 + b].x : 0xfefefefeu;          // 254: a tap no window records
+                pk[a * 2 + b][1] = ok ? w.am[a * 2 + b].y : 0xfefefefeu;
             }
         }
         // two channels (one gradient dword) at a time across the four pixels: few live registers, no divergent control flow before the stores
         uint32_t od[4][4];                                                        // [pixel dy * 2 + dx][dword]
-        char* pp[4]; bool pok[4];
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                const uint32_t ix = min(2u * bx + (uint32_t)dx, (uint32_t)d.w - 1u);
-                pok[dy * 2 + dx] = iok[dy] && (int)(2u * bx) + dx < d.w;
-                pp[dy * 2 + dx] = irow[dy] + (ix * ipix + cg * 16u);
-            }
-        uint4 prev[ACC ? 4 : 1];
-        if (ACC) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) prev[p] = *reinterpret_cast<const uint4*>(pp[p]);
-        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float f[4][2];
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const uint32_t x = q == 0 ? go[w].x : q == 1 ? go[w].y : q == 2 ? go[w].z : go[w].w;
-                f[w][0] = __uint_as_float(x << 16); f[w][1] = __uint_as_float(x & 0xffff0000u);
+            for (int v = 0; v < 4; ++v) {
+                const uint32_t x = q == 0 ? w.go[v].x : q == 1 ? w.go[v].y : q == 2 ? w.go[v].z : w.go[v].w;
+                f[v][0] = __uint_as_float(x << 16); f[v][1] = __uint_as_float(x & 0xffff0000u);
             }
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
@@ -731,7 +743,7 @@ __global__ __launch_bounds__(BLOCK, ACC ? 5 : 8) void maxpool3s2_row_bwd_kernel(
                             g1 += ((word >> (16 * (q & 1) + 8)) & 0xffu) == tap ? f[a * 2 + b][1] : 0.f;
                         }
                     if (ACC) {
-                        const uint4& o = prev[ACC ? dy * 2 + dx : 0];
+                        const uint4& o = w.prev[ACC ? dy * 2 + dx : 0];
                         const uint32_t x = q == 0 ? o.x : q == 1 ? o.y : q == 2 ? o.z : o.w;
                         g0 += __uint_as_float(x << 16); g1 += __uint_as_float(x & 0xffff0000u);
                     }
@@ -740,8 +752,11 @@ __global__ __launch_bounds__(BLOCK, ACC ? 5 : 8) void maxpool3s2_row_bwd_kernel(
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-            if (pok[p]) *reinterpret_cast<uint4*>(pp[p]) = uint4{od[p][0], od[p][1], od[p][2], od[p][3]};
-    }
+            __builtin_amdgcn_raw_buffer_store_b128(pool_u32x4{od[p][0], od[p][1], od[p][2], od[p][3]}, irs[p >> 1],
+                                                   (int)((2u * bx + (uint32_t)(p & 1)) * ipix + cg * 16u), 0, 0);
+    };
+    const int j = chunk * BLOCK + (int)threadIdx.x;
+    if (j < items) { PoolWin<ACC> w; fetch(j, w); finish(j, w); }
 }
 
 // ---- bilinear resize, align_corners=True (infer_model.py:169): src = dst*(in-1)/(out-1) -----------------------------------------
@@ -924,13 +939,12 @@ int check_pool(const din_pool_desc* d, const char* what) {
 }
 inline int avgpool_strip_rows() { const char* e = getenv("DIN_AVGPOOL_STRIP"); return e ? atoi(e) : 1; }   // 0: one thread per output (round 1)
 inline bool is_box3(const din_pool_desc* d) { return d->k == 3 && d->stride == 1 && d->pad == 1 && d->oh == d->h && d->ow == d->w; }
-constexpr int POOL_GRID_CAP = 32768;
 inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 inline bool maxpool_rows() { const char* e = getenv("DIN_MAXPOOL_ROWS"); return e ? atoi(e) != 0 : true; }
 
 }  // namespace
 
-#define POOL_LAUNCH(kern, total, ...) hipLaunchKernelGGL(kern, dim3(grid_1d(total, 256, POOL_GRID_CAP)), dim3(256), 0, as_stream(stream), __VA_ARGS__)
+#define POOL_LAUNCH(kern, total, ...) hipLaunchKernelGGL(kern, dim3(grid_1d(total, 256, env_int("DIN_POOL_GRID_CAP", 32768))), dim3(256), 0, as_stream(stream), __VA_ARGS__)
 
 extern "C" {
 
@@ -945,16 +959,12 @@ int din_maxpool_fwd(const din_pool_desc* d, const void* in, void* out, uint8_t* 
     // DIN_MAXPOOL_STRIP=0 / 2: never / always
     const char* ms = getenv("DIN_MAXPOOL_STRIP");
     const int strip_mode = ms ? atoi(ms) : 1;
-    // row kernel (scalar row bases, max3 with the tap in the low mantissa bits): tools/pool_bench.py; DIN_MAXPOOL_ROWS=0: the kernels below
+    // row kernels (scalar row bases, max3 with the tap in the low mantissa bits): tools/pool_bench.py; DIN_MAXPOOL_ROWS=0: the kernels below
     const bool strip = v == 8 && d->k == 3 && d->stride == 2 && strip_mode != 0 && (d->c >= 128 || strip_mode == 2);
-    const int rows_mode = env_int("DIN_MAXPOOL_ROWS", 1);      // 1: where the strip kernel is not taken (measured: 64 ch 858 -> 733 us; 192 ch 540 vs 555), 2: always
-    if (v == 8 && d->k == 3 && d->stride == 2 && d->pad == 0 && 2 * d->oh + 1 <= d->h && 2 * d->ow + 1 <= d->w &&
-        (rows_mode == 2 || (rows_mode == 1 && !strip))) {
-        if (env_int("DIN_MAXPOOL_BLOCK", 1024) == 1024)      // measured: 1024 threads per row 2 - 3 % faster than 256 on all three maps
-            hipLaunchKernelGGL(maxpool3s2_row_fwd_kernel<1024>, dim3(d->nb * d->oh), dim3(1024), 0, as_stream(stream), *d, make_fastdiv(d->c / 8),
-                               (const bf16_t*)in, (bf16_t*)out, argmax);
-        else
-            hipLaunchKernelGGL(maxpool3s2_row_fwd_kernel<256>, dim3(d->nb * d->oh), dim3(256), 0, as_stream(stream), *d, make_fastdiv(d->c / 8),
+    // measured (same box, us): 64 ch 851 -> 653, 192 ch 539 (strip) -> 502, 288 ch 207 (strip) -> 182
+    if (v == 8 && d->k == 3 && d->stride == 2 && d->pad == 0 && 2 * d->oh + 1 <= d->h && 2 * d->ow + 1 <= d->w && maxpool_rows()) {
+        const int items = d->ow * (d->c / 8);
+        hipLaunchKernelGGL(maxpool3s2_row_fwd_kernel<256>, dim3(d->nb * d->oh * ((items + 255) / 256)), dim3(256), 0, as_stream(stream), *d, make_fastdiv(d->c / 8),
                                (const bf16_t*)in, (bf16_t*)out, argmax);
         DIN_CHECK_LAUNCH("maxpool_fwd");
         return DIN_OK;
@@ -991,17 +1001,12 @@ int din_maxpool_bwd(const din_pool_desc* d, const void* in, const uint8_t* argma
         if (d->k == 3 && d->stride == 2 && d->pad == 0) {
             const int hb = (d->h + 1) / 2, wb = (d->w + 1) / 2;
             if (v == 8 && maxpool_rows()) {
-                        const dim3 grid(d->nb * hb);
+                        const int items = wb * (d->c / 8);
                 const FastDiv cgd = make_fastdiv(d->c / 8);
                 const bf16_t* go = (const bf16_t*)dout; bf16_t* gi = (bf16_t*)din_;
-                // 1024 threads per row where a row holds >= 32 channel groups (measured, tools/pool_bench.py: 288 ch 246 -> 228 us; 64 ch 763 -> 771)
-                if (env_int("DIN_MAXPOOL_BLOCK", d->c >= 256 ? 1024 : 256) == 1024) {
-                    if (accumulate) hipLaunchKernelGGL((maxpool3s2_row_bwd_kernel<1024, true>), grid, dim3(1024), 0, as_stream(stream), *d, cgd, argmax, go, gi);
-                    else hipLaunchKernelGGL((maxpool3s2_row_bwd_kernel<1024, false>), grid, dim3(1024), 0, as_stream(stream), *d, cgd, argmax, go, gi);
-                } else {
-                    if (accumulate) hipLaunchKernelGGL((maxpool3s2_row_bwd_kernel<256, true>), grid, dim3(256), 0, as_stream(stream), *d, cgd, argmax, go, gi);
-                    else hipLaunchKernelGGL((maxpool3s2_row_bwd_kernel<256, false>), grid, dim3(256), 0, as_stream(stream), *d, cgd, argmax, go, gi);
-                }
+                const dim3 grid(d->nb * hb * ((items + 255) / 256));
+                if (accumulate) hipLaunchKernelGGL((maxpool3s2_row_bwd_kernel<256, true>), grid, dim3(256), 0, as_stream(stream), *d, cgd, argmax, go, gi);
+                else hipLaunchKernelGGL((maxpool3s2_row_bwd_kernel<256, false>), grid, dim3(256), 0, as_stream(stream), *d, cgd, argmax, go, gi);
                 DIN_CHECK_LAUNCH("maxpool_bwd");
                 return DIN_OK;
             }

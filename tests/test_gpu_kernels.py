@@ -590,6 +590,7 @@ def test_maxpool_strip_kernel_is_bit_identical(env, shape, monkeypatch):
     d.nb, d.h, d.w, d.c, d.oh, d.ow = nb, h, w, c, oh, ow
     d.k, d.stride, d.pad, d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = 3, 2, 0, c, 0, c, 0, L.DIN_BF16
     res = []
+    monkeypatch.setenv("DIN_MAXPOOL_ROWS", "0")                                   # (the row kernel would take these launches first)
     for mode in ("0", "2"):                                                       # never / always (the default picks by channel count)
         monkeypatch.setenv("DIN_MAXPOOL_STRIP", mode)
         out = torch.full((nb, oh, ow, c), float("nan"), dtype=torch.bfloat16, device="cuda")
@@ -624,7 +625,7 @@ def test_maxpool_row_kernels_are_bit_identical(env, shape, ldi, cioff, ldo, coof
     d.nb, d.h, d.w, d.c, d.oh, d.ow = nb, h, w, c, oh, ow
     d.k, d.stride, d.pad, d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = 3, 2, 0, ldi, cioff, ldo, cooff, L.DIN_BF16
     res = []
-    for mode in ("0", "2"):                                                       # never / always (the default leaves the wide maps' forward to the strip kernel)
+    for mode in ("0", "1"):                                                       # element-per-thread kernels / row kernels (the default)
         monkeypatch.setenv("DIN_MAXPOOL_ROWS", mode)
         monkeypatch.setenv("DIN_MAXPOOL_STRIP", "0")
         out = torch.full((nb, oh, ow, ldo), 5.0, dtype=torch.bfloat16, device="cuda")

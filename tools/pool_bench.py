@@ -50,9 +50,8 @@ def main():
         am = torch.empty(nb, oh, ow, c, device="cuda", dtype=torch.uint8)
         gi = torch.empty_like(xi)
         b1 = xi.numel() * 2 + yo.numel() * 3
-        for rows, nt, blk in (("0", "0", "256"), ("2", "0", "256"), ("2", "0", "1024")):
-            os.environ["DIN_MAXPOOL_ROWS"], os.environ["DIN_MAXPOOL_NT"], os.environ["DIN_MAXPOOL_BLOCK"] = rows, nt, blk
-            rows = f"{rows} nt={nt} block={blk:4s}"
+        for rows in ("0", "1"):                                   # element-per-thread (+ strip) kernels / row kernels
+            os.environ["DIN_MAXPOOL_ROWS"] = rows
             ms = bench(lambda: L.check(lib.din_maxpool_fwd(C.byref(p), xi.data_ptr(), yo.data_ptr(), am.data_ptr(), None)))
             print(f"maxpool fwd rows={rows} {c:3d}ch {h}x{w}: {ms * 1e3:8.1f} us  {b1 / ms / 1e9:6.2f} TB/s")
             ms = bench(lambda: L.check(lib.din_maxpool_bwd(C.byref(p), xi.data_ptr(), am.data_ptr(), yo.data_ptr(), gi.data_ptr(), 1, 0, None)))
@@ -66,14 +65,15 @@ def main():
         xi = torch.randn(nb, h, w, c, device="cuda").to(bf)
         yo = torch.empty(nb, h, w, ldo, device="cuda", dtype=bf)
         bias = torch.randn(c, device="cuda")
-        ms = bench(lambda: L.check(lib.din_avgpool_fwd(C.byref(p), xi.data_ptr(), yo.data_ptr(), bias.data_ptr(), L.CONV_BIAS | L.CONV_RELU, None)))
-        b1 = xi.numel() * 4
-        print(f"avgpool fwd {c:3d}ch {h}x{w} ldo {ldo}: {ms * 1e3:8.1f} us  {b1 / ms / 1e9:6.2f} TB/s")
         q = L.PoolDesc()        # backward: dout is the strided view, din the dense conv output gradient
         q.nb, q.h, q.w, q.c, q.oh, q.ow = nb, h, w, c, h, w
         q.k, q.stride, q.pad, q.ldi, q.cioff, q.ldo, q.cooff, q.dtype = 3, 1, 1, c, 0, ldo, ldo - c, L.DIN_BF16
-        ms = bench(lambda: L.check(lib.din_avgpool_bwd(C.byref(q), yo.data_ptr(), xi.data_ptr(), None, 0, None)))
-        print(f"avgpool bwd {c:3d}ch {h}x{w} ldo {ldo}: {ms * 1e3:8.1f} us  {b1 / ms / 1e9:6.2f} TB/s")
+        b1 = xi.numel() * 4
+        for cap in ("32768",):
+            ms = bench(lambda: L.check(lib.din_avgpool_fwd(C.byref(p), xi.data_ptr(), yo.data_ptr(), bias.data_ptr(), L.CONV_BIAS | L.CONV_RELU, None)))
+            print(f"avgpool fwd cap={cap:10s} {c:3d}ch {h}x{w} ldo {ldo}: {ms * 1e3:8.1f} us  {b1 / ms / 1e9:6.2f} TB/s")
+            ms = bench(lambda: L.check(lib.din_avgpool_bwd(C.byref(q), yo.data_ptr(), xi.data_ptr(), None, 0, None)))
+            print(f"avgpool bwd cap={cap:10s} {c:3d}ch {h}x{w} ldo {ldo}: {ms * 1e3:8.1f} us  {b1 / ms / 1e9:6.2f} TB/s")
 
 
 if __name__ == "__main__":
