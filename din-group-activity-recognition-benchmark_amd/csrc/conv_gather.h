@@ -35,6 +35,10 @@ struct ConvK {
     const unsigned char* u8;        // image layer only: raw uint8 frames [NB][3][H][W], normalised on load (din_conv_desc::in_u8)
 };
 
+// host entries of conv_stream.hip: persistent streaming kernel for 1x1 convolutions with a short reduction (ring kept full across tiles)
+bool conv1x1_stream_eligible(const ConvK& k, int dtype);
+int launch_conv1x1_stream(ConvK k, hipStream_t st);
+
 __device__ __forceinline__ int64_t out_pixel(const ConvK& p, int m) {
     if (p.out_sy == 0) return m;
     int n = m / (p.OH * p.OW);

@@ -2794,6 +2794,11 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
             DIN_FAIL(DIN_E_WORKSPACE, "%s: workspace %lld < %lld bytes", what, (long long)ws_bytes, (long long)g.ws_bytes);
         k.partial = reinterpret_cast<float*>(workspace);
     }
+    if (fast && g.splitk == 1 && k.nsrc == 0 && din_gather::conv1x1_stream_eligible(k, dtype)) {
+        // 1x1 layers with a short reduction over a large map: persistent streaming kernel (conv_stream.hip)
+        if (din_gather::launch_conv1x1_stream(k, st)) DIN_FAIL(DIN_E_LAUNCH, "%s: conv1x1_stream launch failed", what);
+        return DIN_OK;
+    }
     {
         // mid-network multi-tap layers: halo tiles + filter-slab ring (conv_halo_kernel); the stem shapes keep their own kernel below
         HaloPlan hp;
@@ -3011,6 +3016,20 @@ int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t
         const int64_t M = which == 0 ? (int64_t)d->nb * d->oh * d->ow : (int64_t)d->nb * d->h * d->w;
         const int oh_ = which == 0 ? d->oh : d->h, ow_ = which == 0 ? d->ow : d->w;
         if (d->sh == 1 && d->sw == 1 && d->dh == 1 && d->dw == 1 && g.splitk == 1 && plan_halo(d->dtype, d->kh, d->kw, cred, cprod, oh_, ow_, M, hp)) { *bm = 1; *bn = hp.bn; }
+    }
+    {   // 1x1 layers with a short reduction over a large map run conv1x1_stream_kernel (conv_stream.hip): bm = 4
+        // (same conditions as din_gather::conv1x1_stream_eligible, evaluated on the descriptor)
+        const char* sv = getenv("DIN_CONV_STREAM");
+        const int mode = sv ? atoi(sv) : 1;
+        const int cred = which == 0 ? d->cin : d->cout, cprod = which == 0 ? d->cout : d->cin;
+        const int64_t M = which == 0 ? (int64_t)d->nb * d->oh * d->ow : (int64_t)d->nb * d->h * d->w;
+        const int ldr = which == 0 ? d->ldi : d->ldo, offr = which == 0 ? d->cioff : d->cooff;
+        const int ldp = which == 0 ? d->ldo : d->ldi, offp = which == 0 ? d->cooff : d->cioff;
+        const int blocks = (pad_to(cred, 8) / 8 + 7) / 8;
+        if (mode && d->dtype == DIN_BF16 && d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 && !d->in_u8 &&
+            g.splitk == 1 && cprod % 8 == 0 && ldp % 8 == 0 && offp % 8 == 0 && ldr % 8 == 0 && offr % 8 == 0 &&
+            M * ldr * 2 < 0x7fffffffll && M * ldp * 2 < 0x7fffffffll && pad_to(cprod, cprod <= 64 ? 64 : 96) * 4 <= 2048 &&
+            (mode == 2 || (blocks <= 6 && M >= 256 * 1024 && cprod <= 96))) { *bm = 4; *bn = cprod <= 64 ? 64 : 96; }
     }
     {   // stem layers run conv_small_kernel (same conditions as run_gather, for tensors with 16-byte aligned channel offsets): bm = 0
         const int cred = which == 0 ? d->cin : d->cout, cprod = which == 0 ? d->cout : d->cin;
@@ -3233,6 +3252,10 @@ int din_conv1x1_dgrad_multi(int nsrc, const din_conv_src* srcs, int dtype, int n
     g.bm = 128; g.n_px_tiles = (k.M + 127) / 128; g.n_co_tiles = (cin + g.bn - 1) / g.bn;
     k.cpt = KC; k.Q = steps * KC; k.nk = steps; k.wld = k.src[0].wld;
     k.splitk = 1; k.ks_per_split = steps; k.n_co_tiles = g.n_co_tiles; k.remap = 0; k.korder = 0;
+    if (din_gather::conv1x1_stream_eligible(k, dtype)) {
+        if (din_gather::launch_conv1x1_stream(k, as_stream(stream))) DIN_FAIL(DIN_E_LAUNCH, "conv1x1_dgrad_multi: conv1x1_stream launch failed");
+        return DIN_OK;
+    }
     if (dtype == DIN_F32) launch_gather<float>(k, g.n_px_tiles, 128, g.bn, as_stream(stream));
     else launch_gather<bf16_t>(k, g.n_px_tiles, 128, g.bn, as_stream(stream));
     DIN_CHECK_LAUNCH("conv1x1_dgrad_multi");

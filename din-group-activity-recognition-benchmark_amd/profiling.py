@@ -150,6 +150,8 @@ class LaunchTimer:
             if bn.value >= 1000:
                 return f"conv_wgrad_ring_kernel<{bm.value}, {bn.value - 1000}>"
             return f"conv_wgrad_bf16_kernel<{bm.value}>" if d.dtype == L.DIN_BF16 else "conv_wgrad_f32_kernel"
+        if bm.value == 4 and not (self.kind == "dgrad" and "+" in self.name):
+            return f"conv1x1_stream_kernel<{bn.value}>"
         if bm.value == 0:
             return f"conv_small_kernel<..., {bn.value}, ...>"
         if bm.value == 1:

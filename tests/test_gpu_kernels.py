@@ -79,6 +79,12 @@ CONV_CASES = [
     ("gp256_3x3_p0", 2, 64, 83, 79, 512, (3, 3), (1, 1), (0, 0), 1),          # DIN_CONV_BN=256: the 256-filter tile (VGG conv3+)
     ("gp192_dgrad_3x3", 4, 192, 80, 78, 192, (3, 3), (1, 1), (1, 1), 1),
     ("gp128_5x5_176", 4, 64, 80, 78, 176, (5, 5), (1, 1), (2, 2), 1),
+    # persistent streaming 1x1 kernel (conv1x1_stream_kernel<96 | 64>, bf16; forced on these small maps with DIN_CONV_STREAM=2): ragged last pixel
+    # tile, one / several / partial 64-channel blocks, one to three filter tiles, a filter tile wider than the bank, fwd and dgrad (+ mask, accumulate)
+    ("st_64_80", 3, 64, 37, 41, 80, (1, 1), (1, 1), (0, 0), 1),
+    ("st_288_176", 2, 288, 35, 45, 176, (1, 1), (1, 1), (0, 0), 1),
+    ("st_48_8", 1, 48, 19, 23, 8, (1, 1), (1, 1), (0, 0), 1),
+    ("st_192_64_long", 8, 192, 87, 157, 64, (1, 1), (1, 1), (0, 0), 1),      # > 256 items: every workgroup walks several
 ]
 
 
@@ -90,6 +96,8 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
     if name.startswith("halo_"):
         monkeypatch.setenv("DIN_CONV_HALO", "2")        # the planner only picks the halo kernel where it wins; cover every instantiation
         monkeypatch.setenv("DIN_WGRAD_HALO", "2")       # ... and the halo weight-gradient kernel only on launches of >= 256K pixels
+    if name.startswith("st_"):
+        monkeypatch.setenv("DIN_CONV_STREAM", "2")      # ... and the streaming 1x1 kernel only on maps of >= 256K pixels
     if name.startswith("gp"):
         monkeypatch.setenv("DIN_GATHER_PIPE", "2")      # ... and the 256-pixel pipelined tiles only on launches that fill the chip
         monkeypatch.setenv("DIN_CONV_HALO", "0")
@@ -128,6 +136,11 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
         bm, bn = C.c_int32(0), C.c_int32(0)
         lib.din_conv_kernel_tile(C.byref(d), 0, C.byref(bm), C.byref(bn))
         assert bm.value == 2, f"{name}: forward not on the pipelined gather kernel (tile {bm.value} x {bn.value})"
+    if name.startswith("st_") and dtype == "bf16":
+        for which in (0, 1):
+            bm, bn = C.c_int32(0), C.c_int32(0)
+            lib.din_conv_kernel_tile(C.byref(d), which, C.byref(bm), C.byref(bn))
+            assert bm.value == 4, f"{name}: {('forward', 'dgrad')[which]} not on the streaming 1x1 kernel (tile {bm.value} x {bn.value})"
     xin = to_nhwc(x, tdt, ldi)
     wdev, bdev = wt.cuda(), bias.cuda()
     wpk = torch.empty(lib.din_conv_packed_elems(C.byref(d), 0), dtype=tdt, device="cuda")
@@ -207,11 +220,15 @@ def test_stem_dgrad_early_operand_request_is_bit_identical(env, monkeypatch, cou
     assert not bool((changed & ~(xin > 0)).any())                         # nothing was added where the mask is off
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_pipe"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_pipe", "bf16_stream"])
 def test_conv_fwd_two_destinations(env, dtype, monkeypatch):
     """din_conv_fwd2: sibling 1x1 convs of one input as ONE launch -- channels [0, csplit) into the first tensor's view, the rest into a second
-    tensor; equals the separate convs, and nothing outside the two channel ranges is touched.  bf16_pipe: through the 256-pixel tiles."""
+    tensor; equals the separate convs, and nothing outside the two channel ranges is touched.  bf16_pipe: through the 256-pixel tiles;
+    bf16_stream: through the persistent streaming kernel (conv1x1_stream_kernel)."""
     lib, L, nhwc, ops = env
+    monkeypatch.setenv("DIN_CONV_STREAM", "2" if dtype == "bf16_stream" else "0")
+    if dtype == "bf16_stream":
+        dtype = "bf16"
     if dtype == "bf16_pipe":
         monkeypatch.setenv("DIN_GATHER_PIPE", "2")
         dtype = "bf16"
@@ -896,10 +913,14 @@ def test_head_and_adam(env):
         assert rel(d_.detach(), r_.detach()) <= 1e-5
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_conv1x1_dgrad_multi_source(env, dtype):
-    """fused dgrad of three 1x1 convs reading the same tensor == sum of the three separate dgrads (+ mask, + accumulate)"""
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_stream"])
+def test_conv1x1_dgrad_multi_source(env, dtype, monkeypatch):
+    """fused dgrad of three 1x1 convs reading the same tensor == sum of the three separate dgrads (+ mask, + accumulate); bf16_stream: through
+    the persistent streaming kernel (each source = its own 64-channel blocks, the 48- and 104-channel sources end in partial blocks)"""
     lib, L, nhwc, ops = env
+    monkeypatch.setenv("DIN_CONV_STREAM", "2" if dtype == "bf16_stream" else "0")
+    if dtype == "bf16_stream":
+        dtype = "bf16"
     dt = L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
     tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
     g = torch.Generator().manual_seed(21)
