@@ -38,6 +38,7 @@ struct ConvK {
 // host entries of conv_stream.hip: persistent streaming kernel for 1x1 convolutions with a short reduction (ring kept full across tiles)
 bool conv1x1_stream_eligible(const ConvK& k, int dtype);
 int launch_conv1x1_stream(ConvK k, hipStream_t st);
+int conv1x1_stream_tile(int cout);                 // filter tile of a launch producing cout channels (64 | 96 | 192)
 
 __device__ __forceinline__ int64_t out_pixel(const ConvK& p, int m) {
     if (p.out_sy == 0) return m;

@@ -56,13 +56,15 @@ static_assert(sizeof(BlockDesc) == 48, "three 16-byte reads");
 
 // MULTI: reduction over the concatenation of p.src[0 .. nsrc) (fused dgrad).  EPI: ReLU-backward mask and / or accumulate operand.
 // SPLIT: second destination (fused sibling forward launches).
-template <int BN, bool MULTI, bool EPI, bool SPLIT>
+// NSW: ring slots (4 for the 64- / 96-filter tiles; the 192-filter tile's 50-KiB slabs leave room for 3).
+template <int BN, int NSW, bool MULTI, bool EPI, bool SPLIT>
 __global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(ConvK p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int NWV = 8, BM = 128, TI = BN / 32, TJ = 2, PCH = 10, PB = PCH * 16, NSW = 4;
+    constexpr int NWV = 8, BM = 128, TI = BN / 32, TJ = 2, PCH = 10, PB = PCH * 16, LOOK = NSW - 1;
+    static_assert(NSW == 3 || NSW == 4, "wait counts are written for a ring that runs 2 or 3 steps ahead");
     constexpr int NXA = BM * PCH / 64, NXF = (BM + BN) * PCH / 64;      // wave transfers of the pixel rows / of the whole slab (20, 35 | 30)
     constexpr int NTR = (NXF + NWV - 1) / NWV;                          // per wave per step
-    constexpr int SLOT = NXF * 1024, DUMP = NSW * SLOT, BIAS = DUMP + NWV * 1024, TABLE = BIAS + 2048;
+    constexpr int SLOT = NXF * 1024, DUMP = NSW * SLOT, BIAS = DUMP + 1024, TABLE = BIAS + 2048;   // (dump: 1 KiB of zeros, shared)
     constexpr int CPR = BN / 8, CH = BM * CPR / 512, CP = BN * 2 + 16;  // staged epilogue: 16-byte chunks per pixel row / per thread, LDS row pitch
     constexpr int NE = EPI ? 2 * CH : 0;                                // epilogue operand loads per item (mask AND old are always issued)
     constexpr int NSTO = SPLIT ? 2 * CH : CH;                           // stores per item
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(ConvK p) {
         pc16[i] = pcc[i] * 16;
         kind[i] = t < NXA ? 0 : t < NXF ? 1 : 2;
         prw[i] = t < NXA ? row : row - BM;
-        dst0[i] = lds_base + (uint32_t)(t < NXF ? t * 1024 : DUMP + wid * 1024);
+        dst0[i] = lds_base + (uint32_t)(t < NXF ? t * 1024 : DUMP);
     }
     const int n_px = (p.M + BM - 1) / BM, nco = p.n_co_tiles;
     const int G = (int)gridDim.x, Gq = G / nco, Gr = G - Gq * nco;     // item += G  <=>  (pixel tile, filter tile) += (Gq, Gr) with carry
@@ -185,8 +187,9 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(ConvK p) {
     for (int s = 0; s < NSW - 1; ++s)
         if (nxt.pt < n_px) { issue_slab(s, nxt); advance(nxt); }
     // In-order completion by count.  Per step t the wave issues: [NE operand loads if t is the first block of its item], NTR slab transfers
-    // (the slab of step t + 3), [NSTO stores if t is the last block].  Younger than the slab of step s when step s starts: the slabs of s + 1,
-    // s + 2, the stores of the epilogues at steps s - 3, s - 2, s - 1 and the operand loads at s - 2, s - 1 (first(t) == last(t - 1)).
+    // (the slab of step t + LOOK), [NSTO stores if t is the last block].  Younger than the slab of step s when step s starts (LOOK = 3): the slabs
+    // of s + 1, s + 2, the stores of the epilogues at steps s - 3, s - 2, s - 1 and the operand loads at s - 2, s - 1 (first(t) == last(t - 1));
+    // LOOK = 2: the slab of s + 1, the stores at s - 2, s - 1 and the operand loads at s - 1.
     // Once a slab could not be issued (end of the walk) the counts no longer hold: wait for everything.
     bool e1 = false, e2 = false, e3 = false, tail = nxt.pt >= n_px;     // last(s - 1), last(s - 2), last(s - 3)
     u32x4 mk[CH], old[CH];                                              // this thread's chunks of the item's output tile: id = tid + 512 q
@@ -201,8 +204,9 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(ConvK p) {
         for (int ws = 0; ws < NSW; ++ws) {                              // ring slot of this step (compile time)
             if (tail) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else {
-#define DIN_ALLOW(E1, E2, E3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((2 * NTR + NSTO * (E1 + E2 + E3) + NE * (E2 + E3)) > 63 ? 63 : (2 * NTR + NSTO * (E1 + E2 + E3) + NE * (E2 + E3))) : "memory")
-                const int code = (e1 ? 1 : 0) | (e2 ? 2 : 0) | (e3 ? 4 : 0);
+#define DIN_ALLOW(E1, E2, E3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(((LOOK - 1) * NTR + NSTO * (E1 + E2 + (LOOK == 3 ? E3 : 0)) + NE * (E2 + (LOOK == 3 ? E3 : 0))) > 63 ? 63 : \
+                                                                       ((LOOK - 1) * NTR + NSTO * (E1 + E2 + (LOOK == 3 ? E3 : 0)) + NE * (E2 + (LOOK == 3 ? E3 : 0)))) : "memory")
+                const int code = (e1 ? 1 : 0) | (e2 ? 2 : 0) | ((e3 && LOOK == 3) ? 4 : 0);
                 if (code == 0) DIN_ALLOW(0, 0, 0);
                 else if (code == 1) DIN_ALLOW(1, 0, 0);
                 else if (code == 2) DIN_ALLOW(0, 1, 0);
@@ -283,9 +287,9 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(ConvK p) {
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 if (EPI) {
-                    // younger than the operand loads: the slabs issued since (one per step of this item, at most the ring's three in flight)
+                    // younger than the operand loads: the slabs issued since (one per step of this item, at most the ring's LOOK in flight)
                     if (tail) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else if (nblk >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * NTR) : "memory");
+                    else if (nblk >= LOOK) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOOK * NTR) : "memory");
                     else if (nblk == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NTR) : "memory");
                     else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NTR) : "memory");
 #pragma unroll
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(ConvK p) {
 #endif
 }
 
-template <int BN> constexpr size_t stream_lds_bytes() { return (size_t)4 * ((128 + BN) * 10 / 64) * 1024 + 8 * 1024 + 2048 + 1024; }
+template <int BN, int NSW> constexpr size_t stream_lds_bytes() { return (size_t)NSW * ((128 + BN) * 10 / 64) * 1024 + 1024 + 2048 + 1024; }
 
 }  // namespace
 
@@ -344,7 +348,7 @@ bool conv1x1_stream_eligible(const ConvK& k, int dtype) {
                          (k.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM))))
         return false;
     if (k.craw > 0 && k.craw % 4 != 0) return false;
-    const int bn = k.Cout <= 64 ? 64 : 96;
+    const int bn = conv1x1_stream_tile(k.Cout);
     if (((k.Cout + bn - 1) / bn) * bn * 4 > 2048) return false;                      // bias image in LDS
     int blocks = 0;
     const int ns = k.nsrc > 0 ? k.nsrc : 1;
@@ -357,34 +361,45 @@ bool conv1x1_stream_eligible(const ConvK& k, int dtype) {
     if (blocks > 20) return false;                                                   // block table in LDS
     if (mode == 2) return true;
     // measured window (profiles/r03_conv_stream.txt): short reductions over large maps whose filters fit ONE tile -- with two or three filter
-    // tiles every tile re-streams the pixels through the ring and the 128-pixel kernel is as fast or faster
-    return blocks <= 6 && (long long)k.M >= 256 * 1024 && k.Cout <= bn;
+    // tiles every tile re-streams the pixels through the ring and the 128-pixel kernel is as fast or faster; the 192-filter tile (3-slot ring)
+    // pays for forward launches only
+    const bool plain_fwd = k.nsrc == 0 && !(k.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM));
+    const char* wv = getenv("DIN_CONV_STREAM_WIDE");                                 // 0: never the 192-filter tile
+    const bool wide = wv ? atoi(wv) != 0 : true;
+    return blocks <= 6 && (long long)k.M >= 256 * 1024 && (k.Cout <= 96 || (k.Cout <= 192 && plain_fwd && wide));
 }
 
-template <int BN, bool MULTI, bool EPI, bool SPLIT>
+template <int BN, int NSW, bool MULTI, bool EPI, bool SPLIT>
 static void launch_stream(const ConvK& k, dim3 grid, hipStream_t st) {
-    constexpr size_t lds = stream_lds_bytes<BN>();
+    constexpr size_t lds = stream_lds_bytes<BN, NSW>();
+    static_assert(lds <= 160 * 1024, "LDS");
     static bool raised = false;
-    auto kern = conv1x1_stream_kernel<BN, MULTI, EPI, SPLIT>;
+    auto kern = conv1x1_stream_kernel<BN, NSW, MULTI, EPI, SPLIT>;
     if (!raised) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, k);
 }
+template <int BN, int NSW>
+static void launch_stream_bn(const ConvK& k, dim3 grid, hipStream_t st) {
+    const bool multi = k.nsrc > 0, epi = (k.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM)) != 0, split = k.csplit > 0;
+    if (split) launch_stream<BN, NSW, false, false, true>(k, grid, st);
+    else if (multi) { if (epi) launch_stream<BN, NSW, true, true, false>(k, grid, st); else launch_stream<BN, NSW, true, false, false>(k, grid, st); }
+    else { if (epi) launch_stream<BN, NSW, false, true, false>(k, grid, st); else launch_stream<BN, NSW, false, false, false>(k, grid, st); }
+}
+
+int conv1x1_stream_tile(int cout) {
+    const char* e = getenv("DIN_CONV_STREAM_BN");                      // tuning aid: force the filter tile (64 | 96 | 192)
+    if (e && (atoi(e) == 64 || atoi(e) == 96 || atoi(e) == 192)) return atoi(e);
+    return cout <= 64 ? 64 : cout <= 96 ? 96 : 192;
+}
 
 int launch_conv1x1_stream(ConvK k, hipStream_t st) {
-    const int bn = k.Cout <= 64 ? 64 : 96;
+    const int bn = conv1x1_stream_tile(k.Cout);
     k.n_co_tiles = (k.Cout + bn - 1) / bn;
     const long long items = (long long)((k.M + 127) / 128) * k.n_co_tiles;
     const dim3 grid((unsigned)(items < 256 ? items : 256));
-    const bool multi = k.nsrc > 0, epi = (k.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM)) != 0, split = k.csplit > 0;
-    if (bn == 64) {
-        if (split) launch_stream<64, false, false, true>(k, grid, st);
-        else if (multi) { if (epi) launch_stream<64, true, true, false>(k, grid, st); else launch_stream<64, true, false, false>(k, grid, st); }
-        else { if (epi) launch_stream<64, false, true, false>(k, grid, st); else launch_stream<64, false, false, false>(k, grid, st); }
-    } else {
-        if (split) launch_stream<96, false, false, true>(k, grid, st);
-        else if (multi) { if (epi) launch_stream<96, true, true, false>(k, grid, st); else launch_stream<96, true, false, false>(k, grid, st); }
-        else { if (epi) launch_stream<96, false, true, false>(k, grid, st); else launch_stream<96, false, false, false>(k, grid, st); }
-    }
+    if (bn == 64) launch_stream_bn<64, 4>(k, grid, st);
+    else if (bn == 96) launch_stream_bn<96, 4>(k, grid, st);
+    else launch_stream_bn<192, 3>(k, grid, st);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

@@ -79,12 +79,13 @@ CONV_CASES = [
     ("gp256_3x3_p0", 2, 64, 83, 79, 512, (3, 3), (1, 1), (0, 0), 1),          # DIN_CONV_BN=256: the 256-filter tile (VGG conv3+)
     ("gp192_dgrad_3x3", 4, 192, 80, 78, 192, (3, 3), (1, 1), (1, 1), 1),
     ("gp128_5x5_176", 4, 64, 80, 78, 176, (5, 5), (1, 1), (2, 2), 1),
-    # persistent streaming 1x1 kernel (conv1x1_stream_kernel<96 | 64>, bf16; forced on these small maps with DIN_CONV_STREAM=2): ragged last pixel
+    # persistent streaming 1x1 kernel (conv1x1_stream_kernel<64 | 96 | 192>, bf16; forced on these small maps with DIN_CONV_STREAM=2): ragged last pixel
     # tile, one / several / partial 64-channel blocks, one to three filter tiles, a filter tile wider than the bank, fwd and dgrad (+ mask, accumulate)
     ("st_64_80", 3, 64, 37, 41, 80, (1, 1), (1, 1), (0, 0), 1),
     ("st_288_176", 2, 288, 35, 45, 176, (1, 1), (1, 1), (0, 0), 1),
     ("st_48_8", 1, 48, 19, 23, 8, (1, 1), (1, 1), (0, 0), 1),
     ("st_192_64_long", 8, 192, 87, 157, 64, (1, 1), (1, 1), (0, 0), 1),      # > 256 items: every workgroup walks several
+    ("st_96_176", 2, 96, 31, 45, 176, (1, 1), (1, 1), (0, 0), 1),            # the 192-filter tile on its 3-slot ring (forward), 96-filter tile (dgrad)
 ]
 
 
