@@ -3029,7 +3029,7 @@ int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t
         if (mode && d->dtype == DIN_BF16 && d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 && !d->in_u8 &&
             g.splitk == 1 && cprod % 8 == 0 && ldp % 8 == 0 && offp % 8 == 0 && ldr % 8 == 0 && offr % 8 == 0 &&
             M * ldr * 2 < 0x7fffffffll && M * ldp * 2 < 0x7fffffffll && pad_to(cprod, din_gather::conv1x1_stream_tile(cprod)) * 4 <= 2048 &&
-            (mode == 2 || (blocks <= 6 && M >= 256 * 1024 && (cprod <= 96 || (cprod <= 192 && which == 0))))) { *bm = 4; *bn = din_gather::conv1x1_stream_tile(cprod); }
+            (mode == 2 || (blocks <= 6 && M >= (getenv("DIN_CONV_STREAM_MINPIX") ? atoll(getenv("DIN_CONV_STREAM_MINPIX")) : 256 * 1024) && (cprod <= 96 || (cprod <= 192 && which == 0))))) { *bm = 4; *bn = din_gather::conv1x1_stream_tile(cprod); }
     }
     {   // stem layers run conv_small_kernel (same conditions as run_gather, for tensors with 16-byte aligned channel offsets): bm = 0
         const int cred = which == 0 ? d->cin : d->cout, cprod = which == 0 ? d->cout : d->cin;

@@ -366,7 +366,9 @@ bool conv1x1_stream_eligible(const ConvK& k, int dtype) {
     const bool plain_fwd = k.nsrc == 0 && !(k.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM));
     const char* wv = getenv("DIN_CONV_STREAM_WIDE");                                 // 0: never the 192-filter tile
     const bool wide = wv ? atoi(wv) != 0 : true;
-    return blocks <= 6 && (long long)k.M >= 256 * 1024 && (k.Cout <= 96 || (k.Cout <= 192 && plain_fwd && wide));
+    const char* mp = getenv("DIN_CONV_STREAM_MINPIX");
+    const long long minpix = mp ? atoll(mp) : 256 * 1024;
+    return blocks <= 6 && (long long)k.M >= minpix && (k.Cout <= 96 || (k.Cout <= 192 && plain_fwd && wide));
 }
 
 template <int BN, int NSW, bool MULTI, bool EPI, bool SPLIT>

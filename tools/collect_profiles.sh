@@ -32,7 +32,7 @@ for c in 4 32; do
 done
 # rocprofv3 kernel-trace summaries (same command as the default bench line, 5 timed + 2 warm-up steps)
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof_b32 -o x -- python $OLDPWD/bench.py --no-cpu-baseline --no-extras > $OLDPWD/$OUT/prof_b32.log 2>&1)
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof_b4 -o x -- python $OLDPWD/bench.py --no-cpu-baseline --global-batch 4 > $OLDPWD/$OUT/prof_b4.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof_b4 -o x -- python $OLDPWD/bench.py --no-cpu-baseline --no-extras --global-batch 4 > $OLDPWD/$OUT/prof_b4.log 2>&1)
 find $OUT/prof_b32 -name "*kernel_stats.csv" -exec cp {} $OUT/inv3_bf16_b32_kernel_stats.csv \;
 find $OUT/prof_b4 -name "*kernel_stats.csv" -exec cp {} $OUT/inv3_bf16_b4_kernel_stats.csv \;
 # HBM traffic per kernel: two separate PMC passes (kernel-trace only)
