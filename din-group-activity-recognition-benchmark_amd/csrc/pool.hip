@@ -441,6 +441,7 @@ template <int V> struct RawTap;
 template <> struct RawTap<8> {                                          // 8 bf16 channels, kept packed
     uint4 r;
     __device__ __forceinline__ void load(const void* base, int, int64_t i) { r = *reinterpret_cast<const uint4*>((const bf16_t*)base + i); }
+    __device__ __forceinline__ void keep(bool ok) { r.x = ok ? r.x : 0u; r.y = ok ? r.y : 0u; r.z = ok ? r.z : 0u; r.w = ok ? r.w : 0u; }
     __device__ __forceinline__ float get(int e) const {
         const uint32_t w = e < 2 ? r.x : e < 4 ? r.y : e < 6 ? r.z : r.w;
         return (e & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
@@ -449,6 +450,10 @@ template <> struct RawTap<8> {                                          // 8 bf1
 template <> struct RawTap<4> {                                          // 4 channels, fp32 or bf16: converted at load
     Vec<4> r;
     __device__ __forceinline__ void load(const void* base, int dtype, int64_t i) { r = vload<4>(base, dtype, i); }
+    __device__ __forceinline__ void keep(bool ok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r.v[e] = ok ? r.v[e] : 0.f;
+    }
     __device__ __forceinline__ float get(int e) const { return r.v[e]; }
 };
 
@@ -476,6 +481,13 @@ __global__ __launch_bounds__(256) void avgpool3_strip_kernel(int nb, int h, int 
             t[r][2].load(src, dtype, (rowp + min(x + 1, w - 1)) * lds_ + soff + cg * V);
         }
         const bool lok = x > 0, rok = x + 1 < w;
+        // taps outside the map become +0.0 ONCE here (4 selects per tap) instead of a select per use (8 channels x 9 taps x R outputs): the sums
+        // below still add them, in the same order -- same bits
+#pragma unroll
+        for (int r = 0; r < R + 2; ++r) {
+            const bool yok = y0 + r - 1 >= 0 && y0 + r - 1 < h;
+            t[r][0].keep(yok && lok); t[r][1].keep(yok); t[r][2].keep(yok && rok);
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int y = y0 + r;
@@ -484,13 +496,11 @@ __global__ __launch_bounds__(256) void avgpool3_strip_kernel(int nb, int h, int 
 #pragma unroll
             for (int rr = 0; rr < 3; ++rr) {
                 const int q = BWD ? 2 - rr : rr;                        // backward visits rows y+1, y, y-1 and columns x+1, x, x-1
-                const bool yok = y + q - 1 >= 0 && y + q - 1 < h;
 #pragma unroll
                 for (int ss = 0; ss < 3; ++ss) {
                     const int c = BWD ? 2 - ss : ss;
-                    const bool ok = yok && (c == 0 ? lok : c == 2 ? rok : true);
 #pragma unroll
-                    for (int e = 0; e < V; ++e) g.v[e] += ok ? t[r + q][c].get(e) : 0.f;
+                    for (int e = 0; e < V; ++e) g.v[e] += t[r + q][c].get(e);
                 }
             }
             const int64_t off = (((int64_t)n * h + y) * w + x) * ldd + doff + cg * V;
