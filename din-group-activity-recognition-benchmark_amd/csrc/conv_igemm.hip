@@ -602,6 +602,7 @@ __device__ __forceinline__ float prep_u8(uint32_t v) {
 __device__ __forceinline__ void u8_lut_init(bf16_t* lut, int tid) {          // NTHREADS == 256: one entry per thread
     lut[tid] = (bf16_t)(pack_bf16x2(prep_u8((uint32_t)tid), 0.f) & 0xffffu);
 }
+template <int V> struct IcTag { static constexpr int value = V; };
 template <int NTR>
 struct U8Halo {
     // the three bytes of a pixel stay in separate registers until store(): nothing consumes them at load time, so the loads stay in flight
@@ -612,21 +613,28 @@ struct U8Halo {
     template <int NSLOT>
     __device__ __forceinline__ void load(const unsigned char* __restrict__ img, int n, int H, int W, int gy0, int gx0, int wid,
                                          const short (&hyv)[NTR], const short (&hxv)[NTR], const int (&inside)[NTR]) {
+        // every lane ALWAYS loads (coordinates clamped into the image, validity kept as a bit): a load inside `if (inside)` merges with the zero
+        // of the other path at the end of the branch, and the compiler waits for it right there -- five exposed memory latencies per tile
+        // (vmcnt(2) / (1) / (0) after every pixel in the ISA; the image layer ran 5.5 us per tile = 2.7 TB/s because of it)
         const int64_t plane = (int64_t)H * W;
-        const unsigned char* base = img + (int64_t)n * 3 * plane + (int64_t)gy0 * W + gx0;
+        const unsigned char* base = img + (int64_t)n * 3 * plane;
         valid = 0u;
 #pragma unroll
         for (int i = 0; i < NTR; ++i) {
-            r[i] = g[i] = b[i] = 0u;
-            if (wid + 4 * i < NSLOT) {
-                const int gy = gy0 + hyv[i], gx = gx0 + hxv[i];
-                if (inside[i] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                    const unsigned char* q = base + (hyv[i] * W + hxv[i]);
-                    r[i] = q[0]; g[i] = q[plane]; b[i] = q[2 * plane];
-                    valid |= 1u << i;
-                }
-            }
+            const int gy = gy0 + hyv[i], gx = gx0 + hxv[i];
+            const bool ok = wid + 4 * i < NSLOT && inside[i] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const unsigned char* q = base + (int64_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1);
+            // untracked loads (inline asm): the compiler would zero-extend the bytes -- i.e. wait for them -- right here; the caller waits by
+            // count (s_waitcnt vmcnt) before store() and calls landed()
+            asm volatile("global_load_ubyte %0, %1, off" : "=&v"(r[i]) : "v"(q) : "memory");
+            asm volatile("global_load_ubyte %0, %1, off" : "=&v"(g[i]) : "v"(q + plane) : "memory");
+            asm volatile("global_load_ubyte %0, %1, off" : "=&v"(b[i]) : "v"(q + 2 * plane) : "memory");
+            valid |= (ok ? 1u : 0u) << i;
         }
+    }
+    __device__ __forceinline__ void landed() {                       // after the caller's s_waitcnt: ties the registers to this point
+#pragma unroll
+        for (int i = 0; i < NTR; ++i) { asm volatile("" : "+v"(r[i])); asm volatile("" : "+v"(g[i])); asm volatile("" : "+v"(b[i])); }
     }
     // lut: the 256 normalised bf16 values (prep_u8 of every byte, built once per workgroup by u8_lut_init) -- three LDS reads per pixel
     // instead of three fp32 divisions
@@ -753,10 +761,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv_small_kernel(Co
 
     // uint8 frames: the next tile's halo bytes are fetched into registers where the DMA would be issued and written to the other halo
     // buffer after this tile's MFMAs (nobody reads that buffer between the two barriers around them)
-    U8Halo<NTR> u8h;
+    // two register sets: the bytes of tile t + 2G are requested at the top of tile t and written to LDS at the end of tile t + 1 -- a whole tile
+    // period for the loads to land (requested and consumed inside ONE tile their ~2 us were exposed every tile: 5.5 us per tile, 2.7 TB/s)
+    U8Halo<NTR> u8s[2];
     bf16_t* u8lut = reinterpret_cast<bf16_t*>(smem_raw + WBYTES + NBUF * HBYTES);       // 512 bytes behind the halo buffers (host adds them)
     if (U8) { u8_lut_init(u8lut, tid); __syncthreads(); }
-    auto u8_load = [&](int tile) {
+    auto u8_load = [&](int tile, U8Halo<NTR>& u8h) {
         const int n = tile / tiles_img;
         const int tr = tile - n * tiles_img;
         const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
@@ -768,19 +778,35 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv_small_kernel(Co
     int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     bool first = true;
     if (U8) {
-        if (tile < ntiles) { u8_load(tile); u8h.template store<NSLOT>(smem_raw + WBYTES, u8lut, wid, lane); }
+        if (tile < ntiles) {
+            u8_load(tile, u8s[0]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); u8s[0].landed();
+            u8s[0].template store<NSLOT>(smem_raw + WBYTES, u8lut, wid, lane);
+        }
+        if (tile + (int)gridDim.x < ntiles) u8_load(tile + gridDim.x, u8s[1]);
     } else if (tile < ntiles) issue_halo(0, tile);
     __syncthreads();                                                                   // filters visible
-    for (; tile < ntiles; tile += gridDim.x) {
+    // bias once per workgroup (a load inside the tile loop is a compiler-visible wait that also drains the next halo's transfers)
+    f32x4 biasv[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int co = i * 16 + g4 * 4;
+        biasv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if ((p.flags & DIN_CONV_BIAS) && co < p.Cout) biasv[i] = *reinterpret_cast<const f32x4*>(p.bias + co);
+        asm volatile("" : "+v"(biasv[i]));                             // consumed HERE: the compiler's wait for the load stays out of the loop
+    }
+    auto tile_body = [&](auto PARC) {                                                  // PAR: which uint8 register set this tile FILLS
+        constexpr int PAR = decltype(PARC)::value;
         // in-order completion: the halo transfers of this tile are older than the (always NST) stores of the previous tile when
         // double-buffered, so the stores may stay in flight; single-buffered the transfers are the youngest -> drain everything
-        if (NBUF == 2 && !first) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST) : "memory");
+        if (U8) {}                                                                     // (no transfers: the halo was written to LDS by the waves themselves)
+        else if (NBUF == 2 && !first) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         first = false;
         __builtin_amdgcn_s_barrier();                                                  // halo(tile) landed; everyone left the previous tile
         asm volatile("" ::: "memory");
         const bool have_next = tile + (int)gridDim.x < ntiles;
-        if (U8) { if (have_next) u8_load(tile + gridDim.x); }
+        if (U8) { if (tile + 2 * (int)gridDim.x < ntiles) u8_load(tile + 2 * gridDim.x, u8s[PAR]); }
         else if (NBUF == 2 && have_next) issue_halo(cur ^ 1, tile + gridDim.x);
         const u32x4* Hl = reinterpret_cast<const u32x4*>(smem_raw + WBYTES + cur * HBYTES);
         // ---- dgrad epilogue operands (ReLU mask of the produced pixels, accumulate input): requested HERE, a whole MFMA phase before the
@@ -873,7 +899,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv_small_kernel(Co
                     for (int j = 0; j < TJ; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
             }
         }
-        if (U8 && have_next) u8h.template store<NSLOT>(smem_raw + WBYTES + (cur ^ 1) * HBYTES, u8lut, wid, lane);
+        if (U8 && have_next) {
+            // the bytes of tile + G were requested a tile ago; younger: the previous tile's stores and this tile's 3 NTR byte loads (if any)
+            if (tile + 2 * (int)gridDim.x < ntiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * NTR) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            u8s[PAR ^ 1].landed();
+            u8s[PAR ^ 1].template store<NSLOT>(smem_raw + WBYTES + (cur ^ 1) * HBYTES, u8lut, wid, lane);
+        }
         __syncthreads();                                                               // all waves done reading halo(cur)
         // ---- epilogue: stage through the consumed halo buffer, then 16-byte coalesced buffer stores (always NST per wave) -----
         unsigned char* stg = smem_raw + WBYTES + cur * HBYTES;
@@ -881,9 +913,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv_small_kernel(Co
         for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 bv = biasv[i];
                 const int co = i * 16 + g4 * 4;
-                if ((p.flags & DIN_CONV_BIAS) && co < p.Cout) bv = *reinterpret_cast<const f32x4*>(p.bias + co);
 #pragma unroll
                 for (int j = ps * JN; j < (ps + 1) * JN; ++j) {
                     f32x4 v = acc[i][j] + bv;
@@ -931,6 +962,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void conv_small_kernel(Co
             __syncthreads();                                                            // staging buffer free again
             if (tile + (int)gridDim.x < ntiles) issue_halo(0, tile + gridDim.x);
         }
+    };
+    if constexpr (U8) {
+        for (;;) {
+            if (tile >= ntiles) break;
+            tile_body(IcTag<0>{}); tile += gridDim.x;
+            if (tile >= ntiles) break;
+            tile_body(IcTag<1>{}); tile += gridDim.x;
+        }
+    } else {
+        for (; tile < ntiles; tile += gridDim.x) tile_body(IcTag<0>{});
     }
 #endif
 }
@@ -1962,7 +2003,7 @@ __global__ __launch_bounds__(64 * NW, (CPP == 4 && BN == 64) ? 1 : 2) void conv_
     int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     if (tile < ntiles) {
         issue(0, tile);
-        if (U8) { u8_load(tile); u8h.template store<NSLOT_H>(smem_raw, u8lut, wid, lane); }
+        if (U8) { u8_load(tile); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); u8h.landed(); u8h.template store<NSLOT_H>(smem_raw, u8lut, wid, lane); }
     }
     for (; tile < ntiles; tile += gridDim.x) {
         if (U8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -2021,7 +2062,10 @@ __global__ __launch_bounds__(64 * NW, (CPP == 4 && BN == 64) ? 1 : 2) void conv_
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (U8 && have_next) u8h.template store<NSLOT_H>(smem_raw + (cur ^ 1) * STAGE, u8lut, wid, lane);
+        if (U8 && have_next) {                                          // requested at the top of this tile (after the next G tile's transfers)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); u8h.landed();
+            u8h.template store<NSLOT_H>(smem_raw + (cur ^ 1) * STAGE, u8lut, wid, lane);
+        }
         cur ^= 1;
     }
     // ---- this workgroup's partial slab: [BN][NCT * 16] fp32 ------------------------------------------------------------------
