@@ -1084,6 +1084,17 @@ __global__ __launch_bounds__(64 * NWV_, 1) void conv_halo_kernel(ConvK p) {
     }
     const uint32_t wbase = (uint32_t)(2 * HBYTES + (wc * (BN / 2) + frow) * PB + g4 * 16);
 
+    constexpr int NBP = NWV == 16 ? 1 : 2;                             // (sixteen waves: 128 registers)
+    f32x4 biasP[NBP][TI];                                               // bias of the first NBP filter tiles (see the epilogue)
+#pragma unroll
+    for (int ct = 0; ct < NBP; ++ct)
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int co = ct * BN + wc * (BN / 2) + i * 16 + g4 * 4;
+            biasP[ct][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if ((p.flags & DIN_CONV_BIAS) && co < p.Cout) biasP[ct][i] = *reinterpret_cast<const f32x4*>(p.bias + co);
+            asm volatile("" : "+v"(biasP[ct][i]));                      // consumed here: the compiler's wait stays out of the walk
+        }
     // ---- (item, channel block) pair walk ----------------------------------------------------------------------------------------
     const int G = (int)gridDim.x;
     int item = xcd_remap((int)blockIdx.x, G);
@@ -1174,14 +1185,19 @@ __global__ __launch_bounds__(64 * NWV_, 1) void conv_halo_kernel(ConvK p) {
             __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<char*>(reinterpret_cast<const char*>((p.flags & DIN_CONV_MASK) ? p.mask : p.out)) + (long long)cur.n * mimg_bytes, 0,
                 (p.flags & DIN_CONV_MASK) ? (int)mimg_bytes : 0, 0x00020000);
-            // bias first (one batch of loads; a load between the stores would wait for every store before it: vmcnt is in-order)
+            // bias: preloaded before the walk for the first NBP filter tiles (a compiler-visible load here waits with vmcnt(0): it would
+            // drain the slab ring and the next halo once per item)
             f32x4 bv[TI];
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int co = cur.co_tile * BN + wc * (BN / 2) + i * 16 + g4 * 4;
-                bv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if ((p.flags & DIN_CONV_BIAS) && co < p.Cout) bv[i] = *reinterpret_cast<const f32x4*>(p.bias + co);
+                if (cur.co_tile < NBP) bv[i] = cur.co_tile == 0 ? biasP[0][i] : biasP[NBP - 1][i];
+                else { bv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; if ((p.flags & DIN_CONV_BIAS) && co < p.Cout) bv[i] = *reinterpret_cast<const f32x4*>(p.bias + co); }
             }
+            // dgrad operands: ALL of the item's loads first, then all its stores (segment by segment the loads of segment j + 1 waited for the
+            // stores of segment j -- in-order completion -- i.e. TJ exposed round trips per item)
+            u32x2 mk[TJ][TI], old[TJ][TI];
+            int off[TJ][TI];
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 const int q = wp * TJ + j;
@@ -1189,16 +1205,17 @@ __global__ __launch_bounds__(64 * NWV_, 1) void conv_halo_kernel(ConvK p) {
                 const int gy = cur.ty * TH + qy, gx = cur.tx * TW + qx + frow;
                 const bool pok = gy < p.OH && gx < p.OW;
                 const int opx = gy * p.OW + gx;
-                u32x2 mk[TI], old[TI];
-                int off[TI];
 #pragma unroll
-                for (int i = 0; i < TI; ++i) {                                 // all loads of this pixel segment, then all its stores
+                for (int i = 0; i < TI; ++i) {
                     const int co = cur.co_tile * BN + wc * (BN / 2) + i * 16 + g4 * 4;
                     const bool ok = pok && co < p.Cout;                      // Cout % 4 == 0 (host)
-                    off[i] = ok ? (opx * p.ldo + p.cooff + co) * 2 : (int)OOB;
-                    if (p.flags & DIN_CONV_MASK) mk[i] = __builtin_amdgcn_raw_buffer_load_b64(rsM, ok ? (opx * p.ldm + p.moff + co) * 2 : (int)OOB, 0, 0);
-                    if (p.flags & DIN_CONV_ACCUM) old[i] = __builtin_amdgcn_raw_buffer_load_b64(rsO, off[i], 0, 0);
+                    off[j][i] = ok ? (opx * p.ldo + p.cooff + co) * 2 : (int)OOB;
+                    if (p.flags & DIN_CONV_MASK) mk[j][i] = __builtin_amdgcn_raw_buffer_load_b64(rsM, ok ? (opx * p.ldm + p.moff + co) * 2 : (int)OOB, 0, 0);
+                    if (p.flags & DIN_CONV_ACCUM) old[j][i] = __builtin_amdgcn_raw_buffer_load_b64(rsO, off[j][i], 0, 0);
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
 #pragma unroll
                 for (int i = 0; i < TI; ++i) {
                     f32x4 v = acc[i][j] + bv[i];
@@ -1208,18 +1225,17 @@ __global__ __launch_bounds__(64 * NWV_, 1) void conv_halo_kernel(ConvK p) {
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
                     if (p.flags & DIN_CONV_MASK) {
-                        if (!(__uint_as_float(mk[i][0] << 16) > 0.f)) v[0] = 0.f;
-                        if (!(__uint_as_float(mk[i][0] & 0xffff0000u) > 0.f)) v[1] = 0.f;
-                        if (!(__uint_as_float(mk[i][1] << 16) > 0.f)) v[2] = 0.f;
-                        if (!(__uint_as_float(mk[i][1] & 0xffff0000u) > 0.f)) v[3] = 0.f;
+                        if (!(__uint_as_float(mk[j][i][0] << 16) > 0.f)) v[0] = 0.f;
+                        if (!(__uint_as_float(mk[j][i][0] & 0xffff0000u) > 0.f)) v[1] = 0.f;
+                        if (!(__uint_as_float(mk[j][i][1] << 16) > 0.f)) v[2] = 0.f;
+                        if (!(__uint_as_float(mk[j][i][1] & 0xffff0000u) > 0.f)) v[3] = 0.f;
                     }
                     if (p.flags & DIN_CONV_ACCUM) {
-                        v[0] += __uint_as_float(old[i][0] << 16); v[1] += __uint_as_float(old[i][0] & 0xffff0000u);
-                        v[2] += __uint_as_float(old[i][1] << 16); v[3] += __uint_as_float(old[i][1] & 0xffff0000u);
+                        v[0] += __uint_as_float(old[j][i][0] << 16); v[1] += __uint_as_float(old[j][i][0] & 0xffff0000u);
+                        v[2] += __uint_as_float(old[j][i][1] << 16); v[3] += __uint_as_float(old[j][i][1] & 0xffff0000u);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, rsO, off[i], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, rsO, off[j][i], 0, 0);
                 }
-            }
             fresh_item = true;
         }
         if (!has_next) break;
