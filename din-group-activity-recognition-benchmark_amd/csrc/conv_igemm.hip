@@ -38,6 +38,9 @@ using din_gather::staged_tile_store;
 
 namespace {
 
+#ifndef DIN_GATHER_ILV
+#define DIN_GATHER_ILV 1          // in-wave interleaved schedule of the FASTK gather loop (0: the compiler-scheduled loop, for A/B builds)
+#endif
 constexpr int BM = 128;      // pixels per workgroup tile
 constexpr int KC = 8;        // 16-byte chunks per k-step (=> 128 B per tile row)
 constexpr int NTHREADS = 256;
@@ -524,6 +527,63 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
             lds_dma_stage<PA, PB, LR * KC * 16>(ldsA0, rsA, va, soffA, rsB, voffB, soffB);
             prepare();
             int cur = 0;
+#if DIN_GATHER_ILV
+            // In-wave schedule of a k-step (round 3, late): the compiler's own placement of compute() kept ONE fragment of lookahead
+            // (ds_read x2 -> s_waitcnt lgkmcnt -> 2 MFMAs: twelve exposed LDS latencies per k-step) behind five back-to-back transfer
+            // issues that stall the wave while the CU's vector-memory path drains the other seven waves' transfers.  Here: the fragments
+            // of half-step 0 are requested first, the next stage's transfers and the fragment reads of half-step 1 sit one per MFMA between
+            // the MFMAs of half-step 0 (pinned with sched_barrier; a second fragment register set, ~10 fragments live at the peak).
+            // Same operands, same accumulation order: bit-identical results.
+            auto step = [&](auto more_t) {
+                constexpr bool MORE = decltype(more_t)::value;
+                const u32x4* A = smem + cur * BUF;
+                const u32x4* B = A + BM * KC;
+                const uint32_t nx = ldsA0 + (uint32_t)((cur ^ 1) * BUF * 16);
+                constexpr int NKK = KCS / 4, NMF = TI * TJ;
+                u32x4 xf[2][TJ], wf[2][TI];
+                auto rd = [&](int set, int kk, int f) {                  // fragment f of half-step kk: pixel rows first, then filter rows
+                    if (f < TJ) xf[set][f] = A[lds_slot(wm * (BM / WM) + f * 16 + frow, kk * 4 + fchunk)];
+                    else wf[set][f - TJ] = B[lds_slot(wn * (BN / WN) + (f - TJ) * 16 + frow, kk * 4 + fchunk)];
+                };
+#pragma unroll
+                for (int f = 0; f < TI + TJ; ++f) rd(0, 0, f);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) {
+                    const int set = kk & 1;
+                    const int ndma = (kk == 0 && MORE) ? NDMA : 0, nrd = (kk + 1 < NKK) ? TI + TJ : 0;
+                    const int nitems = ndma + nrd, per = (nitems + NMF - 1) / NMF;
+#pragma unroll
+                    for (int mf = 0; mf < NMF; ++mf) {
+                        Mma<T>::run(wf[set][mf / TJ], xf[set][mf % TJ], acc[mf / TJ][mf % TJ]);
+#pragma unroll
+                        for (int q = 0; q < per; ++q) {
+                            const int it = mf * per + q;
+                            if (it < ndma) {
+                                if (it < PA) lds_dma16(nx + (uint32_t)(it * LR * KC * 16), rsA, (int)va[it < PA ? it : 0], soffA);
+                                else lds_dma16(nx + (uint32_t)(it * LR * KC * 16), rsB, voffB[it >= PA ? it - PA : 0], soffB);
+                            } else if (it < nitems) rd(set ^ 1, kk + 1, it - ndma);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            };
+            // the last k-step (nothing left to request) is peeled: two accumulating variants merging inside one loop body cost a copy of
+            // every accumulator per k-step and 192 VGPRs
+            for (int ks = ks_begin; ks + 1 < ks_end; ++ks) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (p.flags & 0x800) lds_dma_stage<PA, PB, LR * KC * 16>(ldsA0 + (uint32_t)((cur ^ 1) * BUF * 16), rsA, va, soffA, rsB, voffB, soffB);
+                else step(std::true_type{});
+                prepare();
+                cur ^= 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (!(p.flags & 0x800)) step(std::false_type{});
+#else
             for (int ks = ks_begin; ks < ks_end; ++ks) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -533,6 +593,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
                 prepare();
                 cur ^= 1;
             }
+#endif
         }
     } else
     if (ks_begin < ks_end) {
