@@ -2636,8 +2636,10 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
                     if (tl < pt || (tl == pt && pad < pp)) { pb = bc; pt = tl; pp = pad; }
                 }
                 // (row padding above 15 % -- the 160-row banks as 192 -- measured +5 % only: those stay on the round-1 choice below)
-                const char* ppv = getenv("DIN_WGRAD_PIPE_PAD");          // tuning aid: allowed row padding in percent (default 15)
-                const int pad_pct = ppv ? atoi(ppv) : 15;
+                // allowed row padding in percent: 20 admits the 160-row banks of Mixed_6c / 6d (160 -> 192 rows: 168 -> 155 us per launch
+                // against conv_wgrad_bf16_kernel<160>, steady-state clocks; profiles/r03_power_clocks.txt).  DIN_WGRAD_PIPE_PAD: tuning aid
+                const char* ppv = getenv("DIN_WGRAD_PIPE_PAD");
+                const int pad_pct = ppv ? atoi(ppv) : 20;
                 if (pp * 100 <= d->cout * (100 + pad_pct)) w.bco = pb;
                 else if (best_pad * 100 <= d->cout * 105 && (best == 192 || kpad * 100 <= w.kcols * 112)) w.bco = best;
                 else w.ring = 0;

@@ -324,3 +324,19 @@ def test_tce_model_keys_and_loadpart():
     cfg.backbone, cfg.lite_dim = "vgg16", 128
     with pytest.raises(NotImplementedError):
         Dynamic_TCE_volleyball(cfg)
+
+
+def test_bench_clock_sampler_degrades_without_a_gpu():
+    """bench.py's sclk / power sampler (amdsmi on a background thread) must never break the bench line: with no driver it reports why."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("din_bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    smp = mod.ClockSampler(0)
+    smp.start()
+    out = smp.stop()
+    assert "sclk_mhz_avg" in out
+    if out["sclk_mhz_avg"] is None:
+        assert "not sampled" in out["note"]
+    else:                                                    # a GPU box: plausible numbers
+        assert 50 <= out["sclk_mhz_avg"] <= 3000
