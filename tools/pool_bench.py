@@ -6,7 +6,7 @@ import torch
 from din_amd import _lib as L
 
 
-def bench(fn, iters=20):
+def bench(fn, iters=int(os.environ.get("DIN_POOL_ITERS", "20"))):      # DIN_POOL_ITERS=2000: steady-state clocks (tools/clock_probe.sh)
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
