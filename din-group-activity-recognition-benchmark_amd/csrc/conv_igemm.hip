@@ -2794,6 +2794,12 @@ void launch_wave8(const ConvK& k, dim3 grid, hipStream_t st) {
             return;
         }
     }
+    if constexpr (sizeof(T) == 2 && (BN == 192 || BN == 160)) {
+        // experiment switch DIN_CONV_RING=3: three 32-deep stages (two in flight, one counted vmcnt per barrier) instead of two 64-deep ones
+        // (one in flight, vmcnt(0)) for the general loop's 8-wave tiles -- same LDS budget (72 vs 80 KiB per workgroup), half the MFMAs per barrier
+        static const bool ring3 = getenv("DIN_CONV_RING") && atoi(getenv("DIN_CONV_RING")) == 3;
+        if (ring3 && !k.remap) { launch_fast<T, 128, BN, 4, 2, 4, 3>(k, grid, st); return; }
+    }
     launch_fast<T, 128, BN, 4, 2, 8, 2>(k, grid, st);
 }
 
