@@ -38,6 +38,9 @@ using din_gather::staged_tile_store;
 
 namespace {
 
+#ifndef DIN_GATHER_PRIO
+#define DIN_GATHER_PRIO 0         // experiment: raised wave priority over the MFMA stream of the interleaved k-step
+#endif
 #ifndef DIN_GATHER_ILV
 #define DIN_GATHER_ILV 1          // in-wave interleaved schedule of the FASTK gather loop (0: the compiler-scheduled loop, for A/B builds)
 #endif
@@ -548,6 +551,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
 #pragma unroll
                 for (int f = 0; f < TI + TJ; ++f) rd(0, 0, f);
                 __builtin_amdgcn_sched_barrier(0);
+#if DIN_GATHER_PRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                 for (int kk = 0; kk < NKK; ++kk) {
                     const int set = kk & 1;
@@ -567,6 +573,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+#if DIN_GATHER_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             };
             // the last k-step (nothing left to request) is peeled: two accumulating variants merging inside one loop body cost a copy of
             // every accumulator per k-step and 192 VGPRs
