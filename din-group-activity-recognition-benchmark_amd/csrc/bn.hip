@@ -18,6 +18,15 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int BN_ROWS_PER_BLOCK = 2048;
+// Rows per workgroup of the statistics kernels: 2048, but at most BN_MAX_BLOCKS workgroups.  Every workgroup ends with 2 C fp64 atomics on the
+// SAME few cache lines, which L2 serialises at ~44 ns per workgroup (measured on din_colsum, tools/colsum_probe.py): the stem maps (22 M rows
+// = 10 753 workgroups of 2048 rows) spent longer in that queue than reading their 1.4 GB.  DIN_BN_MAX_BLOCKS: tuning aid (0 = no cap).
+static int bn_rows_per_block(int64_t rows) {
+    static const int cap = getenv("DIN_BN_MAX_BLOCKS") ? atoi(getenv("DIN_BN_MAX_BLOCKS")) : 1024;
+    int64_t rpb = BN_ROWS_PER_BLOCK;
+    if (cap > 0 && (rows + rpb - 1) / rpb > cap) rpb = (rows + cap - 1) / cap;
+    return (int)rpb;
+}
 
 template <typename T> struct Vec;
 template <> struct Vec<float> {
@@ -45,15 +54,15 @@ template <> struct Vec<bf16_t> {
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int ldx, int cxoff, const T* __restrict__ g, int ldg, int cgoff,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd, int64_t M, int C,
-                                                       double* __restrict__ sums) {
+                                                       double* __restrict__ sums, int rows_per_block) {
     constexpr int V = Vec<T>::V;
     extern __shared__ float red[];                                  // [2][C]
     const int cv = C / V, rpp = 256 / cv;
     const int tid = threadIdx.x, ch = tid % cv, rl = tid / cv;
     for (int i = tid; i < 2 * C; i += 256) red[i] = 0.f;
     __syncthreads();
-    const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS_PER_BLOCK;
-    int64_t r1 = r0 + BN_ROWS_PER_BLOCK;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
     float s1[V], s2[V], mu[V], rs[V];
 #pragma unroll
@@ -66,18 +75,32 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll                                                      // E[(x-s)^2] - E[x-s]^2 does not cancel when |mean| >> std
             for (int e = 0; e < V; ++e) mu[e] = mean[ch * V + e];
         }
-        for (int64_t r = r0 + rl; r < r1; r += rpp) {
-            float xv[V];
-            Vec<T>::load(x + r * ldx + cxoff + ch * V, xv);
+        auto fold = [&](const float (&xv)[V], const float (&gv)[V]) {
             if (BWD) {
-                float gv[V];
-                Vec<T>::load(g + r * ldg + cgoff + ch * V, gv);
 #pragma unroll
                 for (int e = 0; e < V; ++e) { s1[e] += gv[e]; s2[e] += gv[e] * ((xv[e] - mu[e]) * rs[e]); }
             } else {
 #pragma unroll
                 for (int e = 0; e < V; ++e) { const float dv = xv[e] - mu[e]; s1[e] += dv; s2[e] += dv * dv; }
             }
+        };
+        int64_t r = r0 + rl;
+        // four rows per trip: their loads are independent and stay in flight together (a workgroup now walks up to M / 1024 rows)
+        for (; r + 3 * (int64_t)rpp < r1; r += 4 * (int64_t)rpp) {
+            float xv[4][V], gv[4][V];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                Vec<T>::load(x + (r + u * (int64_t)rpp) * ldx + cxoff + ch * V, xv[u]);
+                if (BWD) Vec<T>::load(g + (r + u * (int64_t)rpp) * ldg + cgoff + ch * V, gv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fold(xv[u], gv[u]);
+        }
+        for (; r < r1; r += rpp) {
+            float xv[V], gv[V];
+            Vec<T>::load(x + r * ldx + cxoff + ch * V, xv);
+            if (BWD) Vec<T>::load(g + r * ldg + cgoff + ch * V, gv);
+            fold(xv, gv);
         }
 #pragma unroll
         for (int e = 0; e < V; ++e) { atomicAdd(&red[ch * V + e], s1[e]); atomicAdd(&red[C + ch * V + e], s2[e]); }
@@ -171,14 +194,15 @@ extern "C" {
 int din_bn_stats(const void* x, int dtype, int64_t rows, int c, int ld, int coff, const float* shift, double* sums, void* stream) {
     DIN_REQUIRE(x && sums, "bn_stats: null pointer");
     if (int e = check_view(dtype, rows, c, ld, coff, "bn_stats")) return e;
-    const int blocks = (int)ceil_div64(rows, BN_ROWS_PER_BLOCK);
+    const int rpb = bn_rows_per_block(rows);
+    const int blocks = (int)ceil_div64(rows, rpb);
     const size_t lds = 2 * (size_t)c * sizeof(float);
     if (dtype == DIN_F32)
         hipLaunchKernelGGL((bn_stats_kernel<float, false>), dim3(blocks), dim3(256), lds, as_stream(stream), (const float*)x, ld, coff,
-                           (const float*)nullptr, 0, 0, shift, (const float*)nullptr, rows, c, sums);
+                           (const float*)nullptr, 0, 0, shift, (const float*)nullptr, rows, c, sums, rpb);
     else
         hipLaunchKernelGGL((bn_stats_kernel<bf16_t, false>), dim3(blocks), dim3(256), lds, as_stream(stream), (const bf16_t*)x, ld, coff,
-                           (const bf16_t*)nullptr, 0, 0, shift, (const float*)nullptr, rows, c, sums);
+                           (const bf16_t*)nullptr, 0, 0, shift, (const float*)nullptr, rows, c, sums, rpb);
     DIN_CHECK_LAUNCH("bn_stats");
     return DIN_OK;
 }
@@ -215,14 +239,15 @@ int din_bn_bwd_stats(const void* gz, int ldg, int cgoff, const void* x, int ldx,
     DIN_REQUIRE(gz && x && mean && rstd && sums, "bn_bwd_stats: null pointer");
     if (int e = check_view(dtype, rows, c, ldg, cgoff, "bn_bwd_stats(gz)")) return e;
     if (int e = check_view(dtype, rows, c, ldx, cxoff, "bn_bwd_stats(x)")) return e;
-    const int blocks = (int)ceil_div64(rows, BN_ROWS_PER_BLOCK);
+    const int rpb = bn_rows_per_block(rows);
+    const int blocks = (int)ceil_div64(rows, rpb);
     const size_t lds = 2 * (size_t)c * sizeof(float);
     if (dtype == DIN_F32)
         hipLaunchKernelGGL((bn_stats_kernel<float, true>), dim3(blocks), dim3(256), lds, as_stream(stream), (const float*)x, ldx, cxoff,
-                           (const float*)gz, ldg, cgoff, mean, rstd, rows, c, sums);
+                           (const float*)gz, ldg, cgoff, mean, rstd, rows, c, sums, rpb);
     else
         hipLaunchKernelGGL((bn_stats_kernel<bf16_t, true>), dim3(blocks), dim3(256), lds, as_stream(stream), (const bf16_t*)x, ldx, cxoff,
-                           (const bf16_t*)gz, ldg, cgoff, mean, rstd, rows, c, sums);
+                           (const bf16_t*)gz, ldg, cgoff, mean, rstd, rows, c, sums, rpb);
     DIN_CHECK_LAUNCH("bn_bwd_stats");
     return DIN_OK;
 }

@@ -2381,7 +2381,7 @@ __global__ void colsum_kernel(const T* __restrict__ g, float* __restrict__ out, 
 
 // vectorised form: thread = (row lane r, 16-byte channel chunk c); four rows in flight per thread, LDS cross-row reduce, one atomic
 // per column per block
-template <typename T>
+template <typename T, int U = 4>
 __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ g, float* __restrict__ out, int64_t M, int cout, int ld,
                                                          int coff, int64_t rows_per_block) {
     constexpr int EPC = 16 / sizeof(T);
@@ -2406,12 +2406,12 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ g
     if (r < rows_pp) {
         const T* base = g + coff + c * EPC;
         int64_t row = r0 + r;
-        for (; row + 3 * rows_pp < r1; row += 4 * rows_pp) {
-            const u32x4 v0 = *reinterpret_cast<const u32x4*>(base + row * ld);
-            const u32x4 v1 = *reinterpret_cast<const u32x4*>(base + (row + rows_pp) * ld);
-            const u32x4 v2 = *reinterpret_cast<const u32x4*>(base + (row + 2 * rows_pp) * ld);
-            const u32x4 v3 = *reinterpret_cast<const u32x4*>(base + (row + 3 * rows_pp) * ld);
-            add(v0); add(v1); add(v2); add(v3);
+        for (; row + (U - 1) * rows_pp < r1; row += U * rows_pp) {         // U independent 16-byte loads in flight per thread
+            u32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const u32x4*>(base + (row + u * rows_pp) * ld);
+#pragma unroll
+            for (int u = 0; u < U; ++u) add(v[u]);
         }
         for (; row < r1; row += rows_pp) add(*reinterpret_cast<const u32x4*>(base + row * ld));
     }
@@ -3049,12 +3049,21 @@ static int launch_colsum(int dtype, const void* g, float* out, int64_t M, int c,
     hipMemsetAsync(out, 0, sizeof(float) * c, st);
     const int epc = dtype == DIN_F32 ? 4 : 8;
     if (c % epc == 0 && c / epc <= 256 && ld % epc == 0 && coff % epc == 0) {
-        // ~1024 workgroups, each streaming a contiguous slab of rows (XCD-contiguous order)
-        int64_t rpb = ceil_div64(M, 1024);
+        // 256 workgroups (one per CU), eight 16-byte loads in flight per thread, each streaming a contiguous slab of rows (XCD-contiguous order).
+        // Every workgroup ends with `c` float atomics on the SAME few cache lines, which L2 serialises at ~44 ns per workgroup: the kernel's time
+        // grew with its workgroup count (1024: 45 us, 2048: 64 us, 4096: 110 us on the 192-channel maps; 256: 30 us -- tools/colsum_probe.py;
+        // the seven launches of the default step 335 -> 248 us).  DIN_COLSUM_WGS / DIN_COLSUM_UNROLL: tuning aids
+        static const int wgs = getenv("DIN_COLSUM_WGS") ? atoi(getenv("DIN_COLSUM_WGS")) : 256;
+        static const int unr = getenv("DIN_COLSUM_UNROLL") ? atoi(getenv("DIN_COLSUM_UNROLL")) : 8;
+        int64_t rpb = ceil_div64(M, wgs > 0 ? wgs : 1024);
         if (rpb < 64) rpb = 64;
         int blocks = (int)ceil_div64(M, rpb);
         if (dtype == DIN_F32)
             hipLaunchKernelGGL(colsum_vec_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)g, out, M, c, ld, coff, rpb);
+        else if (unr == 8)
+            hipLaunchKernelGGL((colsum_vec_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)g, out, M, c, ld, coff, rpb);
+        else if (unr == 16)
+            hipLaunchKernelGGL((colsum_vec_kernel<bf16_t, 16>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)g, out, M, c, ld, coff, rpb);
         else
             hipLaunchKernelGGL(colsum_vec_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)g, out, M, c, ld, coff, rpb);
     } else {

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--which", default="fwd", choices=["fwd", "dgrad", "wgrad"])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--flags", type=int, default=8, help="dgrad epilogue flags (8 = ReLU mask, 4 = accumulate)")
+    ap.add_argument("--no-dbias", action="store_true", help="wgrad without the bias gradient (what do its per-workgroup atomics cost?)")
     ap.add_argument("--const", action="store_true", help="constant operands (low toggle rate): shows how much the clock sags on random data")
     a = ap.parse_args()
     lib = L.load()
@@ -81,7 +82,7 @@ def main():
         elif a.which == "dgrad":
             L.check(lib.din_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), dx.data_ptr(), x.data_ptr(), cin, 0, a.flags, ws.data_ptr(), wsb, None))
         else:
-            L.check(lib.din_conv_wgrad(C.byref(d), x.data_ptr(), gy.data_ptr(), dw.data_ptr(), bias.data_ptr(), None, None, None, 0, ws.data_ptr(), wsb, None))
+            L.check(lib.din_conv_wgrad(C.byref(d), x.data_ptr(), gy.data_ptr(), dw.data_ptr(), None if a.no_dbias else bias.data_ptr(), None, None, None, 0, ws.data_ptr(), wsb, None))
     for _ in range(3):
         run()
     torch.cuda.synchronize()
