@@ -18,9 +18,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int BN_ROWS_PER_BLOCK = 2048;
-// Rows per workgroup of the statistics kernels: 2048, but at most BN_MAX_BLOCKS workgroups.  Every workgroup ends with 2 C fp64 atomics on the
-// SAME few cache lines, which L2 serialises at ~44 ns per workgroup (measured on din_colsum, tools/colsum_probe.py): the stem maps (22 M rows
-// = 10 753 workgroups of 2048 rows) spent longer in that queue than reading their 1.4 GB.  DIN_BN_MAX_BLOCKS: tuning aid (0 = no cap).
+// Rows per workgroup of the statistics kernels: 2048, but at most BN_MAX_BLOCKS workgroups (every workgroup ends with 2 C fp64 atomics on the
+// same few cache lines, which L2 serialises: tools/colsum_probe.py).  Measured on the batch-statistics step (bench.py --bn-mode batch, one box):
+// four rows per trip instead of one 93.1 -> 88.7 ms (the loads of a trip are independent: more bytes in flight), the cap on top of it
+// 88.7 -> 87.9-88.5 ms (1024; 256 .. 2048 within noise).  DIN_BN_MAX_BLOCKS: tuning aid (0 = no cap).
 static int bn_rows_per_block(int64_t rows) {
     static const int cap = getenv("DIN_BN_MAX_BLOCKS") ? atoi(getenv("DIN_BN_MAX_BLOCKS")) : 1024;
     int64_t rpb = BN_ROWS_PER_BLOCK;
