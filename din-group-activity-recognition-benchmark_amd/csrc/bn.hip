@@ -180,6 +180,109 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// Row-walk forms of the two apply kernels (default; DIN_BN_APPLY_ROWS=0 restores the element-per-iteration kernels above).  Thread t of a workgroup
+// owns channel chunk t % cv for the whole launch, so the per-channel constants (fp64 sums converted, gamma * rstd, ...) are formed ONCE instead of
+// per element, there is no 64-bit division per element, and four rows' loads are in flight per trip.  The arithmetic per element is the expression
+// of the kernels above with the same operands in the same order: same bits.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_rows_kernel(const T* __restrict__ x, int ldx, int cxoff, const float* __restrict__ a,
+                                                            const float* __restrict__ b, int relu, T* __restrict__ y, int ldy, int cyoff,
+                                                            int64_t M, int C, int rows_per_block) {
+    constexpr int V = Vec<T>::V;
+    const int cv = C / V, rpp = 256 / cv;
+    const int ch = threadIdx.x % cv, rl = threadIdx.x / cv;
+    if (rl >= rpp) return;
+    float av[V], bv[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { av[e] = a[ch * V + e]; bv[e] = b[ch * V + e]; }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    const T* xs = x + cxoff + ch * V;
+    T* ys = y + cyoff + ch * V;
+    auto one = [&](float (&v)[V]) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { const float z = v[e] * av[e] + bv[e]; v[e] = relu ? fmaxf(z, 0.f) : z; }
+    };
+    int64_t r = r0 + rl;
+    for (; r + 3 * (int64_t)rpp < r1; r += 4 * (int64_t)rpp) {
+        float v[4][V];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Vec<T>::load(xs + (r + u * (int64_t)rpp) * ldx, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { one(v[u]); Vec<T>::store(ys + (r + u * (int64_t)rpp) * ldy, v[u]); }
+    }
+    for (; r < r1; r += rpp) {
+        float v[V];
+        Vec<T>::load(xs + r * ldx, v);
+        one(v);
+        Vec<T>::store(ys + r * ldy, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const T* __restrict__ g, int ldg, int cgoff, const T* __restrict__ x, int ldx, int cxoff,
+                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const double* __restrict__ sums,
+                                                                T* __restrict__ dy, int ldy, int cyoff, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int64_t M, int C, int rows_per_block) {
+    constexpr int V = Vec<T>::V;
+    const int cv = C / V, rpp = 256 / cv;
+    const float invM = 1.f / (float)M;
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += 256) { dbeta[c] = (float)sums[c]; dgamma[c] = (float)sums[C + c]; }
+    const int ch = threadIdx.x % cv, rl = threadIdx.x / cv;
+    if (rl >= rpp) return;
+    float mu[V], rs[V], gr[V], k1[V], k2[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const int c = ch * V + e;
+        mu[e] = mean[c]; rs[e] = rstd[c]; gr[e] = gamma[c] * rstd[c];
+        k1[e] = (float)sums[c] * invM; k2[e] = (float)sums[C + c] * invM;
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    const T* gs = g + cgoff + ch * V;
+    const T* xs = x + cxoff + ch * V;
+    T* ds = dy + cyoff + ch * V;
+    auto one = [&](float (&gv)[V], const float (&xv)[V]) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float xh = (xv[e] - mu[e]) * rs[e];
+            gv[e] = gr[e] * (gv[e] - k1[e] - xh * k2[e]);
+        }
+    };
+    int64_t r = r0 + rl;
+    for (; r + 3 * (int64_t)rpp < r1; r += 4 * (int64_t)rpp) {
+        float gv[4][V], xv[4][V];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            Vec<T>::load(gs + (r + u * (int64_t)rpp) * ldg, gv[u]);
+            Vec<T>::load(xs + (r + u * (int64_t)rpp) * ldx, xv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { one(gv[u], xv[u]); Vec<T>::store(ds + (r + u * (int64_t)rpp) * ldy, gv[u]); }
+    }
+    for (; r < r1; r += rpp) {
+        float gv[V], xv[V];
+        Vec<T>::load(gs + r * ldg, gv);
+        Vec<T>::load(xs + r * ldx, xv);
+        one(gv, xv);
+        Vec<T>::store(ds + r * ldy, gv);
+    }
+}
+
+static bool bn_apply_rows() { static const bool on = !(getenv("DIN_BN_APPLY_ROWS") && atoi(getenv("DIN_BN_APPLY_ROWS")) == 0); return on; }
+// rows per workgroup of the row-walk apply kernels: ~2048 workgroups, at least four passes of the workgroup's 256 / (C / V) rows each
+static int bn_apply_rpb(int64_t rows, int c, int v) {
+    const int rpp = 256 / (c / v);
+    int64_t rpb = (rows + 2047) / 2048;
+    if (rpb < 4 * rpp) rpb = 4 * rpp;
+    if (rpb > 8192) rpb = 8192;
+    return (int)rpb;
+}
+
 int check_view(int dtype, int64_t rows, int c, int ld, int coff, const char* what) {
     DIN_REQUIRE(dtype == DIN_F32 || dtype == DIN_BF16, "%s: bad dtype", what);
     const int v = dtype == DIN_F32 ? 4 : 8;
@@ -224,6 +327,17 @@ int din_bn_apply(const void* x, int dtype, int64_t rows, int c, int ldx, int cxo
     if (int e = check_view(dtype, rows, c, ldx, cxoff, "bn_apply(x)")) return e;
     if (int e = check_view(dtype, rows, c, ldy, cyoff, "bn_apply(y)")) return e;
     const int v = dtype == DIN_F32 ? 4 : 8;
+    if (bn_apply_rows()) {
+        const int rpb = bn_apply_rpb(rows, c, v), nblk = (int)ceil_div64(rows, rpb);
+        if (dtype == DIN_F32)
+            hipLaunchKernelGGL(bn_apply_rows_kernel<float>, dim3(nblk), dim3(256), 0, as_stream(stream), (const float*)x, ldx, cxoff, a, b, relu,
+                               (float*)y, ldy, cyoff, rows, c, rpb);
+        else
+            hipLaunchKernelGGL(bn_apply_rows_kernel<bf16_t>, dim3(nblk), dim3(256), 0, as_stream(stream), (const bf16_t*)x, ldx, cxoff, a, b, relu,
+                               (bf16_t*)y, ldy, cyoff, rows, c, rpb);
+        DIN_CHECK_LAUNCH("bn_apply");
+        return DIN_OK;
+    }
     const int blocks = grid_1d(rows * (c / v), 256, 256 * 16);
     if (dtype == DIN_F32)
         hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)x, ldx, cxoff, a, b, relu,
@@ -261,6 +375,17 @@ int din_bn_bwd_apply(const void* gz, int ldg, int cgoff, const void* x, int ldx,
     if (int e = check_view(dtype, rows, c, ldx, cxoff, "bn_bwd_apply(x)")) return e;
     if (int e = check_view(dtype, rows, c, ldy, cyoff, "bn_bwd_apply(dy)")) return e;
     const int v = dtype == DIN_F32 ? 4 : 8;
+    if (bn_apply_rows()) {
+        const int rpb = bn_apply_rpb(rows, c, v), nblk = (int)ceil_div64(rows, rpb);
+        if (dtype == DIN_F32)
+            hipLaunchKernelGGL(bn_bwd_apply_rows_kernel<float>, dim3(nblk), dim3(256), 0, as_stream(stream), (const float*)gz, ldg, cgoff,
+                               (const float*)x, ldx, cxoff, gamma, mean, rstd, sums, (float*)dy, ldy, cyoff, dgamma, dbeta, rows, c, rpb);
+        else
+            hipLaunchKernelGGL(bn_bwd_apply_rows_kernel<bf16_t>, dim3(nblk), dim3(256), 0, as_stream(stream), (const bf16_t*)gz, ldg, cgoff,
+                               (const bf16_t*)x, ldx, cxoff, gamma, mean, rstd, sums, (bf16_t*)dy, ldy, cyoff, dgamma, dbeta, rows, c, rpb);
+        DIN_CHECK_LAUNCH("bn_bwd_apply");
+        return DIN_OK;
+    }
     const int blocks = grid_1d(rows * (c / v), 256, 256 * 16);
     if (dtype == DIN_F32)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)gz, ldg, cgoff,
