@@ -18,7 +18,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "din_hip.h")
 
 DIN_F32, DIN_BF16 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 CONV_BIAS, CONV_RELU, CONV_ACCUM, CONV_MASK = 1, 2, 4, 8
 
 
@@ -82,7 +82,10 @@ SIGNATURES: Dict[str, tuple] = {
     "din_bn_fold_multi": (_I, [_P, _P, _I, _I, _F, _P, _P, _P]),
     "din_bn_fold_bwd_multi": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P, _P]),
     "din_bn_stats": (_I, [_P, _I, _L, _I, _I, _I, _P, _P, _P]),
-    "din_bn_finalize": (_I, [_P, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "din_bn_parts": (_I, [_L]),
+    "din_bn_workspace": (_L, [_L, _I]),
+    "din_bn_reduce": (_I, [_P, _I, _I, _P]),
+    "din_bn_finalize": (_I, [_P, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "din_bn_apply": (_I, [_P, _I, _L, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P]),
     "din_bn_bwd_stats": (_I, [_P, _I, _I, _P, _I, _I, _I, _L, _I, _P, _P, _P, _P]),
     "din_bn_bwd_apply": (_I, [_P, _I, _I, _P, _I, _I, _I, _L, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),

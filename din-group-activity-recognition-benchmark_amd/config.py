@@ -32,6 +32,16 @@ class Config(object):
         for k, v in _DEFAULTS.items():
             setattr(self, k, list(v) if isinstance(v, list) else (dict(v) if isinstance(v, dict) else v))
         self.log_path = None
+        # dataset trees (reference config.py:24-33): used when the directory exists, else the trainer falls back to synthetic clips
+        if dataset_name == "volleyball":
+            self.data_path = "data/volleyball/videos"
+            self.test_seqs = [4, 5, 9, 11, 14, 20, 21, 25, 29, 34, 35, 37, 43, 44, 45, 47]
+            self.train_seqs = [1, 3, 6, 7, 10, 13, 15, 16, 18, 22, 23, 31, 32, 36, 38, 39, 40, 41, 42, 48, 50, 52, 53, 54,
+                               0, 2, 8, 12, 17, 19, 24, 26, 27, 28, 30, 33, 46, 49, 51]      # (the reference's order: it fixes the sample order)
+        else:
+            self.data_path = "data/collective"
+            self.test_seqs = [5, 6, 7, 8, 9, 10, 11, 15, 16, 25, 28, 29]
+            self.train_seqs = [s for s in range(1, 45) if s not in self.test_seqs]
 
     def init_config(self, need_new_folder=True):
         if self.exp_name is None:

@@ -8,8 +8,8 @@
 //   backward: masked gradient gz and y  ->  s1 = sum gz, s2 = sum gz * yhat (din_bn_bwd_stats)  ->
 //             dy = gamma * rstd * (gz - s1 / M - yhat * s2 / M), dgamma = s2, dbeta = s1 (din_bn_bwd_apply)
 // All four passes are HBM-bound streams over [M][C] views (pixel stride ld, channel offset coff): 16-byte lanes along the channels,
-// fp32 partial sums per thread, one fp64 atomic per channel per workgroup (native global_atomic_add_f64), so the statistics do not
-// depend on M in precision.  torch.nn.functional.batch_norm is the arithmetic being replaced (reached from torchvision BasicConv2d).
+// fp64 partial sums per thread, a fixed-order LDS sum per workgroup, one slab per workgroup summed in slab order: the statistics do not
+// depend on M in precision and are bit-reproducible (no atomics anywhere).  torch.nn.functional.batch_norm is the arithmetic being replaced (reached from torchvision BasicConv2d).
 #include "din_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -18,16 +18,16 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int BN_ROWS_PER_BLOCK = 2048;
-// Rows per workgroup of the statistics kernels: 2048, but at most BN_MAX_BLOCKS workgroups (every workgroup ends with 2 C fp64 atomics on the
-// same few cache lines, which L2 serialises: tools/colsum_probe.py).  Measured on the batch-statistics step (bench.py --bn-mode batch, one box):
-// four rows per trip instead of one 93.1 -> 88.7 ms (the loads of a trip are independent: more bytes in flight), the cap on top of it
-// 88.7 -> 87.9-88.5 ms (1024; 256 .. 2048 within noise).  DIN_BN_MAX_BLOCKS: tuning aid (0 = no cap).
+constexpr int BN_MAX_PARTS = 512;
+// Rows per workgroup of the statistics kernels: 2048, but at most BN_MAX_PARTS workgroups.  The decomposition is a function of `rows` ALONE
+// (no environment switch, no device query): together with the fixed summation order below it makes the statistics bit-reproducible run to
+// run and box to box.  Measured in round 3 (bench.py --bn-mode batch): 256 .. 2048 workgroups within noise of each other.
 static int bn_rows_per_block(int64_t rows) {
-    static const int cap = getenv("DIN_BN_MAX_BLOCKS") ? atoi(getenv("DIN_BN_MAX_BLOCKS")) : 1024;
     int64_t rpb = BN_ROWS_PER_BLOCK;
-    if (cap > 0 && (rows + rpb - 1) / rpb > cap) rpb = (rows + cap - 1) / cap;
+    if ((rows + rpb - 1) / rpb > BN_MAX_PARTS) rpb = (rows + BN_MAX_PARTS - 1) / BN_MAX_PARTS;
     return (int)rpb;
 }
+static int bn_parts(int64_t rows) { return (int)ceil_div64(rows, bn_rows_per_block(rows)); }
 
 template <typename T> struct Vec;
 template <> struct Vec<float> {
@@ -50,43 +50,53 @@ template <> struct Vec<bf16_t> {
     }
 };
 
-// thread t of a 256-thread workgroup owns channel chunk t % cv and walks rows t / cv, + rpp, ... of the workgroup's row range
-// (cv = C / V chunks per row, rpp = 256 / cv rows per pass; threads beyond rpp * cv idle)
+// Statistics, DETERMINISTIC form (round 4; the round-3 kernel combined fp32 per-thread partial sums with LDS float atomics and fp64 global
+// atomics: order-dependent bits, and a whole-model test with a zero-margin bound went red on the driver's box).
+//   thread t of a 256-thread workgroup owns channel chunk t % cv and walks rows t / cv, + rpp, ... of the workgroup's row range
+//   (cv = C / V chunks per row, rpp = 256 / cv rows per pass; threads beyond rpp * cv idle);
+//   per-thread accumulators are FLOAT64: the products x * x of fp32 / bf16 inputs are exact in fp64 (24 + 24 significand bits), so
+//   E[x^2] - mean^2 loses nothing to cancellation whatever |mean| / std is and no shift heuristic is needed (an optional shift is still
+//   subtracted, exactly, for callers that pass one);
+//   the workgroup combines its rpp row-lanes through LDS in lane order 0, 1, 2, ... (a fixed-order sum, no atomics) and writes ONE slab
+//   part[blockIdx][2 C]; bn_reduce / bn_finalize add the slabs in block order.  Same input -> same bits, every run.
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int ldx, int cxoff, const T* __restrict__ g, int ldg, int cgoff,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd, int64_t M, int C,
-                                                       double* __restrict__ sums, int rows_per_block) {
+                                                       double* __restrict__ part, int rows_per_block) {
     constexpr int V = Vec<T>::V;
-    extern __shared__ float red[];                                  // [2][C]
+    extern __shared__ double red[];                                 // [rpp][2 C]
     const int cv = C / V, rpp = 256 / cv;
     const int tid = threadIdx.x, ch = tid % cv, rl = tid / cv;
-    for (int i = tid; i < 2 * C; i += 256) red[i] = 0.f;
-    __syncthreads();
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    float s1[V], s2[V], mu[V], rs[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) { s1[e] = 0.f; s2[e] = 0.f; mu[e] = 0.f; rs[e] = 1.f; }
     if (rl < rpp) {
+        double s1[V], s2[V];
+        float mu[V], rs[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) { s1[e] = 0.0; s2[e] = 0.0; mu[e] = 0.f; rs[e] = 1.f; }
         if (BWD) {
 #pragma unroll
             for (int e = 0; e < V; ++e) { mu[e] = mean[ch * V + e]; rs[e] = rstd[ch * V + e]; }
-        } else if (mean) {                                          // forward: sums of (x - shift), shift = the running mean before its update:
-#pragma unroll                                                      // E[(x-s)^2] - E[x-s]^2 does not cancel when |mean| >> std
+        } else if (mean) {
+#pragma unroll
             for (int e = 0; e < V; ++e) mu[e] = mean[ch * V + e];
         }
         auto fold = [&](const float (&xv)[V], const float (&gv)[V]) {
-            if (BWD) {
+            if (BWD) {                                              // xhat is the fp32 expression of bn_bwd_apply; its product with gz is exact in fp64
 #pragma unroll
-                for (int e = 0; e < V; ++e) { s1[e] += gv[e]; s2[e] += gv[e] * ((xv[e] - mu[e]) * rs[e]); }
+                for (int e = 0; e < V; ++e) {
+                    const double gd = (double)gv[e];
+                    s1[e] += gd;
+                    s2[e] = fma(gd, (double)((xv[e] - mu[e]) * rs[e]), s2[e]);
+                }
             } else {
 #pragma unroll
-                for (int e = 0; e < V; ++e) { const float dv = xv[e] - mu[e]; s1[e] += dv; s2[e] += dv * dv; }
+                for (int e = 0; e < V; ++e) { const double dv = (double)xv[e] - (double)mu[e]; s1[e] += dv; s2[e] = fma(dv, dv, s2[e]); }
             }
         };
         int64_t r = r0 + rl;
-        // four rows per trip: their loads are independent and stay in flight together (a workgroup now walks up to M / 1024 rows)
+        // four rows per trip: their loads are independent and stay in flight together
         for (; r + 3 * (int64_t)rpp < r1; r += 4 * (int64_t)rpp) {
             float xv[4][V], gv[4][V];
 #pragma unroll
@@ -104,21 +114,63 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
             fold(xv, gv);
         }
 #pragma unroll
-        for (int e = 0; e < V; ++e) { atomicAdd(&red[ch * V + e], s1[e]); atomicAdd(&red[C + ch * V + e], s2[e]); }
+        for (int e = 0; e < V; ++e) { red[rl * 2 * C + ch * V + e] = s1[e]; red[rl * 2 * C + C + ch * V + e] = s2[e]; }
     }
     __syncthreads();
-    for (int i = tid; i < 2 * C; i += 256) atomicAdd(&sums[i], (double)red[i]);
+    double* out = part + (int64_t)blockIdx.x * 2 * C;
+    for (int i = tid; i < 2 * C; i += 256) {
+        double s = red[i];
+        for (int l = 1; l < rpp; ++l) s += red[l * 2 * C + i];      // lane order: fixed
+        out[i] = s;
+    }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t M, int C, const float* __restrict__ gamma,
+// Fixed-order column sums of a slab stack part[nparts][n] -> out[n].  A workgroup owns 16 columns; its 16 segments each add a contiguous run
+// of slabs in slab order, then segment 0 adds the 16 segment sums in segment order.  (nparts, n) -> one summation tree, whatever the grid.
+__device__ __forceinline__ double bn_column_sum(const double* __restrict__ part, int nparts, int n, int col, int seg, double* lds /*[16][16]*/) {
+    const int per = (nparts + 15) / 16;
+    int p0 = seg * per, p1 = p0 + per;
+    if (p1 > nparts) p1 = nparts;
+    double s = 0.0;
+    if (col < n)
+        for (int p = p0; p < p1; ++p) s += part[(int64_t)p * n + col];
+    lds[seg * 16 + (threadIdx.x & 15)] = s;
+    __syncthreads();
+    double t = 0.0;
+    if (seg == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += lds[k * 16 + (threadIdx.x & 15)];
+    }
+    __syncthreads();
+    return t;                                                       // valid in segment 0
+}
+
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const double* __restrict__ part, int nparts, int n, double* __restrict__ out) {
+    __shared__ double lds[256];
+    const int col = blockIdx.x * 16 + (threadIdx.x & 15), seg = threadIdx.x >> 4;
+    const double t = bn_column_sum(part, nparts, n, col, seg, lds);
+    if (seg == 0 && col < n) out[col] = t;
+}
+
+// ws = [2 C reduced sums][nparts slabs of 2 C]: reduce (nparts > 0) in fixed order, then the per-channel constants
+__global__ __launch_bounds__(256) void bn_finalize_kernel(double* __restrict__ ws, int nparts, int64_t M, int C, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float* __restrict__ a, float* __restrict__ b, float* __restrict__ mean,
                                    float* __restrict__ rstd, const float* __restrict__ shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double ms = sums[c] / (double)M;                          // mean of (x - shift)
+    __shared__ double lds[256];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), seg = threadIdx.x >> 4;
+    double q1, q2;
+    if (nparts > 0) {
+        q1 = bn_column_sum(ws + 2 * C, nparts, 2 * C, c < C ? c : 2 * C, seg, lds);
+        q2 = bn_column_sum(ws + 2 * C, nparts, 2 * C, c < C ? C + c : 2 * C, seg, lds);
+        if (seg == 0 && c < C) { ws[c] = q1; ws[C + c] = q2; }
+    } else if (c < C) {
+        q1 = ws[c]; q2 = ws[C + c];
+    }
+    if (seg != 0 || c >= C) return;
+    const double ms = q1 / (double)M;                               // mean of (x - shift)
     const double mu = ms + (shift ? (double)shift[c] : 0.0);
-    double var = sums[C + c] / (double)M - ms * ms;                 // biased (normalisation) variance
+    double var = q2 / (double)M - ms * ms;                          // biased (normalisation) variance
     if (var < 0.0) var = 0.0;
     const float r = (float)(1.0 / sqrt(var + (double)eps));
     mean[c] = (float)mu; rstd[c] = r;
@@ -295,27 +347,43 @@ int check_view(int dtype, int64_t rows, int c, int ld, int coff, const char* wha
 
 extern "C" {
 
-int din_bn_stats(const void* x, int dtype, int64_t rows, int c, int ld, int coff, const float* shift, double* sums, void* stream) {
-    DIN_REQUIRE(x && sums, "bn_stats: null pointer");
+int din_bn_parts(int64_t rows) { return rows > 0 ? bn_parts(rows) : 0; }
+
+int64_t din_bn_workspace(int64_t rows, int c) {
+    if (rows <= 0 || c <= 0) return 0;
+    return (int64_t)(bn_parts(rows) + 1) * 2 * c * (int64_t)sizeof(double);
+}
+
+int din_bn_stats(const void* x, int dtype, int64_t rows, int c, int ld, int coff, const float* shift, double* ws, void* stream) {
+    DIN_REQUIRE(x && ws, "bn_stats: null pointer");
     if (int e = check_view(dtype, rows, c, ld, coff, "bn_stats")) return e;
     const int rpb = bn_rows_per_block(rows);
     const int blocks = (int)ceil_div64(rows, rpb);
-    const size_t lds = 2 * (size_t)c * sizeof(float);
+    const int v = dtype == DIN_F32 ? 4 : 8;
+    const size_t lds = (size_t)(256 / (c / v)) * 2 * c * sizeof(double);
+    double* part = ws + 2 * c;
     if (dtype == DIN_F32)
         hipLaunchKernelGGL((bn_stats_kernel<float, false>), dim3(blocks), dim3(256), lds, as_stream(stream), (const float*)x, ld, coff,
-                           (const float*)nullptr, 0, 0, shift, (const float*)nullptr, rows, c, sums, rpb);
+                           (const float*)nullptr, 0, 0, shift, (const float*)nullptr, rows, c, part, rpb);
     else
         hipLaunchKernelGGL((bn_stats_kernel<bf16_t, false>), dim3(blocks), dim3(256), lds, as_stream(stream), (const bf16_t*)x, ld, coff,
-                           (const bf16_t*)nullptr, 0, 0, shift, (const float*)nullptr, rows, c, sums, rpb);
+                           (const bf16_t*)nullptr, 0, 0, shift, (const float*)nullptr, rows, c, part, rpb);
     DIN_CHECK_LAUNCH("bn_stats");
     return DIN_OK;
 }
 
-int din_bn_finalize(const double* sums, int64_t rows, int c, const float* gamma, const float* beta, float eps, float momentum,
+int din_bn_reduce(double* ws, int nparts, int c, void* stream) {
+    DIN_REQUIRE(ws && nparts > 0 && c > 0, "bn_reduce: bad argument");
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3((2 * c + 15) / 16), dim3(256), 0, as_stream(stream), (const double*)(ws + 2 * c), nparts, 2 * c, ws);
+    DIN_CHECK_LAUNCH("bn_reduce");
+    return DIN_OK;
+}
+
+int din_bn_finalize(double* ws, int nparts, int64_t rows, int c, const float* gamma, const float* beta, float eps, float momentum,
                     float* running_mean, float* running_var, float* a, float* b, float* mean, float* rstd, const float* shift, void* stream) {
-    DIN_REQUIRE(sums && gamma && beta && a && b && mean && rstd && rows > 0 && c > 0, "bn_finalize: bad argument");
+    DIN_REQUIRE(ws && gamma && beta && a && b && mean && rstd && rows > 0 && c > 0 && nparts >= 0, "bn_finalize: bad argument");
     DIN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running_mean and running_var go together");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), sums, rows, c, gamma, beta, eps, momentum,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 15) / 16), dim3(256), 0, as_stream(stream), ws, nparts, rows, c, gamma, beta, eps, momentum,
                        running_mean, running_var, a, b, mean, rstd, shift);
     DIN_CHECK_LAUNCH("bn_finalize");
     return DIN_OK;
@@ -350,21 +418,23 @@ int din_bn_apply(const void* x, int dtype, int64_t rows, int c, int ldx, int cxo
 }
 
 int din_bn_bwd_stats(const void* gz, int ldg, int cgoff, const void* x, int ldx, int cxoff, int dtype, int64_t rows, int c,
-                     const float* mean, const float* rstd, double* sums, void* stream) {
-    DIN_REQUIRE(gz && x && mean && rstd && sums, "bn_bwd_stats: null pointer");
+                     const float* mean, const float* rstd, double* ws, void* stream) {
+    DIN_REQUIRE(gz && x && mean && rstd && ws, "bn_bwd_stats: null pointer");
     if (int e = check_view(dtype, rows, c, ldg, cgoff, "bn_bwd_stats(gz)")) return e;
     if (int e = check_view(dtype, rows, c, ldx, cxoff, "bn_bwd_stats(x)")) return e;
     const int rpb = bn_rows_per_block(rows);
     const int blocks = (int)ceil_div64(rows, rpb);
-    const size_t lds = 2 * (size_t)c * sizeof(float);
+    const int v = dtype == DIN_F32 ? 4 : 8;
+    const size_t lds = (size_t)(256 / (c / v)) * 2 * c * sizeof(double);
+    double* part = ws + 2 * c;
     if (dtype == DIN_F32)
         hipLaunchKernelGGL((bn_stats_kernel<float, true>), dim3(blocks), dim3(256), lds, as_stream(stream), (const float*)x, ldx, cxoff,
-                           (const float*)gz, ldg, cgoff, mean, rstd, rows, c, sums, rpb);
+                           (const float*)gz, ldg, cgoff, mean, rstd, rows, c, part, rpb);
     else
         hipLaunchKernelGGL((bn_stats_kernel<bf16_t, true>), dim3(blocks), dim3(256), lds, as_stream(stream), (const bf16_t*)x, ldx, cxoff,
-                           (const bf16_t*)gz, ldg, cgoff, mean, rstd, rows, c, sums, rpb);
+                           (const bf16_t*)gz, ldg, cgoff, mean, rstd, rows, c, part, rpb);
     DIN_CHECK_LAUNCH("bn_bwd_stats");
-    return DIN_OK;
+    return din_bn_reduce(ws, blocks, c, stream);
 }
 
 int din_bn_bwd_apply(const void* gz, int ldg, int cgoff, const void* x, int ldx, int cxoff, int dtype, int64_t rows, int c,

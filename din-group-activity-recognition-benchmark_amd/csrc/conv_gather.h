@@ -1,6 +1,15 @@
 // Shared between conv_igemm.hip and conv_gather_pipe.hip: the forward / dgrad kernel argument block and the second half of the staged
 // epilogue (LDS tile -> 16-byte coalesced NHWC stores with the fused ReLU-backward mask / accumulate / second destination).
 #pragma once
+// Timing knock-outs (DIN_GATHER_KNOCK: drop the pixel fetches / filter fetches / MFMAs of the gather kernels -- results are WRONG) and the
+// other experiment switches of rounds 2-3 (DIN_CONV_W16, DIN_CONV_RING) exist only in builds made with -DDIN_EXPERIMENTS
+// (tools/ab_gather.sh builds one into knock_build/); the shipped library never reads those variables and the kernel-side tests fold to
+// `false` at compile time (a stray environment variable must not be able to corrupt every conv).
+#ifdef DIN_EXPERIMENTS
+#define DIN_KNOCK(flags, bit) (((flags) & (bit)) != 0)
+#else
+#define DIN_KNOCK(flags, bit) false
+#endif
 #include "din_common.h"
 
 typedef uint32_t din_u32x4 __attribute__((ext_vector_type(4)));

@@ -246,14 +246,7 @@ __global__ __launch_bounds__(512, 1) void conv_gather_pipe_kernel(ConvK p) {
 }
 
 template <typename K>
-void raise_lds(K kern, size_t lds) {
-    static thread_local std::unordered_map<const void*, size_t> granted;
-    size_t& g = granted[reinterpret_cast<const void*>(kern)];
-    if (g < lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        g = lds;
-    }
-}
+void raise_lds(K kern, size_t lds) { din_raise_lds(reinterpret_cast<const void*>(kern), lds); }
 
 }  // namespace
 

@@ -511,8 +511,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
         for (int i = 0; i < PA; ++i) pixq[i] = (unsigned)(pixoff[i] + cq * 16);
         unsigned va[PA];
         int soffA = 0, soffB = 0;
-        const bool knockA = (p.flags & 0x200) != 0;
-        if (p.flags & 0x400) {
+        const bool knockA = DIN_KNOCK(p.flags, 0x200);
+        if (DIN_KNOCK(p.flags, 0x400)) {
 #pragma unroll
             for (int i = 0; i < PB; ++i) voffB[i] = (int)OOB;
         }
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (p.flags & 0x800) lds_dma_stage<PA, PB, LR * KC * 16>(ldsA0 + (uint32_t)((cur ^ 1) * BUF * 16), rsA, va, soffA, rsB, voffB, soffB);
+                if (DIN_KNOCK(p.flags, 0x800)) lds_dma_stage<PA, PB, LR * KC * 16>(ldsA0 + (uint32_t)((cur ^ 1) * BUF * 16), rsA, va, soffA, rsB, voffB, soffB);
                 else step(std::true_type{});
                 prepare();
                 cur ^= 1;
@@ -591,14 +591,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (!(p.flags & 0x800)) step(std::false_type{});
+            if (!DIN_KNOCK(p.flags, 0x800)) step(std::false_type{});
 #else
             for (int ks = ks_begin; ks < ks_end; ++ks) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 if (ks + 1 < ks_end) lds_dma_stage<PA, PB, LR * KC * 16>(ldsA0 + (uint32_t)((cur ^ 1) * BUF * 16), rsA, va, soffA, rsB, voffB, soffB);
-                if (!(p.flags & 0x800)) compute(cur);
+                if (!DIN_KNOCK(p.flags, 0x800)) compute(cur);
                 prepare();
                 cur ^= 1;
             }
@@ -2723,14 +2723,7 @@ int check_desc(const din_conv_desc* d) {
 // halo kernel eligibility / shape (shared by run_gather and din_conv_kernel_tile).  Returns the filter-tile width (0: not eligible).
 // hipFuncSetAttribute is a slow host call: raise a kernel's dynamic-LDS limit once per (thread, kernel), not per launch
 template <typename K>
-static void raise_lds_limit(K kern, size_t lds) {
-    static thread_local std::unordered_map<const void*, size_t> granted;
-    const void* fn = reinterpret_cast<const void*>(kern);
-    auto it = granted.find(fn);
-    if (it != granted.end() && lds <= it->second) return;
-    hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    granted[fn] = lds;
-}
+static void raise_lds_limit(K kern, size_t lds) { din_raise_lds(reinterpret_cast<const void*>(kern), lds); }
 
 struct HaloPlan { int bn, th, tw, nsw, nwv, n_co_tiles; size_t lds; };
 static bool plan_halo(int dtype, int kh, int kw, int cred, int cprod, int oh, int ow, int64_t M, HaloPlan& hp) {
@@ -2806,7 +2799,11 @@ void launch_wave8(const ConvK& k, dim3 grid, hipStream_t st) {
     if constexpr (sizeof(T) == 2 && (BN == 192 || BN == 160)) {
         // experiment switch DIN_CONV_RING=3: three 32-deep stages (two in flight, one counted vmcnt per barrier) instead of two 64-deep ones
         // (one in flight, vmcnt(0)) for the general loop's 8-wave tiles -- same LDS budget (72 vs 80 KiB per workgroup), half the MFMAs per barrier
+        #ifdef DIN_EXPERIMENTS
         static const bool ring3 = getenv("DIN_CONV_RING") && atoi(getenv("DIN_CONV_RING")) == 3;
+#else
+        constexpr bool ring3 = false;
+#endif
         if (ring3 && !k.remap) { launch_fast<T, 128, BN, 4, 2, 4, 3>(k, grid, st); return; }
     }
     launch_fast<T, 128, BN, 4, 2, 8, 2>(k, grid, st);
@@ -2866,7 +2863,11 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
             else if (bn == 192) {
                 // experiment (DIN_CONV_W16=1 with DIN_CONV_TILE=256): sixteen waves as 8 x 2 on the 256 x 192 tile -- the 128 x 192 kernel's wave
                 // tile and four waves per SIMD, but ONE filter stage per 256 pixels: 64 instead of 80 LDS-DMA transfers per 256-pixel k-step
+                #ifdef DIN_EXPERIMENTS
                 static const bool w16 = getenv("DIN_CONV_W16") && atoi(getenv("DIN_CONV_W16")) == 1;
+#else
+                constexpr bool w16 = false;
+#endif
                 const char* fv = getenv("DIN_CONV_FASTK");
                 const bool fastk = (fv ? atoi(fv) != 0 : true) && !k.remap && k.nsrc == 0 && (k.cpt % 8) == 0 && (k.korder || k.kh * k.kw == 1);
                 if (w16 && fastk) launch_fast<T, 256, 192, 8, 2, 8, 2, true>(k, grid, st);
@@ -2922,7 +2923,10 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
     if (const char* eb = getenv("DIN_CONV_EPI_BATCH")) { if (atoi(eb) == 0) k.flags |= 0x100; }
     // timing experiments only (results are WRONG): DIN_GATHER_KNOCK bit 0 = the pixel-tile transfers of the scalar-walk loop fetch nothing
     // (all lanes out of range: issued, landed as zeros, no cache / HBM access), bit 1 = the same for the filter tile, bit 2 = no MFMA
+    // -- only in -DDIN_EXPERIMENTS builds (conv_gather.h)
+#ifdef DIN_EXPERIMENTS
     if (const char* kn = getenv("DIN_GATHER_KNOCK")) k.flags |= (atoi(kn) & 7) << 9;
+#endif
     if (getenv("DIN_DEBUG_PLAN"))
         fprintf(stderr, "[din] %s M=%d NB=%d HxW=%dx%d Cin=%d Cout=%d k=%dx%d ay=%d cy=%d tile=%dx%d splitk=%d korder=%d remap=%d flags=%d dtype=%d\n", what,
                 k.M, k.NB, k.H, k.W, k.Cin, k.Cout, k.kh, k.kw, k.ay, k.cy, g.bm, g.bn, g.splitk, k.korder, k.remap, k.flags, dtype);
@@ -3429,7 +3433,11 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
     k.cin_pad = wp.cin_pad; k.kcols = wp.kcols; k.kcols_pad = wp.kcols_pad; k.cout_pad = wp.cout_pad;
     k.M = d->nb * d->oh * d->ow; k.n_co_tiles = wp.n_co_tiles; k.n_k_tiles = wp.n_k_tiles;
     k.slices = wp.slices; k.m_per_slice = wp.m_per_slice;
-    { const char* pv = getenv("DIN_WGRAD_PROBE"); k.probe = pv ? atoi(pv) : 0; }
+#ifdef DIN_EXPERIMENTS
+    { const char* pv = getenv("DIN_WGRAD_PROBE"); k.probe = pv ? atoi(pv) : 0; }      // timing probe: results are WRONG when set
+#else
+    k.probe = 0;
+#endif
     dim3 grid(wp.n_co_tiles * wp.n_k_tiles, wp.slices);
     bool bias_fused = false;
     if (d->dtype == DIN_F32) {

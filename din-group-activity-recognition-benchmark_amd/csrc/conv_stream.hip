@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(ConvK p) {
     }
     const int n_px = (p.M + BM - 1) / BM, nco = p.n_co_tiles;
     const int G = (int)gridDim.x, Gq = G / nco, Gr = G - Gq * nco;     // item += G  <=>  (pixel tile, filter tile) += (Gq, Gr) with carry
-    const bool ka = (p.flags & 0x200) != 0, kw = (p.flags & 0x400) != 0;    // DIN_GATHER_KNOCK (timing experiments): fetch nothing
+    const bool ka = DIN_KNOCK(p.flags, 0x200), kw = DIN_KNOCK(p.flags, 0x400);    // DIN_GATHER_KNOCK (timing experiments): fetch nothing
 
     struct Cursor { int pt, ct, b; };                                  // pixel tile, filter tile, block of the reduction
     auto advance = [&](Cursor& c) {
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(ConvK p) {
             // ---- MFMAs of this block ----------------------------------------------------------------------------------------------------
             const int nch = MULTI ? sgpr(table[cur.b].nch) : p.cpt - cur.b * 8;
             const bool two = nch > 4;
-            if (!(p.flags & 0x800)) {                                   // (DIN_GATHER_KNOCK bit 2: no fragment reads / MFMAs)
+            if (!DIN_KNOCK(p.flags, 0x800)) {                                 // (DIN_GATHER_KNOCK bit 2: no fragment reads / MFMAs)
             const unsigned char* slab = smem_raw + ws * SLOT;
             u32x4 wf[2][TI], xf[2][TJ];
 #pragma unroll
@@ -375,9 +375,8 @@ template <int BN, int NSW, bool MULTI, bool EPI, bool SPLIT>
 static void launch_stream(const ConvK& k, dim3 grid, hipStream_t st) {
     constexpr size_t lds = stream_lds_bytes<BN, NSW>();
     static_assert(lds <= 160 * 1024, "LDS");
-    static bool raised = false;
     auto kern = conv1x1_stream_kernel<BN, NSW, MULTI, EPI, SPLIT>;
-    if (!raised) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
+    din_raise_lds(reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, k);
 }
 template <int BN, int NSW>

@@ -207,14 +207,7 @@ __global__ __launch_bounds__(1024, 1) void conv_wgrad_halo_kernel(WgradK p) {
 }
 
 template <typename K>
-void raise_lds(K kern, size_t lds) {
-    static thread_local std::unordered_map<const void*, size_t> granted;
-    size_t& g = granted[reinterpret_cast<const void*>(kern)];
-    if (g < lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        g = lds;
-    }
-}
+void raise_lds(K kern, size_t lds) { din_raise_lds(reinterpret_cast<const void*>(kern), lds); }
 
 constexpr size_t stage_bytes(int cpp, int bnt, int kh, int kw, int th) {
     return (size_t)(((32 + kw - 1) * (th + kh - 1) * cpp * 16 + 1023) / 1024 * 1024) + (size_t)((th * 32 * (bnt / 8) * 16 + 1023) / 1024 * 1024);

@@ -15,6 +15,21 @@ void din_set_error(const char* fmt, ...);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Dynamic-LDS limit of a kernel above 64 KiB.  hipFuncSetAttribute is a slow host call and its effect is PER DEVICE: raise once per
+// (calling thread, current device, kernel), not per launch -- and not once per process, which would leave a second device of the same
+// process at the 64 KiB default.
+#include <unordered_map>
+static inline void din_raise_lds(const void* fn, size_t lds) {
+    static thread_local std::unordered_map<uint64_t, size_t> granted;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t& g = granted[(uint64_t)(uintptr_t)fn * 0x9E3779B97F4A7C15ull + (uint64_t)dev];
+    if (g < lds) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        g = lds;
+    }
+}
+
 // ---- bf16 <-> f32 (round-to-nearest-even; NaN preserved) -----------------------------------------
 typedef uint16_t bf16_t;
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }

@@ -26,7 +26,10 @@ import torch
 from . import _lib as L
 from . import nhwc, ops
 
-SEED_STRIDE = 0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF      # what a replay adds to the device-side seed offset (odd: full period)
+# What a replay adds to the device-side seed offset (odd: full period).  It must NOT be congruent to ops.mask_seed's per-rank increment
+# (0x9E3779B97F4A7C15) mod 2^63: round 3 used that very constant, so rank r at replay k drew the masks rank 0 drew at replay k + r
+# (ADVICE r3).  tests/test_host_cpu.py::test_dropout_seeds_distinct_over_ranks_and_replays pins the property.
+SEED_STRIDE = 0xD1342543DE82EF95 & 0x7FFFFFFFFFFFFFFF
 
 
 class CapturedStep:

@@ -420,15 +420,13 @@ def _bn_train_forward(lib, raw: torch.Tensor, dt: int, rows: int, cout: int, gam
     """batch-statistics BatchNorm (+ReLU) of a raw conv output [rows][cout] into the channel view (ldd, coffd) of dst; updates the
     running statistics in place; returns (batch mean, rstd) for the backward pass"""
     dev = raw.device
-    sums = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
+    ws = torch.empty(lib.din_bn_workspace(rows, cout) // 8, dtype=torch.float64, device=dev)   # reduced sums + one slab per workgroup
     ab = torch.empty(4 * cout, dtype=torch.float32, device=dev)
     a, b, bmean, rstd = ab[:cout], ab[cout:2 * cout], ab[2 * cout:3 * cout], ab[3 * cout:]
-    # sums of (x - shift) with shift = the running mean before this step's update: no cancellation in E[x^2] - mean^2 (fp32 partial sums).
-    # The shift is a COPY: din_bn_finalize overwrites the running mean it also reads the shift from
-    shift = mean.clone()
-    L.check(lib.din_bn_stats(_ptr(raw), dt, rows, cout, cout, 0, _ptr(shift), _ptr(sums), st), "bn_stats")
-    L.check(lib.din_bn_finalize(_ptr(sums), rows, cout, _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(var), _ptr(a), _ptr(b),
-                                _ptr(bmean), _ptr(rstd), _ptr(shift), st), "bn_finalize")
+    # fp64 accumulation with exact products, fixed summation order (csrc/bn.hip): no shift needed, bit-reproducible statistics
+    L.check(lib.din_bn_stats(_ptr(raw), dt, rows, cout, cout, 0, None, _ptr(ws), st), "bn_stats")
+    L.check(lib.din_bn_finalize(_ptr(ws), lib.din_bn_parts(rows), rows, cout, _ptr(gamma), _ptr(beta), BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(var),
+                                _ptr(a), _ptr(b), _ptr(bmean), _ptr(rstd), None, st), "bn_finalize")
     L.check(lib.din_bn_apply(_ptr(raw), dt, rows, cout, cout, 0, _ptr(a), _ptr(b), int(relu), _ptr(dst), ldd, coffd, st), "bn_apply")
     return bmean, rstd
 
@@ -680,11 +678,28 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
         op0 = g.ops[items[0][0]]
         ts0 = g.tensors[op0.src.tid]
         plan, wsb_need = multi_w[key]
+        if any(i not in by_oi for mem in plan for i in mem):
+            # A member received no gradient (a graph that consumes only some branch outputs -- partial heads; not the backbones here): the
+            # fused launch's plan does not apply, so the members that DID get one degrade to the per-layer kernel (this used
+            # to raise in the middle of backward, after the weight gradients had already been deferred)
+            for oi_, gout_, w_, scale_, ldj, coffj, pre in items:
+                opj = g.ops[oi_]
+                dj = _conv_desc(g, opj, nb, dt)
+                dj.ldo, dj.cooff = ldj, coffj
+                o0, o1 = bn.off_list[bn_index[oi_]], bn.off_list[bn_index[oi_] + 1]
+                dwj = _dw_buffer(w_)
+                ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(dj), 2), dev, wtag)
+                with _timed("wgrad", dj, opj.name):
+                    L.check(lib.din_conv_wgrad(C.byref(dj), _ptr(bufs[opj.src.tid]), _ptr(gout_), _ptr(dwj), None if pre else _ptr(bn_dshift[o0:o1]),
+                                               _ptr(scale_), _ptr(w_), _ptr(bn_wdot[o0:o1]), 2, _ptr(ws), wsb, st), "conv_wgrad " + opj.name)
+                grads[offsets[oi_]] = dwj
+                if GRAD_HOOK is not None:
+                    GRAD_HOOK(w_, dwj)
+            bn_touched = True
+            return
         srcs = (L.ConvWSrc * len(plan))()
         keep, outs = [], []
         for j, mem in enumerate(plan):
-            if any(i not in by_oi for i in mem):
-                raise L.DinError("1x1 weight-gradient group: a member received no gradient")      # (cannot happen in the backbones here)
             _oi, gout_, _w, _scale, ldj, coffj, pre = by_oi[mem[0]]
             o0, o1 = bn.off_list[bn_index[mem[0]]], bn.off_list[bn_index[mem[-1]] + 1]
             if len(mem) == 1:
@@ -805,7 +820,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 _, raw, bmean, rstd = aux[oi]
                 td_ = g.tensors[op.dst.tid]
                 rows = nb * td_.h * td_.w
-                sums = torch.zeros(2 * op.dst.c, dtype=torch.float64, device=dev)
+                sums = torch.empty(lib.din_bn_workspace(rows, op.dst.c) // 8, dtype=torch.float64, device=dev)
                 L.check(lib.din_bn_bwd_stats(_ptr(gout), g_ld, g_coff, _ptr(raw), op.dst.c, 0, dt, rows, op.dst.c, _ptr(bmean), _ptr(rstd),
                                              _ptr(sums), st), "bn_bwd_stats")
                 dy = torch.empty((nb, td_.h, td_.w, op.dst.c), dtype=tdt, device=dev)

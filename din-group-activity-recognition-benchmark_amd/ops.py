@@ -256,7 +256,14 @@ def mask_seed(base: int, step: int) -> int:
     rank = 0
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         rank = torch.distributed.get_rank()
-    return (int(base) * 1000003 + rank * 0x9E3779B97F4A7C15 + int(step) * 7919) & 0x7FFFFFFFFFFFFFFF
+    return mask_seed_of(base, rank, step)
+
+
+RANK_SEED_STRIDE = 0x9E3779B97F4A7C15
+
+
+def mask_seed_of(base: int, rank: int, step: int) -> int:
+    return (int(base) * 1000003 + int(rank) * RANK_SEED_STRIDE + int(step) * 7919) & 0x7FFFFFFFFFFFFFFF
 
 
 def layer_norm(x, gamma, beta, res=None, relu=False, drop_p=0.0, seed=0):

@@ -15,6 +15,8 @@ with MAX_N boxes plus bboxes_num [T]); with none given it trains on a synthetic 
 """
 from __future__ import annotations
 
+import os
+
 import random
 import time
 
@@ -197,6 +199,11 @@ def train_net(cfg, training_set=None, validation_set=None, max_steps=None):
     torch.cuda.set_device(device)
     collective = cfg.dataset_name == "collective"
     synth = SyntheticCollective if collective else SyntheticVolleyball
+    if training_set is None and validation_set is None and getattr(cfg, "data_path", None) and os.path.isdir(cfg.data_path):
+        # the real datasets (reference train_net_dynamic.py:57-58 -> dataset.return_dataset): annotation trees + JPEG frames -> uint8 clips,
+        # feature-px boxes, padded tracks (din_amd/volleyball.py, collective.py); without a data tree the synthetic clips stand in
+        from .dataset import return_dataset
+        training_set, validation_set = return_dataset(cfg)
     training_set = training_set or synth(cfg, length=max(cfg.batch_size * 2, 4))
     validation_set = validation_set or synth(cfg, length=max(cfg.test_batch_size, 2), seed=1)
     if cfg.batch_size % world != 0:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DIN_ABI_VERSION 5   /* 5: dropout seeds take an optional device-side offset (din_layernorm_*, din_act_dropout_*), din_counter_add, din_conv1x1_wgrad_multi.   2: din_walk_* take plain / clamp / n_per_clip; + bn, mask_actors.  3: din_roi_align_* take the box grid and a crop channel range.  4: din_conv_desc.in_u8, context-encoding entry points */
+#define DIN_ABI_VERSION 6   /* 6: batch-statistics BatchNorm is deterministic: din_bn_stats / din_bn_bwd_stats write per-workgroup fp64 slabs into a workspace (din_bn_workspace), din_bn_finalize / din_bn_reduce add them in slab order -- no atomics, nothing for the caller to zero.   5: dropout seeds take an optional device-side offset (din_layernorm_*, din_act_dropout_*), din_counter_add, din_conv1x1_wgrad_multi.   2: din_walk_* take plain / clamp / n_per_clip; + bn, mask_actors.  3: din_roi_align_* take the box grid and a crop channel range.  4: din_conv_desc.in_u8, context-encoding entry points */
 
 enum { DIN_F32 = 0, DIN_BF16 = 1 };
 
@@ -192,23 +192,30 @@ int din_bn_fold_bwd_multi(const uint64_t* ptrs, const int32_t* offs, int n, int 
 /* BatchNorm with BATCH statistics: the reference's default for the Inception-v3 backbone in stage 2 -- model.train() without
  * set_bn_eval (train_net_dynamic.py:98-100,170-172; config.py:80) -> torch.nn.functional.batch_norm(training=True) inside torchvision's
  * BasicConv2d.  Views are [rows][c] with pixel stride ld and channel offset coff (elements; multiples of 4 fp32 / 8 bf16).
- *   din_bn_stats     : sums[0..c) += sum_rows (x - shift), sums[c..2c) += sum_rows (x - shift)^2   (fp64 accumulators, zeroed by the
- *                      caller; shift [c] nullable = 0: pass the running mean -- the per-workgroup partial sums are fp32, and
- *                      E[x^2] - mean^2 cancels when |mean| >> std; din_bn_finalize must get the SAME shift)
- *   din_bn_finalize  : mean, rstd = 1/sqrt(biased var + eps); a = gamma*rstd, b = beta - mean*a; running_mean/var (may be NULL) updated
+ * Workspace ws (fp64, din_bn_workspace(rows, c) bytes, NOT zeroed by the caller): ws[0..2c) = the reduced sums, then din_bn_parts(rows)
+ * slabs of 2c partial sums, one per workgroup of the statistics kernel.  Everything is summed in a fixed order (fp64 per-thread
+ * accumulators with exact products, lane-ordered LDS sum, slab-ordered reduce): the same input gives the same bits on every run.
+ *   din_bn_stats     : slab[p][0..c) = sum over the rows of part p of (x - shift), slab[p][c..2c) = sum (x - shift)^2   (shift [c] nullable
+ *                      = 0; fp64 accumulation makes it unnecessary -- kept for callers that have one; din_bn_finalize must get the SAME)
+ *   din_bn_finalize  : ws[0..2c) = slab sums in slab order (nparts > 0; nparts == 0: ws[0..2c) already holds them); mean,
+ *                      rstd = 1/sqrt(biased var + eps); a = gamma*rstd, b = beta - mean*a; running_mean/var (may be NULL) updated
  *                      in place with `momentum` and the unbiased variance, as torch does
  *   din_bn_apply     : y = a*x + b (relu != 0: max(.,0)) -- x and y may be views of different tensors
- *   din_bn_bwd_stats : sums[0..c) += sum gz, sums[c..2c) += sum gz*xhat, xhat = (x - mean)*rstd   (gz: gradient at the BN output,
- *                      already masked by the ReLU that follows)
- *   din_bn_bwd_apply : dy = gamma*rstd*(gz - s1/rows - xhat*s2/rows); dgamma = s2, dbeta = s1                                   */
-int din_bn_stats(const void* x, int dtype, int64_t rows, int c, int ld, int coff, const float* shift, double* sums, void* stream);
-int din_bn_finalize(const double* sums, int64_t rows, int c, const float* gamma, const float* beta, float eps, float momentum,
+ *   din_bn_bwd_stats : ws[0..c) = sum gz, ws[c..2c) = sum gz*xhat, xhat = (x - mean)*rstd   (gz: gradient at the BN output,
+ *                      already masked by the ReLU that follows); slabs + din_bn_reduce inside
+ *   din_bn_reduce    : ws[0..2c) = sum of nparts slabs at ws + 2c, in slab order (for producers that fill the slabs themselves)
+ *   din_bn_bwd_apply : dy = gamma*rstd*(gz - s1/rows - xhat*s2/rows); dgamma = s2, dbeta = s1   (sums = ws of din_bn_bwd_stats)        */
+int din_bn_parts(int64_t rows);
+int64_t din_bn_workspace(int64_t rows, int c);
+int din_bn_stats(const void* x, int dtype, int64_t rows, int c, int ld, int coff, const float* shift, double* ws, void* stream);
+int din_bn_reduce(double* ws, int nparts, int c, void* stream);
+int din_bn_finalize(double* ws, int nparts, int64_t rows, int c, const float* gamma, const float* beta, float eps, float momentum,
                     float* running_mean, float* running_var, float* a, float* b, float* mean, float* rstd, const float* shift,
                     void* stream);
 int din_bn_apply(const void* x, int dtype, int64_t rows, int c, int ldx, int cxoff, const float* a, const float* b, int relu,
                  void* y, int ldy, int cyoff, void* stream);
 int din_bn_bwd_stats(const void* gz, int ldg, int cgoff, const void* x, int ldx, int cxoff, int dtype, int64_t rows, int c,
-                     const float* mean, const float* rstd, double* sums, void* stream);
+                     const float* mean, const float* rstd, double* ws, void* stream);
 int din_bn_bwd_apply(const void* gz, int ldg, int cgoff, const void* x, int ldx, int cxoff, int dtype, int64_t rows, int c,
                      const float* gamma, const float* mean, const float* rstd, const double* sums, void* dy, int ldy, int cyoff,
                      float* dgamma, float* dbeta, void* stream);

@@ -23,7 +23,7 @@ def test_library_exports_every_header_symbol():
         assert hasattr(lib, n), f"{n} declared in include/din_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes table out of sync with include/din_hip.h"
     loaded = _lib.load()
-    assert loaded.din_abi_version() == _lib.ABI_VERSION == 5 and loaded.din_build_arch() == b"gfx950"
+    assert loaded.din_abi_version() == _lib.ABI_VERSION == 6 and loaded.din_build_arch() == b"gfx950"
 
 
 def test_conv_planning_is_callable_without_gpu():
@@ -340,3 +340,107 @@ def test_bench_clock_sampler_degrades_without_a_gpu():
         assert "not sampled" in out["note"]
     else:                                                    # a GPU box: plausible numbers
         assert 50 <= out["sclk_mhz_avg"] <= 3000
+
+
+def test_dropout_seeds_distinct_over_ranks_and_replays():
+    """Every (rank, step) pair draws its own dropout mask, eager and under graph replay (the replay stride used to equal the
+    per-rank stride mod 2^63, so rank r at replay k repeated rank 0's masks of replay k + r).  A captured step's device-side seed is
+    mask_seed_of(base, rank, step0) + replay * SEED_STRIDE (csrc/din_common.h fold_seed: sum mod 2^63)."""
+    from din_amd import graph_step, ops
+    M = 0x7FFFFFFFFFFFFFFF
+    assert graph_step.SEED_STRIDE % 2 == 1
+    assert (graph_step.SEED_STRIDE - ops.RANK_SEED_STRIDE) & M != 0
+    for base in (1, 2, 17):
+        seen = {}
+        for rank in range(8):
+            for replay in range(512):
+                s = (ops.mask_seed_of(base, rank, 3) + replay * graph_step.SEED_STRIDE) & M
+                assert s not in seen, (base, rank, replay, seen[s])
+                seen[s] = (rank, replay)
+        eager = {ops.mask_seed_of(base, rank, step) for rank in range(8) for step in range(2048)}
+        assert len(eager) == 8 * 2048
+
+
+# ---- SURVEY 8(f)-1: dataset -> tensor contract, pinned by the reference's own datasets (tools/gen_golden.py --only dataset) -------------
+def _tree(golden_dir, name):
+    return os.path.join(golden_dir, "dataset_tree", name)
+
+
+def test_volleyball_dataset_matches_reference_golden(golden_dir):
+    """annotation parsing, uint8 frames (decode + bilinear resize + CHW), track boxes in feature px (bit-exact float32: the integer-like
+    box assignment the RoI stage consumes), short tracks padded by repetition, label tensors -- against what the reference's
+    VolleyballDataset produced from the same tree (volleyball.py:223-275)."""
+    import pickle
+    import numpy as np
+    from din_amd import volleyball as V
+    z = np.load(os.path.join(golden_dir, "dataset_volleyball.npz"))
+    root = _tree(golden_dir, "volleyball")
+    anns = V.volley_read_dataset(root, [1, 4])
+    frames = V.volley_all_frames(anns)
+    assert np.array_equal(np.array(frames), z["frames"])
+    for sid in anns:
+        for fid, a in anns[sid].items():
+            assert np.array_equal(a["bboxes"], z[f"ann.{sid}.{fid}.bboxes"]) and a["actions"] == list(z[f"ann.{sid}.{fid}.actions"])
+            assert a["group_activity"] == int(z[f"ann.{sid}.{fid}.group_activity"]) and a["file_name"] == f"{fid}.jpg"
+    with open(os.path.join(root, "tracks_normalized.pkl"), "rb") as fh:
+        tracks = pickle.load(fh)
+    for tag, fsize in (("vgg", (2, 3)), ("inv3", (87, 157))):
+        ds = V.VolleyballDataset(anns, tracks, frames, root, (64, 96), fsize, "dynamic_volleyball", num_boxes=12, num_before=1, num_after=1)
+        assert len(ds) == 3
+        for i in range(len(ds)):
+            images, boxes, actions, activities = ds[i]
+            assert images.dtype == torch.uint8 and boxes.dtype == torch.float32 and actions.dtype == torch.int64 and activities.dtype == torch.int64
+            assert np.array_equal(images.numpy(), z[f"images.{i}"]), "decoded / resized frames differ from the reference's"
+            assert np.array_equal(boxes.numpy(), z[f"boxes.{tag}.{i}"]), "feature-px boxes must be bit-identical to the reference's"
+            assert np.array_equal(actions.numpy(), z[f"actions.{i}"]) and np.array_equal(activities.numpy(), z[f"activities.{i}"])
+    # the padded clips really are padded by repetition of the leading boxes (10 and 7 tracked players of 12)
+    b10, b7 = z["boxes.vgg.1"], z["boxes.vgg.2"]
+    assert np.array_equal(b10[:, 10:], b10[:, :2]) and np.array_equal(b7[:, 7:], b7[:, :5])
+    # float32 mode = the reference's tensor exactly
+    f32 = V.VolleyballDataset(anns, tracks, frames, root, (64, 96), (2, 3), num_boxes=12, num_before=1, num_after=1, uint8_images=False)[0][0]
+    assert f32.dtype == torch.float32 and np.array_equal(f32.numpy(), z["images.0"].astype(np.float32))
+    # fewer than half the players tracked: the reference crashes in its reshape; here the boxes wrap around cyclically
+    few = V.pad_by_repetition(np.arange(20.0).reshape(5, 4), 12)
+    assert few.shape == (12, 4) and np.array_equal(few[5:10], few[:5]) and np.array_equal(few[10:], few[:2])
+
+
+def test_collective_dataset_matches_reference_golden(golden_dir):
+    """collective.py:40-81,165-225: anchors (fid % 10 == 1), majority activity skipping 'NA', 6->5 / 5->4 class maps, boxes normalised by
+    the sequence's frame size then scaled to feature px, zero-box padding with action -1 and the real count in bboxes_num."""
+    import numpy as np
+    from din_amd import collective as Cc
+    z = np.load(os.path.join(golden_dir, "dataset_collective.npz"))
+    root = _tree(golden_dir, "collective")
+    anns = Cc.collective_read_dataset(root, [1, 15])
+    frames = Cc.collective_all_frames(anns)
+    assert np.array_equal(np.array(frames), z["frames"])
+    for sid in anns:
+        for fid, a in anns[sid].items():
+            assert np.array_equal(np.asarray(a["bboxes"], dtype=np.float64), z[f"ann.{sid}.{fid}.bboxes"])
+            assert a["actions"] == list(z[f"ann.{sid}.{fid}.actions"]) and a["group_activity"] == int(z[f"ann.{sid}.{fid}.group_activity"])
+    assert anns[15][11]["group_activity"] == 3                   # 'NA' was the most common action: the runner-up (Walking) decides
+    ds = Cc.CollectiveDataset(anns, frames, root, (64, 96), (2, 3), num_boxes=13, num_frames=3)
+    for i in range(len(ds)):
+        images, boxes, actions, activities, count = ds[i]
+        assert images.dtype == torch.uint8 and count.dtype == torch.int32
+        assert np.array_equal(images.numpy(), z[f"images.{i}"]) and np.array_equal(boxes.numpy(), z[f"boxes.{i}"])
+        assert np.array_equal(actions.numpy(), z[f"actions.{i}"]) and np.array_equal(activities.numpy(), z[f"activities.{i}"])
+        assert np.array_equal(count.numpy(), z[f"bboxes_num.{i}"])
+        n = int(count[0])
+        assert float(boxes[:, n:].abs().max() if n < 13 else 0.0) == 0.0 and (n == 13 or int(actions[:, n:].max()) == -1)
+    assert sorted(int(ds[i][4][0]) for i in range(len(ds))) == [3, 5, 6, 13]
+
+
+def test_return_dataset_builds_both_datasets(golden_dir):
+    from din_amd.config import Config
+    from din_amd.dataset import return_dataset
+    cfg = Config("volleyball")
+    cfg.data_path, cfg.train_seqs, cfg.test_seqs = _tree(golden_dir, "volleyball"), [1], [4]
+    cfg.image_size, cfg.out_size, cfg.num_before, cfg.num_after, cfg.training_stage = (64, 96), (2, 3), 1, 1, 2
+    tr, te = return_dataset(cfg)
+    assert len(tr) == 2 and len(te) == 1 and tr[0][0].shape == (3, 3, 64, 96) and te[0][1].shape == (3, 12, 4)
+    cfg = Config("collective")
+    cfg.data_path, cfg.train_seqs, cfg.test_seqs = _tree(golden_dir, "collective"), [1], [15]
+    cfg.image_size, cfg.out_size, cfg.num_frames, cfg.num_boxes, cfg.training_stage = (64, 96), (2, 3), 3, 13, 2
+    tr, te = return_dataset(cfg)
+    assert len(tr) == 2 and len(te) == 2 and len(tr[0]) == 5 and tr[0][1].shape == (3, 13, 4)

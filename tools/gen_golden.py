@@ -155,6 +155,11 @@ def install_stubs():
               inception_v3=lambda pretrained=False: _Inception3(),
               vgg19=ident, resnet18=ident, resnet50=ident, alexnet=ident)
     tvt = mod("torchvision.transforms")
+    # torchvision==0.4.0 (README.md:45) transforms.functional.resize(img, size, interpolation=Image.BILINEAR) for a PIL image and a
+    # (h, w) size is `img.resize(size[::-1], interpolation)` -- third-party, absent from the tree: restated from the published source
+    from PIL import Image as _Image
+    tvt.functional = mod("torchvision.transforms.functional",
+                         resize=lambda img, size, interpolation=_Image.BILINEAR: img.resize(tuple(size)[::-1], interpolation))
     tv.models, tv.transforms = tvm, tvt
     ra = mod("roi_align")
     ram = mod("roi_align.roi_align", RoIAlign=_RoIAlignStub)
@@ -724,12 +729,121 @@ def collective_case(name, refim, refcfg, out_dir, seed=200):
     print(f"[collective] {name}: logits {e:.2e}, worst grad {eg:.2e}, loss {loss.item():.6f}")
 
 
+def _synthetic_jpeg(path, h, w, rng):
+    """a smooth random field + noise, saved as JPEG (fixture input: committed under tests/golden/dataset_tree/)"""
+    from PIL import Image
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.stack([127 + 110 * np.sin(yy / rng.uniform(5, 17) + rng.uniform(0, 6)) * np.cos(xx / rng.uniform(5, 23) + rng.uniform(0, 6))
+                    for _ in range(3)], -1) + rng.normal(0, 9, (h, w, 3))
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    Image.fromarray(np.clip(img, 0, 255).astype(np.uint8)).save(path, quality=88)
+
+
+def dataset_cases(out_dir):
+    """the dataset -> tensor contract, pinned by the reference's OWN VolleyballDataset / CollectiveDataset
+    (volleyball.py:146-275, collective.py:96-225) run over a small synthetic annotation tree.  The tree (annotation files, the tracks
+    pickle, tiny JPEGs) is written under <out>/dataset_tree and committed as fixture INPUT; the tensors the reference produces from it go
+    to dataset_volleyball.npz / dataset_collective.npz.  np.float (removed in numpy 1.24; collective.py:212 uses it) is aliased to the
+    builtin float it always was, in this harness only."""
+    import importlib
+    import pickle
+    if not hasattr(np, "float"):
+        np.float = float
+    refv = importlib.import_module("volleyball")
+    refc = importlib.import_module("collective")
+    tree = os.path.join(out_dir, "dataset_tree")
+    rng = np.random.default_rng(2024)
+    # ---------------- volleyball: <root>/<sid>/annotations.txt, <root>/<sid>/<src>/<fid>.jpg, <root>/tracks_normalized.pkl
+    vroot = os.path.join(tree, "volleyball")
+    people = {(1, 10): 12, (1, 20): 10, (4, 30): 7}                 # 12: no padding; 10 and 7 (>= 6): padded by repetition
+    before, after = 1, 1
+    tracks = {}
+    lines = {}
+    for (sid, src), n in people.items():
+        acts = [refv.ACTIONS[int(a)] for a in rng.integers(0, 9, n)]
+        xywh = np.stack([rng.integers(0, 1100, n), rng.integers(100, 500, n), rng.integers(30, 120, n), rng.integers(80, 220, n)], 1)
+        row = "%d.jpg %s " % (src, refv.ACTIVITIES[int(rng.integers(0, 8))]) + " ".join(
+            "%d %d %d %d %s" % (*xywh[i], acts[i]) for i in range(n))
+        lines.setdefault(sid, []).append(row)
+        tracks[(sid, src)] = {}
+        base = np.stack([rng.uniform(0.25, 0.6, n), rng.uniform(0.02, 0.9, n)], 1)
+        for fid in range(src - before, src + after + 1):
+            yx = base + rng.normal(0, 0.004, (n, 2))
+            hw = np.stack([rng.uniform(0.15, 0.33, n), rng.uniform(0.03, 0.08, n)], 1)
+            tracks[(sid, src)][fid] = np.concatenate([yx, np.minimum(yx + hw, 1.0)], 1)          # (y1, x1, y2, x2), float64
+            _synthetic_jpeg(os.path.join(vroot, str(sid), str(src), "%d.jpg" % fid), 72, 128, rng)
+    for sid, rows in lines.items():
+        with open(os.path.join(vroot, str(sid), "annotations.txt"), "w") as fh:
+            fh.write("".join(r + "\n" for r in rows))
+    with open(os.path.join(vroot, "tracks_normalized.pkl"), "wb") as fh:
+        pickle.dump(tracks, fh, protocol=2)
+    anns = refv.volley_read_dataset(vroot, [1, 4])
+    frames = refv.volley_all_frames(anns)
+    rec = {"frames": np.array(frames, dtype=np.int64)}
+    for tag, fsize in (("vgg", (2, 3)), ("inv3", (87, 157))):
+        ds = refv.VolleyballDataset(anns, tracks, frames, vroot, (64, 96), fsize, "dynamic_volleyball", num_boxes=12, num_before=before,
+                                    num_after=after, is_training=True, is_finetune=False)
+        for i in range(len(ds)):
+            images, bboxes, actions, activities = ds[i]
+            assert images.dtype == torch.float32 and torch.equal(images, images.round()) and images.min() >= 0 and images.max() <= 255
+            if tag == "vgg":
+                rec[f"images.{i}"] = images.to(torch.uint8).numpy()
+                rec[f"actions.{i}"], rec[f"activities.{i}"] = actions.numpy(), activities.numpy()
+            rec[f"boxes.{tag}.{i}"] = bboxes.numpy()
+    for sid in anns:
+        for fid, a in anns[sid].items():
+            rec[f"ann.{sid}.{fid}.bboxes"] = np.asarray(a["bboxes"])
+            rec[f"ann.{sid}.{fid}.actions"] = np.asarray(a["actions"])
+            rec[f"ann.{sid}.{fid}.group_activity"] = np.int64(a["group_activity"])
+    np.savez_compressed(os.path.join(out_dir, "dataset_volleyball.npz"), **rec)
+    print(f"[dataset] volleyball: {len(frames)} clips of {before + after + 1} frames, people {sorted(people.values())}")
+    # ---------------- collective: <root>/seq%02d/annotations.txt (tab separated), <root>/seq%02d/frame%04d.jpg
+    croot = os.path.join(tree, "collective")
+    nf = 3
+    plan = {1: {1: 3, 11: 13}, 15: {1: 6, 11: 5}}                   # sid -> anchor frame -> people (13 = num_boxes: no padding); seq15 is 450x800
+    for sid, anchors in plan.items():
+        H_, W_ = refc.FRAMES_SIZE[sid]
+        rows = []
+        for fid in range(1, 14):
+            n = anchors.get(fid, int(rng.integers(1, 6)))
+            if (sid, fid) == (15, 11):
+                acts = [1, 1, 1, 5, 5]                                # 'NA' is the most common: the activity is the runner-up (Walking)
+            else:
+                acts = [int(a) for a in rng.integers(1, 7, n)]
+                if all(a == 1 for a in acts):
+                    acts[0] = 3
+            for j in range(n):
+                w_, h_ = int(rng.integers(20, 90)), int(rng.integers(60, 200))
+                x_, y_ = int(rng.integers(0, W_ - w_)), int(rng.integers(0, H_ - h_))
+                rows.append("%d\t%d\t%d\t%d\t%d\t%d\t%d" % (fid, x_, y_, w_, h_, acts[j], 1))
+            if fid in (1, 2, 3, 11, 12, 13):
+                _synthetic_jpeg(os.path.join(croot, "seq%02d" % sid, "frame%04d.jpg" % fid), 60, 90, rng)
+        with open(os.path.join(croot, "seq%02d" % sid, "annotations.txt"), "w") as fh:
+            fh.write("".join(r + "\n" for r in rows))
+    canns = refc.collective_read_dataset(croot, [1, 15])
+    cframes = refc.collective_all_frames(canns)
+    rec = {"frames": np.array(cframes, dtype=np.int64)}
+    ds = refc.CollectiveDataset(canns, cframes, croot, (64, 96), (2, 3), num_boxes=13, num_frames=nf, is_training=True, is_finetune=False)
+    for i in range(len(ds)):
+        images, bboxes, actions, activities, bboxes_num = ds[i]
+        assert torch.equal(images, images.round())
+        rec[f"images.{i}"], rec[f"boxes.{i}"] = images.to(torch.uint8).numpy(), bboxes.numpy()
+        rec[f"actions.{i}"], rec[f"activities.{i}"], rec[f"bboxes_num.{i}"] = actions.numpy(), activities.numpy(), bboxes_num.numpy()
+    for sid in canns:
+        for fid, a in canns[sid].items():
+            rec[f"ann.{sid}.{fid}.bboxes"] = np.asarray(a["bboxes"], dtype=np.float64)
+            rec[f"ann.{sid}.{fid}.actions"] = np.asarray(a["actions"])
+            rec[f"ann.{sid}.{fid}.group_activity"] = np.int64(a["group_activity"])
+    np.savez_compressed(os.path.join(out_dir, "dataset_collective.npz"), **rec)
+    print(f"[dataset] collective: {len(cframes)} clips of {nf} frames, anchors {cframes}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--skip-big", action="store_true")
-    ap.add_argument("--only", default="", help="'inv3': only the two reduced-size Inception fixtures; 'tce': only (re)generate the Dynamic_TCE_volleyball fixtures; 'full': only the two full-size 720x1280 fixtures")
+    ap.add_argument("--only", default="", help="'inv3': only the two reduced-size Inception fixtures; 'tce': only (re)generate the Dynamic_TCE_volleyball fixtures; 'full': only the two full-size 720x1280 fixtures; 'dataset': only the dataset -> tensor contract fixtures (SURVEY 8f-1)")
     a = ap.parse_args()
     sys.dont_write_bytecode = True
     install_stubs()
@@ -767,6 +881,9 @@ def main():
         return
     if a.only == "full":
         full_cases()
+        return
+    if a.only == "dataset":
+        dataset_cases(a.out)
         return
     prep_case(refutils, a.out)
     f32, f64 = torch.float32, torch.float64
@@ -819,6 +936,7 @@ def main():
         hier_case("hier_k13_k31_t10_c1024", refdin, a.out)
     collective_case("collective_vgg16_96x160", refim, refcfg, a.out)
     tce_cases()
+    dataset_cases(a.out)
     if not a.skip_big:
         full_cases()
     print("golden vectors written to", a.out)

@@ -21,6 +21,17 @@ if [ "${1:-run}" = build ]; then
   ls -la knock_build/noremap/libdin_hip.so
   exit 0
 fi
+if [ "${1:-run}" = build-experiments ]; then
+  # the library WITH the timing knock-outs / experiment switches compiled in (DIN_GATHER_KNOCK, DIN_CONV_W16, DIN_CONV_RING): never shipped
+  mkdir -p knock_build/experiments
+  FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wno-unused-result -Wno-unused-value -DDIN_EXPERIMENTS"
+  for f in $CS/*.hip; do /opt/rocm/bin/hipcc $FL -c $f -o knock_build/experiments/$(basename $f .hip).o 2>/dev/null & done
+  /opt/rocm/bin/hipcc $FL -x hip -c $CS/din_error.cpp -o knock_build/experiments/din_error.o
+  wait
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o knock_build/experiments/libdin_hip.so knock_build/experiments/*.o
+  ls -la knock_build/experiments/libdin_hip.so
+  exit 0
+fi
 ROUNDS=${2:-3}
 SEL="conv or wgrad or halo or gather or stem or dgrad or image"
 python - <<'PY' &
