@@ -1076,7 +1076,7 @@ def test_partial_1x1_group_degrades_to_per_layer_wgrad(gpu, monkeypatch):
     """A graph that consumes only SOME outputs of a block-entry 1x1 group (a partial head): the fused weight-gradient launch
     (din_conv1x1_wgrad_multi) cannot run -- its plan covers every member -- so the members that did receive a gradient fall back to the
     per-layer kernel instead of raising in the middle of backward (nhwc.flush_wgrad_multi).  Checked against the same graph with
-    the fusion switched off: identical kernels then, so identical bits; the unused member has no gradient either way."""
+    the fusion switched off: identical kernels then (1e-4: their epilogues use fp32 atomics); the unused member has no gradient either way."""
     from din_amd import nhwc
     L = nhwc.L
     h, w, nb = 48, 64, 2
@@ -1119,7 +1119,8 @@ def test_partial_1x1_group_degrades_to_per_layer_wgrad(gpu, monkeypatch):
         if n.startswith("b."):
             assert g2 is None and g0 is None, n
         elif not n.split(".")[-1].startswith("running"):
-            assert g2 is not None and g0 is not None and torch.equal(g2, g0), n
+            # same kernels either way; their epilogues add fp32 partial sums with atomics (order-dependent last bits): 1e-4, not bitwise
+            assert g2 is not None and g0 is not None and rel(g2, g0) <= 1e-4, n
 
 
 def test_dataset_loader_feeds_model_through_device_feed(gpu, golden_dir):
