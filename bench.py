@@ -126,12 +126,12 @@ def cpu_baseline(workload, T, N, H, W, budget_s=12.0, lite=None, hierarchical=Fa
             out = O.dynamic_volleyball_forward(ocfg, p, images, boxes)
         F.cross_entropy(out["activities"], labels).backward()
 
-    # Thread count: probed on a PROXY of the same model at a quarter of the pixels (one step each, ascending 32 / 64 / 128 / 256 capped
+    # Thread count: probed on a PROXY of the same model at a quarter of the pixels (one step each, ascending 16 / 32 / 64 / 128 / 256 capped
     # at the host's logical CPUs; the climb stops once a count is > 1.3x slower than the best so far -- torch-CPU does not scale to
     # every SMT thread of a 2-socket host: 256 threads were measured 40x slower than 64 on a 2 x EPYC 9575F box, which is why the
     # full-size step is not used for probing).  The quoted number is then the MEAN of `timed` full-size steps (>= 3) after one
     # untimed warm-up step at the fastest count; `cores` = that count.
-    cands = sorted({max(1, min(ncpu, c)) for c in (32, 64, 128, 256)})
+    cands = sorted({max(1, min(ncpu, c)) for c in (16, 32, 64, 128, 256)})
     def fm_size(x):                                            # feature-map extent of the trunk for an image extent x (layer arithmetic)
         if backbone == "vgg16":
             return x // 32

@@ -11,42 +11,62 @@
 // fp64 partial sums per thread, a fixed-order LDS sum per workgroup, one slab per workgroup summed in slab order: the statistics do not
 // depend on M in precision and are bit-reproducible (no atomics anywhere).  torch.nn.functional.batch_norm is the arithmetic being replaced (reached from torchvision BasicConv2d).
 #include "din_common.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BN_ROWS_PER_BLOCK = 2048;
-constexpr int BN_MAX_PARTS = 512;
-// Rows per workgroup of the statistics kernels: 2048, but at most BN_MAX_PARTS workgroups.  The decomposition is a function of `rows` ALONE
-// (no environment switch, no device query): together with the fixed summation order below it makes the statistics bit-reproducible run to
-// run and box to box.  Measured in round 3 (bench.py --bn-mode batch): 256 .. 2048 workgroups within noise of each other.
-static int bn_rows_per_block(int64_t rows) {
-    int64_t rpb = BN_ROWS_PER_BLOCK;
-    if ((rows + rpb - 1) / rpb > BN_MAX_PARTS) rpb = (rows + BN_MAX_PARTS - 1) / BN_MAX_PARTS;
+// Rows per workgroup of the statistics kernels.  The decomposition is a function of (`rows`, direction) ALONE (no environment switch in the
+// shipped build, no device query): together with the fixed summation order below it makes the statistics bit-reproducible run to run and
+// box to box.  Targets measured with tools/bn_bench.py on the trunk's views (profiles/r04_bn_bench.txt): the forward statistics want
+// ~1024 workgroups (4.8 -> 5.9 TB/s on the stem layers, 2.6 -> 5.3 TB/s on the 43 x 78 maps, which 2048-row workgroups left at 158
+// workgroups on 256 CUs); the backward statistics (two streams per row, twice the slab) are fastest at ~512.
+constexpr int BN_PARTS_FWD = 1024, BN_PARTS_BWD = 512, BN_MIN_ROWS = 256;
+static int bn_rows_per_block(int64_t rows, bool bwd) {
+    int64_t maxp = bwd ? BN_PARTS_BWD : BN_PARTS_FWD, rpb = BN_MIN_ROWS;
+#ifdef DIN_EXPERIMENTS
+    if (const char* e = getenv("DIN_BN_RPB")) rpb = atoi(e);
+    if (const char* e = getenv(bwd ? "DIN_BN_PARTS_BWD" : "DIN_BN_PARTS")) maxp = atoi(e);
+#endif
+    if ((rows + rpb - 1) / rpb > maxp) rpb = (rows + maxp - 1) / maxp;
     return (int)rpb;
 }
-static int bn_parts(int64_t rows) { return (int)ceil_div64(rows, bn_rows_per_block(rows)); }
+static int bn_parts(int64_t rows, bool bwd = false) { return (int)ceil_div64(rows, bn_rows_per_block(rows, bwd)); }
 
+// Non-temporal loads for the statistics kernels (the raw conv output / gradient maps are hundreds of MB, read once per pass): measured
+// +10 % on the stem-sized views (5.9 -> 6.7 TB/s forward, 6.1 -> 6.9 backward; tools/bn_bench.py, profiles/r04_bn_bench.txt).  Non-temporal
+// STORES lose on the narrow channel views of the concatenated block outputs (96-byte rows on a 576-byte pitch: 65 -> 125 us), so the apply
+// kernels keep plain stores; their LOADS are non-temporal too (the strided gradient views of the concatenated block outputs gain 10-25 %:
+// Mixed_5 apply 62 -> 50 / 132 -> 95 us, backward apply 103 -> 93 / 167 -> 153 us; the contiguous stem views are unchanged).
+// DIN_BN_NT (build flag, experiments): 0 none, 1 statistics loads only, 2 statistics + apply-kernel loads (shipped).
+#ifndef DIN_BN_NT
+#define DIN_BN_NT 2
+#endif
+#define BN_LD(T, p) (*reinterpret_cast<const T*>(p))
+#define BN_LD_NT(T, p) __builtin_nontemporal_load(reinterpret_cast<const T*>(p))
+#define BN_ST(T, p, v) (*reinterpret_cast<T*>(p) = (v))
 template <typename T> struct Vec;
 template <> struct Vec<float> {
     static constexpr int V = 4;
+    template <bool NT = (DIN_BN_NT >= 2)>
     __device__ static void load(const float* p, float (&v)[4]) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(p);
+        const f32x4 x = NT ? BN_LD_NT(f32x4, p) : BN_LD(f32x4, p);
         v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
     }
-    __device__ static void store(float* p, const float (&v)[4]) { *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]}; }
+    __device__ static void store(float* p, const float (&v)[4]) { BN_ST(f32x4, p, (f32x4{v[0], v[1], v[2], v[3]})); }
 };
 template <> struct Vec<bf16_t> {
     static constexpr int V = 8;
+    template <bool NT = (DIN_BN_NT >= 2)>
     __device__ static void load(const bf16_t* p, float (&v)[8]) {
-        const u32x4 x = *reinterpret_cast<const u32x4*>(p);
+        const u32x4 x = NT ? BN_LD_NT(u32x4, p) : BN_LD(u32x4, p);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(x[e] << 16); v[2 * e + 1] = __uint_as_float(x[e] & 0xffff0000u); }
     }
     __device__ static void store(bf16_t* p, const float (&v)[8]) {
-        *reinterpret_cast<u32x4*>(p) = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        BN_ST(u32x4, p, (u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}));
     }
 };
 
@@ -101,16 +121,16 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
             float xv[4][V], gv[4][V];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                Vec<T>::load(x + (r + u * (int64_t)rpp) * ldx + cxoff + ch * V, xv[u]);
-                if (BWD) Vec<T>::load(g + (r + u * (int64_t)rpp) * ldg + cgoff + ch * V, gv[u]);
+                Vec<T>::template load<(DIN_BN_NT >= 1)>(x + (r + u * (int64_t)rpp) * ldx + cxoff + ch * V, xv[u]);
+                if (BWD) Vec<T>::template load<(DIN_BN_NT >= 1)>(g + (r + u * (int64_t)rpp) * ldg + cgoff + ch * V, gv[u]);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) fold(xv[u], gv[u]);
         }
         for (; r < r1; r += rpp) {
             float xv[V], gv[V];
-            Vec<T>::load(x + r * ldx + cxoff + ch * V, xv);
-            if (BWD) Vec<T>::load(g + r * ldg + cgoff + ch * V, gv);
+            Vec<T>::template load<(DIN_BN_NT >= 1)>(x + r * ldx + cxoff + ch * V, xv);
+            if (BWD) Vec<T>::template load<(DIN_BN_NT >= 1)>(g + r * ldg + cgoff + ch * V, gv);
             fold(xv, gv);
         }
 #pragma unroll
@@ -329,7 +349,11 @@ static bool bn_apply_rows() { static const bool on = !(getenv("DIN_BN_APPLY_ROWS
 // rows per workgroup of the row-walk apply kernels: ~2048 workgroups, at least four passes of the workgroup's 256 / (C / V) rows each
 static int bn_apply_rpb(int64_t rows, int c, int v) {
     const int rpp = 256 / (c / v);
-    int64_t rpb = (rows + 2047) / 2048;
+    int64_t wgs = 2048;
+#ifdef DIN_EXPERIMENTS
+    if (const char* e = getenv("DIN_BN_APPLY_WGS")) wgs = atoi(e);
+#endif
+    int64_t rpb = (rows + wgs - 1) / wgs;
     if (rpb < 4 * rpp) rpb = 4 * rpp;
     if (rpb > 8192) rpb = 8192;
     return (int)rpb;
@@ -351,13 +375,14 @@ int din_bn_parts(int64_t rows) { return rows > 0 ? bn_parts(rows) : 0; }
 
 int64_t din_bn_workspace(int64_t rows, int c) {
     if (rows <= 0 || c <= 0) return 0;
-    return (int64_t)(bn_parts(rows) + 1) * 2 * c * (int64_t)sizeof(double);
+    const int parts = bn_parts(rows, false) > bn_parts(rows, true) ? bn_parts(rows, false) : bn_parts(rows, true);
+    return (int64_t)(parts + 1) * 2 * c * (int64_t)sizeof(double);
 }
 
 int din_bn_stats(const void* x, int dtype, int64_t rows, int c, int ld, int coff, const float* shift, double* ws, void* stream) {
     DIN_REQUIRE(x && ws, "bn_stats: null pointer");
     if (int e = check_view(dtype, rows, c, ld, coff, "bn_stats")) return e;
-    const int rpb = bn_rows_per_block(rows);
+    const int rpb = bn_rows_per_block(rows, false);
     const int blocks = (int)ceil_div64(rows, rpb);
     const int v = dtype == DIN_F32 ? 4 : 8;
     const size_t lds = (size_t)(256 / (c / v)) * 2 * c * sizeof(double);
@@ -422,7 +447,7 @@ int din_bn_bwd_stats(const void* gz, int ldg, int cgoff, const void* x, int ldx,
     DIN_REQUIRE(gz && x && mean && rstd && ws, "bn_bwd_stats: null pointer");
     if (int e = check_view(dtype, rows, c, ldg, cgoff, "bn_bwd_stats(gz)")) return e;
     if (int e = check_view(dtype, rows, c, ldx, cxoff, "bn_bwd_stats(x)")) return e;
-    const int rpb = bn_rows_per_block(rows);
+    const int rpb = bn_rows_per_block(rows, true);
     const int blocks = (int)ceil_div64(rows, rpb);
     const int v = dtype == DIN_F32 ? 4 : 8;
     const size_t lds = (size_t)(256 / (c / v)) * 2 * c * sizeof(double);

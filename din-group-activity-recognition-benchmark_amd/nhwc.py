@@ -56,6 +56,7 @@ def require_gpu(*tensors: torch.Tensor) -> None:
 # ------------------------------------------------------------------------------------------------
 import contextlib as _contextlib
 LAUNCH_TIMER = None
+TIMING_ACTIVE = lambda: LAUNCH_TIMER is not None      # noqa: E731  (profiling.install narrows it to "events are being recorded right now")
 
 
 def _timed(kind, d, name=""):
@@ -581,7 +582,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
     tdt = torch_dtype(dt)
     st = _stream()
     main = torch.cuda.current_stream()
-    side = side_stream(dev) if (WGRAD_SIDE_STREAM and LAUNCH_TIMER is None) else None
+    side = side_stream(dev) if (WGRAD_SIDE_STREAM and not TIMING_ACTIVE()) else None
     wtag = ""
     gbufs: Dict[int, torch.Tensor] = dict(out_grads)
 

@@ -196,7 +196,9 @@ class LaunchTimer:
 
 def install() -> None:
     nhwc.LAUNCH_TIMER = LaunchTimer
+    nhwc.TIMING_ACTIVE = lambda: PROFILE is not None      # per-launch events only make sense on one stream: bracketed steps run single-stream
 
 
 def uninstall() -> None:
     nhwc.LAUNCH_TIMER = None
+    nhwc.TIMING_ACTIVE = lambda: False

@@ -7,6 +7,7 @@
 #         bench      default bench line -> <tag>_bench.json ;  bench:<args...> with ',' for spaces, e.g. bench:--bn-mode,batch
 #         stats      rocprofv3 --kernel-trace --stats of the default bench -> <tag>_kernel_stats.csv
 #         smoke      __graft_entry__.smoke()
+#         env:K=V / unset:K   environment for the following steps;   sh:<command with , for spaces>   anything else (last lines shown)
 set -u
 cd "$(dirname "$0")/../.."
 TAG=$1; shift
@@ -25,13 +26,16 @@ for step in "$@"; do
                cp $OUT/test_margins.txt $OUT/${TAG}_test_margins_run$i.txt 2>/dev/null
              done ;;
     bench)   timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?"; cat $OUT/${TAG}_bench.json ;;
-    bench:*) a=${step#bench:}; n=$(echo "$a" | tr -c 'a-zA-Z0-9' '_'); timeout 900 python bench.py ${a//,/ } > $OUT/${TAG}_bench_$n.json 2> $OUT/${TAG}_bench_$n.err
+    bench:*) a=${step#bench:}; n=$(echo "$a${BTAG:-}" | tr -c 'a-zA-Z0-9' '_'); timeout 900 python bench.py ${a//,/ } > $OUT/${TAG}_bench_$n.json 2> $OUT/${TAG}_bench_$n.err
              echo "bench $a rc=$?"; cat $OUT/${TAG}_bench_$n.json ;;
     stats)   rm -rf /tmp/prof; (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d /tmp/prof -o r -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-extras > /tmp/prof.log 2>&1)
              f=$(find /tmp/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -60 "$f" > $OUT/${TAG}_kernel_stats.csv; tail -2 /tmp/prof.log ;;
     stats:*) a=${step#stats:}; n=$(echo "$a" | tr -c 'a-zA-Z0-9' '_'); rm -rf /tmp/prof
              (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d /tmp/prof -o r -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-extras ${a//,/ } > /tmp/prof.log 2>&1)
              f=$(find /tmp/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -60 "$f" > $OUT/${TAG}_kernel_stats_$n.csv; tail -2 /tmp/prof.log ;;
+    env:*)   export "${step#env:}"; echo "export ${step#env:}" ;;
+    unset:*) unset "${step#unset:}" ;;
+    sh:*)    c=${step#sh:}; echo "+ ${c//,/ }"; bash -c "${c//,/ }" 2>&1 | tail -${TAILN:-5} ;;
     smoke)   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ;;
     *)       echo "unknown step $step" ;;
   esac
