@@ -28,10 +28,10 @@ for step in "$@"; do
     bench)   timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?"; cat $OUT/${TAG}_bench.json ;;
     bench:*) a=${step#bench:}; n=$(echo "$a${BTAG:-}" | tr -c 'a-zA-Z0-9' '_'); timeout 900 python bench.py ${a//,/ } > $OUT/${TAG}_bench_$n.json 2> $OUT/${TAG}_bench_$n.err
              echo "bench $a rc=$?"; cat $OUT/${TAG}_bench_$n.json ;;
-    stats)   rm -rf /tmp/prof; (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d /tmp/prof -o r -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-extras > /tmp/prof.log 2>&1)
+    stats)   rm -rf /tmp/prof; (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-extras > /tmp/prof.log 2>&1)
              f=$(find /tmp/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -60 "$f" > $OUT/${TAG}_kernel_stats.csv; tail -2 /tmp/prof.log ;;
     stats:*) a=${step#stats:}; n=$(echo "$a" | tr -c 'a-zA-Z0-9' '_'); rm -rf /tmp/prof
-             (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d /tmp/prof -o r -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-extras ${a//,/ } > /tmp/prof.log 2>&1)
+             (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-extras ${a//,/ } > /tmp/prof.log 2>&1)
              f=$(find /tmp/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -60 "$f" > $OUT/${TAG}_kernel_stats_$n.csv; tail -2 /tmp/prof.log ;;
     env:*)   export "${step#env:}"; echo "export ${step#env:}" ;;
     unset:*) unset "${step#unset:}" ;;
