@@ -18,7 +18,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "din_hip.h")
 
 DIN_F32, DIN_BF16 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 CONV_BIAS, CONV_RELU, CONV_ACCUM, CONV_MASK = 1, 2, 4, 8
 
 
@@ -73,6 +73,8 @@ SIGNATURES: Dict[str, tuple] = {
     "din_conv_fwd2": (_I, [_CD, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "din_conv_dgrad": (_I, [_CD, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P]),
     "din_conv1x1_dgrad_multi": (_I, [_I, C.POINTER(ConvSrc), _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
+    "din_conv_dgrad_x_fused": (_I, [_CD]),
+    "din_conv_dgrad_x": (_I, [_CD, _P, _P, _P, _P, _I, _I, _I, C.POINTER(ConvSrc), _P, _L, _P]),
     "din_conv1x1_wgrad_multi_workspace": (_L, [_I, C.POINTER(ConvWSrc), _I, _L, _I]),
     "din_conv1x1_wgrad_multi": (_I, [_I, C.POINTER(ConvWSrc), _I, _L, _I, _I, _I, _P, _I, _P, _L, _P]),
     "din_conv_wgrad": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P]),

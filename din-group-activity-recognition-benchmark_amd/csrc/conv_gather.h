@@ -37,6 +37,10 @@ struct ConvK {
     // concatenation of the sources' channels; source b = its own tensor (pixel stride, channel offset) + its own filter bank
     int nsrc;
     struct Src { const void* in; const void* w; long long in_bytes, w_bytes; int cpt, ld, coff, wld; } src[4];
+    // extra 1x1 source of a single-source launch (nsrc == 0, xsteps > 0): after the launch's own reduction, xsteps more k-steps read src[0]
+    // AT THE OUTPUT PIXEL (a 1x1 / stride-1 conv over the same input view: its dgrad lands on the same pixels) -- din_conv_dgrad_x folds the
+    // block-entry 1x1 of Mixed_6a into the parity-class launches of the strided 3x3 beside it (one pass over dX instead of two)
+    int xsteps;
     // second destination (fused sibling convs that read one tensor): produced channels >= csplit go to out2 (pixel stride ldo2, channel
     // offset cooff2 + (channel - csplit)); csplit == 0: single destination.  Staged (aligned) epilogue only, no mask / accumulate.
     void* out2; int ldo2, cooff2, csplit;

@@ -75,7 +75,7 @@ __device__ __forceinline__ void lds_dma_stage(uint32_t lds_addr, __amdgpu_buffer
                                               __amdgpu_buffer_rsrc_t rsB, const int (&vb)[NB], int soffB) {
 #define DIN_DMA_FIRST(V, R, S) "s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 " V ", " R ", " S " offen lds\n\t"
 #define DIN_DMA_NEXT(V, R, S) "s_add_u32 m0, m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 " V ", " R ", " S " offen lds\n\t"
-    static_assert(NA == 2 && NB >= 1 && NB <= 3, "instantiated for the 8-wave 128-pixel tiles");
+    static_assert(NA == 2 && NB >= 1 && NB <= 4, "instantiated for the 8-wave 128-pixel and the 6-wave 96-pixel tiles");
     if constexpr (NB == 1)
         asm volatile(DIN_DMA_FIRST("%6", "%1", "%3") DIN_DMA_NEXT("%7", "%1", "%3") DIN_DMA_NEXT("%8", "%2", "%4")
                      :: "s"(lds_addr), "s"(rsA), "s"(rsB), "s"(soffA), "s"(soffB), "n"(STRIDE), "v"(va[0]), "v"(va[1]), "v"(vb[0])
@@ -84,10 +84,15 @@ __device__ __forceinline__ void lds_dma_stage(uint32_t lds_addr, __amdgpu_buffer
         asm volatile(DIN_DMA_FIRST("%6", "%1", "%3") DIN_DMA_NEXT("%7", "%1", "%3") DIN_DMA_NEXT("%8", "%2", "%4") DIN_DMA_NEXT("%9", "%2", "%4")
                      :: "s"(lds_addr), "s"(rsA), "s"(rsB), "s"(soffA), "s"(soffB), "n"(STRIDE), "v"(va[0]), "v"(va[1]), "v"(vb[0]), "v"(vb[1])
                      : "memory", "m0", "scc");
-    else
+    else if constexpr (NB == 3)
         asm volatile(DIN_DMA_FIRST("%6", "%1", "%3") DIN_DMA_NEXT("%7", "%1", "%3") DIN_DMA_NEXT("%8", "%2", "%4") DIN_DMA_NEXT("%9", "%2", "%4")
                      DIN_DMA_NEXT("%10", "%2", "%4")
                      :: "s"(lds_addr), "s"(rsA), "s"(rsB), "s"(soffA), "s"(soffB), "n"(STRIDE), "v"(va[0]), "v"(va[1]), "v"(vb[0]), "v"(vb[1]), "v"(vb[2])
+                     : "memory", "m0", "scc");
+    else
+        asm volatile(DIN_DMA_FIRST("%6", "%1", "%3") DIN_DMA_NEXT("%7", "%1", "%3") DIN_DMA_NEXT("%8", "%2", "%4") DIN_DMA_NEXT("%9", "%2", "%4")
+                     DIN_DMA_NEXT("%10", "%2", "%4") DIN_DMA_NEXT("%11", "%2", "%4")
+                     :: "s"(lds_addr), "s"(rsA), "s"(rsB), "s"(soffA), "s"(soffB), "n"(STRIDE), "v"(va[0]), "v"(va[1]), "v"(vb[0]), "v"(vb[1]), "v"(vb[2]), "v"(vb[3])
                      : "memory", "m0", "scc");
 #undef DIN_DMA_FIRST
 #undef DIN_DMA_NEXT
@@ -268,8 +273,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_generic_kernel(ConvK 
 // FASTK (bf16 8-wave tiles; host: whole k-steps per tap, no tap remap, k-order = taps inside channel chunks): every piece of per-step
 // loader state is scalar except one validity select per tile row, the offsets of the NEXT transfer are prepared while the current
 // stage is multiplied (so only the transfers themselves sit between the barrier and the MFMAs), and no other mode is compiled in.
-template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS, bool MULTI = false, bool FASTK = false>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK p) {
+template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS, bool MULTI = false, bool FASTK = false, bool XSRC = false>
+// (second argument = waves per SIMD the register allocation must leave room for: the 8-wave 128-pixel bf16 tiles run TWO workgroups per CU
+//  = four waves per SIMD = at most 128 VGPRs.  Left at 2, a harmless-looking edit -- round 4: the knock-out switches turned compile-time
+//  constants -- moved the FASTK 128 x 192 instantiation from 125 to 131 registers: one workgroup per CU, 186 -> 259 us per launch, -1.6 ms per
+//  step, caught only by diffing kernel_stats.csv against the previous round's.)
+__global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && BMT == 128 && WM * WN == 8) ? 4 : (WM * WN == 6 ? 3 : 2)) void conv_gather_fast_kernel(ConvK p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the host pass only needs the launch stub (the LDS-DMA builtin is device-only)
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BM = BMT;                                  // shadows the file-level default inside this kernel
@@ -301,6 +310,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
     {
         const int nk_s = (p.Q + KCS - 1) / KCS;
         if (ks_end > nk_s) ks_end = nk_s;
+    }
+    [[maybe_unused]] const int ks_x0 = ks_end;                 // XSRC: k-steps >= ks_x0 read the extra 1x1 source (never with split-K)
+    if constexpr (XSRC) {
+        static_assert(!MULTI && !FASTK && KCS == 8, "XSRC: general single-source loop");
+        ks_end += p.xsteps;
     }
     const int ntaps = p.kh * p.kw;
     if (p.remap && tid < 32) wtap_lds[tid] = tid < ntaps ? (int)p.wtap[tid] : 0;
@@ -404,10 +418,41 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
 
     // LDS byte address of this wave's RW rows of pass 0 in stage 0 (wave-uniform -> SGPR)
     const uint32_t ldsA0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(smem + (wid * RW) * KC));
+    // XSRC: resources of the extra source (its tensor from the first image of the tile on, its packed 1x1 bank)
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rsXA = rsA, rsXB = rsB;
+    [[maybe_unused]] long long x_px0 = 0;
+    if constexpr (XSRC) {
+        const ConvK::Src& sr = p.src[0];
+        x_px0 = (long long)n_first * (p.out_sy == 0 ? p.OH * p.OW : p.out_H * p.out_W);
+        long long rem = sr.in_bytes - x_px0 * sr.ld * (long long)sizeof(T);
+        if (rem > 0x7fffffffll) rem = 0x7fffffffll;
+        rsXA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(sr.in)) + x_px0 * sr.ld * (long long)sizeof(T), 0,
+                                                 (int)(rem > 0 ? rem : 0), 0x00020000);
+        rsXB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(sr.w), 0, (int)sr.w_bytes, 0x00020000);
+    }
     // issue the DMA of k-step ks into stage `buf`: PA + PB wave-level 1-KiB transfers per wave, no VGPRs, no ds_write
     auto issue_dma = [&](int buf, int ks) {
         const uint32_t A = ldsA0 + (uint32_t)(buf * BUF * 16);
         const uint32_t B = A + (uint32_t)(BM * KC * 16);
+        if constexpr (XSRC) {
+            if (ks >= ks_x0) {
+                const ConvK::Src& sr = p.src[0];
+                const int cc = (ks - ks_x0) * KC;
+                const bool cok = (cc + cq) < sr.cpt;
+                const int chan = sr.coff * (int)sizeof(T) + (cc + cq) * 16, ldb = sr.ld * (int)sizeof(T);
+#pragma unroll
+                for (int i = 0; i < PA; ++i) {
+                    const int m = m_first + r0 + LR * i;
+                    unsigned vo = OOB;
+                    if (cok && m < p.M) vo = (unsigned)((int)(out_pixel(p, m) - x_px0) * ldb + chan);
+                    lds_dma16(A + (uint32_t)(LR * i * KC * 16), rsXA, (int)vo, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < PB; ++i)
+                    lds_dma16(B + (uint32_t)(LR * i * KC * 16), rsXB, ((co_tile * BN + r0 + LR * i) * sr.wld + cq) * 16, cc * 16);
+                return;
+            }
+        }
         int remapB = 0;                                    // per-lane chunk offset (bytes) into the packed bank, remap mode only
         int korderB = 0;                                   // scalar chunk offset of this k-step in the packed bank (korder mode)
         if constexpr (MULTI) {
@@ -499,7 +544,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_fast_kernel(ConvK
     constexpr int NDMA = PA + PB;                                  // wave-level DMAs per stage per wave (issued unconditionally)
     static_assert((NS - 2) * NDMA <= 63, "vmcnt field");
     if constexpr (FASTK) {
-        static_assert(!MULTI && NS == 2 && PA == 2, "FASTK: 8-wave 128-pixel tiles, double-buffered");
+        static_assert(!MULTI && NS == 2 && PA == 2, "FASTK: 8-wave 128-pixel / 6-wave 96-pixel tiles, double-buffered");
         // scalar walk over k-steps: ks -> (channel chunk ks / ntaps, tap ks % ntaps); td = byte delta of the tap, fa / fb = scalar byte
         // offsets of the step inside a pixel's channels / inside a packed filter row
         int tap = ks_begin % ntaps, tr = (tap * inv_kw) >> 16, tc = tap - tr * p.kw;
@@ -2528,6 +2573,13 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype, bool str
     }
     g.cout_pad = pad_to(cprod, 128);
     g.n_co_tiles = (cprod + g.bn - 1) / g.bn;
+    // 96-pixel tiles (6 waves) when the 128-pixel tiles number between one and two per CU and the 96-pixel ones still fit one round (512 slots)
+    if (dtype == DIN_BF16 && g.bm == 128 && g.bn != 256 && !strided_out) {
+        const char* tv = getenv("DIN_CONV_TILE96");
+        const int mode = tv ? atoi(tv) : 1;                    // 0: off, 1: by the rule, 2: always (tests)
+        const int64_t n128 = ((int64_t)M + 127) / 128 * g.n_co_tiles, n96 = ((int64_t)M + 95) / 96 * g.n_co_tiles;
+        if (mode == 2 || (mode == 1 && n128 > 288 && n96 <= 512)) g.bm = 96;
+    }
     g.n_px_tiles = (M + g.bm - 1) / g.bm;
     // split-K only when the launch cannot fill the chip and the reduction is long
     int tiles = g.n_co_tiles * g.n_px_tiles;
@@ -2758,19 +2810,33 @@ static bool plan_halo(int dtype, int kh, int kw, int cred, int cprod, int oh, in
     return hp.lds <= 160 * 1024;
 }
 
-template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS, bool FASTK = false>
+template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS, bool FASTK = false, bool XSRC = false>
 void launch_fast(const ConvK& k, dim3 grid, hipStream_t st) {
     constexpr int LR_ = 64 * WM * WN / KCS, BNP_ = (BN + LR_ - 1) / LR_ * LR_;       // filter rows padded to whole loader passes
     size_t stage = (size_t)NS * (BMT + BNP_) * KCS * 16 + (k.remap ? 128 : 0);   // stage ring (+ remap table)
     // a single k-step (1x1 layers with <= 64 input channels: Conv2d_3b, the 64-channel dgrads) only ever touches ring stage 0: ask for one
     // stage, so that more of these memory-bound workgroups are resident per CU and their loads / stores overlap (DIN_CONV_ONESTAGE=0: off)
     static const bool one_stage_ok = !(getenv("DIN_CONV_ONESTAGE") && atoi(getenv("DIN_CONV_ONESTAGE")) == 0);
-    if (one_stage_ok && !k.remap && k.ks_per_split * (8 / KCS) <= 1) stage = (size_t)(BMT + BNP_) * KCS * 16;
+    if (one_stage_ok && !k.remap && k.xsteps == 0 && k.ks_per_split * (8 / KCS) <= 1) stage = (size_t)(BMT + BNP_) * KCS * 16;
     size_t epi = (size_t)BMT * (BN * sizeof(T) + 16);
     size_t lds = stage > epi ? stage : epi;
-    auto kern = conv_gather_fast_kernel<T, BMT, BN, WM, WN, KCS, NS, false, FASTK>;
+    auto kern = conv_gather_fast_kernel<T, BMT, BN, WM, WN, KCS, NS, false, FASTK, XSRC>;
     if (lds > 65536) raise_lds_limit(kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, st, k);
+}
+
+// 6-wave 96 x BN tile (3 x 2 waves: the 8-wave tile's 32 x BN/2 wave tile, 48 rows per loader pass): for launches whose 128-pixel tiles
+// number between one and two per CU -- the 43 x 78 maps of Mixed_6 at 4 clips per GPU, 315 tiles on 512 slots: a quarter of the CUs run two
+// workgroups and set the launch's time while the others wait; 420 tiles of 96 pixels still fit in one round and every workgroup is a quarter
+// shorter (DIN_CONV_TILE96=0: off)
+template <typename T, int BN>
+void launch_wave6(const ConvK& k, dim3 grid, hipStream_t st) {
+    static_assert(sizeof(T) == 2, "bf16 only");
+    const char* fv = getenv("DIN_CONV_FASTK");
+    const bool want = fv ? atoi(fv) != 0 : true;
+    const bool fastk = want && !k.remap && k.nsrc == 0 && (k.cpt % 8) == 0 && (k.korder || k.kh * k.kw == 1);
+    if (fastk) launch_fast<T, 96, BN, 3, 2, 8, 2, true>(k, grid, st);
+    else launch_fast<T, 96, BN, 3, 2, 8, 2>(k, grid, st);
 }
 
 // 8-wave 128 x BN tile: the scalar-walk specialisation (FASTK) whenever the launch qualifies (bf16, whole k-steps per tap, no tap remap,
@@ -2852,7 +2918,13 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
     //   others  : 2 stages x 8 chunks           -- MFMA-dense tiles lose 8-10 % when the stage (and the barrier interval) is halved
     const char* pv = getenv("DIN_CONV_PIPE");
     const int pipe = pv ? atoi(pv) : -1;
-    if (bm == 256 && bn == 64) { if (pipe != 0) launch_fast<T, 256, 64, 4, 1, 4, 4>(k, grid, st); else launch_fast<T, 256, 64, 4, 1, 8, 2>(k, grid, st); }
+    if (bm == 96) {
+        if constexpr (sizeof(T) == 2) {
+            if (bn == 64) launch_wave6<T, 64>(k, grid, st); else if (bn == 96) launch_wave6<T, 96>(k, grid, st); else if (bn == 128) launch_wave6<T, 128>(k, grid, st);
+            else if (bn == 160) launch_wave6<T, 160>(k, grid, st); else launch_wave6<T, 192>(k, grid, st);
+        }
+    }
+    else if (bm == 256 && bn == 64) { if (pipe != 0) launch_fast<T, 256, 64, 4, 1, 4, 4>(k, grid, st); else launch_fast<T, 256, 64, 4, 1, 8, 2>(k, grid, st); }
     else if (bm == 256 && bn == 256) {
         if constexpr (sizeof(T) == 2) { if (pipe == 1) launch_fast<T, 256, 256, 4, 2, 4, 4>(k, grid, st); else launch_fast<T, 256, 256, 4, 2, 8, 2>(k, grid, st); }
     }
@@ -2884,7 +2956,10 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
     }
     // 128 x 96: four waves (eight measured 5-14 % slower on Conv2d_3b) -- except the parity classes of a strided dgrad, whose scattered,
     // epilogue-bound tiles gain 5 % from eight waves (Mixed_6a.branch3x3 dgrad 1379 -> 1312 us)
-    else if (bn == 96) { if ((pipe == 8 || (k.remap && pipe != 4)) && sizeof(T) == 2) launch_fast<T, 128, 96, 4, 2, 8, 2>(k, grid, st); else launch_fast<T, 128, 96, 2, 2, 8, 2>(k, grid, st); }
+    else if (bn == 96) {
+        if constexpr (sizeof(T) == 2) { if (k.xsteps > 0) { launch_fast<T, 128, 96, 4, 2, 8, 2, false, true>(k, grid, st); return; } }
+        if ((pipe == 8 || (k.remap && pipe != 4)) && sizeof(T) == 2) launch_fast<T, 128, 96, 4, 2, 8, 2>(k, grid, st); else launch_fast<T, 128, 96, 2, 2, 8, 2>(k, grid, st);
+    }
     else if (bn == 160) { if (pipe != 4 && sizeof(T) == 2) launch_wave8<T, 160>(k, grid, st); else launch_fast<T, 128, 160, 2, 2, 8, 2>(k, grid, st); }
     // 128 x {128,160,192}: 8 waves (4 x 2, four per SIMD at two workgroups per CU) -- same LDS ring, more waves to hide the stage waits:
     // +8..12 % on the 7-tap layers, +24 % on thin-K dgrads (bf16 only; DIN_CONV_PIPE=4 restores the 4-wave form)
@@ -2908,6 +2983,7 @@ bool want_gather_pipe(int dtype, int64_t M, int cred, int taps, int bn, int spli
 int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_bytes, hipStream_t st, const char* what) {
     const bool fast = k.divy == 1 && k.divx == 1 && k.kh * k.kw <= 32;
     if (!fast && g.bn != 64 && g.bn != 128) { g.bn = 128; g.n_co_tiles = (k.Cout + 127) / 128; }
+    if (g.bm == 96 && (!fast || k.remap || g.splitk > 1 || k.nsrc > 0 || dtype != DIN_BF16)) { g.bm = 128; g.n_px_tiles = (k.M + 127) / 128; }
     if (g.bm == 256 && (!fast || k.remap || g.splitk > 1)) {
         g.bm = 128; if (g.bn == 256) g.bn = 128;
         g.n_px_tiles = (k.M + 127) / 128; g.n_co_tiles = (k.Cout + g.bn - 1) / g.bn;
@@ -2936,7 +3012,7 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
             DIN_FAIL(DIN_E_WORKSPACE, "%s: workspace %lld < %lld bytes", what, (long long)ws_bytes, (long long)g.ws_bytes);
         k.partial = reinterpret_cast<float*>(workspace);
     }
-    if (fast && g.splitk == 1 && k.nsrc == 0 && din_gather::conv1x1_stream_eligible(k, dtype)) {
+    if (fast && g.splitk == 1 && k.nsrc == 0 && k.xsteps == 0 && din_gather::conv1x1_stream_eligible(k, dtype)) {
         // 1x1 layers with a short reduction over a large map: persistent streaming kernel (conv_stream.hip)
         if (din_gather::launch_conv1x1_stream(k, st)) DIN_FAIL(DIN_E_LAUNCH, "%s: conv1x1_stream launch failed", what);
         return DIN_OK;
@@ -3200,13 +3276,13 @@ int din_conv_kernel_variant(const din_conv_desc* d, int which, int32_t* flags) {
     int32_t bm = 0, bn = 0;
     if (int e = din_conv_kernel_tile(d, which, &bm, &bn)) return e;
     *flags = 0;
-    if (bm != 128 || d->dtype != DIN_BF16) return DIN_OK;          // the 8-wave / FASTK instantiations exist for bf16 128 x BN tiles only
+    if ((bm != 128 && bm != 96) || d->dtype != DIN_BF16) return DIN_OK;   // the 8-wave / FASTK instantiations exist for bf16 128 x BN (and 96 x BN: 6 waves) tiles only
     const char* pv = getenv("DIN_CONV_PIPE");
     const int pipe = pv ? atoi(pv) : -1;
     const bool strided = which == 1 && (d->sh > 1 || d->sw > 1);
-    const bool wave8 = ((bn == 64 || bn == 128 || bn == 160 || bn == 192) && pipe != 4 && pipe != 1) ||
+    const bool wave8 = bm == 96 || ((bn == 64 || bn == 128 || bn == 160 || bn == 192) && pipe != 4 && pipe != 1) ||
                        (bn == 96 && (pipe == 8 || (strided && pipe != 4)));       // (the parity classes of a strided dgrad: launch_gather)
-    if (wave8) *flags |= 2;
+    if (wave8 && bm != 96) *flags |= 2;
     const int ntaps = d->kh * d->kw, cred = which == 0 ? d->cin : d->cout;
     const int cpt = pad_to(cred, 8) / 8;
     GatherPlan g = which == 0 ? plan_gather(d->nb * d->oh * d->ow, d->cin, d->cout, ntaps, d->dtype)
@@ -3310,8 +3386,49 @@ int din_conv_fwd2(const din_conv_desc* d, const void* in, const void* wpk, const
     return run_gather(k, g, d->dtype, workspace, workspace_bytes, as_stream(stream), "conv_fwd2");
 }
 
+static int conv_dgrad_impl(const din_conv_desc* d, const void* dout, const void* wpk_t, void* din_, const void* mask, int ldm,
+                           int moff, int flags, void* workspace, int64_t workspace_bytes, void* stream, const din_conv_src* x);
+
 int din_conv_dgrad(const din_conv_desc* d, const void* dout, const void* wpk_t, void* din_, const void* mask, int ldm,
                    int moff, int flags, void* workspace, int64_t workspace_bytes, void* stream) {
+    return conv_dgrad_impl(d, dout, wpk_t, din_, mask, ldm, moff, flags, workspace, workspace_bytes, stream, nullptr);
+}
+
+// whether the parity-class launches of this strided dgrad can carry an extra 1x1 source (conv_gather_fast_kernel<..., XSRC>: bf16, 128 x 96
+// tiles, no split-K)
+static bool dgrad_x_fused(const din_conv_desc* d) {
+    if (getenv("DIN_DGRAD_X") && atoi(getenv("DIN_DGRAD_X")) == 0) return false;
+    if (d->dtype != DIN_BF16 || !(d->sh > 1 || d->sw > 1) || d->dh != 1 || d->dw != 1 || d->kh * d->kw > 32) return false;
+    for (int py = 0; py < d->sh; ++py)
+        for (int px = 0; px < d->sw; ++px) {
+            const int Ha = (d->h - py + d->sh - 1) / d->sh, Wa = (d->w - px + d->sw - 1) / d->sw;
+            if (Ha <= 0 || Wa <= 0) continue;
+            const int r0c = (py + d->ph) % d->sh, s0c = (px + d->pw) % d->sw;
+            const int khs = r0c < d->kh ? (d->kh - r0c + d->sh - 1) / d->sh : 0;
+            const int kws = s0c < d->kw ? (d->kw - s0c + d->sw - 1) / d->sw : 0;
+            const GatherPlan g = plan_gather(d->nb * Ha * Wa, d->cout, d->cin, khs * kws, d->dtype, true);
+            if (g.bn != 96 || g.splitk != 1) return false;
+        }
+    return true;
+}
+
+int din_conv_dgrad_x_fused(const din_conv_desc* d) { return (d && check_desc(d) == DIN_OK && dgrad_x_fused(d)) ? 1 : 0; }
+
+int din_conv_dgrad_x(const din_conv_desc* d, const void* dout, const void* wpk_t, void* din_, const void* mask, int ldm, int moff, int flags,
+                     const din_conv_src* x, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    DIN_REQUIRE(x && x->dout && x->wpk_t && x->cout > 0, "conv_dgrad_x: null extra source");
+    const int epc = epc_of(d->dtype);
+    DIN_REQUIRE(x->ldo % epc == 0 && x->cooff % epc == 0 && x->ldo >= x->cooff + pad_to(x->cout, epc),
+                "conv_dgrad_x: extra source stride/offset must be multiples of %d and cover cout (+zero pad)", epc);
+    if (dgrad_x_fused(d)) return conv_dgrad_impl(d, dout, wpk_t, din_, mask, ldm, moff, flags, workspace, workspace_bytes, stream, x);
+    // not a shape the fused kernel serves: the two launches it replaces (the second accumulates; the mask is linear)
+    if (int e = conv_dgrad_impl(d, dout, wpk_t, din_, mask, ldm, moff, flags, workspace, workspace_bytes, stream, nullptr)) return e;
+    return din_conv1x1_dgrad_multi(1, x, d->dtype, d->nb, d->h, d->w, d->cin, d->ldi, d->cioff, din_, mask, ldm, moff, flags | DIN_CONV_ACCUM, stream);
+}
+
+static int conv_dgrad_impl(const din_conv_desc* d, const void* dout, const void* wpk_t, void* din_, const void* mask, int ldm,
+                           int moff, int flags, void* workspace, int64_t workspace_bytes, void* stream, const din_conv_src* x) {
     if (int e = check_desc(d)) return e;
     DIN_REQUIRE(dout && wpk_t && din_, "conv_dgrad: null pointer");
     DIN_REQUIRE(!d->in_u8, "conv_dgrad: in_u8 is a din_conv_fwd / din_conv_wgrad option");
@@ -3361,6 +3478,15 @@ int din_conv_dgrad(const din_conv_desc* d, const void* dout, const void* wpk_t, 
             c.remap = 1; c.wld = wld_full;
             for (int rr = 0; rr < khs; ++rr)
                 for (int ss = 0; ss < kws; ++ss) c.wtap[rr * kws + ss] = (unsigned char)((r0c + d->sh * rr) * d->kw + (s0c + d->sw * ss));
+            if (x) {                                   // extra 1x1 source at the output pixel (din_conv_dgrad_x)
+                ConvK::Src& o = c.src[0];
+                o.in = x->dout; o.w = x->wpk_t; o.ld = x->ldo; o.coff = x->cooff;
+                o.cpt = pad_to(x->cout, epc2) / epc2;
+                o.wld = (o.cpt + KC - 1) / KC * KC;
+                o.in_bytes = (long long)d->nb * d->h * d->w * x->ldo * 2;
+                o.w_bytes = (long long)pad_to(d->cin, 256) * o.wld * 16;
+                c.xsteps = (o.cpt + KC - 1) / KC;
+            }
             GatherPlan g = plan_gather(c.M, d->cout, d->cin, c.kh * c.kw, d->dtype, true);
             if (int e = run_gather(c, g, d->dtype, workspace, workspace_bytes, as_stream(stream), "conv_dgrad(strided)")) return e;
         }

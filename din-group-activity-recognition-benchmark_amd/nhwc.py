@@ -86,6 +86,7 @@ FUSE_1X1_DGRAD = _os.environ.get("DIN_FUSE_1X1", "1") != "0"     # fuse the dgra
 FUSE_FWD_SIBLINGS = _os.environ.get("DIN_FUSE_FWD", "1") != "0"   # run Graph.fwd_groups (sibling 1x1 convs) as one two-destination launch
 FUSE_WGRAD_SIBLINGS = _os.environ.get("DIN_FUSE_WGRAD", "1") != "0"  # ... and the wgrads of the members that share the second tensor as one launch
 FUSE_WGRAD_1X1 = _os.environ.get("DIN_FUSE_WGRAD_1X1", "1") != "0"   # weight gradients of ALL 1x1 convs reading one view in one launch (din_conv1x1_wgrad_multi)
+FUSE_DGRAD_X = _os.environ.get("DIN_FUSE_DGRAD_X", "1") != "0"       # a lone 1x1's dgrad rides in the strided sibling's launches (din_conv_dgrad_x: Mixed_6a)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -671,6 +672,19 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
     member_of = {oi: key for key, v in groups.items() for oi in v}
     remaining = {key: len(v) for key, v in groups.items()}
     pending: Dict[Tuple[int, int, int], list] = {key: [] for key in groups}
+    # a lone 1x1 / stride-1 conv whose input view is also read by a STRIDED conv earlier in program order (InceptionB: branch3x3dbl_1 beside
+    # branch3x3): the reverse pass meets the 1x1 first, parks its dgrad operands, and the strided conv's dgrad carries them (din_conv_dgrad_x)
+    x_host: Dict[int, int] = {}                               # 1x1 op index -> strided op index that will carry its dgrad
+    x_parked: Dict[int, tuple] = {}                           # strided op index -> (1x1 op index, its gout, pixel stride, channel offset)
+    if FUSE_DGRAD_X and dt == L.DIN_BF16:
+        for oi, op in enumerate(g.ops):
+            if (op.kind == "conv" and op.k == (1, 1) and op.s == (1, 1) and op.p == (0, 0) and op.src.tid != g.input_tid and oi not in member_of
+                    and op.pooled is None):
+                for oj in range(oi - 1, -1, -1):
+                    o2 = g.ops[oj]
+                    if o2.kind == "conv" and o2.src == op.src and (o2.s[0] > 1 or o2.s[1] > 1) and oj not in x_host.values():
+                        x_host[oi] = oj
+                        break
 
     def flush_wgrad_multi(key, items):
         """the deferred weight gradients of a 1x1 group (multi_w): ONE launch reads the block input once and produces every member's dW"""
@@ -794,6 +808,21 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
             need = lib.din_conv1x1_wgrad_multi_workspace(len(plan), probe, dt, nb * ts_.h * ts_.w, g.ops[members[0]].src.c) if 2 <= len(plan) <= 4 else 0
             if need > 0:
                 multi_w[key] = (plan, need)
+    def dgrad_parked(host_oi):
+        """the strided conv that was to carry a parked 1x1 dgrad received no gradient itself: the 1x1's dgrad runs alone"""
+        oi_, gout_, ldj, coffj = x_parked.pop(host_oi)
+        opj = g.ops[oi_]
+        tsj = g.tensors[opj.src.tid]
+        dj = _conv_desc(g, opj, nb, dt)
+        dj.ldo, dj.cooff = ldj, coffj
+        gsrc, acc = grad_target(opj.src)
+        flags = (L.CONV_ACCUM if acc else 0) | (L.CONV_MASK if tsj.relu_masked else 0)
+        ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(dj), 1), dev)
+        with _timed("dgrad", dj, opj.name):
+            L.check(lib.din_conv_dgrad(C.byref(dj), _ptr(gout_), _ptr(pcache.wpt[oi_]), _ptr(gsrc),
+                                       _ptr(bufs[opj.src.tid]) if tsj.relu_masked else None, tsj.c, opj.src.coff, flags,
+                                       _ptr(ws), wsb, st), "conv_dgrad " + opj.name)
+
     for oi in range(len(g.ops) - 1, -1, -1):
         op = g.ops[oi]
         if op.dst.tid not in gbufs:
@@ -801,6 +830,8 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 remaining[member_of[oi]] -= 1
                 if remaining[member_of[oi]] == 0:
                     flush_group(member_of[oi])
+            if oi in x_parked:
+                dgrad_parked(oi)
             continue                                  # nothing flows back through this op
         gout = gbufs[op.dst.tid]
         src_needs_grad = op.src.tid != g.input_tid
@@ -936,15 +967,27 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 remaining[key] -= 1
                 if remaining[key] == 0:
                     flush_group(key)
+            elif src_needs_grad and oi in x_host and dshift_pre is None:
+                x_parked[x_host[oi]] = (oi, gout, g_ld, g_coff)        # carried by the strided sibling's dgrad (below, when the pass reaches it)
             elif src_needs_grad:
                 gsrc, acc = grad_target(op.src)
                 wpt = pcache.wpt[oi]
                 flags = (L.CONV_ACCUM if acc else 0) | (L.CONV_MASK if ts.relu_masked else 0)
                 ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 1), dev)
-                with _timed("dgrad", d, op.name):
-                    L.check(lib.din_conv_dgrad(C.byref(d), _ptr(gout), _ptr(wpt), _ptr(gsrc),
-                                               _ptr(bufs[op.src.tid]) if ts.relu_masked else None, ts.c, op.src.coff, flags,
-                                               _ptr(ws), wsb, st), "conv_dgrad " + op.name)
+                if oi in x_parked:
+                    xi, xg, xld, xcoff = x_parked.pop(oi)
+                    xs = L.ConvSrc()
+                    xs.dout, xs.wpk_t = xg.data_ptr(), pcache.wpt[xi].data_ptr()
+                    xs.cout, xs.ldo, xs.cooff = g.ops[xi].dst.c, xld, xcoff
+                    with _timed("dgrad", d, op.name + "+" + g.ops[xi].name):
+                        L.check(lib.din_conv_dgrad_x(C.byref(d), _ptr(gout), _ptr(wpt), _ptr(gsrc),
+                                                     _ptr(bufs[op.src.tid]) if ts.relu_masked else None, ts.c, op.src.coff, flags,
+                                                     C.byref(xs), _ptr(ws), wsb, st), "conv_dgrad_x " + op.name)
+                else:
+                    with _timed("dgrad", d, op.name):
+                        L.check(lib.din_conv_dgrad(C.byref(d), _ptr(gout), _ptr(wpt), _ptr(gsrc),
+                                                   _ptr(bufs[op.src.tid]) if ts.relu_masked else None, ts.c, op.src.coff, flags,
+                                                   _ptr(ws), wsb, st), "conv_dgrad " + op.name)
         elif src_needs_grad:
             d = _pool_desc(g, op, nb, dt)
             gsrc, acc = grad_target(op.src)

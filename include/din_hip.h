@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DIN_ABI_VERSION 6   /* 6: batch-statistics BatchNorm is deterministic: din_bn_stats / din_bn_bwd_stats write per-workgroup fp64 slabs into a workspace (din_bn_workspace), din_bn_finalize / din_bn_reduce add them in slab order -- no atomics, nothing for the caller to zero.   5: dropout seeds take an optional device-side offset (din_layernorm_*, din_act_dropout_*), din_counter_add, din_conv1x1_wgrad_multi.   2: din_walk_* take plain / clamp / n_per_clip; + bn, mask_actors.  3: din_roi_align_* take the box grid and a crop channel range.  4: din_conv_desc.in_u8, context-encoding entry points */
+#define DIN_ABI_VERSION 7   /* 7: din_conv_dgrad_x (a strided dgrad that carries the 1x1 / stride-1 dgrad of a sibling conv reading the same view).   6: batch-statistics BatchNorm is deterministic: din_bn_stats / din_bn_bwd_stats write per-workgroup fp64 slabs into a workspace (din_bn_workspace), din_bn_finalize / din_bn_reduce add them in slab order -- no atomics, nothing for the caller to zero.   5: dropout seeds take an optional device-side offset (din_layernorm_*, din_act_dropout_*), din_counter_add, din_conv1x1_wgrad_multi.   2: din_walk_* take plain / clamp / n_per_clip; + bn, mask_actors.  3: din_roi_align_* take the box grid and a crop channel range.  4: din_conv_desc.in_u8, context-encoding entry points */
 
 enum { DIN_F32 = 0, DIN_BF16 = 1 };
 
@@ -142,6 +142,17 @@ typedef struct din_conv_src {
 } din_conv_src;
 int din_conv1x1_dgrad_multi(int nsrc, const din_conv_src* srcs, int dtype, int nb, int h, int w, int cin, int ldi,
                             int cioff, void* din, const void* mask, int ldm, int moff, int flags, void* stream);
+/* din_conv_dgrad of a STRIDED conv plus the dgrad of ONE 1x1 / stride-1 conv `x` that reads the same input view, in the same launches:
+ * din (op)= mask(conv^T(dout) + conv1x1^T(x->dout)).  torchvision's InceptionB (backbone.py MyInception_v3 Mixed_6a, through torchvision
+ * inception.py InceptionB.forward: branch3x3 = 3x3 stride 2 and branch3x3dbl_1 = 1x1 both read the block input): the 1x1's 64 channels ride
+ * as one more k-step of the four parity-class launches of the 3x3, so the 288-channel gradient map is read-modify-written once, not twice.
+ * x->wpk_t = the 1x1's bank packed with transposed=1 (as for din_conv1x1_dgrad_multi).  Shapes the fused kernel does not serve (fp32,
+ * stride 1, tiles other than 128 x 96, split-K; DIN_DGRAD_X=0) run as din_conv_dgrad followed by din_conv1x1_dgrad_multi with ACCUM --
+ * same result up to the rounding of the intermediate sum.                                                                      */
+int din_conv_dgrad_x(const din_conv_desc* d, const void* dout, const void* wpk_t, void* din, const void* mask, int ldm, int moff, int flags,
+                     const din_conv_src* x, void* workspace, int64_t workspace_bytes, void* stream);
+/* 1 when din_conv_dgrad_x serves this descriptor with the fused kernel, 0 when it runs the two-launch form.  Host-only planning call. */
+int din_conv_dgrad_x_fused(const din_conv_desc* d);
 /* dw: [cout][cin][kh][kw] fp32, overwritten (or += when accumulate!=0), multiplied by scale[cout] when scale
  * is given.  dbias (nullable) [cout] fp32 = column sums of dout.  wdot (nullable) [cout] fp32 =
  * <w[co,:], dw_raw[co,:]> (needs w) -- the BatchNorm-eval scale gradient.  accumulate bit 1 (value 2): dbias / wdot were zeroed by

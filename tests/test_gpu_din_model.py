@@ -1072,6 +1072,49 @@ def test_inception_bf16_stationary_wgrad_kernels_match_general_kernels(gpu, monk
         assert rel(outs[0][k], gb_) <= 2e-4, (k, rel(outs[0][k], gb_))
 
 
+def test_inception_bf16_mixed6a_dgrad_fold_matches_separate_launches(gpu, monkeypatch):
+    """bf16 backbone backward with the dgrad of Mixed_6a.branch3x3dbl_1 (1x1) riding in the parity-class launches of Mixed_6a.branch3x3
+    (din_conv_dgrad_x, nhwc.FUSE_DGRAD_X) against the same backbone with the two dgrads as separate launches: every parameter gradient
+    below Mixed_6a sees the block-input gradient, so all of them are compared (one bf16 rounding of the 288-channel gradient map instead
+    of two: <= 4e-3 of the largest entry), the layers above run the same launches."""
+    from din_amd import nhwc
+    from din_amd.backbone.backbone import MyInception_v3
+    g = torch.Generator().manual_seed(47)
+    images = torch.randint(0, 256, (2, 3, 299, 363), generator=g, dtype=torch.uint8)
+    sd = {}
+    for k, v in MyInception_v3(compute_dtype="bf16").state_dict().items():
+        if not v.dtype.is_floating_point:
+            sd[k] = v
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(v.shape, generator=g) + 0.5
+        elif k.endswith("conv.weight"):
+            sd[k] = torch.randn(v.shape, generator=g) * (2.0 / (v.shape[1] * v.shape[2] * v.shape[3])) ** 0.5
+        else:
+            sd[k] = torch.randn(v.shape, generator=g) * 0.1 + (1.0 if k.endswith("bn.weight") else 0.0)
+    outs = []
+    lib = nhwc.L.load()
+    real = lib.din_conv_dgrad_x
+    for mode in (True, False):
+        monkeypatch.setattr(nhwc, "FUSE_DGRAD_X", mode)
+        m = MyInception_v3(compute_dtype="bf16")
+        m.load_state_dict(sd)
+        m = m.to(gpu).eval()
+        calls = []
+        monkeypatch.setattr(lib, "din_conv_dgrad_x", lambda *a, _r=real: (calls.append(1), _r(*a))[1])
+        feats = m(images.to(gpu))
+        sum((f.float() ** 2).mean() for f in feats).backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(lib, "din_conv_dgrad_x", real)
+        outs.append({k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+        assert len(calls) == (1 if mode else 0), calls                   # Mixed_6a is the only InceptionB block of the trunk
+    assert outs[0].keys() == outs[1].keys()
+    for k, gb_ in outs[1].items():
+        if k.startswith(("Mixed_6", "Mixed_7")):
+            assert rel(outs[0][k], gb_) <= 1e-5, (k, rel(outs[0][k], gb_))   # at and above the block: same launches (fp32 atomics in their epilogues)
+        else:
+            assert rel(outs[0][k], gb_) <= 4e-3, (k, rel(outs[0][k], gb_))
+
+
 def test_partial_1x1_group_degrades_to_per_layer_wgrad(gpu, monkeypatch):
     """A graph that consumes only SOME outputs of a block-entry 1x1 group (a partial head): the fused weight-gradient launch
     (din_conv1x1_wgrad_multi) cannot run -- its plan covers every member -- so the members that did receive a gradient fall back to the

@@ -88,6 +88,14 @@ CONV_CASES = [
     ("st_48_8", 1, 48, 19, 23, 8, (1, 1), (1, 1), (0, 0), 1),
     ("st_192_64_long", 8, 192, 87, 157, 64, (1, 1), (1, 1), (0, 0), 1),      # > 256 items: every workgroup walks several
     ("st_96_176", 2, 96, 31, 45, 176, (1, 1), (1, 1), (0, 0), 1),            # the 192-filter tile on its 3-slot ring (forward), 96-filter tile (dgrad)
+    # 96-pixel tiles on six waves (conv_gather_fast_kernel<bf16, 96, BN, 3, 2, ...>; the planner takes them when the 128-pixel tiles number
+    # between one and two per CU -- forced here with DIN_CONV_TILE96=2): FASTK walk (7-tap, whole 64-channel steps) and the general loop
+    # (k-steps that straddle taps), every filter-tile width, ragged last tile, fwd + dgrad (mask, accumulate)
+    ("t96_7x1_128_192", 2, 128, 43, 78, 192, (7, 1), (1, 1), (3, 0), 1),
+    ("t96_1x7_192_160", 2, 192, 43, 78, 160, (1, 7), (1, 1), (0, 3), 1),
+    ("t96_1x1_256_128", 1, 256, 43, 78, 128, (1, 1), (1, 1), (0, 0), 1),
+    ("t96_3x3_48_96", 2, 48, 29, 37, 96, (3, 3), (1, 1), (1, 1), 1),
+    ("t96_1x1_64_64", 1, 64, 41, 47, 64, (1, 1), (1, 1), (0, 0), 1),
 ]
 
 
@@ -101,6 +109,10 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
         monkeypatch.setenv("DIN_WGRAD_HALO", "2")       # ... and the halo weight-gradient kernel only on launches of >= 256K pixels
     if name.startswith("st_"):
         monkeypatch.setenv("DIN_CONV_STREAM", "2")      # ... and the streaming 1x1 kernel only on maps of >= 256K pixels
+    if name.startswith("t96_"):
+        monkeypatch.setenv("DIN_CONV_TILE96", "2")
+        monkeypatch.setenv("DIN_CONV_HALO", "0")
+        monkeypatch.setenv("DIN_CONV_STREAM", "0")
     if name.startswith("gp"):
         monkeypatch.setenv("DIN_GATHER_PIPE", "2")      # ... and the 256-pixel pipelined tiles only on launches that fill the chip
         monkeypatch.setenv("DIN_CONV_HALO", "0")
@@ -139,6 +151,11 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
         bm, bn = C.c_int32(0), C.c_int32(0)
         lib.din_conv_kernel_tile(C.byref(d), 0, C.byref(bm), C.byref(bn))
         assert bm.value == 2, f"{name}: forward not on the pipelined gather kernel (tile {bm.value} x {bn.value})"
+    if name.startswith("t96_") and dtype == "bf16":
+        for which in (0, 1):
+            bm, bn = C.c_int32(0), C.c_int32(0)
+            lib.din_conv_kernel_tile(C.byref(d), which, C.byref(bm), C.byref(bn))
+            assert bm.value == 96, f"{name}: {('forward', 'dgrad')[which]} not on the 96-pixel tile ({bm.value} x {bn.value})"
     if name.startswith("st_") and dtype == "bf16":
         for which in (0, 1):
             bm, bn = C.c_int32(0), C.c_int32(0)
@@ -965,6 +982,77 @@ def test_conv1x1_dgrad_multi_source(env, dtype, monkeypatch):
                                         L.CONV_MASK | L.CONV_ACCUM, None))
     torch.cuda.synchronize()
     assert rel(from_nhwc(dx, cin), xr.grad + xr.grad * (x > 0).float()) <= 2 * tol
+
+
+@pytest.mark.parametrize("case", [("fused_bf16", "bf16", 288, 21, 25, 1, "1"), ("fused_bf16_p1_ragged", "bf16", 96, 20, 27, 1, "1"),
+                                  ("fallback_bf16", "bf16", 288, 21, 25, 1, "0"), ("fallback_fp32", "fp32", 288, 13, 15, 0, "1"),
+                                  ("fallback_bf16_tile160", "bf16", 160, 21, 25, 0, "1")], ids=lambda c: c[0])
+def test_conv_dgrad_x_strided_plus_1x1(env, case, monkeypatch):
+    """din_conv_dgrad_x: the dgrad of a 3x3 / stride-2 conv carrying the dgrad of a 1x1 / stride-1 conv that reads the same view (InceptionB:
+    Mixed_6a.branch3x3 + branch3x3dbl_1) == autograd of the sum of both, plain / + mask + accumulate; the fused kernel (bf16, 96-wide parity
+    tiles: extra k-steps at the output pixel, partial last 64-channel block of the 1x1) and the two-launch form for every other shape."""
+    lib, L, nhwc, ops = env
+    name, dtype, cin, h, w, pad, switch = case
+    monkeypatch.setenv("DIN_DGRAD_X", switch)
+    dt = L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
+    tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    g = torch.Generator().manual_seed(33)
+    nb, cout, cx = 2, 64, 72                      # 72 channels of the 1x1: one whole 64-channel k-step + a partial one
+    x = torch.randn(nb, cin, h, w, generator=g)
+    w3 = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    w1 = torch.randn(cx, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    if dtype == "bf16":
+        x, w3, w1 = x.bfloat16().float(), w3.bfloat16().float(), w1.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    y3 = F.conv2d(xr, w3, stride=2, padding=pad)
+    y1 = F.conv2d(xr, w1)
+    g3, g1 = torch.randn(y3.shape, generator=g), torch.randn(y1.shape, generator=g)
+    if dtype == "bf16":
+        g3, g1 = g3.bfloat16().float(), g1.bfloat16().float()
+    ((y3 * g3).sum() + (y1 * g1).sum()).backward()
+    oh, ow = y3.shape[2:]
+    d = L.ConvDesc()
+    d.nb, d.h, d.w, d.cin, d.oh, d.ow, d.cout = nb, h, w, cin, oh, ow, cout
+    d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.dh, d.dw = 3, 3, 2, 2, pad, pad, 1, 1
+    ldo3 = cout + 16
+    d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = cin + 8, 8, ldo3, 8, dt
+    d1 = L.ConvDesc()
+    d1.nb, d1.h, d1.w, d1.cin, d1.oh, d1.ow, d1.cout = nb, h, w, cin, h, w, cx
+    d1.kh = d1.kw = d1.sh = d1.sw = d1.dh = d1.dw = 1
+    d1.ph = d1.pw = 0
+    ldo1 = cx + 24
+    d1.ldi, d1.cioff, d1.ldo, d1.cooff, d1.dtype = cin + 8, 8, ldo1, 16, dt
+    assert lib.din_conv_dgrad_x_fused(C.byref(d)) == (1 if name.startswith("fused") else 0), "planner: fused kernel / two-launch form"
+    wpt3 = torch.empty(lib.din_conv_packed_elems(C.byref(d), 1), dtype=tdt, device="cuda")
+    L.check(lib.din_conv_pack_weights(C.byref(d), w3.cuda().data_ptr(), None, wpt3.data_ptr(), 1, None))
+    wpt1 = torch.empty(lib.din_conv_packed_elems(C.byref(d1), 1), dtype=tdt, device="cuda")
+    L.check(lib.din_conv_pack_weights(C.byref(d1), w1.cuda().data_ptr(), None, wpt1.data_ptr(), 1, None))
+    g3d, g1d = to_nhwc(g3, tdt, ldo3, 8), to_nhwc(g1, tdt, ldo1, 16)
+    xs = L.ConvSrc()
+    xs.dout, xs.wpk_t, xs.cout, xs.ldo, xs.cooff = g1d.data_ptr(), wpt1.data_ptr(), cx, ldo1, 16
+    xin = to_nhwc(x, tdt, cin + 8, 8)
+    dx = torch.full((nb, h, w, cin + 8), 3.0, dtype=tdt, device="cuda")
+    wsb = lib.din_conv_workspace_bytes(C.byref(d), 1)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device="cuda")
+    L.check(lib.din_conv_dgrad_x(C.byref(d), g3d.data_ptr(), wpt3.data_ptr(), dx.data_ptr(), None, 0, 0, 0, C.byref(xs), ws.data_ptr(), wsb, None))
+    torch.cuda.synchronize()
+    tol = 5e-5 if dtype == "fp32" else 2e-2
+    assert rel(from_nhwc(dx, cin, 8), xr.grad) <= tol
+    assert float(dx[..., :8].float().min()) == 3.0 and float(dx[..., :8].float().max()) == 3.0, "wrote outside its channel range"
+    L.check(lib.din_conv_dgrad_x(C.byref(d), g3d.data_ptr(), wpt3.data_ptr(), dx.data_ptr(), xin.data_ptr(), cin + 8, 8,
+                                 L.CONV_MASK | L.CONV_ACCUM, C.byref(xs), ws.data_ptr(), wsb, None))
+    torch.cuda.synchronize()
+    assert rel(from_nhwc(dx, cin, 8), xr.grad + xr.grad * (x > 0).float()) <= 2 * tol
+    if name.startswith("fused"):
+        # same bits as the kernel's own reduction order allows: against the two-launch form, within bf16 rounding of the intermediate sum
+        monkeypatch.setenv("DIN_DGRAD_X", "0")
+        dx2 = torch.zeros((nb, h, w, cin + 8), dtype=tdt, device="cuda")
+        L.check(lib.din_conv_dgrad_x(C.byref(d), g3d.data_ptr(), wpt3.data_ptr(), dx2.data_ptr(), None, 0, 0, 0, C.byref(xs), ws.data_ptr(), wsb, None))
+        monkeypatch.setenv("DIN_DGRAD_X", "1")
+        dx1 = torch.zeros((nb, h, w, cin + 8), dtype=tdt, device="cuda")
+        L.check(lib.din_conv_dgrad_x(C.byref(d), g3d.data_ptr(), wpt3.data_ptr(), dx1.data_ptr(), None, 0, 0, 0, C.byref(xs), ws.data_ptr(), wsb, None))
+        torch.cuda.synchronize()
+        assert rel(from_nhwc(dx1, cin, 8), from_nhwc(dx2, cin, 8)) <= 1e-2
 
 
 PIPE_CASES = [

@@ -7,6 +7,7 @@
 #         bench      default bench line -> <tag>_bench.json ;  bench:<args...> with ',' for spaces, e.g. bench:--bn-mode,batch
 #         stats      rocprofv3 --kernel-trace --stats of the default bench -> <tag>_kernel_stats.csv
 #         smoke      __graft_entry__.smoke()
+#         seq:<args> launch sequence of one step (tools/launch_sequence.py over a rocprofv3 kernel trace) -> <tag>_launch_sequence_<args>.txt
 #         env:K=V / unset:K   environment for the following steps;   sh:<command with , for spaces>   anything else (last lines shown)
 set -u
 cd "$(dirname "$0")/../.."
@@ -33,6 +34,9 @@ for step in "$@"; do
     stats:*) a=${step#stats:}; n=$(echo "$a" | tr -c 'a-zA-Z0-9' '_'); rm -rf /tmp/prof
              (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-extras ${a//,/ } > /tmp/prof.log 2>&1)
              f=$(find /tmp/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -60 "$f" > $OUT/${TAG}_kernel_stats_$n.csv; tail -2 /tmp/prof.log ;;
+    seq:*)   a=${step#seq:}; n=$(echo "$a" | tr -c 'a-zA-Z0-9' '_'); rm -rf /tmp/tr
+             (cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o t -- python $OLDPWD/bench.py --steps 3 --warmup 2 --no-extras --no-cpu-baseline ${a//,/ } > /tmp/tr.log 2>&1)
+             python tools/launch_sequence.py /tmp/tr > $OUT/${TAG}_launch_sequence_$n.txt 2>&1; head -4 $OUT/${TAG}_launch_sequence_$n.txt ;;
     env:*)   export "${step#env:}"; echo "export ${step#env:}" ;;
     unset:*) unset "${step#unset:}" ;;
     sh:*)    c=${step#sh:}; echo "+ ${c//,/ }"; bash -c "${c//,/ }" 2>&1 | tail -${TAILN:-5} ;;
