@@ -49,7 +49,8 @@ WORKLOADS = {
 COLLECTIVE = {"H": 480, "W": 720, "N": 13, "T": 10, "activities": 4, "global_batch": 8, "dropout": 0.5}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0                               # HBM3E spec peak, MI355X_MICROARCH.md (6.3 TB/s is what a plain copy achieves)
-TRAFFIC_FILE = "r03_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) else "r02_pmc_traffic.json"
+# newest committed per-kernel HBM traffic table (profiles/rNN_pmc_traffic.json: tools/pmc_traffic.py over two rocprofv3 --pmc passes)
+TRAFFIC_FILE = (sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")) or ["r03_pmc_traffic.json"])[-1]
 
 
 def make_cfg(workload, T=3, N=12, H=720, W=1280, lite=None, hierarchical=False):

@@ -75,7 +75,7 @@ __device__ __forceinline__ void lds_dma_stage(uint32_t lds_addr, __amdgpu_buffer
                                               __amdgpu_buffer_rsrc_t rsB, const int (&vb)[NB], int soffB) {
 #define DIN_DMA_FIRST(V, R, S) "s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 " V ", " R ", " S " offen lds\n\t"
 #define DIN_DMA_NEXT(V, R, S) "s_add_u32 m0, m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 " V ", " R ", " S " offen lds\n\t"
-    static_assert(NA == 2 && NB >= 1 && NB <= 4, "instantiated for the 8-wave 128-pixel and the 6-wave 96-pixel tiles");
+    static_assert(NA == 2 && NB >= 1 && NB <= 3, "instantiated for the 8-wave 128-pixel tiles");
     if constexpr (NB == 1)
         asm volatile(DIN_DMA_FIRST("%6", "%1", "%3") DIN_DMA_NEXT("%7", "%1", "%3") DIN_DMA_NEXT("%8", "%2", "%4")
                      :: "s"(lds_addr), "s"(rsA), "s"(rsB), "s"(soffA), "s"(soffB), "n"(STRIDE), "v"(va[0]), "v"(va[1]), "v"(vb[0])
@@ -84,15 +84,10 @@ __device__ __forceinline__ void lds_dma_stage(uint32_t lds_addr, __amdgpu_buffer
         asm volatile(DIN_DMA_FIRST("%6", "%1", "%3") DIN_DMA_NEXT("%7", "%1", "%3") DIN_DMA_NEXT("%8", "%2", "%4") DIN_DMA_NEXT("%9", "%2", "%4")
                      :: "s"(lds_addr), "s"(rsA), "s"(rsB), "s"(soffA), "s"(soffB), "n"(STRIDE), "v"(va[0]), "v"(va[1]), "v"(vb[0]), "v"(vb[1])
                      : "memory", "m0", "scc");
-    else if constexpr (NB == 3)
+    else
         asm volatile(DIN_DMA_FIRST("%6", "%1", "%3") DIN_DMA_NEXT("%7", "%1", "%3") DIN_DMA_NEXT("%8", "%2", "%4") DIN_DMA_NEXT("%9", "%2", "%4")
                      DIN_DMA_NEXT("%10", "%2", "%4")
                      :: "s"(lds_addr), "s"(rsA), "s"(rsB), "s"(soffA), "s"(soffB), "n"(STRIDE), "v"(va[0]), "v"(va[1]), "v"(vb[0]), "v"(vb[1]), "v"(vb[2])
-                     : "memory", "m0", "scc");
-    else
-        asm volatile(DIN_DMA_FIRST("%6", "%1", "%3") DIN_DMA_NEXT("%7", "%1", "%3") DIN_DMA_NEXT("%8", "%2", "%4") DIN_DMA_NEXT("%9", "%2", "%4")
-                     DIN_DMA_NEXT("%10", "%2", "%4") DIN_DMA_NEXT("%11", "%2", "%4")
-                     :: "s"(lds_addr), "s"(rsA), "s"(rsB), "s"(soffA), "s"(soffB), "n"(STRIDE), "v"(va[0]), "v"(va[1]), "v"(vb[0]), "v"(vb[1]), "v"(vb[2]), "v"(vb[3])
                      : "memory", "m0", "scc");
 #undef DIN_DMA_FIRST
 #undef DIN_DMA_NEXT
@@ -278,7 +273,7 @@ template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS, bool MUL
 //  = four waves per SIMD = at most 128 VGPRs.  Left at 2, a harmless-looking edit -- round 4: the knock-out switches turned compile-time
 //  constants -- moved the FASTK 128 x 192 instantiation from 125 to 131 registers: one workgroup per CU, 186 -> 259 us per launch, -1.6 ms per
 //  step, caught only by diffing kernel_stats.csv against the previous round's.)
-__global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && BMT == 128 && WM * WN == 8) ? 4 : (WM * WN == 6 ? 3 : 2)) void conv_gather_fast_kernel(ConvK p) {
+__global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && BMT == 128 && WM * WN == 8) ? 4 : 2) void conv_gather_fast_kernel(ConvK p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the host pass only needs the launch stub (the LDS-DMA builtin is device-only)
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BM = BMT;                                  // shadows the file-level default inside this kernel
@@ -544,7 +539,7 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && BMT == 128 && WM *
     constexpr int NDMA = PA + PB;                                  // wave-level DMAs per stage per wave (issued unconditionally)
     static_assert((NS - 2) * NDMA <= 63, "vmcnt field");
     if constexpr (FASTK) {
-        static_assert(!MULTI && NS == 2 && PA == 2, "FASTK: 8-wave 128-pixel / 6-wave 96-pixel tiles, double-buffered");
+        static_assert(!MULTI && NS == 2 && PA == 2, "FASTK: 8-wave 128-pixel tiles, double-buffered");
         // scalar walk over k-steps: ks -> (channel chunk ks / ntaps, tap ks % ntaps); td = byte delta of the tap, fa / fb = scalar byte
         // offsets of the step inside a pixel's channels / inside a packed filter row
         int tap = ks_begin % ntaps, tr = (tap * inv_kw) >> 16, tc = tap - tr * p.kw;
@@ -2573,13 +2568,6 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype, bool str
     }
     g.cout_pad = pad_to(cprod, 128);
     g.n_co_tiles = (cprod + g.bn - 1) / g.bn;
-    // 96-pixel tiles (6 waves) when the 128-pixel tiles number between one and two per CU and the 96-pixel ones still fit one round (512 slots)
-    if (dtype == DIN_BF16 && g.bm == 128 && g.bn != 256 && !strided_out) {
-        const char* tv = getenv("DIN_CONV_TILE96");
-        const int mode = tv ? atoi(tv) : 1;                    // 0: off, 1: by the rule, 2: always (tests)
-        const int64_t n128 = ((int64_t)M + 127) / 128 * g.n_co_tiles, n96 = ((int64_t)M + 95) / 96 * g.n_co_tiles;
-        if (mode == 2 || (mode == 1 && n128 > 288 && n96 <= 512)) g.bm = 96;
-    }
     g.n_px_tiles = (M + g.bm - 1) / g.bm;
     // split-K only when the launch cannot fill the chip and the reduction is long
     int tiles = g.n_co_tiles * g.n_px_tiles;
@@ -2825,20 +2813,6 @@ void launch_fast(const ConvK& k, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, st, k);
 }
 
-// 6-wave 96 x BN tile (3 x 2 waves: the 8-wave tile's 32 x BN/2 wave tile, 48 rows per loader pass): for launches whose 128-pixel tiles
-// number between one and two per CU -- the 43 x 78 maps of Mixed_6 at 4 clips per GPU, 315 tiles on 512 slots: a quarter of the CUs run two
-// workgroups and set the launch's time while the others wait; 420 tiles of 96 pixels still fit in one round and every workgroup is a quarter
-// shorter (DIN_CONV_TILE96=0: off)
-template <typename T, int BN>
-void launch_wave6(const ConvK& k, dim3 grid, hipStream_t st) {
-    static_assert(sizeof(T) == 2, "bf16 only");
-    const char* fv = getenv("DIN_CONV_FASTK");
-    const bool want = fv ? atoi(fv) != 0 : true;
-    const bool fastk = want && !k.remap && k.nsrc == 0 && (k.cpt % 8) == 0 && (k.korder || k.kh * k.kw == 1);
-    if (fastk) launch_fast<T, 96, BN, 3, 2, 8, 2, true>(k, grid, st);
-    else launch_fast<T, 96, BN, 3, 2, 8, 2>(k, grid, st);
-}
-
 // 8-wave 128 x BN tile: the scalar-walk specialisation (FASTK) whenever the launch qualifies (bf16, whole k-steps per tap, no tap remap,
 // taps-inside-chunks k-order or a single tap); DIN_CONV_FASTK=0 keeps the general loop
 template <typename T, int BN>
@@ -2918,13 +2892,7 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
     //   others  : 2 stages x 8 chunks           -- MFMA-dense tiles lose 8-10 % when the stage (and the barrier interval) is halved
     const char* pv = getenv("DIN_CONV_PIPE");
     const int pipe = pv ? atoi(pv) : -1;
-    if (bm == 96) {
-        if constexpr (sizeof(T) == 2) {
-            if (bn == 64) launch_wave6<T, 64>(k, grid, st); else if (bn == 96) launch_wave6<T, 96>(k, grid, st); else if (bn == 128) launch_wave6<T, 128>(k, grid, st);
-            else if (bn == 160) launch_wave6<T, 160>(k, grid, st); else launch_wave6<T, 192>(k, grid, st);
-        }
-    }
-    else if (bm == 256 && bn == 64) { if (pipe != 0) launch_fast<T, 256, 64, 4, 1, 4, 4>(k, grid, st); else launch_fast<T, 256, 64, 4, 1, 8, 2>(k, grid, st); }
+    if (bm == 256 && bn == 64) { if (pipe != 0) launch_fast<T, 256, 64, 4, 1, 4, 4>(k, grid, st); else launch_fast<T, 256, 64, 4, 1, 8, 2>(k, grid, st); }
     else if (bm == 256 && bn == 256) {
         if constexpr (sizeof(T) == 2) { if (pipe == 1) launch_fast<T, 256, 256, 4, 2, 4, 4>(k, grid, st); else launch_fast<T, 256, 256, 4, 2, 8, 2>(k, grid, st); }
     }
@@ -2983,7 +2951,6 @@ bool want_gather_pipe(int dtype, int64_t M, int cred, int taps, int bn, int spli
 int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_bytes, hipStream_t st, const char* what) {
     const bool fast = k.divy == 1 && k.divx == 1 && k.kh * k.kw <= 32;
     if (!fast && g.bn != 64 && g.bn != 128) { g.bn = 128; g.n_co_tiles = (k.Cout + 127) / 128; }
-    if (g.bm == 96 && (!fast || k.remap || g.splitk > 1 || k.nsrc > 0 || dtype != DIN_BF16)) { g.bm = 128; g.n_px_tiles = (k.M + 127) / 128; }
     if (g.bm == 256 && (!fast || k.remap || g.splitk > 1)) {
         g.bm = 128; if (g.bn == 256) g.bn = 128;
         g.n_px_tiles = (k.M + 127) / 128; g.n_co_tiles = (k.Cout + g.bn - 1) / g.bn;
@@ -3276,13 +3243,13 @@ int din_conv_kernel_variant(const din_conv_desc* d, int which, int32_t* flags) {
     int32_t bm = 0, bn = 0;
     if (int e = din_conv_kernel_tile(d, which, &bm, &bn)) return e;
     *flags = 0;
-    if ((bm != 128 && bm != 96) || d->dtype != DIN_BF16) return DIN_OK;   // the 8-wave / FASTK instantiations exist for bf16 128 x BN (and 96 x BN: 6 waves) tiles only
+    if (bm != 128 || d->dtype != DIN_BF16) return DIN_OK;          // the 8-wave / FASTK instantiations exist for bf16 128 x BN tiles only
     const char* pv = getenv("DIN_CONV_PIPE");
     const int pipe = pv ? atoi(pv) : -1;
     const bool strided = which == 1 && (d->sh > 1 || d->sw > 1);
-    const bool wave8 = bm == 96 || ((bn == 64 || bn == 128 || bn == 160 || bn == 192) && pipe != 4 && pipe != 1) ||
+    const bool wave8 = ((bn == 64 || bn == 128 || bn == 160 || bn == 192) && pipe != 4 && pipe != 1) ||
                        (bn == 96 && (pipe == 8 || (strided && pipe != 4)));       // (the parity classes of a strided dgrad: launch_gather)
-    if (wave8 && bm != 96) *flags |= 2;
+    if (wave8) *flags |= 2;
     const int ntaps = d->kh * d->kw, cred = which == 0 ? d->cin : d->cout;
     const int cpt = pad_to(cred, 8) / 8;
     GatherPlan g = which == 0 ? plan_gather(d->nb * d->oh * d->ow, d->cin, d->cout, ntaps, d->dtype)
@@ -3623,6 +3590,9 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
                     (void)words;
                 }
             }
+            // one slice of a 1x1 layer, nothing for the reduce launch to do (no scale, no <w, dW>, no accumulate, no channel padding): straight into dW
+            if (wp.slices == 1 && !wp.atomic && d->kh * d->kw == 1 && !scale && !wdot && !accumulate && wp.cin_pad == d->cin &&
+                !(getenv("DIN_WGRAD_DIRECT") && atoi(getenv("DIN_WGRAD_DIRECT")) == 0)) k.direct = dw;
             if (int e = din_wgrad::launch_wgrad_pipe(k, wp.bco, wp.bk, grid, st)) return e;
         } else if (wp.ring) {
             if (dbias) {
@@ -3666,7 +3636,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
     }
     DIN_CHECK_LAUNCH("conv_wgrad");
     if (wdot && !prezeroed && hipMemsetAsync(wdot, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
-    {
+    if (k.direct == nullptr) {
         int kc_total = d->kh * d->kw * wp.cin_pad;
         dim3 rgrid(d->cout, (kc_total + 255) / 256);
         const int rslices = (wp.pipe && wp.atomic) ? 1 : wp.slices;

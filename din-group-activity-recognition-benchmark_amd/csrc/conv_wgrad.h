@@ -16,6 +16,9 @@ struct WgradK {
     const unsigned char* u8;   // image-layer small kernel only: raw uint8 frames [NB][3][H][W], normalised on load (din_conv_desc::in_u8)
     int atomic;     // pipe kernel: 1 = every workgroup ADDS its tile into slice 0 of `partial` (fp32 atomics, buffer zeroed by the host)
     int pace_base;  // this launch's tag in the progress words: a word counts only inside (pace_base, pace_base + 2^20] (no per-launch memset)
+    float* direct;  // pipe kernel, optional: a launch with ONE slice of a 1x1 layer without scale writes its tiles straight into dW [Cout][Cin]
+                    // (the partial buffer and the reduce launch exist to add slices and un-permute taps: nothing to do here -- the
+                    // 1024 x 26400 embedding layer, 108 MB of fp32 per step, was written, read and written again: 28 + 76 us per step)
     int* pace;      // pipe kernel, optional: [slices * n_co_tiles][n_k_tiles] progress words (zeroed by the host).  The k-tile workgroups of
                     // one (filter tile, pixel slice) stream the same dY rows; each publishes the stage it is at and a workgroup that is
                     // more than PACE_SLACK stages ahead of the slowest sibling naps (bounded), so the siblings stay inside the window an

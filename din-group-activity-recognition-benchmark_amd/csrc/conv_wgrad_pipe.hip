@@ -355,6 +355,16 @@ __global__ __launch_bounds__(128 * WN, 1) void conv_wgrad_pipe_kernel(WgradK p) 
                     for (int e = 0; e < 16; ++e)
                         atomicAdd(dst + (int64_t)(co0 + 32 * i + 8 * (e >> 2) + (e & 3)) * p.kcols_pad + kc0 + 32 * j, acc[i][j][e]);
         }
+    } else if (p.direct != nullptr) {                               // one slice, 1x1, no scale: the tile IS the gradient
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < XJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = co0 + 32 * i + 8 * (e >> 2) + (e & 3), kc = kc0 + 32 * j;
+                    if (co < p.Cout && kc < p.Cin) p.direct[(int64_t)co * p.Cin + kc] = acc[i][j][e];
+                }
     } else {
 #pragma unroll
         for (int i = 0; i < TI; ++i)

@@ -163,10 +163,8 @@ class LaunchTimer:
         multi = self.kind == "dgrad" and "+" in self.name
         if not multi:
             L.load().din_conv_kernel_variant(C.byref(d), which, C.byref(fl))
-        BM, BN = (128 if bm.value == 2 or (multi and bm.value == 96) else bm.value), bn.value      # (multi-source launches stay on the 128-pixel kernel)
-        if BM == 96:
-            geo = "3, 2, 8, 2"                                          # the 6-wave tile of small launches (conv_igemm.hip launch_wave6)
-        elif BM == 256:
+        BM, BN = (128 if bm.value == 2 else bm.value), bn.value      # (multi-source launches stay on the 128-pixel kernel)
+        if BM == 256:
             geo = "4, 1, 4, 4" if BN == 64 else ("2, 2, 8, 2" if BN in (96, 160) else "4, 2, 8, 2")
         elif multi:
             geo = "4, 2, 8, 2" if (BN % 64 == 0 and d.dtype == L.DIN_BF16) else "2, 2, 8, 2"

@@ -88,14 +88,6 @@ CONV_CASES = [
     ("st_48_8", 1, 48, 19, 23, 8, (1, 1), (1, 1), (0, 0), 1),
     ("st_192_64_long", 8, 192, 87, 157, 64, (1, 1), (1, 1), (0, 0), 1),      # > 256 items: every workgroup walks several
     ("st_96_176", 2, 96, 31, 45, 176, (1, 1), (1, 1), (0, 0), 1),            # the 192-filter tile on its 3-slot ring (forward), 96-filter tile (dgrad)
-    # 96-pixel tiles on six waves (conv_gather_fast_kernel<bf16, 96, BN, 3, 2, ...>; the planner takes them when the 128-pixel tiles number
-    # between one and two per CU -- forced here with DIN_CONV_TILE96=2): FASTK walk (7-tap, whole 64-channel steps) and the general loop
-    # (k-steps that straddle taps), every filter-tile width, ragged last tile, fwd + dgrad (mask, accumulate)
-    ("t96_7x1_128_192", 2, 128, 43, 78, 192, (7, 1), (1, 1), (3, 0), 1),
-    ("t96_1x7_192_160", 2, 192, 43, 78, 160, (1, 7), (1, 1), (0, 3), 1),
-    ("t96_1x1_256_128", 1, 256, 43, 78, 128, (1, 1), (1, 1), (0, 0), 1),
-    ("t96_3x3_48_96", 2, 48, 29, 37, 96, (3, 3), (1, 1), (1, 1), 1),
-    ("t96_1x1_64_64", 1, 64, 41, 47, 64, (1, 1), (1, 1), (0, 0), 1),
 ]
 
 
@@ -109,10 +101,6 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
         monkeypatch.setenv("DIN_WGRAD_HALO", "2")       # ... and the halo weight-gradient kernel only on launches of >= 256K pixels
     if name.startswith("st_"):
         monkeypatch.setenv("DIN_CONV_STREAM", "2")      # ... and the streaming 1x1 kernel only on maps of >= 256K pixels
-    if name.startswith("t96_"):
-        monkeypatch.setenv("DIN_CONV_TILE96", "2")
-        monkeypatch.setenv("DIN_CONV_HALO", "0")
-        monkeypatch.setenv("DIN_CONV_STREAM", "0")
     if name.startswith("gp"):
         monkeypatch.setenv("DIN_GATHER_PIPE", "2")      # ... and the 256-pixel pipelined tiles only on launches that fill the chip
         monkeypatch.setenv("DIN_CONV_HALO", "0")
@@ -151,11 +139,6 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
         bm, bn = C.c_int32(0), C.c_int32(0)
         lib.din_conv_kernel_tile(C.byref(d), 0, C.byref(bm), C.byref(bn))
         assert bm.value == 2, f"{name}: forward not on the pipelined gather kernel (tile {bm.value} x {bn.value})"
-    if name.startswith("t96_") and dtype == "bf16":
-        for which in (0, 1):
-            bm, bn = C.c_int32(0), C.c_int32(0)
-            lib.din_conv_kernel_tile(C.byref(d), which, C.byref(bm), C.byref(bn))
-            assert bm.value == 96, f"{name}: {('forward', 'dgrad')[which]} not on the 96-pixel tile ({bm.value} x {bn.value})"
     if name.startswith("st_") and dtype == "bf16":
         for which in (0, 1):
             bm, bn = C.c_int32(0), C.c_int32(0)
@@ -1368,3 +1351,35 @@ def test_conv1x1_wgrad_multi_source(env, monkeypatch, cin, couts):
             assert rel(dev["db"], db_ref) <= 2e-5, j
         else:
             assert float(dev["db"].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape", [(144, 26400, 1024), (37, 776, 200)], ids=["fc_emb_1_cfg1_4clips", "ragged"])
+def test_lowp_linear_and_direct_wgrad_epilogue(env, shape, monkeypatch):
+    """ops.linear(lowp=True): the embedding layer of the benchmarked mode (infer_model.py:183 fc_emb_1, K*K*D = 26400 -> 1024; bf16 operands, fp32
+    accumulation) against torch on the bf16-rounded operands -- y, dX, dW, dbias -- and the single-slice weight gradient written straight from the
+    pipelined kernel's accumulators (WgradK::direct) against the partial-buffer + reduce form of the same launch: bit-identical."""
+    lib, L, nhwc, ops = env
+    rows, cin, cout = shape
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, cin, generator=g)).bfloat16().float()
+    w = (torch.randn(cout, cin, generator=g) * cin ** -0.5).bfloat16().float()
+    b = torch.randn(cout, generator=g) * 0.1
+    cot = torch.randn(rows, cout, generator=g).bfloat16().float()
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.linear(xr, wr, br)
+    yr.backward(cot)
+    outs = []
+    for direct in ("1", "0"):
+        monkeypatch.setenv("DIN_WGRAD_DIRECT", direct)
+        xd, wd, bd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        y = ops.linear(xd, wd, bd, lowp=True)
+        y.backward(cot.cuda())
+        torch.cuda.synchronize()
+        outs.append((y.detach(), xd.grad, wd.grad, bd.grad))
+    y, dx, dw, db = outs[0]
+    assert rel(y, yr) <= 1e-2                       # bf16 output rounding
+    assert rel(dx, xr.grad) <= 1e-2
+    assert rel(dw, wr.grad) <= 1e-4                 # fp32 result of bf16 products
+    assert rel(db, br.grad) <= 1e-4
+    assert torch.equal(outs[0][2], outs[1][2]), "direct epilogue and reduce launch disagree"
+    assert torch.equal(outs[0][3], outs[1][3])

@@ -128,10 +128,13 @@ FULL_CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", 
 
 
 def test_full_size_fixtures_are_present_and_seed_reproducible():
-    """the two 720x1280 fixtures (tools/gen_golden.py::full_case; the oracle was held against the reference when they were written --
+    """the 720x1280 fixtures (tools/gen_golden.py::full_case: two tie-free draws + the un-searched one; the oracle was held against the reference when they were written --
     re-running it here would take minutes): both backbones present, the seed recipe still regenerates the stored labels, every stage
     probe and gradient record is there"""
-    assert {os.path.basename(p) for p in FULL_CASES} == {"full_inv3_720x1280_b1.npz", "full_vgg16_720x1280_cfg1_b2.npz"}
+    assert {os.path.basename(p) for p in FULL_CASES} == {"full_inv3_720x1280_b1.npz", "full_vgg16_720x1280_cfg1_b2.npz",
+                                                         "full_inv3_720x1280_b1_seed401_unsearched.npz"}
+    un = np.load([p for p in FULL_CASES if "unsearched" in p][0])
+    assert int(un["searched"]) == 0 and int(un["seed"]) == 401 and int(un["near_ties"]) >= 0 and float(un["min_actor_gap"]) >= 0.0
     for path in FULL_CASES:
         z = np.load(path)
         B, T, N, H, W, OH, OW = [int(v) for v in z["meta"][:7]]

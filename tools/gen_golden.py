@@ -420,7 +420,7 @@ def _probe_idx(numel, count=8192):
     return (torch.arange(count, dtype=torch.int64) * (numel // count))
 
 
-def full_case(name, refim, refcfg, out_dir, *, backbone, OH, OW, D, B, seed, H=720, W=1280, T=3, N=12, NFB=1024):
+def full_case(name, refim, refcfg, out_dir, *, backbone, OH, OW, D, B, seed, H=720, W=1280, T=3, N=12, NFB=1024, search=True):
     """ONE full-size 720x1280 run of the reference's Dynamic_volleyball (infer_model.py:141-234), fwd + backward of the
     CE loss, eval mode.  Inputs and the 29 M weights are NOT stored: both sides regenerate them from the seed recipe of
     oracle.din_oracle.synth_inputs / synth_params.  Stored: logits, loss, per-stage feature probes taken with forward hooks on the
@@ -460,11 +460,12 @@ def full_case(name, refim, refcfg, out_dir, *, backbone, OH, OW, D, B, seed, H=7
             top2 = s_.topk(2, dim=2).values
             live = top2[:, :, 0] > 0
             min_gap = float(((top2[:, :, 0] - top2[:, :, 1])[live] / s_.abs().max()).min())
-        print(f"[full] {name}: seed {seed}: smallest relative top-2 gap of the actor max {min_gap:.2e}")
-        if min_gap >= 5e-6:
+            near_ties = int((((top2[:, :, 0] - top2[:, :, 1]) / s_.abs().max() < 5e-6) & live).sum())
+        print(f"[full] {name}: seed {seed}: smallest relative top-2 gap of the actor max {min_gap:.2e} ({near_ties} windows under 5e-6)")
+        if min_gap >= 5e-6 or not search:      # search=False: the FIRST draw, near-ties and all (one fixture that was not chosen to be easy)
             break
         seed += 1000
-    assert min_gap >= 5e-6
+    assert min_gap >= 5e-6 or not search
     del inter0, s_, top2
     missing, unexpected = model.load_state_dict(p, strict=False)
     bad = [k for k in missing if "num_batches_tracked" not in k and "zero_padding" not in k]
@@ -510,7 +511,10 @@ def full_case(name, refim, refcfg, out_dir, *, backbone, OH, OW, D, B, seed, H=7
         close(got, torch.from_numpy(probes["feat." + key + ".sample"]), 2e-4, name + ".feat." + key)
     eg = 0.0
     for k, v in ref_grads.items():
-        eg = max(eg, close(po[k].grad, v, 1e-2, name + ".grad." + k))
+        if search:
+            eg = max(eg, close(po[k].grad, v, 1e-2, name + ".grad." + k))
+        else:                                  # an un-searched draw may route a near-tied actor-max window differently in the oracle's own fp32 run
+            eg = max(eg, float((po[k].grad - v).abs().max() / (v.abs().max() + 1e-30)))
     # Yardstick for the gradient comparisons: how far the reference's OWN fp32 run is from exact arithmetic.  Below a max-pool / ReLU a
     # 1e-7 perturbation of an activation can re-route a gradient element (near-tied pool windows, pre-activations at zero), so the fp32
     # reference differs from its fp64 self by up to a few 1e-2 in the first layers; any other fp32 summation order differs from the
@@ -533,7 +537,8 @@ def full_case(name, refim, refcfg, out_dir, *, backbone, OH, OW, D, B, seed, H=7
                kernels=np.array([(3, 3)], dtype=np.int64), ratios=np.array([1], dtype=np.int64), seed=np.int64(seed),
                dtype=np.array("float32"), logits=ref_logits.numpy(), loss=np.float64(loss.item()), labels=labels.numpy(),
                ref_seconds_fwd_bwd=np.float64(t_ref), ref_threads=np.int64(torch.get_num_threads()),
-               yard_logits=np.float64(yard_logits), min_actor_gap=np.float64(min_gap))
+               yard_logits=np.float64(yard_logits), min_actor_gap=np.float64(min_gap), near_ties=np.int64(near_ties), searched=np.int64(1 if search else 0),
+               oracle_vs_ref_worst_grad=np.float64(eg))
     for k, v in yard.items():
         rec["yard." + k] = np.float64(v)
     rec.update(g64)
@@ -843,7 +848,7 @@ def main():
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--skip-big", action="store_true")
-    ap.add_argument("--only", default="", help="'inv3': only the two reduced-size Inception fixtures; 'tce': only (re)generate the Dynamic_TCE_volleyball fixtures; 'full': only the two full-size 720x1280 fixtures; 'dataset': only the dataset -> tensor contract fixtures (SURVEY 8f-1)")
+    ap.add_argument("--only", default="", help="'inv3': only the two reduced-size Inception fixtures; 'tce': only (re)generate the Dynamic_TCE_volleyball fixtures; 'full': only the two full-size 720x1280 fixtures; 'full_unsearched': the un-searched full-size Inception draw; 'dataset': only the dataset -> tensor contract fixtures (SURVEY 8f-1)")
     a = ap.parse_args()
     sys.dont_write_bytecode = True
     install_stubs()
@@ -881,6 +886,10 @@ def main():
         return
     if a.only == "full":
         full_cases()
+        return
+    if a.only == "full_unsearched":
+        # the first draw of another seed, NOT searched for a tie-free actor max (the searched fixtures above skip such draws)
+        full_case("full_inv3_720x1280_b1_seed401_unsearched", refim, refcfg, a.out, backbone="inv3", OH=87, OW=157, D=1056, B=1, seed=401, search=False)
         return
     if a.only == "dataset":
         dataset_cases(a.out)
