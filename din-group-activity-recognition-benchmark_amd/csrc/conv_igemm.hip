@@ -1107,18 +1107,22 @@ __global__ __launch_bounds__(64 * NWV_, 1) void conv_halo_kernel(ConvK p) {
     // 8 waves: wave = (pixel group wp of 64 pixels, filter half wc): two waves per SIMD, so one wave's waits (barrier, vmcnt, LDS
     // latency) hide behind the other's MFMAs -- with 4 waves (one per SIMD) the kernel ran at 20 % MFMA utilisation
     // NWV_ = 16: pixel groups of 32 instead of 64 pixels (four waves per SIMD; the LDS budget then allows a 2-slot filter ring only)
-    constexpr int NWV = NWV_, NTAPS = KH * KW, TI = BN / 32, TJ = 32 / NWV;
+    // BN = 80 (Conv2d_4a's data gradient, 192 -> 80 channels): the first filter half takes 48 rows (three 16-row tiles), the second 32 (two) --
+    // a sixth fewer MFMAs than padding the bank to 96 rows; the two kinds of wave alternate on every SIMD (waves go to SIMDs round-robin)
+    constexpr int NWV = NWV_, NTAPS = KH * KW, TI = (BN + 31) / 32, TJ = 32 / NWV;
+    constexpr int WCR = BN == 80 ? 48 : BN / 2;                       // rows of the first filter half
     constexpr int HWW = TW + KW - 1, HWH = TH + KH - 1, HPX = HWW * HWH;
     constexpr int PCH = 10, PB = PCH * 16;                            // row pitch: 10 chunks = 160 bytes
     constexpr int NTR_H = (HPX * PCH + 64 * NWV - 1) / (64 * NWV), HBYTES = NTR_H * 1024 * NWV;
     constexpr int NTR_W = (BN * PCH + 64 * NWV - 1) / (64 * NWV), WBYTES = NTR_W * 1024 * NWV;
-    static_assert(TH * TW == 256 && TW % 16 == 0 && NTAPS > NSW && BN % 32 == 0, "tile shape");
+    static_assert(TH * TW == 256 && TW % 16 == 0 && NTAPS > NSW && (BN % 32 == 0 || BN == 80), "tile shape");
     constexpr int NST = TI * TJ;                                       // epilogue stores per wave per item
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int frow = lane & 15, g4 = lane >> 4;
-    const int wp = wid & (NWV / 2 - 1), wc = wid / (NWV / 2);
+    const int wp = wid & (NWV / 2 - 1), wc = __builtin_amdgcn_readfirstlane(wid / (NWV / 2));
+    const int tiw = wc == 0 ? TI : (BN - WCR) / 16;                    // 16-row filter tiles of this wave (scalar)
     const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw;
     const uint32_t ldsWv = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(wid * 1024));
 
@@ -1192,7 +1196,7 @@ __global__ __launch_bounds__(64 * NWV_, 1) void conv_halo_kernel(ConvK p) {
         const int qy = TW == 32 ? (q >> 1) : q, qx = TW == 32 ? (q & 1) * 16 : 0;
         xbase[j] = (uint32_t)(((qy + yb) * HWW + qx + frow + xb) * PB + g4 * 16);
     }
-    const uint32_t wbase = (uint32_t)(2 * HBYTES + (wc * (BN / 2) + frow) * PB + g4 * 16);
+    const uint32_t wbase = (uint32_t)(2 * HBYTES + (wc * WCR + frow) * PB + g4 * 16);
 
     constexpr int NBP = NWV == 16 ? 1 : 2;                             // (sixteen waves: 128 registers)
     f32x4 biasP[NBP][TI];                                               // bias of the first NBP filter tiles (see the epilogue)
@@ -1200,7 +1204,7 @@ __global__ __launch_bounds__(64 * NWV_, 1) void conv_halo_kernel(ConvK p) {
     for (int ct = 0; ct < NBP; ++ct)
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
-            const int co = ct * BN + wc * (BN / 2) + i * 16 + g4 * 4;
+            const int co = ct * BN + wc * WCR + i * 16 + g4 * 4;
             biasP[ct][i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if ((p.flags & DIN_CONV_BIAS) && co < p.Cout) biasP[ct][i] = *reinterpret_cast<const f32x4*>(p.bias + co);
             asm volatile("" : "+v"(biasP[ct][i]));                      // consumed here: the compiler's wait stays out of the walk
@@ -1264,27 +1268,31 @@ __global__ __launch_bounds__(64 * NWV_, 1) void conv_halo_kernel(ConvK p) {
             const uint32_t woff = (uint32_t)(wslot * WBYTES);
             u32x4 wf[2][TI], xf[2][TJ];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) wf[0][i] = *reinterpret_cast<const u32x4*>(smem_raw + wbase + woff + i * 16 * PB);
+            for (int i = 0; i < TI; ++i) if (i < tiw) wf[0][i] = *reinterpret_cast<const u32x4*>(smem_raw + wbase + woff + i * 16 * PB);
 #pragma unroll
             for (int j = 0; j < TJ; ++j) xf[0][j] = *reinterpret_cast<const u32x4*>(smem_raw + xbase[j] + xoff);
             __builtin_amdgcn_sched_barrier(0);
             if (two) {
 #pragma unroll
-                for (int i = 0; i < TI; ++i) wf[1][i] = *reinterpret_cast<const u32x4*>(smem_raw + wbase + woff + i * 16 * PB + 64);
+                for (int i = 0; i < TI; ++i) if (i < tiw) wf[1][i] = *reinterpret_cast<const u32x4*>(smem_raw + wbase + woff + i * 16 * PB + 64);
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) xf[1][j] = *reinterpret_cast<const u32x4*>(smem_raw + xbase[j] + xoff + 64);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
+                if (i < tiw) {
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) Mma<T>::run(wf[0][i], xf[0][j], acc[i][j]);
+                    for (int j = 0; j < TJ; ++j) Mma<T>::run(wf[0][i], xf[0][j], acc[i][j]);
+                }
             __builtin_amdgcn_sched_barrier(0);
             if (two) {
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
+                    if (i < tiw) {
 #pragma unroll
-                    for (int j = 0; j < TJ; ++j) Mma<T>::run(wf[1][i], xf[1][j], acc[i][j]);
+                        for (int j = 0; j < TJ; ++j) Mma<T>::run(wf[1][i], xf[1][j], acc[i][j]);
+                    }
             }
             wslot = wslot + 1 == NSW ? 0 : wslot + 1;
             if (tap == NSW - 2) fresh_item = false;
@@ -1300,7 +1308,7 @@ __global__ __launch_bounds__(64 * NWV_, 1) void conv_halo_kernel(ConvK p) {
             f32x4 bv[TI];
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
-                const int co = cur.co_tile * BN + wc * (BN / 2) + i * 16 + g4 * 4;
+                const int co = cur.co_tile * BN + wc * WCR + i * 16 + g4 * 4;
                 if (cur.co_tile < NBP) bv[i] = cur.co_tile == 0 ? biasP[0][i] : biasP[NBP - 1][i];
                 else { bv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; if ((p.flags & DIN_CONV_BIAS) && co < p.Cout) bv[i] = *reinterpret_cast<const f32x4*>(p.bias + co); }
             }
@@ -1317,7 +1325,7 @@ __global__ __launch_bounds__(64 * NWV_, 1) void conv_halo_kernel(ConvK p) {
                 const int opx = gy * p.OW + gx;
 #pragma unroll
                 for (int i = 0; i < TI; ++i) {
-                    const int co = cur.co_tile * BN + wc * (BN / 2) + i * 16 + g4 * 4;
+                    const int co = cur.co_tile * BN + wc * WCR + i * 16 + g4 * 4;
                     const bool ok = pok && co < p.Cout;                      // Cout % 4 == 0 (host)
                     off[j][i] = ok ? (opx * p.ldo + p.cooff + co) * 2 : (int)OOB;
                     if (p.flags & DIN_CONV_MASK) mk[j][i] = __builtin_amdgcn_raw_buffer_load_b64(rsM, ok ? (opx * p.ldm + p.moff + co) * 2 : (int)OOB, 0, 0);
@@ -2776,6 +2784,7 @@ static bool plan_halo(int dtype, int kh, int kw, int cred, int cprod, int oh, in
     const int t96 = (cprod + 95) / 96, t64 = (cprod + 63) / 64;
     hp.bn = (t96 < t64 || (t96 == t64 && t96 * 96 <= t64 * 64)) ? 96 : 64;
     hp.n_co_tiles = hp.bn == 96 ? t96 : t64;
+    const bool bn80 = k33 && cprod > 64 && cprod <= 80;   // 48 + 32 rows (16-wave kernel only, below)
     if (hp.n_co_tiles * hp.bn * 100 > cprod * 125) return false;
     // measured (profiles/r01_halo_probe.txt): wins 15-22 % on 3x3 layers whose filters fit ONE tile (no halo re-read per filter tile);
     // loses against the 128x192 / 128x160 gather tiles on the wide 192-filter and 7-tap layers.  DIN_CONV_HALO=2 forces it everywhere.
@@ -2793,7 +2802,10 @@ static bool plan_halo(int dtype, int kh, int kw, int cred, int cprod, int oh, in
         const char* wv = getenv("DIN_HALO_WAVES");
         const int want = wv ? atoi(wv) : 16;
         const size_t hb16 = (size_t)((hpx * 10 + 1023) / 1024) * 16384, wb16 = (size_t)((hp.bn * 10 + 1023) / 1024) * 16384;
-        if (want == 16 && k33 && 2 * hb16 + 2 * wb16 <= 160 * 1024) { hp.nwv = 16; hp.nsw = 2; hp.lds = 2 * hb16 + 2 * wb16; }
+        if (want == 16 && k33 && 2 * hb16 + 2 * wb16 <= 160 * 1024) {
+            hp.nwv = 16; hp.nsw = 2; hp.lds = 2 * hb16 + 2 * wb16;
+            if (bn80) hp.bn = 80;                               // (same 16 KiB slab slots: 80 x 10 chunks <= one transfer per wave)
+        }
     }
     return hp.lds <= 160 * 1024;
 }
@@ -3008,7 +3020,9 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
                     raise_lds_limit(kern, hp.lds);
                     hipLaunchKernelGGL(kern, grid, dim3(1024), hp.lds, st, k);
                 };
-                if (hp.bn == 64) launch16(conv_halo_kernel<64, 3, 3, 8, 32, 2, 16>); else launch16(conv_halo_kernel<96, 3, 3, 8, 32, 2, 16>);
+                if (hp.bn == 64) launch16(conv_halo_kernel<64, 3, 3, 8, 32, 2, 16>);
+                else if (hp.bn == 80) launch16(conv_halo_kernel<80, 3, 3, 8, 32, 2, 16>);
+                else launch16(conv_halo_kernel<96, 3, 3, 8, 32, 2, 16>);
             }
             else if (k.kh == 3 && k.kw == 3) { if (hp.bn == 64) launch(conv_halo_kernel<64, 3, 3, 8, 32, 3>); else launch(conv_halo_kernel<96, 3, 3, 8, 32, 3>); }
             else if (k.kh == 1 && k.kw == 7) { if (hp.bn == 64) launch(conv_halo_kernel<64, 1, 7, 16, 16, 3>); else launch(conv_halo_kernel<96, 1, 7, 16, 16, 3>); }

@@ -70,6 +70,7 @@ CONV_CASES = [
     ("halo_3x3_80_192_p0", 2, 80, 181, 321, 192, (3, 3), (1, 1), (0, 0), 1),
     ("halo_5x5_48_64", 6, 48, 87, 157, 64, (5, 5), (1, 1), (2, 2), 1),
     ("halo_3x3_96_96", 6, 96, 87, 157, 96, (3, 3), (1, 1), (1, 1), 1),        # (+ the three shapes of conv_wgrad_halo_kernel: dW stationary)
+    ("halo_3x3_96_80", 6, 96, 87, 157, 80, (3, 3), (1, 1), (1, 1), 1),        # 80 filters: conv_halo_kernel<80>, 48 + 32 rows (also the dgrad of halo_3x3_80_192_p0)
     ("halo_1x7_128_160", 20, 128, 43, 78, 160, (1, 7), (1, 1), (0, 3), 1),
     ("halo_7x1_160_192", 20, 160, 43, 78, 192, (7, 1), (1, 1), (3, 0), 1),
     # 256-pixel software-pipelined tiles (conv_gather_pipe_kernel<128 | 192 | 256>, bf16; forced on these small shapes with DIN_GATHER_PIPE=2):

@@ -3,9 +3,13 @@ set -u
 cd "$(dirname "$0")/../.."
 O=gpurun_out; mkdir -p $O
 B="--steps 20 --no-extras --no-cpu-baseline"
-timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -k "unsearched or lowp_linear" -s 2>&1 | grep -E "un-searched|passed|failed|Error" | cut -c1-400
-timeout 600 python bench.py $B --global-batch 4 > $O/r04f_b4_direct.json 2> $O/r04f_b4_direct.err
-DIN_WGRAD_DIRECT=0 timeout 600 python bench.py $B --global-batch 4 > $O/r04f_b4_reduce.json 2> $O/r04f_b4_reduce.err
-timeout 600 python bench.py $B --global-batch 4 > $O/r04f_b4_direct2.json 2> $O/r04f_b4_direct2.err
-DIN_WGRAD_DIRECT=0 timeout 600 python bench.py $B --global-batch 4 > $O/r04f_b4_reduce2.json 2> $O/r04f_b4_reduce2.err
-python tools/bench_summary.py $O/r04f_*.json
+timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -k "halo_3x3" 2>&1 | tail -3
+for i in 1 2; do
+  python tools/conv_bench.py --layer inc_4a_3x3 --which dgrad --flags 12 --iters 300
+  DIN_HALO_BN80=0 python tools/conv_bench.py --layer inc_4a_3x3 --which dgrad --flags 12 --iters 300
+done
+timeout 600 python bench.py $B > $O/r04g_b32_bn80.json 2> $O/r04g_b32_bn80.err
+DIN_HALO_BN80=0 timeout 600 python bench.py $B > $O/r04g_b32_bn96.json 2> $O/r04g_b32_bn96.err
+timeout 600 python bench.py $B > $O/r04g_b32_bn80b.json 2> $O/r04g_b32_bn80b.err
+DIN_HALO_BN80=0 timeout 600 python bench.py $B > $O/r04g_b32_bn96b.json 2> $O/r04g_b32_bn96b.err
+python tools/bench_summary.py $O/r04g_*.json
