@@ -2911,6 +2911,16 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
     else if (bm == 256) {
         if constexpr (sizeof(T) == 2) {
             if (bn == 96) launch_fast<T, 256, 96, 2, 2, 8, 2>(k, grid, st);
+#ifdef DIN_EXPERIMENTS
+            // experiment (round 4, DIN_CONV_W16=1 with DIN_CONV_TILE=256): the 256-pixel sixteen-wave tile for the 160- / 128-filter 7-tap layers
+            // (Mixed_6b-6d: 98 / 85 instead of 71 / 64 FLOP per staged byte)
+            else if ((bn == 160 || bn == 128) && getenv("DIN_CONV_W16") && atoi(getenv("DIN_CONV_W16")) == 1) {
+                const char* fv = getenv("DIN_CONV_FASTK");
+                const bool fastk = (fv ? atoi(fv) != 0 : true) && !k.remap && k.nsrc == 0 && (k.cpt % 8) == 0 && (k.korder || k.kh * k.kw == 1);
+                if (bn == 160) { if (fastk) launch_fast<T, 256, 160, 8, 2, 8, 2, true>(k, grid, st); else launch_fast<T, 256, 160, 8, 2, 8, 2>(k, grid, st); }
+                else { if (fastk) launch_fast<T, 256, 128, 8, 2, 8, 2, true>(k, grid, st); else launch_fast<T, 256, 128, 8, 2, 8, 2>(k, grid, st); }
+            }
+#endif
             else if (bn == 160) launch_fast<T, 256, 160, 2, 2, 8, 2>(k, grid, st);
             else if (bn == 192) {
                 // experiment (DIN_CONV_W16=1 with DIN_CONV_TILE=256): sixteen waves as 8 x 2 on the 256 x 192 tile -- the 128 x 192 kernel's wave

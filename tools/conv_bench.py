@@ -36,6 +36,10 @@ LAYERS = {  # name: (nb, h, w, cin, cout, k, s, p)
     "k_1x1_192": (96, 43, 78, 192, 192, 1, 1, 0),
     "k_1x1_1536": (96, 43, 78, 1536, 192, 1, 1, 0),
     "inc_6e_1x7": (96, 43, 78, 192, 192, (1, 7), 1, (0, 3)),
+    "inc_6b_1x7": (96, 43, 78, 128, 128, (1, 7), 1, (0, 3)),
+    "inc_6b_7x1": (96, 43, 78, 128, 128, (7, 1), 1, (3, 0)),
+    "inc_6c_7x1": (96, 43, 78, 160, 160, (7, 1), 1, (3, 0)),
+    "inc_6c_7x1_192": (96, 43, 78, 160, 192, (7, 1), 1, (3, 0)),
 }
 
 def main():
