@@ -273,7 +273,12 @@ template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS, bool MUL
 //  = four waves per SIMD = at most 128 VGPRs.  Left at 2, a harmless-looking edit -- round 4: the knock-out switches turned compile-time
 //  constants -- moved the FASTK 128 x 192 instantiation from 125 to 131 registers: one workgroup per CU, 186 -> 259 us per launch, -1.6 ms per
 //  step, caught only by diffing kernel_stats.csv against the previous round's.)
+#ifdef DIN_EXPERIMENTS
+// (experiment, round 4: four-wave 128-pixel tiles on 32-deep stages, THREE workgroups per CU = three barrier domains: <= 168 VGPRs)
+__global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && BMT == 128 && WM * WN == 8) ? 4 : ((sizeof(T) == 2 && BMT == 128 && WM * WN == 4 && KCS == 4 && NS == 2 && FASTK) ? 3 : 2)) void conv_gather_fast_kernel(ConvK p) {
+#else
 __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && BMT == 128 && WM * WN == 8) ? 4 : 2) void conv_gather_fast_kernel(ConvK p) {
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)      // the host pass only needs the launch stub (the LDS-DMA builtin is device-only)
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BM = BMT;                                  // shadows the file-level default inside this kernel
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && BMT == 128 && WM *
     constexpr int NDMA = PA + PB;                                  // wave-level DMAs per stage per wave (issued unconditionally)
     static_assert((NS - 2) * NDMA <= 63, "vmcnt field");
     if constexpr (FASTK) {
-        static_assert(!MULTI && NS == 2 && PA == 2, "FASTK: 8-wave 128-pixel tiles, double-buffered");
+        static_assert(!MULTI && NS == 2 && PA == 2, "FASTK: 128-pixel tiles whose loader covers 64 rows per pass, double-buffered");
         // scalar walk over k-steps: ks -> (channel chunk ks / ntaps, tap ks % ntaps); td = byte delta of the tap, fa / fb = scalar byte
         // offsets of the step inside a pixel's channels / inside a packed filter row
         int tap = ks_begin % ntaps, tr = (tap * inv_kw) >> 16, tc = tap - tr * p.kw;
@@ -2843,6 +2848,12 @@ void launch_wave8(const ConvK& k, dim3 grid, hipStream_t st) {
                 return;
             }
         }
+#ifdef DIN_EXPERIMENTS
+        if constexpr (BN >= 128) {
+            static const bool wg3 = getenv("DIN_CONV_WG3") && atoi(getenv("DIN_CONV_WG3")) == 1;
+            if (fastk && wg3) { launch_fast<T, 128, BN, 2, 2, 4, 2, true>(k, grid, st); return; }
+        }
+#endif
         if (fastk) {
             launch_fast<T, 128, BN, 4, 2, 8, 2, true>(k, grid, st);
             return;
