@@ -42,8 +42,9 @@ def test_occupancy_critical_kernels_hold_their_register_budgets():
         for blk in re.split(r"remark: Function Name: ", open(f).read())[1:]:
             name = blk.split()[0]
             v, a = re.search(r" VGPRs: (\d+)", blk), re.search(r"AGPRs: (\d+)", blk)
-            sp = re.search(r"VGPRs Spill: (\d+)", blk)
-            usage[name] = (int(v.group(1)) + int(a.group(1)), int(sp.group(1)) if sp else 0)
+            sp, sc = re.search(r"VGPRs Spill: (\d+)", blk), re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk)
+            # (scratch counts as a spill: the hand-counted vmcnt of the LDS-DMA rings does not survive compiler-made memory traffic)
+            usage[name] = (int(v.group(1)) + int(a.group(1)), (int(sp.group(1)) if sp else 0) + (int(sc.group(1)) if sc else 0))
     assert len(usage) > 100, "resource remarks look truncated"
     checked = 0
     for name, (regs, spill) in usage.items():
@@ -53,12 +54,12 @@ def test_occupancy_critical_kernels_hold_their_register_budgets():
             budget = 128
         elif re.search(r"conv_halo_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi16E", name):     # sixteen waves in one workgroup
             budget = 128
-        elif "conv_wgrad_pipe_kernel" in name and name.rstrip("E").endswith(("Lb1ELi16", "Lb0ELi16")):
+        elif re.search(r"conv_wgrad_pipe_kernelILi\d+ELi256ELb[01]ELi8E", name):        # sixteen waves (wave grid 2 x 8) in one workgroup
             budget = 128
         if budget is not None:
             checked += 1
             assert regs <= budget and spill == 0, f"{name}: {regs} registers (+{spill} spilled) > {budget}: a workgroup per CU is lost"
-    assert checked >= 8, checked
+    assert checked >= 14, checked
 
 
 def test_conv_planning_is_callable_without_gpu():
