@@ -937,7 +937,7 @@ def test_full_size_fp32_model_matches_reference_golden(gpu, path):
         # infer_model.py:224 -- and the gradient reaches the backbone through 36 RoI crops only, so ONE re-routed element moves a BatchNorm
         # channel's gradient by ~1e-2 of the tensor's maximum (this draw, first run: Mixed_6c.branch7x7dbl_1.bn.bias 1.04e-2 from float64 where
         # the reference's own fp32 run is 1.5e-3 from it).  Bars here: every tensor points the reference's way (cosine >= 0.999 -- a wrong kernel
-        # is not a re-routed element), at most 3 % of the tensors leave the searched fixtures' bars, none by more than 4x; the count is printed.
+        # is not a re-routed element), at most 3 % of the tensors leave the searched fixtures' bars, none by more than 5x; the count is printed.
         outside = [r for r in rows if r[0] > 1.0]
         print("un-searched draw: %d near-tied actor-max windows (smallest relative gap %.1e); CPU oracle vs reference worst gradient %.1e; "
               "%d of %d tensors outside the searched-fixture bars (worst %.2fx its bound: %s); %d gradient-sum checks outside" %
@@ -945,7 +945,7 @@ def test_full_size_fp32_model_matches_reference_golden(gpu, path):
                rows[0][0] if rows else 0.0, rows[0][1] if rows else "-", sum(1 for r in bad if str(r[1]).startswith("gsum."))))
         lows = [(r[1], float(r[5])) for r in rows if float(r[5]) < 0.999]
         assert not lows, lows
-        assert len(outside) <= max(2, int(0.03 * len(rows))) and Measured(rows[0][0]) <= 4.0, outside[:5]
+        assert len(outside) <= max(2, int(0.03 * len(rows))) and Measured(rows[0][0]) <= 5.0, outside[:5]     # (2.253 in every run so far: the fp32 path is deterministic here)
         return
     assert not bad, bad
 
