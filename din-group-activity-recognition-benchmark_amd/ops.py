@@ -184,12 +184,22 @@ class GridConvFunction(torch.autograd.Function):
         gy = gy.contiguous().to(tdt)
         st = _stream()
         dx = dw = db = None
+        dw_installed = False
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw = torch.empty_like(weight)
+            # data parallelism: the weight gradient goes straight into the parameter's slot of its all-reduce bucket (parallel.GradBuckets through
+            # nhwc.GRAD_BUFFER, as for the backbone's conv weights) -- the embedding layer's 108 MB gradient is 93 % of the model's bytes, copying it
+            # into the bucket cost a 108 MB device copy per step, and reporting it (GRAD_HOOK) starts its all-reduce under the whole backbone backward
+            from . import nhwc as _nhwc
+            buf = _nhwc.GRAD_BUFFER(weight) if _nhwc.GRAD_BUFFER is not None else None
+            dw = buf if buf is not None else torch.empty_like(weight)
             db = torch.empty(weight.shape[0], dtype=torch.float32, device=x.device) if ctx.has_bias else None
             ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 2), x.device, "wgrad")   # not shared with split-K launches
             L.check(lib.din_conv_wgrad(C.byref(d), _ptr(x), _ptr(gy), _ptr(dw), _ptr(db), None, None, None, 0, _ptr(ws), wsb, st),
                     "grid_conv_wgrad")
+            if _nhwc.GRAD_HOOK is not None:
+                _nhwc.GRAD_HOOK(weight, dw)
+            if buf is not None and _nhwc.GRAD_ASSIGN is not None and _nhwc.GRAD_ASSIGN(weight, dw):
+                dw_installed = True                              # .grad IS the bucket slot now: autograd gets None (it would clone a shared tensor)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wpt = torch.empty(lib.din_conv_packed_elems(C.byref(d), 1), dtype=tdt, device=x.device)
@@ -198,7 +208,7 @@ class GridConvFunction(torch.autograd.Function):
             L.check(lib.din_conv_dgrad(C.byref(d), _ptr(gy), _ptr(wpt), _ptr(dx), None, 0, 0, 0, _ptr(ws), wsb, st), "grid_conv_dgrad")
             if ctx.lowp:
                 dx = dx.float()
-        return dx, dw, db, None, None
+        return dx, (None if dw_installed else dw), db, None, None
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], lowp: bool = False) -> torch.Tensor:

@@ -100,11 +100,16 @@ class GradBuckets:
         self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
         self._views = {}
         self._slot = {}
+        self._bkeys: List[List[int]] = []                        # per bucket: its parameters' data_ptrs (taken once: parameters do not move)
         for bi, bkt in enumerate(self.buckets):
-            off = 0
+            off, keys = 0, []
             for p in bkt:
-                self._slot[p.data_ptr()] = (bi, off)
+                k = p.data_ptr()
+                self._slot[k] = (bi, off)
+                keys.append(k)
                 off += p.numel()
+            self._bkeys.append(keys)
+        self._arrived = [0] * len(self.buckets)                  # hooked gradients reported per bucket this step
 
     def _view_of(self, p: torch.nn.Parameter) -> torch.Tensor:
         key = p.data_ptr()
@@ -146,16 +151,16 @@ class GradBuckets:
 
     def _pack(self, bi: int, grads: List[Optional[torch.Tensor]]) -> torch.Tensor:
         flat = self._flat_of(bi)
-        pieces, moved, off = [], [], 0
+        base = flat.data_ptr()
+        moved, off = [], 0
         for p, g in zip(self.buckets[bi], grads):
             n = p.numel()
             if g is None:
                 g = torch.zeros(n, dtype=torch.float32, device=flat.device)
             # a gradient that already lives at its slot (written there by the conv executor through nhwc.GRAD_BUFFER, or the previous
             # step's view accumulated into in place) needs no packing
-            if not (g.dtype == torch.float32 and g.is_contiguous() and g.data_ptr() == flat.data_ptr() + 4 * off):
+            if not (g.data_ptr() == base + 4 * off and g.dtype == torch.float32 and g.is_contiguous()):
                 moved.append((off, n, g))
-            pieces.append(g)
             off += n
         # pack the stragglers (fused sibling groups, BN vectors, FCs): one launch per RUN of adjacent slots, not one per tensor
         i = 0
@@ -183,10 +188,12 @@ class GradBuckets:
             # gradient and allreduce() would then replace the accumulated .grad with it
             raise RuntimeError("parallel.GradBuckets: gradient accumulation (p.grad kept between backward passes) is not supported with the "
                                "overlapped all-reduce; call optimizer.zero_grad() before every backward pass")
-        self._got[key] = grad
         bi, _ = self._slot[key]
-        if bi < self._early and bi not in self._inflight and all(q.data_ptr() in self._got for q in self.buckets[bi]):
-            flat = self._pack(bi, [self._got[q.data_ptr()] for q in self.buckets[bi]])
+        if key not in self._got:
+            self._arrived[bi] += 1                               # (a counter, not a scan of the bucket per report: the scan was O(n^2) data_ptr() calls
+        self._got[key] = grad                                    #  per step -- ~2 ms of host time on the 4-clip step, which the bucket path made host-bound)
+        if bi < self._early and bi not in self._inflight and self._arrived[bi] == len(self._bkeys[bi]):
+            flat = self._pack(bi, [self._got[k] for k in self._bkeys[bi]])
             self._inflight[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def allreduce(self, world: Optional[int] = None, async_op: bool = True, scale_in_optimizer: bool = False) -> None:
@@ -211,12 +218,17 @@ class GradBuckets:
                 h.wait()
             if not scale_in_optimizer:
                 self._flat[bi].div_(world)
-            for p in self.buckets[bi]:
-                p.grad = self._view_of(p)                        # cached view of the reduced flat buffer (no per-step view construction)
+            for p, k in zip(self.buckets[bi], self._bkeys[bi]):
+                v = self._views.get(k)
+                if v is None:
+                    v = self._view_of(p)
+                if p.grad is not v:
+                    p.grad = v                                   # cached view of the reduced flat buffer (no per-step view construction)
         self.grad_scale = 1.0 / world if scale_in_optimizer else 1.0
         # ---- bookkeeping for the next step
         self._inflight.clear()
         self._got.clear()
+        self._arrived = [0] * len(self.buckets)
         if self._learned is None and self._hook_order:
             # every rank saw the same order (same graph): hooked weights first, in arrival order, then everything else
             self._learned = list(dict.fromkeys(self._hook_order))

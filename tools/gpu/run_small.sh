@@ -3,17 +3,11 @@ set -u
 cd "$(dirname "$0")/../.."
 O=gpurun_out; mkdir -p $O
 B="--steps 20 --no-extras --no-cpu-baseline"
-timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -k "wgrad or pipe" 2>&1 | tail -3
-for l in inc_6e_7x1 inc_6c_1x7 inc_6b_1x7 inc_6c_7x1_192 inc_6a_3x3; do
-  for r in 1 2; do
-    echo -n "light (0.6)   "; python tools/conv_bench.py --layer $l --which wgrad --iters 1000 | tail -1
-    echo -n "light (0.5)   "; DIN_WGRAD_LIGHT_COST=0.5 python tools/conv_bench.py --layer $l --which wgrad --iters 1000 | tail -1
-    echo -n "light (0.75)  "; DIN_WGRAD_LIGHT_COST=0.75 python tools/conv_bench.py --layer $l --which wgrad --iters 1000 | tail -1
-    echo -n "uniform       "; DIN_WGRAD_LIGHT=0 python tools/conv_bench.py --layer $l --which wgrad --iters 1000 | tail -1
-  done
+DIN_SINGLE_DEVICE=1 DIN_DIST_BACKEND=gloo DIN_CHECK_ALLREDUCE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 2 --global-batch 8 --no-cpu-baseline 2>&1 | grep -E "allreduce check|metric|Error|error" | cut -c1-200
+for i in 1 2; do
+  timeout 600 python bench.py $B --global-batch 4 > $O/r04p_b4_plain$i.json 2> $O/r04p_b4_plain$i.err
+  timeout 600 python bench.py $B --global-batch 4 --force-buckets 2>$O/r04p_b4_buckets$i.err | grep '"metric"' > $O/r04p_b4_buckets$i.json
 done
-timeout 600 python bench.py $B > $O/r04l_b32_light.json 2> $O/r04l_b32_light.err
-DIN_WGRAD_LIGHT=0 timeout 600 python bench.py $B > $O/r04l_b32_uniform.json 2> $O/r04l_b32_uniform.err
-timeout 600 python bench.py $B > $O/r04l_b32_light2.json 2> $O/r04l_b32_light2.err
-DIN_WGRAD_LIGHT=0 timeout 600 python bench.py $B > $O/r04l_b32_uniform2.json 2> $O/r04l_b32_uniform2.err
-python tools/bench_summary.py $O/r04l_*.json
+tail -3 $O/r04p_b4_buckets1.err
+python tools/bench_summary.py $O/r04p_*.json
+timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -k "train_net or captured or checkpoint or adam or trainer" 2>&1 | tail -3
