@@ -2,11 +2,16 @@
 set -u
 cd "$(dirname "$0")/../.."
 O=gpurun_out; mkdir -p $O
-for c in 4 32; do
-  MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python bench.py --global-batch $c --steps 20 --warmup 5 \
-      --no-cpu-baseline --force-buckets 2>&1 | grep '"metric"' > $O/r04r_bench_inv3_bf16_b${c}_forced_buckets.json
+B="--steps 20 --no-extras --no-cpu-baseline"
+timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -k "pf_1x1 or (test_conv_fwd_dgrad_wgrad and 1x1)" 2>&1 | tail -3
+for l in inc_6e_1x1_768 k_1x1_1536 k_1x1_192 inc_5d_1x1_288; do
+  for r in 1 2; do
+    echo "touch  $(DIN_CONV_STREAM=0 python tools/conv_bench.py --layer $l --which fwd --iters 2000 | tail -1)"
+    echo "plain  $(DIN_CONV_STREAM=0 DIN_CONV_L2_TOUCH=0 python tools/conv_bench.py --layer $l --which fwd --iters 2000 | tail -1)"
+  done
 done
-python tools/bench_summary.py $O/r04r_*.json
-DIN_SINGLE_DEVICE=1 DIN_DIST_BACKEND=gloo DIN_CHECK_ALLREDUCE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
-    --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 2 --global-batch 8 --no-cpu-baseline > $O/r04r_two_ranks_one_device.log 2>&1
-tail -3 $O/r04r_two_ranks_one_device.log | cut -c1-200
+timeout 600 python bench.py $B > $O/r04u_b32_touch.json 2> $O/r04u_b32_touch.err
+DIN_CONV_L2_TOUCH=0 timeout 600 python bench.py $B > $O/r04u_b32_plain.json 2> $O/r04u_b32_plain.err
+timeout 600 python bench.py $B > $O/r04u_b32_touch2.json 2> $O/r04u_b32_touch2.err
+DIN_CONV_L2_TOUCH=0 timeout 600 python bench.py $B > $O/r04u_b32_plain2.json 2> $O/r04u_b32_plain2.err
+python tools/bench_summary.py $O/r04u_*.json
