@@ -57,9 +57,20 @@ class _GraphBackbone(nn.Module):
         return self._graphs[key], dt
 
     def _ordered_params(self, graph: Graph) -> List[torch.Tensor]:
-        table = dict(self.named_parameters())
-        table.update(dict(self.named_buffers()))
-        return [table[n] for n in graph.param_names()]
+        # cached per graph: walking named_parameters() / named_buffers() of ~300 modules is milliseconds of host time per step -- as much as the
+        # whole forward dispatch on the 4-clip step.  `_apply` (.to / .cuda / .float: buffers are REPLACED there) drops the cache.
+        cache = self.__dict__.setdefault("_ordered_cache", {})
+        hit = cache.get(id(graph))
+        if hit is None:
+            table = dict(self.named_parameters())
+            table.update(dict(self.named_buffers()))
+            hit = cache[id(graph)] = [table[n] for n in graph.param_names()]
+        return hit
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_ordered_cache", None)
+        self.__dict__.pop("_bn_modules", None)
+        return super()._apply(fn, *args, **kwargs)
 
     def forward_nhwc(self, images: torch.Tensor, prenormalised: bool = False):
         """images [NB,3,H,W] (uint8 or float, 0..255 unless prenormalised).  Returns (list of NHWC buffers, graph)."""
