@@ -256,7 +256,7 @@ def test_inception_bf16_features_and_grads_track_fp32(gpu):
         if ref_g.norm() == 0:
             continue
         cos = Measured(float((got.flatten() @ ref_g.flatten()) / (got.norm() * ref_g.norm() + 1e-30)), "cos")
-        assert cos >= 0.9, (k, cos)
+        assert cos >= 0.995, (k, cos)                     # (lowest measured: 0.99967; the floor was 0.9 until round 4)
 
 
 def test_inception_sibling_fusion_matches_separate_launches(gpu, monkeypatch):
