@@ -40,6 +40,8 @@ LAYERS = {  # name: (nb, h, w, cin, cout, k, s, p)
     "inc_6b_7x1": (96, 43, 78, 128, 128, (7, 1), 1, (3, 0)),
     "inc_6c_7x1": (96, 43, 78, 160, 160, (7, 1), 1, (3, 0)),
     "inc_6c_7x1_192": (96, 43, 78, 160, 192, (7, 1), 1, (3, 0)),
+    "k_1x1_768_64": (96, 43, 78, 768, 64, 1, 1, 0),
+    "k_1x1_1536_64": (96, 43, 78, 1536, 64, 1, 1, 0),
 }
 
 def main():
