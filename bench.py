@@ -287,6 +287,87 @@ class ClockSampler:
                 "source": "amdsmi gpu_metrics (mean of the XCDs' current_gfxclks), one sample per 100 ms inside the timed region"}
 
 
+def _self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without torchrun's environment: re-execute under torch.distributed.run, one rank per GPU (the driver's own
+    form, BASELINE.json metric at 2 / 4 / 8 GPUs).  Before round 5 this case silently measured ONE GPU (WORLD_SIZE unset -> world 1)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC for RCCL; must be set before the ranks start their HIP runtime
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: --gpus {n} without WORLD_SIZE: launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def _rank_device_check(rank: int, world: int, gpus: int, dev) -> dict:
+    """Every multi-rank run proves on its first step that the collective library sees `world` ranks on `world` distinct devices and that
+    an all-reduce really sums over them (replaces nn.DataParallel, reference train_net_dynamic.py:95-96).  Returns the `rccl` block of the
+    JSON line."""
+    assert dist.is_initialized() and dist.get_world_size() == gpus == world, (dist.is_initialized() and dist.get_world_size(), gpus, world)
+    backend = dist.get_backend()
+    on_gpu = dev.type == "cuda"
+    ident = (rank, torch.cuda.current_device() if on_gpu else -1, torch.cuda.get_device_properties(dev).name if on_gpu else "cpu",
+             os.getpid())
+    ids = [None] * world
+    dist.all_gather_object(ids, ident)
+    assert len({i[3] for i in ids}) == world, f"ranks share a process: {ids}"
+    if on_gpu and os.environ.get("DIN_SINGLE_DEVICE") != "1":
+        assert backend == "nccl", f"GPU ranks must talk through RCCL (backend 'nccl'), got {backend}"
+        assert len({i[1] for i in ids}) == world, f"ranks share devices: {ids}"
+    probe = torch.ones(1, device=dev) * (rank + 1)
+    dist.all_reduce(probe)
+    assert float(probe) == world * (world + 1) / 2, float(probe)
+    info = {"backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend, "world_size": world,
+            "devices": [i[1] for i in ids], "device_name": ids[0][2], "pids_distinct": True, "allreduce_probe_sum": float(probe)}
+    if rank == 0:
+        print(f"rank/device check: {info}", file=sys.stderr, flush=True)
+    return info
+
+
+def _dry_run_dist(a) -> None:
+    """--dry-run-dist: the launch / rendezvous / sharding / all-reduce / JSON plumbing of a multi-rank run WITHOUT the model (CPU test of
+    the N > 1 entry path under gloo; the product path itself needs the MI355X and is not touched here)."""
+    from din_amd import parallel
+    rank, local, world = parallel.init_from_env()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local) if (torch.cuda.is_available() and os.environ.get("DIN_DIST_BACKEND") != "gloo") else torch.device("cpu")
+    rccl = _rank_device_check(rank, world, a.gpus, dev) if world > 1 else None
+    gb = a.global_batch or 32
+    mine = parallel.shard_range(gb, rank, world)
+    torch.manual_seed(0)
+    net = torch.nn.Linear(16, 8).to(dev)
+    parallel.broadcast_parameters(net)
+    clips = (torch.arange(gb * 16, dtype=torch.float32).reshape(gb, 16) / 100.0).to(dev)
+    buckets = parallel.GradBuckets(net.parameters(), overlap=False) if world > 1 else None
+    t0 = time.perf_counter()
+    for _ in range(a.warmup + a.steps):
+        net.zero_grad()
+        (net(clips[mine.start:mine.stop]).pow(2).sum() / gb).backward()
+        if buckets is not None:
+            buckets.allreduce()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ref = torch.nn.Linear(16, 8).to(dev)
+    ref.load_state_dict(net.state_dict())
+    (ref(clips).pow(2).sum() / gb).backward()
+    scale = float(world) if world > 1 else 1.0                  # local losses are divided by the GLOBAL batch: the rank average is 1/world of the full gradient
+    err = max(float((p.grad * scale - q.grad).abs().max()) for p, q in zip(net.parameters(), ref.parameters()))
+    assert err <= 1e-5, err
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no model): launch + rendezvous + shard + gradient all-reduce", "value": None, "unit": "clips/sec",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / max(a.steps + a.warmup, 1) * 1e3, 3),
+                          "higher_is_better": True, "scaling": "strong", "dry_run": True, "rccl": rccl,
+                          "config": {"global_batch": gb, "clips_per_gpu": len(mine), "parallelism": f"dp{world}"},
+                          "allreduce_max_abs_err_vs_full_batch": err}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -315,7 +396,14 @@ def main():
     ap.add_argument("--bn-mode", default="eval", choices=["eval", "batch"],
                     help="Inception BatchNorm: 'eval' = cfg.set_bn_eval (running statistics, folded; results independent of the GPU count), "
                          "'batch' = the reference's stage-2 default (batch statistics of the rank's frames + running-stat update)")
+    ap.add_argument("--dry-run-dist", action="store_true",
+                    help="no model: only the multi-rank launch, rendezvous, clip sharding, a gradient all-reduce and the JSON line "
+                         "(tests/test_host_cpu.py runs `bench.py --gpus 2 --dry-run-dist` under gloo)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(a.gpus))
+    if a.dry_run_dist:
+        return _dry_run_dist(a)
 
     from din_amd import parallel, profiling
     profiling.install()
@@ -323,7 +411,7 @@ def main():
     from din_amd.optim import FusedAdam
 
     rank, local, world = parallel.init_from_env()
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus {a.gpus}` (it starts its own ranks) or torchrun"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     collective = a.workload.startswith("collective")
@@ -352,20 +440,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group(backend="nccl", rank=0, world_size=1)
     buckets = parallel.GradBuckets(params, force=a.force_buckets) if (world > 1 or a.force_buckets) else None
-    if world > 1 and os.environ.get("DIN_CHECK_ALLREDUCE") == "1":
-        # tools/rccl_selfcheck.sh: the collective library really sees N ranks on N distinct devices (one process per GPU)
-        assert dist.get_world_size() == a.gpus == world, (dist.get_world_size(), a.gpus, world)
-        ids = [None] * world
-        dist.all_gather_object(ids, (rank, torch.cuda.current_device(), torch.cuda.get_device_properties(dev).name))
-        if torch.cuda.is_available() and os.environ.get("DIN_SINGLE_DEVICE") != "1":
-            assert dist.get_backend() == "nccl", dist.get_backend()
-            assert len({i[1] for i in ids}) == world, f"ranks share devices: {ids}"
-        probe = torch.ones(1, device=dev) * (rank + 1)
-        dist.all_reduce(probe)
-        assert float(probe) == world * (world + 1) / 2, float(probe)
-        if rank == 0:
-            print(f"rccl selfcheck: backend {dist.get_backend()}, world_size {dist.get_world_size()}, devices {[i[1] for i in ids]} ({ids[0][2]}), "
-                  f"sum of ranks+1 over the ring = {float(probe):.0f}", file=sys.stderr, flush=True)
+    # always (not only under DIN_CHECK_ALLREDUCE): N ranks, N distinct devices, an all-reduce that sums over all of them
+    rccl_info = _rank_device_check(rank, world, a.gpus, dev) if world > 1 else None
 
     mine = parallel.shard_range(a.global_batch, rank, world)
     B = len(mine)
@@ -628,6 +704,7 @@ def main():
                        "bn_mode": ("running statistics (set_bn_eval)" if cfg.set_bn_eval else "batch statistics (reference stage-2 default)")
                                   if backbone == "inv3" else "n/a"},
             "roofline": roofline,
+            "rccl": rccl_info,
             "clocks": clocks,
             "conv_time_frac_sampled_step": round(conv_time / (elapsed / a.steps), 4),
             "host_enqueue_ms_per_step": round(host_enqueue_s / a.steps * 1e3, 3),

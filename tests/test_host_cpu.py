@@ -209,6 +209,27 @@ def test_gloo_world2_gradient_allreduce(tmp_path):
     assert "RANK_OK_0" in res.stdout and "RANK_OK_1" in res.stdout
 
 
+def test_bench_gpus2_plain_launch_starts_two_ranks():
+    """`python bench.py --gpus 2` WITHOUT torchrun's environment must start its own two ranks (it used to measure one GPU
+    silently), prove N ranks / N processes / a summing all-reduce on its first step and carry that in the JSON line.  --dry-run-dist swaps the
+    model (which needs the MI355X) for a small host-side gradient; everything around it is the real entry path."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DIN_DIST_BACKEND"] = "gloo"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-dist", "--steps", "2", "--warmup", "1",
+                          "--global-batch", "5"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["rccl"]["world_size"] == 2 and out["rccl"]["allreduce_probe_sum"] == 3.0
+    assert out["config"]["clips_per_gpu"] == 3 and out["config"]["parallelism"] == "dp2"       # 5 clips: ranks get 3 + 2
+    # a rank count that does not match --gpus is an error, not a silent single-GPU run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-dist"], env=env2, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res2.returncode != 0 and "WORLD_SIZE=1" in res2.stderr
+
+
 def _small_cfg(dataset="volleyball"):
     from din_amd.config import Config
     cfg = Config(dataset)
