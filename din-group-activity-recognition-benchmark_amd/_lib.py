@@ -18,7 +18,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "din_hip.h")
 
 DIN_F32, DIN_BF16 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 CONV_BIAS, CONV_RELU, CONV_ACCUM, CONV_MASK = 1, 2, 4, 8
 
 
@@ -58,6 +58,8 @@ _CD, _PD = C.POINTER(ConvDesc), C.POINTER(PoolDesc)
 SIGNATURES: Dict[str, tuple] = {
     "din_abi_version": (_I, []),
     "din_last_error_string": (C.c_char_p, []),
+    "din_set_option": (_I, [C.c_char_p, C.c_char_p]),
+    "din_get_option": (_I, [C.c_char_p, C.c_char_p, _I]),
     "din_build_arch": (C.c_char_p, []),
     "din_prep_images_f32": (_I, [_P, _P, _L, _P]),
     "din_prep_images_nhwc": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
@@ -174,7 +176,26 @@ def load():
     if lib.din_build_arch() != b"gfx950":
         raise DinError("libdin_hip.so was not built for gfx950")
     _lib = lib
+    if os.environ.get("DIN_OPTIONS_FROM_ENV") == "1":
+        # tuning tools only (tools/gpu/lease.sh, tools/conv_bench.py A/B runs): forward the DIN_* variables of THIS process once, at load
+        # time, as library options.  Nothing else ever carries the environment into the library.
+        for k, v in os.environ.items():
+            if k.startswith("DIN_") and k not in ("DIN_OPTIONS_FROM_ENV", "DIN_LIB_PATH"):
+                lib.din_set_option(k.encode(), v.encode())
     return lib
+
+
+def set_option(name: str, value) -> None:
+    """Select a kernel variant for the tests / tuning tools (include/din_hip.h: din_set_option); value None = back to the shipped choice."""
+    check(load().din_set_option(name.encode(), None if value is None else str(value).encode()), f"set_option({name})")
+
+
+def get_option(name: str):
+    buf = C.create_string_buffer(256)
+    rc = load().din_get_option(name.encode(), buf, 256)
+    if rc < 0:
+        check(rc, f"get_option({name})")
+    return buf.value.decode() if rc == 1 else None
 
 
 def check(rc: int, what: str = "") -> None:

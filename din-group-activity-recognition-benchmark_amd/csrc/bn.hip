@@ -27,8 +27,8 @@ constexpr int BN_PARTS_FWD = 1024, BN_PARTS_BWD = 512, BN_MIN_ROWS = 256;
 static int bn_rows_per_block(int64_t rows, bool bwd) {
     int64_t maxp = bwd ? BN_PARTS_BWD : BN_PARTS_FWD, rpb = BN_MIN_ROWS;
 #ifdef DIN_EXPERIMENTS
-    if (const char* e = getenv("DIN_BN_RPB")) rpb = atoi(e);
-    if (const char* e = getenv(bwd ? "DIN_BN_PARTS_BWD" : "DIN_BN_PARTS")) maxp = atoi(e);
+    if (const char* e = DIN_OPT("DIN_BN_RPB")) rpb = atoi(e);
+    if (const char* e = bwd ? DIN_OPT("DIN_BN_PARTS_BWD") : DIN_OPT("DIN_BN_PARTS")) maxp = atoi(e);
 #endif
     if ((rows + rpb - 1) / rpb > maxp) rpb = (rows + maxp - 1) / maxp;
     return (int)rpb;
@@ -345,13 +345,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const T* __restr
     }
 }
 
-static bool bn_apply_rows() { static const bool on = !(getenv("DIN_BN_APPLY_ROWS") && atoi(getenv("DIN_BN_APPLY_ROWS")) == 0); return on; }
+static bool bn_apply_rows() { static const bool on = !(DIN_OPT("DIN_BN_APPLY_ROWS") && atoi(DIN_OPT("DIN_BN_APPLY_ROWS")) == 0); return on; }
 // rows per workgroup of the row-walk apply kernels: ~2048 workgroups, at least four passes of the workgroup's 256 / (C / V) rows each
 static int bn_apply_rpb(int64_t rows, int c, int v) {
     const int rpp = 256 / (c / v);
     int64_t wgs = 2048;
 #ifdef DIN_EXPERIMENTS
-    if (const char* e = getenv("DIN_BN_APPLY_WGS")) wgs = atoi(e);
+    if (const char* e = DIN_OPT("DIN_BN_APPLY_WGS")) wgs = atoi(e);
 #endif
     int64_t rpb = (rows + wgs - 1) / wgs;
     if (rpb < 4 * rpp) rpb = 4 * rpp;

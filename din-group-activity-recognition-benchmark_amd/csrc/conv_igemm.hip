@@ -2545,7 +2545,7 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype, bool str
     g.nk = (g.Q + KC - 1) / KC;
     g.bn = cprod <= 64 ? 64 : 128;
     g.bm = 128;
-    if (cprod > 64 && !(getenv("DIN_CONV_BN") && atoi(getenv("DIN_CONV_BN")) == 128)) {
+    if (cprod > 64 && !(DIN_OPT("DIN_CONV_BN") && atoi(DIN_OPT("DIN_CONV_BN")) == 128)) {
         // filter-tile width in {96,128,160,192}: least padded filters, ties to the wider tile (fewer re-reads of the pixel tile).
         // Inception's 96/160/192/288/384-filter layers otherwise waste 25-37 % of a 128-wide tile.
         // fewest filter tiles first (each tile re-reads the pixel tile), then least padding
@@ -2556,7 +2556,7 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype, bool str
             if (tl < best_tiles || (tl == best_tiles && pad < best_pad)) { best = bnc; best_tiles = tl; best_pad = pad; }
         }
         g.bn = best;
-        if (const char* fb = getenv("DIN_CONV_BN")) { const int v = atoi(fb); if (v == 96 || v == 128 || v == 160 || v == 192 || v == 256) g.bn = v; }   // tuning / test override
+        if (const char* fb = DIN_OPT("DIN_CONV_BN")) { const int v = atoi(fb); if (v == 96 || v == 128 || v == 160 || v == 192 || v == 256) g.bn = v; }   // tuning / test override
         // parity classes of a strided dgrad write every other pixel of dX: each tile's epilogue is a scattered write, and more, narrower
         // tiles per CU overlap it better -- 3 x 96 beats 2 x 160 on the 288-channel stride-2 dgrad (1642 -> 1427 us)
         if (strided_out && g.bn == 160 && cprod % 96 == 0) g.bn = 96;
@@ -2569,7 +2569,7 @@ GatherPlan plan_gather(int M, int cred, int cprod, int taps, int dtype, bool str
     //                                                        workgroup / CU measured 8..25 % SLOWER: no prologue/epilogue overlap)
     g.nk = (taps * g.cpt + KC - 1) / KC;
     const int64_t tiles256 = ((int64_t)M + 255) / 256;
-    const char* force = getenv("DIN_CONV_TILE");
+    const char* force = DIN_OPT("DIN_CONV_TILE");
     if (g.bn == 64) {
         // fp32: 256x64 (4 waves, 2 workgroups / CU).  bf16: 128x64 on 8 waves measured +6..14 % on the 1x1 / dgrad launches, -2.5 % on the
         // 5x5 forward (DIN_CONV_TILE=256 restores 256x64)
@@ -2612,7 +2612,7 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
     if (w.v2) {
         // filter-tile width in {64,96,128,160}: least padding, ties to the wider tile (192 -> 2 x 96, 288 -> 3 x 96, 384 -> 3 x 128)
         if (d->cout <= 64) w.bco = 64;
-        else if (!(getenv("DIN_CONV_BN") && atoi(getenv("DIN_CONV_BN")) == 128)) {
+        else if (!(DIN_OPT("DIN_CONV_BN") && atoi(DIN_OPT("DIN_CONV_BN")) == 128)) {
             // fewest filter tiles first; on a tie keep 128 when cout > 128 (measured: 192 as 2 x 96 is slower than 2 x 128),
             // otherwise the least padded width
             int best = 128, best_tiles = (d->cout + 127) / 128, best_pad = best_tiles * 128;
@@ -2627,7 +2627,7 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
     // stem layers (conv_wgrad_small_kernel): small = 1: 32 -> <=32, 2: 32 -> <=64 (stride 1), 3: image layer (<= 8 channels, stride 2)
     w.small = 0;
     {
-        const char* sv = getenv("DIN_CONV_SMALL");
+        const char* sv = DIN_OPT("DIN_CONV_SMALL");
         const bool want = sv ? atoi(sv) != 0 : true;
         const int64_t M = (int64_t)d->nb * d->oh * d->ow;
         const bool common = want && d->dtype == DIN_BF16 && d->kh == 3 && d->kw == 3 && d->dh == 1 && d->dw == 1 && d->cout % 8 == 0 &&
@@ -2638,7 +2638,7 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
     }
     // narrow mid-network layers (conv_wgrad_halo.hip): small = 4 -- dW stationary in registers, halo tiles, two filter-row classes
     if (!w.small) {
-        const char* hv = getenv("DIN_WGRAD_HALO");
+        const char* hv = DIN_OPT("DIN_WGRAD_HALO");
         const int64_t M = (int64_t)d->nb * d->oh * d->ow;
         int bnt = 0;
         const int hmode = hv ? atoi(hv) : 1;                      // 0: off, 1: launches of >= 128K pixels (12 frames of 87x157 measured +3..34 %), 2: any size (tests)
@@ -2671,7 +2671,7 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
     // ring kernel (BCO x 256 tiles, one workgroup per CU): wide filter banks with enough k columns -- fewest filter tiles, then least padding
     w.ring = 0;
     {
-        const char* rv = getenv("DIN_WGRAD_RING");
+        const char* rv = DIN_OPT("DIN_WGRAD_RING");
         const int mode = rv ? atoi(rv) : 1;
         if (w.v2 && mode && d->cout >= (mode == 2 ? 64 : 112) && w.kcols >= 256) {
             w.ring = 1;
@@ -2685,7 +2685,7 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
             // quarter of the MFMAs); at equal tile height the two-workgroups-per-CU v3 kernel is faster
             // (8-wave ring: +25..40 % on 192-row banks, +5..11 % on exact 128 / 256-row banks, behind v3 when rows or k columns pad)
             const int kpad = pad_to(w.kcols, 256);
-            const char* pe = getenv("DIN_WGRAD_PIPE");
+            const char* pe = DIN_OPT("DIN_WGRAD_PIPE");
             const int pipe_mode = pe ? atoi(pe) : 1;
             if (pipe_mode == 1) {
                 // wide banks run the pipelined kernel with rows padded to the next of {128, 192, 256} whatever their k-column padding:
@@ -2700,7 +2700,7 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
                 // (row padding above 15 % -- the 160-row banks as 192 -- measured +5 % only: those stay on the round-1 choice below)
                 // allowed row padding in percent: 20 admits the 160-row banks of Mixed_6c / 6d (160 -> 192 rows: 168 -> 155 us per launch
                 // against conv_wgrad_bf16_kernel<160>, steady-state clocks; profiles/r03_power_clocks.txt).  DIN_WGRAD_PIPE_PAD: tuning aid
-                const char* ppv = getenv("DIN_WGRAD_PIPE_PAD");
+                const char* ppv = DIN_OPT("DIN_WGRAD_PIPE_PAD");
                 const int pad_pct = ppv ? atoi(ppv) : 20;
                 if (pp * 100 <= d->cout * (100 + pad_pct)) w.bco = pb;
                 else if (best_pad * 100 <= d->cout * 105 && (best == 192 || kpad * 100 <= w.kcols * 112)) w.bco = best;
@@ -2711,15 +2711,15 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
     }
     int ring_bk = 256;
     {
-        const char* rv = getenv("DIN_WGRAD_RING");
+        const char* rv = DIN_OPT("DIN_WGRAD_RING");
         const int mode = rv ? atoi(rv) : 1;
         // 64 / 96-row banks: the 8-wave ring with 128 k columns (two workgroups per CU) beats v3 by ~20 %; 128 rows: equal, 160: behind
         if (!w.ring && w.v2 && mode != 0 && (mode == 3 || w.bco == 64 || w.bco == 96)) { w.ring = 1; ring_bk = 128; }
     }
     const int bk = w.ring ? ring_bk : WG_TILE;
     {   // BCO x 256 ring tiles whose wave tile is whole 32x32 MFMA tiles run the software-pipelined kernel (conv_wgrad_pipe.hip)
-        const char* pe = getenv("DIN_WGRAD_PIPE");          // (read per call: the tests switch them inside one process)
-        const char* ae = getenv("DIN_WGRAD_ATOMIC");
+        const char* pe = DIN_OPT("DIN_WGRAD_PIPE");          // (read per call: the tests switch them inside one process)
+        const char* ae = DIN_OPT("DIN_WGRAD_ATOMIC");
         const int pipe_env = pe ? atoi(pe) : 1, atomic_env = ae ? atoi(ae) : 0;   // 0: ring kernel, 1: pipe (wide choice), 3: pipe (round-1 tile choice)
         if (w.ring && ring_bk == 256 && (w.bco == 128 || w.bco == 192 || w.bco == 256) && pipe_env) { w.pipe = 1; w.atomic = atomic_env; }
     }
@@ -2733,7 +2733,7 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
     int tiles = w.n_co_tiles * w.n_k_tiles;
     // v2/v3 kernels: ~4 workgroups per CU; short reductions (small per-GPU batch) take 2 -- every workgroup writes a full partial tile, so
     // halving them halves the partial traffic (4-clip step 12.47 -> 12.14 ms).  The ring kernel sets its own count below.
-    static const int want_env = getenv("DIN_WGRAD_BLOCKS") ? atoi(getenv("DIN_WGRAD_BLOCKS")) : 0;
+    static const int want_env = DIN_OPT("DIN_WGRAD_BLOCKS") ? atoi(DIN_OPT("DIN_WGRAD_BLOCKS")) : 0;
     const int want_total = want_env > 0 ? want_env : (M < 128 * 1024 ? 512 : 1024);
     int want = (want_total + tiles - 1) / tiles;
     if (w.ring) {                                      // one resident workgroup per CU: a single full round (or two for long slices)
@@ -2780,7 +2780,7 @@ static void raise_lds_limit(K kern, size_t lds) { din_raise_lds(reinterpret_cast
 
 struct HaloPlan { int bn, th, tw, nsw, nwv, n_co_tiles; size_t lds; };
 static bool plan_halo(int dtype, int kh, int kw, int cred, int cprod, int oh, int ow, int64_t M, HaloPlan& hp) {
-    const char* hv = getenv("DIN_CONV_HALO");
+    const char* hv = DIN_OPT("DIN_CONV_HALO");
     if (hv && atoi(hv) == 0) return false;
     if (dtype != DIN_BF16 || cred < 32 || cred % 8 != 0 || cprod % 8 != 0 || cprod < 40 || M < 64 * 1024) return false;
     const bool k33 = kh == 3 && kw == 3, k17 = kh == 1 && kw == 7, k71 = kh == 7 && kw == 1;
@@ -2804,7 +2804,7 @@ static bool plan_halo(int dtype, int kh, int kw, int cred, int cprod, int oh, in
     hp.nsw = 3;
     hp.lds = 2 * hbytes + 3 * wbytes;
     {   // sixteen waves (3x3 tiles only): transfers cover 16 KiB, the filter ring shrinks to two slots to stay inside 160 KiB
-        const char* wv = getenv("DIN_HALO_WAVES");
+        const char* wv = DIN_OPT("DIN_HALO_WAVES");
         const int want = wv ? atoi(wv) : 16;
         const size_t hb16 = (size_t)((hpx * 10 + 1023) / 1024) * 16384, wb16 = (size_t)((hp.bn * 10 + 1023) / 1024) * 16384;
         if (want == 16 && k33 && 2 * hb16 + 2 * wb16 <= 160 * 1024) {
@@ -2821,7 +2821,7 @@ void launch_fast(const ConvK& k, dim3 grid, hipStream_t st) {
     size_t stage = (size_t)NS * (BMT + BNP_) * KCS * 16 + (k.remap ? 128 : 0);   // stage ring (+ remap table)
     // a single k-step (1x1 layers with <= 64 input channels: Conv2d_3b, the 64-channel dgrads) only ever touches ring stage 0: ask for one
     // stage, so that more of these memory-bound workgroups are resident per CU and their loads / stores overlap (DIN_CONV_ONESTAGE=0: off)
-    static const bool one_stage_ok = !(getenv("DIN_CONV_ONESTAGE") && atoi(getenv("DIN_CONV_ONESTAGE")) == 0);
+    static const bool one_stage_ok = !(DIN_OPT("DIN_CONV_ONESTAGE") && atoi(DIN_OPT("DIN_CONV_ONESTAGE")) == 0);
     if (one_stage_ok && !k.remap && k.xsteps == 0 && k.ks_per_split * (8 / KCS) <= 1) stage = (size_t)(BMT + BNP_) * KCS * 16;
     size_t epi = (size_t)BMT * (BN * sizeof(T) + 16);
     size_t lds = stage > epi ? stage : epi;
@@ -2835,13 +2835,13 @@ void launch_fast(const ConvK& k, dim3 grid, hipStream_t st) {
 template <typename T, int BN>
 void launch_wave8(const ConvK& k, dim3 grid, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
-        const char* fv = getenv("DIN_CONV_FASTK");
+        const char* fv = DIN_OPT("DIN_CONV_FASTK");
         const bool want = fv ? atoi(fv) != 0 : true;
         const bool fastk = want && !k.remap && k.nsrc == 0 && (k.cpt % 8) == 0 && (k.korder || k.kh * k.kw == 1);
         if constexpr (BN == 192) {
             // wave grid 2 x 4 (64 pixels x 48 filters per wave: 4 + 3 fragments per 12 MFMAs) instead of 4 x 2 (32 x 96: 2 + 6): an eighth
             // fewer LDS fragment reads for the same tile (experiment switch DIN_CONV_WAVEGRID=24)
-            static const bool grid24 = getenv("DIN_CONV_WAVEGRID") && atoi(getenv("DIN_CONV_WAVEGRID")) == 24;
+            static const bool grid24 = DIN_OPT("DIN_CONV_WAVEGRID") && atoi(DIN_OPT("DIN_CONV_WAVEGRID")) == 24;
             if (grid24) {
                 if (fastk) launch_fast<T, 128, BN, 2, 4, 8, 2, true>(k, grid, st);
                 else launch_fast<T, 128, BN, 2, 4, 8, 2>(k, grid, st);
@@ -2850,7 +2850,7 @@ void launch_wave8(const ConvK& k, dim3 grid, hipStream_t st) {
         }
 #ifdef DIN_EXPERIMENTS
         if constexpr (BN >= 128) {
-            static const bool wg3 = getenv("DIN_CONV_WG3") && atoi(getenv("DIN_CONV_WG3")) == 1;
+            static const bool wg3 = DIN_OPT("DIN_CONV_WG3") && atoi(DIN_OPT("DIN_CONV_WG3")) == 1;
             if (fastk && wg3) { launch_fast<T, 128, BN, 2, 2, 4, 2, true>(k, grid, st); return; }
         }
 #endif
@@ -2863,7 +2863,7 @@ void launch_wave8(const ConvK& k, dim3 grid, hipStream_t st) {
         // experiment switch DIN_CONV_RING=3: three 32-deep stages (two in flight, one counted vmcnt per barrier) instead of two 64-deep ones
         // (one in flight, vmcnt(0)) for the general loop's 8-wave tiles -- same LDS budget (72 vs 80 KiB per workgroup), half the MFMAs per barrier
         #ifdef DIN_EXPERIMENTS
-        static const bool ring3 = getenv("DIN_CONV_RING") && atoi(getenv("DIN_CONV_RING")) == 3;
+        static const bool ring3 = DIN_OPT("DIN_CONV_RING") && atoi(DIN_OPT("DIN_CONV_RING")) == 3;
 #else
         constexpr bool ring3 = false;
 #endif
@@ -2875,7 +2875,7 @@ void launch_wave8(const ConvK& k, dim3 grid, hipStream_t st) {
 template <typename T, int BN>
 void launch_fast_multi(const ConvK& k, dim3 grid, hipStream_t st) {
     size_t epi = (size_t)128 * (BN * sizeof(T) + 16);
-    const char* pv = getenv("DIN_CONV_PIPE");
+    const char* pv = DIN_OPT("DIN_CONV_PIPE");
     if (sizeof(T) == 2 && (BN % 64 == 0 || (pv && atoi(pv) == 8)) && !(pv && atoi(pv) == 4)) {   // 8 waves (bf16) where the filter tile is whole 64-row loader passes
         size_t stage8 = (size_t)2 * (128 + (BN + 63) / 64 * 64) * 8 * 16;
         size_t lds8 = stage8 > epi ? stage8 : epi;
@@ -2913,7 +2913,7 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
     // ring geometry per tile, from A/B runs of tools/conv_bench.py (DIN_CONV_PIPE=0/1 switches the alternatives):
     //   256x64  : 4 stages x 4 chunks (80 KiB)  -- short-K, latency-bound launches gain 9 % from the deeper ring
     //   others  : 2 stages x 8 chunks           -- MFMA-dense tiles lose 8-10 % when the stage (and the barrier interval) is halved
-    const char* pv = getenv("DIN_CONV_PIPE");
+    const char* pv = DIN_OPT("DIN_CONV_PIPE");
     const int pipe = pv ? atoi(pv) : -1;
     if (bm == 256 && bn == 64) { if (pipe != 0) launch_fast<T, 256, 64, 4, 1, 4, 4>(k, grid, st); else launch_fast<T, 256, 64, 4, 1, 8, 2>(k, grid, st); }
     else if (bm == 256 && bn == 256) {
@@ -2925,8 +2925,8 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
 #ifdef DIN_EXPERIMENTS
             // experiment (round 4, DIN_CONV_W16=1 with DIN_CONV_TILE=256): the 256-pixel sixteen-wave tile for the 160- / 128-filter 7-tap layers
             // (Mixed_6b-6d: 98 / 85 instead of 71 / 64 FLOP per staged byte)
-            else if ((bn == 160 || bn == 128) && getenv("DIN_CONV_W16") && atoi(getenv("DIN_CONV_W16")) == 1) {
-                const char* fv = getenv("DIN_CONV_FASTK");
+            else if ((bn == 160 || bn == 128) && DIN_OPT("DIN_CONV_W16") && atoi(DIN_OPT("DIN_CONV_W16")) == 1) {
+                const char* fv = DIN_OPT("DIN_CONV_FASTK");
                 const bool fastk = (fv ? atoi(fv) != 0 : true) && !k.remap && k.nsrc == 0 && (k.cpt % 8) == 0 && (k.korder || k.kh * k.kw == 1);
                 if (bn == 160) { if (fastk) launch_fast<T, 256, 160, 8, 2, 8, 2, true>(k, grid, st); else launch_fast<T, 256, 160, 8, 2, 8, 2>(k, grid, st); }
                 else { if (fastk) launch_fast<T, 256, 128, 8, 2, 8, 2, true>(k, grid, st); else launch_fast<T, 256, 128, 8, 2, 8, 2>(k, grid, st); }
@@ -2937,11 +2937,11 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
                 // experiment (DIN_CONV_W16=1 with DIN_CONV_TILE=256): sixteen waves as 8 x 2 on the 256 x 192 tile -- the 128 x 192 kernel's wave
                 // tile and four waves per SIMD, but ONE filter stage per 256 pixels: 64 instead of 80 LDS-DMA transfers per 256-pixel k-step
                 #ifdef DIN_EXPERIMENTS
-                static const bool w16 = getenv("DIN_CONV_W16") && atoi(getenv("DIN_CONV_W16")) == 1;
+                static const bool w16 = DIN_OPT("DIN_CONV_W16") && atoi(DIN_OPT("DIN_CONV_W16")) == 1;
 #else
                 constexpr bool w16 = false;
 #endif
-                const char* fv = getenv("DIN_CONV_FASTK");
+                const char* fv = DIN_OPT("DIN_CONV_FASTK");
                 const bool fastk = (fv ? atoi(fv) != 0 : true) && !k.remap && k.nsrc == 0 && (k.cpt % 8) == 0 && (k.korder || k.kh * k.kw == 1);
                 if (w16 && fastk) launch_fast<T, 256, 192, 8, 2, 8, 2, true>(k, grid, st);
                 else if (w16) launch_fast<T, 256, 192, 8, 2, 8, 2>(k, grid, st);
@@ -2974,7 +2974,7 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
 // on 1x1 / 1x7 forwards and on every dgrad (one workgroup per CU: no prologue / epilogue overlap; 64-byte instead of 128-byte gather
 // segments per pixel), 520 vs 523 clips/s end to end (profiles/r02_gather_pipe_experiment.txt).
 bool want_gather_pipe(int dtype, int64_t M, int cred, int taps, int bn, int splitk, int n_co_tiles) {
-    const char* ev = getenv("DIN_GATHER_PIPE");
+    const char* ev = DIN_OPT("DIN_GATHER_PIPE");
     const int mode = ev ? atoi(ev) : 0;
     if (!mode || dtype != DIN_BF16 || cred % 32 != 0 || taps > 32 || taps < 1 || splitk != 1 || !din_gather::gather_pipe_tile_ok(bn)) return false;
     const int64_t tiles = (M + 255) / 256 * n_co_tiles;
@@ -2991,19 +2991,19 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
     k.cpt = g.cpt; k.Q = g.Q; k.nk = g.nk;
     if (!k.remap) k.wld = g.nk * KC;
     {
-        const char* ko = getenv("DIN_CONV_KORDER");
+        const char* ko = DIN_OPT("DIN_CONV_KORDER");
         const bool want = ko ? atoi(ko) != 0 : true;
         k.korder = (want && fast && !k.remap && g.splitk == 1 && (g.cpt % KC) == 0 && k.kh * k.kw > 1) ? 1 : 0;
     }
     k.splitk = g.splitk; k.ks_per_split = g.ks_per_split; k.n_co_tiles = g.n_co_tiles;
-    if (const char* eb = getenv("DIN_CONV_EPI_BATCH")) { if (atoi(eb) == 0) k.flags |= 0x100; }
+    if (const char* eb = DIN_OPT("DIN_CONV_EPI_BATCH")) { if (atoi(eb) == 0) k.flags |= 0x100; }
     // timing experiments only (results are WRONG): DIN_GATHER_KNOCK bit 0 = the pixel-tile transfers of the scalar-walk loop fetch nothing
     // (all lanes out of range: issued, landed as zeros, no cache / HBM access), bit 1 = the same for the filter tile, bit 2 = no MFMA
     // -- only in -DDIN_EXPERIMENTS builds (conv_gather.h)
 #ifdef DIN_EXPERIMENTS
-    if (const char* kn = getenv("DIN_GATHER_KNOCK")) k.flags |= (atoi(kn) & 7) << 9;
+    if (const char* kn = DIN_OPT("DIN_GATHER_KNOCK")) k.flags |= (atoi(kn) & 7) << 9;
 #endif
-    if (getenv("DIN_DEBUG_PLAN"))
+    if (DIN_OPT("DIN_DEBUG_PLAN"))
         fprintf(stderr, "[din] %s M=%d NB=%d HxW=%dx%d Cin=%d Cout=%d k=%dx%d ay=%d cy=%d tile=%dx%d splitk=%d korder=%d remap=%d flags=%d dtype=%d\n", what,
                 k.M, k.NB, k.H, k.W, k.Cin, k.Cout, k.kh, k.kw, k.ay, k.cy, g.bm, g.bn, g.splitk, k.korder, k.remap, k.flags, dtype);
     if (k.csplit > 0 && (!fast || g.splitk > 1)) DIN_FAIL(DIN_E_ARG, "%s: two destinations need the staged epilogue of the buffer-addressed kernel", what);
@@ -3054,7 +3054,7 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
     }
     {
         // stem layers: stationary filters + halo tiles (conv_small_kernel)
-        const char* sv = getenv("DIN_CONV_SMALL");
+        const char* sv = DIN_OPT("DIN_CONV_SMALL");
         const bool want = sv ? atoi(sv) != 0 : true;
         const bool common = want && dtype == DIN_BF16 && fast && !k.remap && k.nsrc == 0 && k.csplit == 0 && g.splitk == 1 && k.kh == 3 && k.kw == 3 &&
                             k.Cout <= 64 && k.Cout % 8 == 0 && k.cooff % 8 == 0 && k.ldo % 8 == 0 && k.ldi % 8 == 0 && k.cioff % 8 == 0 &&
@@ -3076,10 +3076,10 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
             const size_t lds = (size_t)(image ? 3 * bnS * 64 : 9 * bnS * g.cpt * 16) + (size_t)nbuf * hbytes + (k.u8 ? 512 : 0);   // (+ the uint8 -> bf16 table)
             dim3 grid(512);
             // dgrad launches with a mask / accumulate operand: the variant that requests them a tile phase early (DIN_CONV_SMALL_EPI=0: in the store loop)
-            const bool epi = (k.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM)) && !(getenv("DIN_CONV_SMALL_EPI") && atoi(getenv("DIN_CONV_SMALL_EPI")) == 0);
+            const bool epi = (k.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM)) && !(DIN_OPT("DIN_CONV_SMALL_EPI") && atoi(DIN_OPT("DIN_CONV_SMALL_EPI")) == 0);
             // the image layer's 42 KiB workgroups fit three to a CU: 768 persistent workgroups measured 690 -> 618 us on the 96 frames
             // (1024: no better, four do not fit); DIN_CONV_IMAGE_GRID overrides
-            if (image) { const char* gv = getenv("DIN_CONV_IMAGE_GRID"); grid.x = gv && atoi(gv) > 0 ? atoi(gv) : 768; }
+            if (image) { const char* gv = DIN_OPT("DIN_CONV_IMAGE_GRID"); grid.x = gv && atoi(gv) > 0 ? atoi(gv) : 768; }
             auto launch = [&](auto kern) {
                 if (lds > 65536) raise_lds_limit(kern, lds);
                 hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, st, k);
@@ -3091,7 +3091,7 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
             }
             else {
                 // the two 80 KiB variants (one workgroup per CU) run on eight waves; DIN_CONV_SMALL_WAVES=4 restores four
-                const bool w8 = !(getenv("DIN_CONV_SMALL_WAVES") && atoi(getenv("DIN_CONV_SMALL_WAVES")) == 4);
+                const bool w8 = !(DIN_OPT("DIN_CONV_SMALL_WAVES") && atoi(DIN_OPT("DIN_CONV_SMALL_WAVES")) == 4);
                 auto launch8 = [&](auto kern) {
                     if (lds > 65536) raise_lds_limit(kern, lds);
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, k);
@@ -3135,8 +3135,8 @@ static int launch_colsum(int dtype, const void* g, float* out, int64_t M, int c,
         // Every workgroup ends with `c` float atomics on the SAME few cache lines, which L2 serialises at ~44 ns per workgroup: the kernel's time
         // grew with its workgroup count (1024: 45 us, 2048: 64 us, 4096: 110 us on the 192-channel maps; 256: 30 us -- tools/colsum_probe.py;
         // the seven launches of the default step 335 -> 248 us).  DIN_COLSUM_WGS / DIN_COLSUM_UNROLL: tuning aids
-        static const int wgs = getenv("DIN_COLSUM_WGS") ? atoi(getenv("DIN_COLSUM_WGS")) : 256;
-        static const int unr = getenv("DIN_COLSUM_UNROLL") ? atoi(getenv("DIN_COLSUM_UNROLL")) : 8;
+        static const int wgs = DIN_OPT("DIN_COLSUM_WGS") ? atoi(DIN_OPT("DIN_COLSUM_WGS")) : 256;
+        static const int unr = DIN_OPT("DIN_COLSUM_UNROLL") ? atoi(DIN_OPT("DIN_COLSUM_UNROLL")) : 8;
         int64_t rpb = ceil_div64(M, wgs > 0 ? wgs : 1024);
         if (rpb < 64) rpb = 64;
         int blocks = (int)ceil_div64(M, rpb);
@@ -3184,7 +3184,7 @@ int din_conv_pack_weights(const din_conv_desc* d, const float* w, const float* s
     int rows_pad = pad_to(cprod, 256);
     int64_t total = (int64_t)rows_pad * kelems;
     hipStream_t st = as_stream(stream);
-    if (d->kh == 1 && d->kw == 1 && total >= (1 << 20) && !(getenv("DIN_PACK_TILES") && atoi(getenv("DIN_PACK_TILES")) == 0)) {
+    if (d->kh == 1 && d->kw == 1 && total >= (1 << 20) && !(DIN_OPT("DIN_PACK_TILES") && atoi(DIN_OPT("DIN_PACK_TILES")) == 0)) {
         // (tap-major k = channel index for a single tap; the padded tail of every row / the padded rows are written as zeros)
         dim3 grid((kelems + 63) / 64, (rows_pad + 63) / 64);
         if (d->dtype == DIN_F32) hipLaunchKernelGGL(conv_pack_1x1_kernel<float>, grid, dim3(256), 0, st, w, scale, (float*)wpk, d->cout, d->cin, rows_pad, kelems, transposed);
@@ -3248,7 +3248,7 @@ int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t
     }
     {   // 1x1 layers with a short reduction over a large map run conv1x1_stream_kernel (conv_stream.hip): bm = 4
         // (same conditions as din_gather::conv1x1_stream_eligible, evaluated on the descriptor)
-        const char* sv = getenv("DIN_CONV_STREAM");
+        const char* sv = DIN_OPT("DIN_CONV_STREAM");
         const int mode = sv ? atoi(sv) : 1;
         const int cred = which == 0 ? d->cin : d->cout, cprod = which == 0 ? d->cout : d->cin;
         const int64_t M = which == 0 ? (int64_t)d->nb * d->oh * d->ow : (int64_t)d->nb * d->h * d->w;
@@ -3258,12 +3258,12 @@ int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t
         if (mode && d->dtype == DIN_BF16 && d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 && !d->in_u8 &&
             g.splitk == 1 && cprod % 8 == 0 && ldp % 8 == 0 && offp % 8 == 0 && ldr % 8 == 0 && offr % 8 == 0 &&
             M * ldr * 2 < 0x7fffffffll && M * ldp * 2 < 0x7fffffffll && pad_to(cprod, din_gather::conv1x1_stream_tile(cprod)) * 4 <= 2048 &&
-            (mode == 2 || (blocks <= 6 && M >= (getenv("DIN_CONV_STREAM_MINPIX") ? atoll(getenv("DIN_CONV_STREAM_MINPIX")) : 256 * 1024) && (cprod <= 96 || (cprod <= 192 && which == 0))))) { *bm = 4; *bn = din_gather::conv1x1_stream_tile(cprod); }
+            (mode == 2 || (blocks <= 6 && M >= (DIN_OPT("DIN_CONV_STREAM_MINPIX") ? atoll(DIN_OPT("DIN_CONV_STREAM_MINPIX")) : 256 * 1024) && (cprod <= 96 || (cprod <= 192 && which == 0))))) { *bm = 4; *bn = din_gather::conv1x1_stream_tile(cprod); }
     }
     {   // stem layers run conv_small_kernel (same conditions as run_gather, for tensors with 16-byte aligned channel offsets): bm = 0
         const int cred = which == 0 ? d->cin : d->cout, cprod = which == 0 ? d->cout : d->cin;
         const int64_t M = which == 0 ? (int64_t)d->nb * d->oh * d->ow : (int64_t)d->nb * d->h * d->w;
-        const char* sv = getenv("DIN_CONV_SMALL");
+        const char* sv = DIN_OPT("DIN_CONV_SMALL");
         if ((sv ? atoi(sv) != 0 : true) && d->dtype == DIN_BF16 && d->kh == 3 && d->kw == 3 && d->sh == 1 && d->sw == 1 && d->dh == 1 &&
             d->dw == 1 && (cred == 32 || cred == 64) && cprod <= 64 && cprod % 8 == 0 && !(cred == 64 && cprod > 32) && g.splitk == 1 &&
             M >= 256 * 1024) { *bm = 0; *bn = cprod <= 32 ? 32 : 64; }
@@ -3279,7 +3279,7 @@ int din_conv_kernel_variant(const din_conv_desc* d, int which, int32_t* flags) {
     if (int e = din_conv_kernel_tile(d, which, &bm, &bn)) return e;
     *flags = 0;
     if (bm != 128 || d->dtype != DIN_BF16) return DIN_OK;          // the 8-wave / FASTK instantiations exist for bf16 128 x BN tiles only
-    const char* pv = getenv("DIN_CONV_PIPE");
+    const char* pv = DIN_OPT("DIN_CONV_PIPE");
     const int pipe = pv ? atoi(pv) : -1;
     const bool strided = which == 1 && (d->sh > 1 || d->sw > 1);
     const bool wave8 = ((bn == 64 || bn == 128 || bn == 160 || bn == 192) && pipe != 4 && pipe != 1) ||
@@ -3289,8 +3289,8 @@ int din_conv_kernel_variant(const din_conv_desc* d, int which, int32_t* flags) {
     const int cpt = pad_to(cred, 8) / 8;
     GatherPlan g = which == 0 ? plan_gather(d->nb * d->oh * d->ow, d->cin, d->cout, ntaps, d->dtype)
                               : plan_gather(d->nb * (strided ? (d->h + d->sh - 1) / d->sh * ((d->w + d->sw - 1) / d->sw) : d->h * d->w), d->cout, d->cin, ntaps, d->dtype, strided);
-    const char* ko = getenv("DIN_CONV_KORDER");
-    const char* fv = getenv("DIN_CONV_FASTK");
+    const char* ko = DIN_OPT("DIN_CONV_KORDER");
+    const char* fv = DIN_OPT("DIN_CONV_FASTK");
     const bool fast = ntaps <= 32 && (which == 0 || (d->sh == 1 && d->sw == 1));      // stride-1 gather: divy == divx == 1, no tap remap
     const bool korder = (ko ? atoi(ko) != 0 : true) && fast && g.splitk == 1 && cpt % KC == 0 && ntaps > 1;
     if (wave8 && fast && cpt % KC == 0 && (korder || ntaps == 1) && (fv ? atoi(fv) != 0 : true)) *flags |= 1;
@@ -3350,9 +3350,9 @@ int din_conv_accepts_u8(const din_conv_desc* d) {
     if (d->cin != 3 || d->cout > 32 || d->cout % 8 != 0 || d->ldo % 8 != 0 || d->cooff % 8 != 0) return 0;
     if ((int64_t)d->nb * d->oh * d->ow < 256 * 1024) return 0;
     if ((long long)d->h * d->w * 16 >= 0x7fffffffll || (long long)d->oh * d->ow * d->ldo * 2 >= 0x7fffffffll) return 0;
-    const char* sv = getenv("DIN_CONV_SMALL");
+    const char* sv = DIN_OPT("DIN_CONV_SMALL");
     if (sv && atoi(sv) == 0) return 0;
-    const char* uv = getenv("DIN_CONV_U8");
+    const char* uv = DIN_OPT("DIN_CONV_U8");
     if (uv && atoi(uv) == 0) return 0;
     din_conv_desc t = *d;
     t.in_u8 = 0; t.ldi = 8; t.cioff = 0;             // the plan of the prepared-tensor form must pick the image-layer wgrad kernel
@@ -3399,7 +3399,7 @@ int din_conv_dgrad(const din_conv_desc* d, const void* dout, const void* wpk_t, 
 // whether the parity-class launches of this strided dgrad can carry an extra 1x1 source (conv_gather_fast_kernel<..., XSRC>: bf16, 128 x 96
 // tiles, no split-K)
 static bool dgrad_x_fused(const din_conv_desc* d) {
-    if (getenv("DIN_DGRAD_X") && atoi(getenv("DIN_DGRAD_X")) == 0) return false;
+    if (DIN_OPT("DIN_DGRAD_X") && atoi(DIN_OPT("DIN_DGRAD_X")) == 0) return false;
     if (d->dtype != DIN_BF16 || !(d->sh > 1 || d->sw > 1) || d->dh != 1 || d->dw != 1 || d->kh * d->kw > 32) return false;
     for (int py = 0; py < d->sh; ++py)
         for (int px = 0; px < d->sw; ++px) {
@@ -3562,7 +3562,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
     k.M = d->nb * d->oh * d->ow; k.n_co_tiles = wp.n_co_tiles; k.n_k_tiles = wp.n_k_tiles;
     k.slices = wp.slices; k.m_per_slice = wp.m_per_slice;
 #ifdef DIN_EXPERIMENTS
-    { const char* pv = getenv("DIN_WGRAD_PROBE"); k.probe = pv ? atoi(pv) : 0; }      // timing probe: results are WRONG when set
+    { const char* pv = DIN_OPT("DIN_WGRAD_PROBE"); k.probe = pv ? atoi(pv) : 0; }      // timing probe: results are WRONG when set
 #else
     k.probe = 0;
 #endif
@@ -3594,7 +3594,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
                 hipLaunchKernelGGL(kern, dim3(WGRAD_SMALL_GRID), dim3(NTHREADS), lds, st, k);
             };
             if (wp.small == 1) launch(conv_wgrad_small_kernel<4, 32, 1>);
-            else if (wp.small == 2 && !(getenv("DIN_WGRAD_SMALL_WAVES") && atoi(getenv("DIN_WGRAD_SMALL_WAVES")) == 4)) {
+            else if (wp.small == 2 && !(DIN_OPT("DIN_WGRAD_SMALL_WAVES") && atoi(DIN_OPT("DIN_WGRAD_SMALL_WAVES")) == 4)) {
                 if (lds > 65536) raise_lds_limit(conv_wgrad_small_kernel<4, 64, 1, false, 8>, lds);
                 hipLaunchKernelGGL((conv_wgrad_small_kernel<4, 64, 1, false, 8>), dim3(WGRAD_SMALL_GRID), dim3(512), lds, st, k);
             }
@@ -3611,7 +3611,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
             if (wp.atomic && hipMemsetAsync(k.partial, 0, sizeof(float) * (size_t)wp.cout_pad * wp.kcols_pad, st) != hipSuccess)
                 DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad: memset");
             {   // sibling pacing words behind the partial tiles (workspace sized for them in plan_wgrad)
-                const char* pe = getenv("DIN_WGRAD_PACE");
+                const char* pe = DIN_OPT("DIN_WGRAD_PACE");
                 const int want = pe ? atoi(pe) : 1;
                 const size_t words = (size_t)wp.slices * wp.n_co_tiles * 8;                 // rows of 8 words (one s_load_dwordx8)
                 // measured (tools/pace_experiment.sh, profiles/r02_wgrad_pacing.txt): Conv2d_4a (3 k tiles) 6.67 -> 3.12 GB fetched per launch at
@@ -3627,7 +3627,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
             }
             // one slice of a 1x1 layer, nothing for the reduce launch to do (no scale, no <w, dW>, no accumulate, no channel padding): straight into dW
             if (wp.slices == 1 && !wp.atomic && d->kh * d->kw == 1 && !scale && !wdot && !accumulate && wp.cin_pad == d->cin &&
-                !(getenv("DIN_WGRAD_DIRECT") && atoi(getenv("DIN_WGRAD_DIRECT")) == 0)) k.direct = dw;
+                !(DIN_OPT("DIN_WGRAD_DIRECT") && atoi(DIN_OPT("DIN_WGRAD_DIRECT")) == 0)) k.direct = dw;
             if (int e = din_wgrad::launch_wgrad_pipe(k, wp.bco, wp.bk, grid, st)) return e;
         } else if (wp.ring) {
             if (dbias) {
@@ -3687,7 +3687,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
 }
 
 static bool wgrad_multi_plan(int nsrc, const din_conv_wsrc* srcs, int dtype, int64_t pixels, int cin, din_wgrad::Wg1x1K* k) {
-    const char* ev = getenv("DIN_WGRAD_1X1_MULTI");
+    const char* ev = DIN_OPT("DIN_WGRAD_1X1_MULTI");
     const int mode = ev ? atoi(ev) : 1;                        // 0: off, 1: launches of >= 128K pixels, 2: any size (tests)
     if (!mode || dtype != DIN_BF16 || !srcs || nsrc < 2 || nsrc > 4 || (pixels < 128 * 1024 && mode != 2) || pixels <= 0) return false;
     int couts[4];

@@ -335,7 +335,7 @@ template <int BN, int NSW> constexpr size_t stream_lds_bytes() { return (size_t)
 }  // namespace
 
 // 0: never, 1: where measured to win (default), 2: every eligible launch (tests)
-static int stream_mode() { const char* e = getenv("DIN_CONV_STREAM"); return e ? atoi(e) : 1; }
+static int stream_mode() { const char* e = DIN_OPT("DIN_CONV_STREAM"); return e ? atoi(e) : 1; }
 
 bool conv1x1_stream_eligible(const ConvK& k, int dtype) {
     const int mode = stream_mode();
@@ -364,9 +364,9 @@ bool conv1x1_stream_eligible(const ConvK& k, int dtype) {
     // tiles every tile re-streams the pixels through the ring and the 128-pixel kernel is as fast or faster; the 192-filter tile (3-slot ring)
     // pays for forward launches only
     const bool plain_fwd = k.nsrc == 0 && !(k.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM));
-    const char* wv = getenv("DIN_CONV_STREAM_WIDE");                                 // 0: never the 192-filter tile
+    const char* wv = DIN_OPT("DIN_CONV_STREAM_WIDE");                                 // 0: never the 192-filter tile
     const bool wide = wv ? atoi(wv) != 0 : true;
-    const char* mp = getenv("DIN_CONV_STREAM_MINPIX");
+    const char* mp = DIN_OPT("DIN_CONV_STREAM_MINPIX");
     const long long minpix = mp ? atoll(mp) : 256 * 1024;
     return blocks <= 6 && (long long)k.M >= minpix && (k.Cout <= 96 || (k.Cout <= 192 && plain_fwd && wide));
 }
@@ -388,7 +388,7 @@ static void launch_stream_bn(const ConvK& k, dim3 grid, hipStream_t st) {
 }
 
 int conv1x1_stream_tile(int cout) {
-    const char* e = getenv("DIN_CONV_STREAM_BN");                      // tuning aid: force the filter tile (64 | 96 | 192)
+    const char* e = DIN_OPT("DIN_CONV_STREAM_BN");                      // tuning aid: force the filter tile (64 | 96 | 192)
     if (e && (atoi(e) == 64 || atoi(e) == 96 || atoi(e) == 192)) return atoi(e);
     return cout <= 64 ? 64 : cout <= 96 ? 96 : 192;
 }

@@ -399,7 +399,7 @@ int launch_wgrad_pipe(const WgradK& k, int bco, int bk, dim3 grid, hipStream_t s
     const size_t lds = wgrad_pipe_lds_bytes(bco, bk);
     // wave grid of the workgroup: 2 x 8 (sixteen waves, four per SIMD, (BCO/2) x 32 wave tiles; default: +6 % on the dominant kernel inside
     // the training step over 2 x 4, whose 60 % fewer fragment reads do not matter), DIN_WGRAD_PIPE_WAVES=8: 2 x 4, =4: 2 x 2 (-13 %)
-    const char* wv = getenv("DIN_WGRAD_PIPE_WAVES");
+    const char* wv = DIN_OPT("DIN_WGRAD_PIPE_WAVES");
     const int waves = wv ? atoi(wv) : 16;
     const bool four = waves == 4 && bco <= 192, sixteen = waves == 16;   // (the four-wave 256-row tile spills: scratch traffic would break the vmcnt count)
     auto launch = [&](auto kern, int threads) {

@@ -347,7 +347,7 @@ int din_walk_bwd(const float* x, const float* pred, int cp, const float* a, cons
     const size_t tile_b = (size_t)p.hp * p.wp * CH * sizeof(float), tab_b = (size_t)t * n * 3 * p.k2 * sizeof(float);
     // feature gradient scattered straight into dx (fp32 L2 atomics): measured 320 -> 118 us on 32 clips x 36 positions against the LDS dP tile,
     // whose ds_add_f32 traffic alone cost 230 us (a knock-out of the LDS atomics: 95 us).  DIN_WALK_BWD_GLOBAL=0 keeps the LDS tile when it fits.
-    const char* gx = getenv("DIN_WALK_BWD_GLOBAL");
+    const char* gx = DIN_OPT("DIN_WALK_BWD_GLOBAL");
     const bool global_dx = 2 * tile_b + tab_b > 160 * 1024 || !(gx && atoi(gx) == 0);
     const size_t lds = (global_dx ? 1 : 2) * tile_b + tab_b;
     DIN_REQUIRE(lds <= 160 * 1024, "din_walk_bwd: T x N grid too large for one LDS tile (%zu bytes)", lds);
@@ -363,7 +363,7 @@ int din_walk_bwd(const float* x, const float* pred, int cp, const float* a, cons
     // position (the round-1 launch) cost 298 us on 32 clips x 36 positions, almost all of it re-staging.  DIN_WALK_BWD_GROUPS overrides.
     const int full = (t * n + WALK_BWD_WAVES - 1) / WALK_BWD_WAVES;
     int ngroups = (1024 + b * nchunks - 1) / (b * nchunks);
-    { const char* gv = getenv("DIN_WALK_BWD_GROUPS"); if (gv && atoi(gv) > 0) ngroups = atoi(gv); }
+    { const char* gv = DIN_OPT("DIN_WALK_BWD_GROUPS"); if (gv && atoi(gv) > 0) ngroups = atoi(gv); }
     if (ngroups > full) ngroups = full;
     p.ngroups = ngroups;
     if (global_dx) hipLaunchKernelGGL(din_walk_bwd_kernel<true>, dim3(b * nchunks * ngroups), dim3(WALK_BWD_WAVES * 64), lds, st, p);

@@ -947,14 +947,14 @@ int check_pool(const din_pool_desc* d, const char* what) {
     DIN_REQUIRE(d->nb > 0 && d->h > 0 && d->w > 0 && d->oh > 0 && d->ow > 0 && d->c > 0, "%s: empty tensor", what);
     return DIN_OK;
 }
-inline int avgpool_strip_rows() { const char* e = getenv("DIN_AVGPOOL_STRIP"); return e ? atoi(e) : 1; }   // 0: one thread per output (round 1)
+inline int avgpool_strip_rows() { const char* e = DIN_OPT("DIN_AVGPOOL_STRIP"); return e ? atoi(e) : 1; }   // 0: one thread per output (round 1)
 inline bool is_box3(const din_pool_desc* d) { return d->k == 3 && d->stride == 1 && d->pad == 1 && d->oh == d->h && d->ow == d->w; }
-inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-inline bool maxpool_rows() { const char* e = getenv("DIN_MAXPOOL_ROWS"); return e ? atoi(e) != 0 : true; }
+inline int pool_grid_cap() { const char* e = DIN_OPT("DIN_POOL_GRID_CAP"); return e ? atoi(e) : 32768; }
+inline bool maxpool_rows() { const char* e = DIN_OPT("DIN_MAXPOOL_ROWS"); return e ? atoi(e) != 0 : true; }
 
 }  // namespace
 
-#define POOL_LAUNCH(kern, total, ...) hipLaunchKernelGGL(kern, dim3(grid_1d(total, 256, env_int("DIN_POOL_GRID_CAP", 32768))), dim3(256), 0, as_stream(stream), __VA_ARGS__)
+#define POOL_LAUNCH(kern, total, ...) hipLaunchKernelGGL(kern, dim3(grid_1d(total, 256, pool_grid_cap())), dim3(256), 0, as_stream(stream), __VA_ARGS__)
 
 extern "C" {
 
@@ -967,7 +967,7 @@ int din_maxpool_fwd(const din_pool_desc* d, const void* in, void* out, uint8_t* 
     const Dec3 dd = make_dec(d->c / v, d->ow, d->oh, total);
     // column strips for the wide maps (measured, tools/pool_bench.py: 192 ch 570 -> 537 us, 288 ch 285 -> 201 us; 64 ch 864 -> 1027 us: not there);
     // DIN_MAXPOOL_STRIP=0 / 2: never / always
-    const char* ms = getenv("DIN_MAXPOOL_STRIP");
+    const char* ms = DIN_OPT("DIN_MAXPOOL_STRIP");
     const int strip_mode = ms ? atoi(ms) : 1;
     // row kernels (scalar row bases, max3 with the tap in the low mantissa bits): tools/pool_bench.py; DIN_MAXPOOL_ROWS=0: the kernels below
     const bool strip = v == 8 && d->k == 3 && d->stride == 2 && strip_mode != 0 && (d->c >= 128 || strip_mode == 2);
@@ -1098,7 +1098,7 @@ int din_bilinear_fwd(const din_pool_desc* d, const void* in, void* out, void* st
     if (int e = check_pool(d, "bilinear_fwd")) return e;
     DIN_REQUIRE(in && out, "bilinear_fwd: null pointer");
     const int v = wide8(d) ? 8 : 4;
-    const char* ce = getenv("DIN_BILINEAR_CELLS");
+    const char* ce = DIN_OPT("DIN_BILINEAR_CELLS");
     const int cells_env = ce ? atoi(ce) : 1;
     if (cells_env && d->oh >= d->h && d->ow >= d->w && d->h > 1 && d->w > 1) {          // up-sampling: one thread per source cell
         const int64_t total = (int64_t)d->nb * d->h * d->w * (d->c / v);
@@ -1123,7 +1123,7 @@ int din_bilinear_bwd(const din_pool_desc* d, const void* dout, void* din_, const
     const Dec3 dd = make_dec(d->c / v, d->w, d->h, total);
     // candidate window per axis: outputs with source coordinate in (i - 1, i + 1) -> at most 2 / scale + 3 of them
     const float scy = d->oh > 1 ? (float)(d->h - 1) / (float)(d->oh - 1) : 0.f, scx = d->ow > 1 ? (float)(d->w - 1) / (float)(d->ow - 1) : 0.f;
-    const char* he = getenv("DIN_BILINEAR_HOIST");
+    const char* he = DIN_OPT("DIN_BILINEAR_HOIST");
     const bool hoist = (he ? atoi(he) != 0 : true) && scy > 0.f && scx > 0.f && 2.f / scy + 3.f <= 8.f && 2.f / scx + 3.f <= 8.f;
     if (hoist) {
         if (v == 8) POOL_LAUNCH((bilinear_bwd_hoisted_kernel<8, 8>), total, *d, dd, dout, din_, mask, accumulate);

@@ -16,7 +16,9 @@
  *    blocks costs nothing).
  *  - dtype: DIN_F32 (parity mode, fp32 storage + fp32 MFMA accumulate) or DIN_BF16 (throughput mode:
  *    bf16 storage, fp32 MFMA accumulate).  Everything after RoIAlign is always fp32.
- *  - stateless and re-entrant: safe from autograd worker threads, concurrently on different streams.
+ *  - stateless and re-entrant: safe from autograd worker threads, concurrently on different streams.  The
+ *    library never reads the process environment: kernel-selection switches used by the tests and the
+ *    tuning tools are process-wide OPTIONS set through din_set_option (unset = the shipped choice).
  */
 #ifndef DIN_HIP_H
 #define DIN_HIP_H
@@ -28,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DIN_ABI_VERSION 7   /* 7: din_conv_dgrad_x (a strided dgrad that carries the 1x1 / stride-1 dgrad of a sibling conv reading the same view).   6: batch-statistics BatchNorm is deterministic: din_bn_stats / din_bn_bwd_stats write per-workgroup fp64 slabs into a workspace (din_bn_workspace), din_bn_finalize / din_bn_reduce add them in slab order -- no atomics, nothing for the caller to zero.   5: dropout seeds take an optional device-side offset (din_layernorm_*, din_act_dropout_*), din_counter_add, din_conv1x1_wgrad_multi.   2: din_walk_* take plain / clamp / n_per_clip; + bn, mask_actors.  3: din_roi_align_* take the box grid and a crop channel range.  4: din_conv_desc.in_u8, context-encoding entry points */
+#define DIN_ABI_VERSION 8   /* 8: din_set_option / din_get_option replace every getenv() of the library (tests select kernels through the ABI; a stray environment variable can no longer change a launch).   7: din_conv_dgrad_x (a strided dgrad that carries the 1x1 / stride-1 dgrad of a sibling conv reading the same view).   6: batch-statistics BatchNorm is deterministic: din_bn_stats / din_bn_bwd_stats write per-workgroup fp64 slabs into a workspace (din_bn_workspace), din_bn_finalize / din_bn_reduce add them in slab order -- no atomics, nothing for the caller to zero.   5: dropout seeds take an optional device-side offset (din_layernorm_*, din_act_dropout_*), din_counter_add, din_conv1x1_wgrad_multi.   2: din_walk_* take plain / clamp / n_per_clip; + bn, mask_actors.  3: din_roi_align_* take the box grid and a crop channel range.  4: din_conv_desc.in_u8, context-encoding entry points */
 
 enum { DIN_F32 = 0, DIN_BF16 = 1 };
 
@@ -44,6 +46,13 @@ int din_abi_version(void);
 const char* din_last_error_string(void);
 /* name of the device code object's target ("gfx950"); lets the host fail loudly on a wrong build */
 const char* din_build_arch(void);
+/* Process-wide tuning / test options ("DIN_CONV_HALO" = "2", ...; value NULL = unset).  They select between kernels that
+ * compute the same result (tests cover every instantiation through them; tools/ A/B them); production code never sets any.
+ * Thread-safe; a launch reads each option it consults exactly once.  The reference has no counterpart (its only knobs are
+ * the Config fields, config.py:10-104, which stay in the Python layer). */
+int din_set_option(const char* name, const char* value);
+/* copies the current value into buf (empty string when unset); returns 1 if set, 0 if unset, negative on error */
+int din_get_option(const char* name, char* buf, int buf_bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * Row P  prep_images  (utils.py:8-19): y = ((x/255) - 0.5) * 2, same three fp32 roundings.

@@ -18,6 +18,28 @@ def golden_dir():
     return GOLDEN
 
 
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """Kernel-selection switches go to the library THROUGH THE C ABI: `monkeypatch.setenv("DIN_...", v)` in a GPU test also calls
+    din_set_option("DIN_...", v) (include/din_hip.h) and the option is restored when the test ends.  libdin_hip.so itself never reads the
+    environment; the environment half of the call remains for the few switches the Python host layer owns
+    (DIN_POOL_COMMUTE, DIN_ROI_COMPOSE, DIN_FUSE_*)."""
+    from din_amd import _lib
+    setenv, touched = monkeypatch.setenv, {}
+
+    def setenv_and_option(name, value, prepend=None):
+        setenv(name, value, prepend)
+        if name.startswith("DIN_") and os.path.exists(_lib.LIB_PATH):
+            if name not in touched:
+                touched[name] = _lib.get_option(name)
+            _lib.set_option(name, value)
+
+    monkeypatch.setenv = setenv_and_option
+    yield monkeypatch
+    for name, old in touched.items():
+        _lib.set_option(name, old)
+
+
 # ---- tolerance margins ---------------------------------------------------------------------------------------------------------------
 # Every error figure / cosine the GPU tests compare against a tolerance is a Measured: comparing it records (test, line, value, bound),
 # and the session writes the worst margin per assert to gpurun_out/test_margins.txt (copied to profiles/rNN_test_margins.txt).  An

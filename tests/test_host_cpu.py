@@ -23,7 +23,26 @@ def test_library_exports_every_header_symbol():
         assert hasattr(lib, n), f"{n} declared in include/din_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes table out of sync with include/din_hip.h"
     loaded = _lib.load()
-    assert loaded.din_abi_version() == _lib.ABI_VERSION == 7 and loaded.din_build_arch() == b"gfx950"
+    assert loaded.din_abi_version() == _lib.ABI_VERSION == 8 and loaded.din_build_arch() == b"gfx950"
+
+
+def test_options_go_through_the_abi_not_the_environment(monkeypatch):
+    """din_set_option / din_get_option (ABI 8): the library holds named options, and nothing in csrc/ calls getenv()."""
+    import glob
+    from din_amd import _lib
+    assert _lib.get_option("DIN_TEST_OPTION") is None
+    _lib.set_option("DIN_TEST_OPTION", 2)
+    assert _lib.get_option("DIN_TEST_OPTION") == "2"
+    _lib.set_option("DIN_TEST_OPTION", None)
+    assert _lib.get_option("DIN_TEST_OPTION") is None
+    with pytest.raises(_lib.DinError):
+        _lib.set_option("NOT_A_DIN_NAME", 1)
+    monkeypatch.setenv("DIN_CONV_HALO", "2")                     # the conftest fixture forwards it ...
+    assert _lib.get_option("DIN_CONV_HALO") == "2"
+    csrc = os.path.join(ROOT, "din-group-activity-recognition-benchmark_amd", "csrc")
+    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.h")):
+        code = "\n".join(l.split("//")[0] for l in open(f).read().splitlines())
+        assert "getenv(" not in code, f"{os.path.basename(f)} reads the process environment"
 
 
 def test_occupancy_critical_kernels_hold_their_register_budgets():

@@ -1,6 +1,8 @@
 // Standalone harness of csrc/conv_line.hip (the loader / consumer tap-line kernel): checks it against a naive fp32 kernel on random
 // operands and times it in steady state.  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o line_probe line_probe.hip
-#include "../../din-group-activity-recognition-benchmark_amd/csrc/conv_line.hip"
+#define DIN_LINE_KNOCK 1
+#include "conv_line32.hip"
+#include "conv_line64.hip"
 #include <vector>
 #include <random>
 #include <cstring>
@@ -84,7 +86,30 @@ int main(int argc, char** argv) {
         k.Cout = c.Cout; k.cpt = cpt; k.ncb = (cpt + 7) / 8; k.taps = c.taps; k.shift0 = c.shift0; k.dshift = c.dshift; k.wld = wld;
         k.flags = c.flags; k.in_bytes = (long long)xin * 2; k.w_bytes = (long long)wel * 2;
         k.n_co_tiles = 1; k.ntiles = (Q + 255) / 256;
-        if (din_line::launch_line(k, c.bn, ncu, 0)) { printf("%s: no kernel\n", c.name); continue; }
+      {   // the 64-channel-stage build (3-slot ring, one stage in flight per loader wave): same operands, timed only
+        din_line64::LineK k6{};
+        k6.in = k.in; k6.w = k.w; k6.out = k.out; k6.bias = k.bias; k6.mask = k.mask; k6.err = d_err; k6.prof = nullptr;
+        k6.L = k.L; k6.OUTER = k.OUTER; k6.HW = k.HW; k6.strideA = k.strideA; k6.strideB = k.strideB; k6.Q = k.Q;
+        k6.ldi = k.ldi; k6.cioff = k.cioff; k6.ldo = k.ldo; k6.cooff = k.cooff; k6.ldm = k.ldm; k6.moff = k.moff;
+        k6.Cout = k.Cout; k6.cpt = k.cpt; k6.ncb = (k.cpt + 7) / 8; k6.taps = k.taps; k6.shift0 = k.shift0; k6.dshift = k.dshift; k6.wld = k.wld;
+        k6.flags = k.flags; k6.in_bytes = k.in_bytes; k6.w_bytes = k.w_bytes;
+        for (int v6 = 0; v6 < 2; ++v6) {
+            if (din_line64::launch_line(k6, c.bn, ncu, 0, v6)) continue;
+            for (int i = 0; i < 20; ++i) din_line64::launch_line(k6, c.bn, ncu, 0, v6);
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            const int n = reps / 2 + 1;
+            hipEventRecord(e0);
+            for (int i = 0; i < n; ++i) din_line64::launch_line(k6, c.bn, ncu, 0, v6);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("%-30s 64-channel stages v%d %8.1f us %7.1f TF\n", c.name, v6, ms * 1e3 / n, 2.0 * Q * c.Cout * c.Cin * c.taps / (ms * 1e3 / n) / 1e6);
+        }
+      }
+      const int variants[] = {0, 1, 2, 17, 18, 20, 23};
+      for (int vi = 0; vi < (&c == &cases[0] ? 7 : (c.bn == 128 ? 3 : 2)); ++vi) {
+        const int variant = variants[vi];
+        hipMemset(dout, 0xff, oel * 2); hipMemset(dmax, 0, 4); hipMemset(dbad, 0, 4);
+        if (din_line::launch_line(k, c.bn, ncu, 0, variant)) { printf("%s: no kernel\n", c.name); continue; }
         hipError_t e = hipDeviceSynchronize();
         int herr = 0; hipMemcpy(&herr, d_err, 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess || herr) { printf("%-30s FAILED: %s, hand-off abort %d\n", c.name, hipGetErrorString(e), herr); if (e != hipSuccess) return 1; }
@@ -95,15 +120,31 @@ int main(int argc, char** argv) {
         // timing: warm, then `reps` back-to-back launches (steady-state clocks need ~0.3 s)
         const int n = (long long)Q * c.Cin * c.taps > 100000000ll ? reps : reps / 4 + 1;
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        for (int i = 0; i < 20; ++i) din_line::launch_line(k, c.bn, ncu, 0);
+        for (int i = 0; i < 20; ++i) din_line::launch_line(k, c.bn, ncu, 0, variant);
         hipEventRecord(e0);
-        for (int i = 0; i < n; ++i) din_line::launch_line(k, c.bn, ncu, 0);
+        for (int i = 0; i < n; ++i) din_line::launch_line(k, c.bn, ncu, 0, variant);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         const double us = ms * 1e3 / n, tf = 2.0 * Q * c.Cout * c.Cin * c.taps / us / 1e6;
         hipMemcpy(&herr, d_err, 4, hipMemcpyDeviceToHost);
-        printf("%-30s %8.1f us %7.1f TF   max |err| %.4f  bad %d / %zu  abort %d\n", c.name, us, tf, maxerr, nbad, oel, herr);
+        printf("%-30s v%-2d %8.1f us %7.1f TF   max |err| %.4f  bad %d / %zu  abort %d\n", c.name, variant, us, tf, maxerr, nbad, oel, herr);
+        if (c.bn == 192 && c.NB > 3 && variant == 0) {                               // instrumented build: where do the waves spend their cycles?
+            const int grid = k.ntiles < ncu ? k.ntiles : ncu;
+            uint32_t* dprof; hipMalloc(&dprof, (size_t)grid * 10 * 8 * 4); hipMemset(dprof, 0, (size_t)grid * 10 * 8 * 4);
+            LineK kp = k; kp.prof = dprof;
+            for (int i = 0; i < 3; ++i) din_line::launch_line(kp, c.bn, ncu, 0);
+            hipDeviceSynchronize();
+            std::vector<uint32_t> hp((size_t)grid * 10 * 8);
+            hipMemcpy(hp.data(), dprof, hp.size() * 4, hipMemcpyDeviceToHost);
+            double cs[5] = {0, 0, 0, 0, 0}, ls[5] = {0, 0, 0, 0, 0};
+            for (int g = 0; g < grid; ++g) for (int w = 0; w < 10; ++w) for (int f = 0; f < 5; ++f) (w < 8 ? cs : ls)[f] += hp[((size_t)g * 10 + w) * 8 + f];
+            for (int f = 0; f < 5; ++f) { cs[f] /= grid * 8.0; ls[f] /= grid * 2.0; }
+            printf("    consumer wave (mean): %.0f cycles total, %.0f waiting on full flags, %.0f epilogue, %.1f stages prefetched, %.1f blocking\n", cs[0], cs[1], cs[2], cs[3], cs[4]);
+            printf("    loader wave   (mean): %.0f cycles total, %.0f waiting on free flags, %.0f waiting for landings, %.0f F items, %.0f P items\n", ls[0], ls[1], ls[2], ls[3], ls[4]);
+            hipFree(dprof);
+        }
         fflush(stdout);
+      }
         hipFree(dx); hipFree(dw); hipFree(dm); hipFree(dout); hipFree(db); hipFree(dref); hipFree(dmax); hipFree(dbad);
     }
     return 0;
