@@ -2,6 +2,7 @@
 the CPU oracle.  Tolerances: fp32 logits / features 1e-4 rel (north_star); integer corner indices bit-exact."""
 import glob
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -12,6 +13,8 @@ from oracle import din_oracle as O
 from tests.test_oracle_golden import load_din_case, load_model_case, DIN_CASES, MODEL_CASES
 
 from tests.conftest import Measured
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -555,6 +558,27 @@ def test_train_net_collective_runs_through_the_collective_loops(gpu, tmp_path):
     tr, te = infos[0]["train"], infos[0]["test"]
     assert np.isfinite(tr["loss"]) and np.isfinite(te["loss"]) and tr["activities_conf"].shape == (5, 5)
     assert int(tr["activities_conf"].sum()) == 4 and int(te["activities_conf"].sum()) == 2
+
+
+def test_dropin_modules_run_the_one_argument_train_net(gpu, tmp_path, monkeypatch):
+    """through the zero-edit drop-in directory (`dropin/` first on the module path, then the reference launcher's own two
+    lines, scripts/train_volleyball_stage2_dynamic.py:1-5), `train_net(cfg)` -- ONE argument, as the reference calls it
+    (train_net_dynamic.py:27) -- trains and tests one epoch on the synthetic stand-in for the dataset and writes the reference's checkpoint."""
+    import importlib
+    monkeypatch.syspath_prepend(os.path.join(ROOT, "dropin"))
+    for name in ("train_net_dynamic", "config"):
+        sys.modules.pop(name, None)
+    ns = {}
+    exec("from train_net_dynamic import *\ncfg = Config('volleyball')", ns)
+    assert ns["train_net"].__module__ == "din_amd.train_net_dynamic"
+    cfg, ref = ns["cfg"], _trainer_cfg("volleyball", tmp_path)
+    for k, v in vars(ref).items():                                   # the small geometry of the other trainer tests, set the way a launcher does
+        setattr(cfg, k, v)
+    cfg.max_epoch, cfg.data_path = 1, str(tmp_path / "no_such_dataset_tree")
+    infos = ns["train_net"](cfg)
+    assert len(infos) == 1 and np.isfinite(infos[0]["train"]["loss"]) and np.isfinite(infos[0]["test"]["loss"])
+    assert glob.glob(str(tmp_path / "stage2_epoch1_*.pth"))
+    importlib.invalidate_caches()
 
 
 from tests.test_oracle_golden import MODE_CASES, load_mode_case

@@ -249,6 +249,52 @@ def test_bench_gpus2_plain_launch_starts_two_ranks():
     assert res2.returncode != 0 and "WORLD_SIZE=1" in res2.stderr
 
 
+DROPIN_DRIVER = r"""
+import os, sys
+script = sys.argv[1]
+sys.path.append(".")                                   # what the reference's launchers do (scripts/train_*.py:2): AFTER PYTHONPATH
+if script:
+    # the reference's own launcher, unmodified, up to (not including) its final train_net(cfg) call -- that call needs the MI355X
+    src = open(script).read().rstrip().splitlines()
+    assert src[-1].strip() == "train_net(cfg)", src[-1]
+    exec(compile("\n".join(src[:-1]), script, "exec"))
+else:
+    from train_net_dynamic import *
+    cfg = Config('volleyball')
+import inspect, train_net_dynamic, config, infer_model, utils, dataset, volleyball, collective
+import backbone.backbone, infer_module.dynamic_infer_module, roi_align.roi_align
+assert train_net.__module__ == "din_amd.train_net_dynamic" and Config.__module__ == "din_amd.config", (train_net.__module__, Config.__module__)
+assert all(m.__file__.startswith(os.environ["DROPIN_DIR"]) for m in (train_net_dynamic, config, infer_model, utils, dataset, volleyball, collective))
+sig = inspect.signature(train_net)
+assert list(sig.parameters)[0] == "cfg" and all(p.default is not inspect._empty for p in list(sig.parameters.values())[1:]), sig
+for name in ("Dynamic_volleyball", "Dynamic_collective", "train_volleyball", "test_volleyball", "return_dataset", "prep_images", "VolleyballDataset",
+             "CollectiveDataset", "set_bn_eval", "adjust_lr"):
+    assert name in globals(), name
+from backbone.backbone import MyVGG16, MyInception_v3
+from infer_module.dynamic_infer_module import Dynamic_Person_Inference, Multi_Dynamic_Inference, Hierarchical_Dynamic_Inference
+from roi_align.roi_align import RoIAlign
+print("DROPIN_OK", cfg.dataset_name, cfg.inference_module_name, cfg.backbone, cfg.num_frames)
+"""
+
+
+def test_dropin_directory_resolves_the_reference_launcher_imports(tmp_path):
+    """a zero-edit drop-in.  With `dropin/` on PYTHONPATH the reference launcher's own lines (`sys.path.append(".")`,
+    `from train_net_dynamic import *`, `cfg=Config('volleyball')`, its cfg field assignments: scripts/train_volleyball_stage2_dynamic.py:1-60)
+    resolve to the MI355X implementation.  Where the reference tree is present (the build container) its launchers are EXECUTED unmodified up to
+    the final train_net(cfg) call (run on the GPU in tests/test_gpu_din_model.py); elsewhere the two import lines are."""
+    dropin = os.path.join(ROOT, "dropin")
+    driver = tmp_path / "driver.py"
+    driver.write_text(DROPIN_DRIVER)
+    env = dict(os.environ, PYTHONPATH=dropin, DROPIN_DIR=dropin)
+    ref = "/root/reference/scripts"
+    scripts = [os.path.join(ref, n) for n in ("train_volleyball_stage2_dynamic.py", "train_collective_stage2_dynamic.py",
+                                              "train_volleyball_stage2_dynamic_tce.py")] if os.path.isdir(ref) else []
+    for script in scripts + [""]:
+        res = subprocess.run([sys.executable, str(driver), script], env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                             text=True, timeout=300)
+        assert res.returncode == 0 and "DROPIN_OK" in res.stdout, (script, res.stdout[-3000:])
+
+
 def _small_cfg(dataset="volleyball"):
     from din_amd.config import Config
     cfg = Config(dataset)
