@@ -37,6 +37,18 @@ def _cpad_image(dt: int) -> int:
     return 4 if dt == L.DIN_F32 else 8
 
 
+# bumped whenever ANY module (re)binds a Parameter / buffer object: cached parameter lists are then rebuilt (one integer compare per step)
+_PARAM_EPOCH = [0]
+
+
+def _bump_param_epoch(*_args, **_kwargs):
+    _PARAM_EPOCH[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump_param_epoch)
+torch.nn.modules.module.register_module_buffer_registration_hook(_bump_param_epoch)
+
+
 class _GraphBackbone(nn.Module):
     """Common machinery: lazily builds (and caches) the NHWC graph for an input size and runs it."""
 
@@ -59,13 +71,17 @@ class _GraphBackbone(nn.Module):
     def _ordered_params(self, graph: Graph) -> List[torch.Tensor]:
         # cached per graph: walking named_parameters() / named_buffers() of ~300 modules is milliseconds of host time per step -- as much as the
         # whole forward dispatch on the 4-clip step.  `_apply` (.to / .cuda / .float: buffers are REPLACED there) drops the cache.
+        # A parameter / buffer object replaced WITHOUT _apply (load_state_dict(assign=True), module.weight = nn.Parameter(...), pruning
+        # re-registration) is caught by `_param_epoch`, which every such path bumps (register_parameter / register_buffer /
+        # __setattr__ of a tensor / _load_from_state_dict on any submodule -- hooked once, below).
         cache = self.__dict__.setdefault("_ordered_cache", {})
+        epoch = _PARAM_EPOCH[0]
         hit = cache.get(id(graph))
-        if hit is None:
+        if hit is None or hit[0] != epoch:
             table = dict(self.named_parameters())
             table.update(dict(self.named_buffers()))
-            hit = cache[id(graph)] = [table[n] for n in graph.param_names()]
-        return hit
+            hit = cache[id(graph)] = (epoch, [table[n] for n in graph.param_names()])
+        return hit[1]
 
     def _apply(self, fn, *args, **kwargs):
         self.__dict__.pop("_ordered_cache", None)

@@ -23,7 +23,7 @@ def return_dataset(cfg, uint8_images: bool = True):
     elif cfg.dataset_name == "collective":
         train_anns, test_anns = collective_read_dataset(cfg.data_path, cfg.train_seqs), collective_read_dataset(cfg.data_path, cfg.test_seqs)
         mk = lambda frames, training: CollectiveDataset(                                                    # noqa: E731
-            train_anns if training else test_anns, frames, cfg.data_path, cfg.image_size, cfg.out_size, num_boxes=cfg.num_boxes,
+            train_anns if training else test_anns, frames, cfg.data_path, cfg.image_size, cfg.out_size,   # (num_boxes: the class default 13, as reference dataset.py:36-42 -- NOT cfg.num_boxes)
             num_frames=cfg.num_frames, is_training=training, is_finetune=finetune, uint8_images=uint8_images)
         train_frames, test_frames = collective_all_frames(train_anns), collective_all_frames(test_anns)
     else:

@@ -66,6 +66,9 @@ def _timed(kind, d, name=""):
 # Called as GRAD_HOOK(weight, dweight) right after a conv layer's weight gradient has been enqueued (backward order: last layer
 # first).  parallel.GradBuckets uses it to start a bucket's all-reduce while the rest of the backward pass is still running.
 GRAD_HOOK = None
+# diagnostics (tools/bf16_grad_cosine.py): GRAD_TAP(tensor id, producing op's name, complete gradient buffer [nb, h, w, c_total]) is called in
+# graph_backward each time the reverse pass reaches a producer of a tensor -- its gradient is complete then.  None in production.
+GRAD_TAP = None
 # Called as GRAD_BUFFER(weight) before a conv layer's weight gradient is computed; may return the fp32 tensor (weight's shape) the kernel
 # should write into -- parallel.GradBuckets hands out the weight's slot of its flat all-reduce bucket, so no packing copy is needed.
 GRAD_BUFFER = None
@@ -834,6 +837,8 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 dgrad_parked(oi)
             continue                                  # nothing flows back through this op
         gout = gbufs[op.dst.tid]
+        if GRAD_TAP is not None:
+            GRAD_TAP(op.dst.tid, op.name, gout)
         src_needs_grad = op.src.tid != g.input_tid
         ts = g.tensors[op.src.tid]
         if op.kind == "conv":
@@ -1004,6 +1009,11 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
         # order for our graphs only per view, so free conservatively when no earlier op writes this tensor
         if not any(o.dst.tid == op.dst.tid for o in g.ops[:oi]):
             gbufs.pop(op.dst.tid, None)
+    #  a 1x1's parked data gradient is only consumed when its strided host op reaches its own dgrad branch: a graph whose host
+    # takes another path must not drop it silently
+    if x_parked:
+        raise L.DinError(f"graph_backward: parked 1x1 data gradients were never carried by their strided sibling (ops {sorted(x_parked)}): "
+                         "the fused strided + 1x1 dgrad (din_conv_dgrad_x) does not serve this graph shape")
     if side is not None:
         main.wait_stream(side)                        # parameter gradients are complete for whoever runs next on the main stream
     if bn is not None and bn_touched and not bn_train:

@@ -85,6 +85,8 @@ def tracks_to_boxes(track: np.ndarray, feature_size: Tuple[int, int]) -> np.ndar
 def pad_by_repetition(rows, num: int):
     """first rows repeated cyclically up to `num` (volleyball.py:258-260 for n >= num / 2)"""
     n = len(rows)
+    if n == 0 or n > num:
+        raise ValueError(f"pad_by_repetition: {n} annotated boxes cannot be padded to num_boxes = {num}")
     if n == num:
         return rows
     idx = np.arange(num) % n
@@ -100,6 +102,10 @@ class VolleyballDataset(data.Dataset):
                  num_before=4, num_after=4, is_training=True, is_finetune=False, uint8_images=True):
         self.anns, self.tracks, self.frames = anns, tracks, frames
         self.images_path, self.image_size, self.feature_size = images_path, tuple(image_size), tuple(feature_size)
+        if inference_module_name == "arg_volleyball":
+            # (reference volleyball.py:207-212: ARG samples 3 random frames in training and a fixed 9-frame order in test -- a stage-2 baseline
+            #  outside the DIN path; refusing is better than silently feeding it full windows)
+            raise NotImplementedError("VolleyballDataset: the 'arg_volleyball' frame sampling is not ported (DIN stage-2 path only)")
         self.inference_module_name = inference_module_name
         self.num_boxes, self.num_before, self.num_after = num_boxes, num_before, num_after
         self.is_training, self.is_finetune, self.uint8_images = is_training, is_finetune, uint8_images
