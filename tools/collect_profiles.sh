@@ -42,7 +42,7 @@ F=$(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1); W=$(find $OU
 python tools/pmc_traffic.py "$F" "$W" $OUT/pmc_traffic.json
 rm -rf $OUT/prof_b32 $OUT/prof_b4 $OUT/pmc_fetch $OUT/pmc_write
 # multi-GPU path, dry: two ranks share this one device (gloo), every rank checks that all ranks hold identical averaged gradients
-DIN_SINGLE_DEVICE=1 DIN_DIST_BACKEND=gloo DIN_CHECK_ALLREDUCE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
-    --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 2 --global-batch 8 --no-cpu-baseline > $OUT/two_ranks_one_device.log 2>&1
+# (round 5: launched PLAINLY, the way the driver calls it -- bench.py starts its own two ranks)
+DIN_SINGLE_DEVICE=1 DIN_DIST_BACKEND=gloo DIN_CHECK_ALLREDUCE=1 timeout 600 python bench.py --gpus 2 --steps 3 --warmup 2 --global-batch 8 --no-cpu-baseline > $OUT/two_ranks_one_device.log 2>&1
 tail -4 $OUT/two_ranks_one_device.log | cut -c1-300
 ls -la $OUT | head -50
