@@ -1,6 +1,8 @@
 import ctypes as C, os, sys
 sys.path.insert(0, "/root/repo")
 import torch
+import os as _os
+_os.environ.setdefault("DIN_OPTIONS_FROM_ENV", "1")   # tuning tool: DIN_* variables of this process become library options (din_set_option) at load
 from din_amd import _lib as L
 from tools.pool_bench import bench
 lib = L.load(); nb = 96; bf = torch.bfloat16

@@ -9,6 +9,8 @@ import os
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os
+_os.environ.setdefault("DIN_OPTIONS_FROM_ENV", "1")   # tuning tool: DIN_* variables of this process become library options (din_set_option) at load
 from din_amd import _lib as L  # noqa: E402
 
 SHAPES = [  # (name, rows, c, ld of the gradient view, coff)

@@ -14,6 +14,7 @@ cd "$(dirname "$0")/../.."
 TAG=$1; shift
 OUT=gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
+export DIN_OPTIONS_FROM_ENV=1        # env:K=V steps below reach the library as options (ABI 8: it never reads the environment itself)
 for step in "$@"; do
   case "$step" in
     suite)   timeout 3000 python -m pytest tests -q -m gpu -p no:cacheprovider > $OUT/${TAG}_suite.log 2>&1; echo "suite rc=$?"; tail -3 $OUT/${TAG}_suite.log

@@ -5,6 +5,8 @@ software-pipelined 32x32x16 kernel (default) and its atomic-accumulate epilogue 
 import argparse, ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import os as _os
+_os.environ.setdefault("DIN_OPTIONS_FROM_ENV", "1")   # tuning tool: DIN_* variables of this process become library options (din_set_option) at load
 from din_amd import _lib as L
 
 LAYERS = {  # name: (h, w, cin, cout, k, s, p)
