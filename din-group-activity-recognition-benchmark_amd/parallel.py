@@ -183,15 +183,15 @@ class GradBuckets:
         self._hook_order.append(key)
         if self._learned is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not self.force):
             return                                               # first step: only learn the order (single process: nothing to send)
+        if key in self._got and self._got[key].data_ptr() != grad.data_ptr():
+            # (ADVICE r4) a weight applied twice in one forward reports two partial gradients: the bucket would be sent after the first
+            raise RuntimeError("parallel.GradBuckets: a parameter passed directly to more than one conv / linear op per backward pass is not "
+                               "supported with the overlapped all-reduce (its bucket would leave after the first partial gradient)")
         if self._by_ptr[key].grad is not None and self._by_ptr[key].grad.data_ptr() != grad.data_ptr():
             # a live .grad means the caller accumulates over micro-batches: the early all-reduce would send only THIS micro-batch's
             # gradient and allreduce() would then replace the accumulated .grad with it
             raise RuntimeError("parallel.GradBuckets: gradient accumulation (p.grad kept between backward passes) is not supported with the "
                                "overlapped all-reduce; call optimizer.zero_grad() before every backward pass")
-        if key in self._got and self._got[key].data_ptr() != grad.data_ptr():
-            # (ADVICE r4) a weight applied twice in one forward reports two partial gradients: the bucket would be sent after the first
-            raise RuntimeError("parallel.GradBuckets: a parameter passed directly to more than one conv / linear op per backward pass is not "
-                               "supported with the overlapped all-reduce (its bucket would leave after the first partial gradient)")
         bi, _ = self._slot[key]
         if key not in self._got:
             self._arrived[bi] += 1                               # (a counter, not a scan of the bucket per report: the scan was O(n^2) data_ptr() calls

@@ -212,6 +212,20 @@ for step in range(3):
     b.allreduce()
     for p, q in zip(lin.parameters(), ref.parameters()):
         assert torch.allclose(p.grad, q.grad, atol=1e-6), (step, (p.grad - q.grad).abs().max())
+# (ADVICE r4) a parameter reported twice in one backward with two different gradient tensors -- a weight passed directly to two conv / linear
+# ops -- must be refused loudly: its bucket would already have left with the first partial gradient
+for p in lin.parameters():
+    p.grad = None
+lin(clips[mine]).pow(2).mean().backward()
+w0 = weights[0]
+b._on_grad(w0, w0.grad)
+try:
+    b._on_grad(w0, w0.grad.clone())
+    raise SystemExit("second report of one parameter was accepted")
+except RuntimeError as e:
+    assert "more than one conv / linear op" in str(e), e
+b._on_grad(weights[1], weights[1].grad)
+b.allreduce()
 dist.barrier()
 sys.stdout.write(f"RANK_OK_{rank}\n"); sys.stdout.flush()
 """
