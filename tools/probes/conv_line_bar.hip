@@ -145,7 +145,7 @@ __device__ __forceinline__ void loader(const LineK& p, unsigned char* smem, int 
 }
 
 // ---- consumer waves --------------------------------------------------------------------------------------------------------------------------
-template <int BN, int WM, int WN, int NL, int R, int G, bool PROF>
+template <int BN, int WM, int WN, int NL, int R, int G, bool PROF, int STAG>
 __device__ __forceinline__ void consumer(const LineK& p, unsigned char* smem, int wid, int lane) {
     constexpr int TI = BN / WN / 32, TJ = TP / WM / 32, BNW = BN / WN, PXW = TP / WM;
     static_assert(BN % (32 * WN) == 0 && TP % (32 * WM) == 0 && TJ * 8 <= 32, "wave tile = whole 32 x 32 MFMA tiles");
@@ -223,6 +223,9 @@ __device__ __forceinline__ void consumer(const LineK& p, unsigned char* smem, in
             __builtin_amdgcn_s_barrier();                      // stage gs (and, G = 2, gs + 1) has landed; everyone is done with stage gs - 1
             asm volatile("" ::: "memory");
             if constexpr (PROF) { const uint32_t d = (uint32_t)(__builtin_readcyclecounter() - b0); t_bar += d; if (g == 0) t_first += d; }
+            // the two consumer waves of a SIMD (w and w + 4) leave the barrier in lock-step and then alternate MFMAs fairly: both do their fragment
+            // reads / masking at the same time and the matrix pipe idles.  A one-off delay of the second wave puts them half a sub-step apart.
+            if constexpr (STAG > 0) { if (wid >= 4) __builtin_amdgcn_s_sleep(STAG); }
             if (!have) { set_stage(t, gl, gs); rdw(0, 0); }
             const bool last_tap = t + 1 == p.taps;
             const bool exists = g + 1 < nst;
@@ -330,14 +333,14 @@ __device__ __forceinline__ void consumer(const LineK& p, unsigned char* smem, in
     }
 }
 
-template <int BN, int WM, int WN, int NL, int R, int G, bool PROF = false>
+template <int BN, int WM, int WN, int NL, int R, int G, bool PROF = false, int STAG = 0>
 __global__ __launch_bounds__(64 * (WM * WN + NL), 1) void conv_lineb_kernel(LineK p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wid >= WM * WN) loader<BN, WM * WN, NL, R, G, PROF>(p, smem, wid - WM * WN, lane);
-    else consumer<BN, WM, WN, NL, R, G, PROF>(p, smem, wid, lane);
+    else consumer<BN, WM, WN, NL, R, G, PROF, STAG>(p, smem, wid, lane);
 #endif
 }
 
@@ -355,6 +358,11 @@ int launch_lineb(LineK lk, int bn, int ncu, hipStream_t st, int variant = 0) {
     else if (bn == 128 && lk.prof) go(conv_lineb_kernel<128, 4, 2, 2, 5, 2, true>, lds_bytes<128, 5>(), 640);
     else if (bn == 192 && variant == 0) go(conv_lineb_kernel<192, 4, 2, 2, 3, 1>, lds_bytes<192, 3>(), 640);
     else if (bn == 192 && variant == 1) go(conv_lineb_kernel<192, 4, 2, 2, 3, 2>, lds_bytes<192, 3>(), 640);
+    else if (bn == 192 && variant == 2) go(conv_lineb_kernel<192, 4, 2, 2, 3, 1, false, 1>, lds_bytes<192, 3>(), 640);
+    else if (bn == 192 && variant == 3) go(conv_lineb_kernel<192, 4, 2, 2, 3, 1, false, 2>, lds_bytes<192, 3>(), 640);
+    else if (bn == 192 && variant == 4) go(conv_lineb_kernel<192, 4, 2, 2, 3, 1, false, 3>, lds_bytes<192, 3>(), 640);
+    else if (bn == 128 && variant == 2) go(conv_lineb_kernel<128, 4, 2, 2, 5, 2, false, 1>, lds_bytes<128, 5>(), 640);
+    else if (bn == 128 && variant == 3) go(conv_lineb_kernel<128, 4, 2, 2, 5, 2, false, 2>, lds_bytes<128, 5>(), 640);
     else if (bn == 160 && variant == 0) go(conv_lineb_kernel<160, 8, 1, 2, 4, 2>, lds_bytes<160, 4>(), 640);
     else if (bn == 160 && variant == 1) go(conv_lineb_kernel<160, 8, 1, 2, 4, 1>, lds_bytes<160, 4>(), 640);
     else if (bn == 128 && variant == 0) go(conv_lineb_kernel<128, 4, 2, 2, 5, 2>, lds_bytes<128, 5>(), 640);

@@ -109,6 +109,9 @@ int main(int argc, char** argv) {
             {"gen 1 (flags, 64-channel stages)", [&] { return c.bn == 160 ? -1 : din_line64::launch_line(k6, c.bn, ncu, 0, 0); }},
             {"gen 3 (barrier) variant 0", [&] { return din_lineb::launch_lineb(kb, c.bn, ncu, 0, 0); }},
             {"gen 3 (barrier) variant 1", [&] { return din_lineb::launch_lineb(kb, c.bn, ncu, 0, 1); }},
+            {"gen 3 + stagger s_sleep 1", [&] { return din_lineb::launch_lineb(kb, c.bn, ncu, 0, 2); }},
+            {"gen 3 + stagger s_sleep 2", [&] { return din_lineb::launch_lineb(kb, c.bn, ncu, 0, 3); }},
+            {"gen 3 + stagger s_sleep 3", [&] { return din_lineb::launch_lineb(kb, c.bn, ncu, 0, 4); }},
         };
         for (const Runner& r : runners) {
             hipMemset(dout, 0xff, oel * 2); hipMemset(dmax, 0, 4); hipMemset(dbad, 0, 4); hipMemset(d_err, 0, 4);
