@@ -292,6 +292,12 @@ def _self_launch(n: int) -> int:
     form, BASELINE.json metric at 2 / 4 / 8 GPUs).  Before round 5 this case silently measured ONE GPU (WORLD_SIZE unset -> world 1)."""
     import socket
     import subprocess
+    if os.environ.get("DIN_DIST_BACKEND") != "gloo" and os.environ.get("DIN_SINGLE_DEVICE") != "1":
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:                                           # say so HERE, once, instead of N tracebacks from inside the ranks
+            print(f"bench.py: --gpus {n} needs {n} visible GPUs, this node shows {have} (one rank per GPU over RCCL; "
+                  f"DIN_SINGLE_DEVICE=1 DIN_DIST_BACKEND=gloo runs the N-rank control flow on one device for debugging)", file=sys.stderr, flush=True)
+            return 2
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
