@@ -52,6 +52,9 @@ struct ConvK {
 bool conv1x1_stream_eligible(const ConvK& k, int dtype);
 int launch_conv1x1_stream(ConvK k, hipStream_t st);
 int conv1x1_stream_tile(int cout);                 // filter tile of a launch producing cout channels (64 | 96 | 192)
+// host entries of conv_regw.hip: 1x1 convolutions with a 640..768-channel reduction over a large map, filters resident in registers
+bool conv1x1_regw_eligible(const ConvK& k, int dtype);
+int launch_conv1x1_regw(const ConvK& k, hipStream_t st);
 
 __device__ __forceinline__ int64_t out_pixel(const ConvK& p, int m) {
     if (p.out_sy == 0) return m;

@@ -3012,6 +3012,11 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
             DIN_FAIL(DIN_E_WORKSPACE, "%s: workspace %lld < %lld bytes", what, (long long)ws_bytes, (long long)g.ws_bytes);
         k.partial = reinterpret_cast<float*>(workspace);
     }
+    if (fast && g.splitk == 1 && k.nsrc == 0 && k.xsteps == 0 && din_gather::conv1x1_regw_eligible(k, dtype)) {
+        // 1x1 layers with a 640..768-channel reduction over a large map (the Mixed_6 block entries): filters resident in registers (conv_regw.hip)
+        if (din_gather::launch_conv1x1_regw(k, st)) DIN_FAIL(DIN_E_LAUNCH, "%s: conv1x1_regw launch failed", what);
+        return DIN_OK;
+    }
     if (fast && g.splitk == 1 && k.nsrc == 0 && k.xsteps == 0 && din_gather::conv1x1_stream_eligible(k, dtype)) {
         // 1x1 layers with a short reduction over a large map: persistent streaming kernel (conv_stream.hip)
         if (din_gather::launch_conv1x1_stream(k, st)) DIN_FAIL(DIN_E_LAUNCH, "%s: conv1x1_stream launch failed", what);
@@ -3259,6 +3264,20 @@ int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t
             g.splitk == 1 && cprod % 8 == 0 && ldp % 8 == 0 && offp % 8 == 0 && ldr % 8 == 0 && offr % 8 == 0 &&
             M * ldr * 2 < 0x7fffffffll && M * ldp * 2 < 0x7fffffffll && pad_to(cprod, din_gather::conv1x1_stream_tile(cprod)) * 4 <= 2048 &&
             (mode == 2 || (blocks <= 6 && M >= (DIN_OPT("DIN_CONV_STREAM_MINPIX") ? atoll(DIN_OPT("DIN_CONV_STREAM_MINPIX")) : 256 * 1024) && (cprod <= 96 || (cprod <= 192 && which == 0))))) { *bm = 4; *bn = din_gather::conv1x1_stream_tile(cprod); }
+    }
+    {   // 1x1 layers with a 640..768-channel reduction over a large map run conv1x1_regw_kernel (conv_regw.hip, filters resident in registers):
+        // bm = 5, bn = 192 (same conditions as din_gather::conv1x1_regw_eligible, evaluated on the descriptor; single destination, no accumulate)
+        const char* rv = DIN_OPT("DIN_CONV_REGW");
+        const int mode = rv ? atoi(rv) : 1;
+        const int cred = which == 0 ? d->cin : d->cout, cprod = which == 0 ? d->cout : d->cin;
+        const int64_t M = which == 0 ? (int64_t)d->nb * d->oh * d->ow : (int64_t)d->nb * d->h * d->w;
+        const int ldr = which == 0 ? d->ldi : d->ldo, offr = which == 0 ? d->cioff : d->cooff;
+        const int ldp = which == 0 ? d->ldo : d->ldi, offp = which == 0 ? d->cooff : d->cioff;
+        const int nks = cred % 32 == 0 ? (cred + 63) / 64 * 2 : 0;      // (a multi-source launch pads EACH source to whole stages: din_conv1x1_dgrad_multi decides itself)
+        const char* mp = DIN_OPT("DIN_CONV_REGW_MINPIX");
+        if (mode && d->dtype == DIN_BF16 && d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 && !d->in_u8 &&
+            g.splitk == 1 && (nks == 20 || nks == 24) && cprod <= 768 && cprod % 8 == 0 && ldp % 8 == 0 && offp % 8 == 0 &&
+            ldr % 8 == 0 && offr % 8 == 0 && M * ldr * 2 < 0x7fffffffll && (mode == 2 || M >= (mp ? atoll(mp) : 96 * 1024))) { *bm = 5; *bn = 192; }
     }
     {   // stem layers run conv_small_kernel (same conditions as run_gather, for tensors with 16-byte aligned channel offsets): bm = 0
         const int cred = which == 0 ? d->cin : d->cout, cprod = which == 0 ? d->cout : d->cin;
@@ -3531,6 +3550,15 @@ int din_conv1x1_dgrad_multi(int nsrc, const din_conv_src* srcs, int dtype, int n
     g.bm = 128; g.n_px_tiles = (k.M + 127) / 128; g.n_co_tiles = (cin + g.bn - 1) / g.bn;
     k.cpt = KC; k.Q = steps * KC; k.nk = steps; k.wld = k.src[0].wld;
     k.splitk = 1; k.ks_per_split = steps; k.n_co_tiles = g.n_co_tiles; k.remap = 0; k.korder = 0;
+    if (DIN_OPT("DIN_DEBUG_PLAN"))
+        fprintf(stderr, "[din] conv1x1_dgrad_multi M=%d nsrc=%d couts=%d,%d,%d,%d ld=%d,%d,%d,%d coff=%d,%d,%d,%d cin=%d flags=%d regw=%d\n", k.M, nsrc, srcs[0].cout,
+                nsrc > 1 ? srcs[1].cout : 0, nsrc > 2 ? srcs[2].cout : 0, nsrc > 3 ? srcs[3].cout : 0, srcs[0].ldo, nsrc > 1 ? srcs[1].ldo : 0,
+                nsrc > 2 ? srcs[2].ldo : 0, nsrc > 3 ? srcs[3].ldo : 0, srcs[0].cooff, nsrc > 1 ? srcs[1].cooff : 0, nsrc > 2 ? srcs[2].cooff : 0,
+                nsrc > 3 ? srcs[3].cooff : 0, cin, flags, (int)din_gather::conv1x1_regw_eligible(k, dtype));
+    if (din_gather::conv1x1_regw_eligible(k, dtype)) {
+        if (din_gather::launch_conv1x1_regw(k, as_stream(stream))) DIN_FAIL(DIN_E_LAUNCH, "conv1x1_dgrad_multi: conv1x1_regw launch failed");
+        return DIN_OK;
+    }
     if (din_gather::conv1x1_stream_eligible(k, dtype)) {
         if (din_gather::launch_conv1x1_stream(k, as_stream(stream))) DIN_FAIL(DIN_E_LAUNCH, "conv1x1_dgrad_multi: conv1x1_stream launch failed");
         return DIN_OK;

@@ -152,6 +152,8 @@ class LaunchTimer:
             return f"conv_wgrad_bf16_kernel<{bm.value}>" if d.dtype == L.DIN_BF16 else "conv_wgrad_f32_kernel"
         if bm.value == 4 and not (self.kind == "dgrad" and "+" in self.name):
             return f"conv1x1_stream_kernel<{bn.value}>"
+        if bm.value == 5:                                             # (multi-source dgrads included: the descriptor carries the summed reduction)
+            return f"conv1x1_regw_kernel<{24 if (d.cin if self.kind == 'fwd' else d.cout) > 640 else 20}, ...>"
         if bm.value == 0:
             return f"conv_small_kernel<..., {bn.value}, ...>"
         if bm.value == 1:

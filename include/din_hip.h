@@ -120,8 +120,9 @@ int din_conv_fwd2(const din_conv_desc* d, const void* in, const void* wpk, const
                   int csplit, int craw, int flags, void* workspace, int64_t workspace_bytes, void* stream);
 /* which tile variant the planner picks (which: 0 fwd, 1 dgrad -> pixels x filters of conv_gather_*_kernel; 2 wgrad -> filter rows x
  * k columns of conv_wgrad_*_kernel, bn = 1000 + k columns for conv_wgrad_ring_kernel; bm = 0 -> the stationary-filter stem kernels
- * conv_small_kernel / conv_wgrad_small_kernel with bn filters; bm = 1 -> conv_halo_kernel): lets a
- * profiler-side caller name the kernel a launch resolves to */
+ * conv_small_kernel / conv_wgrad_small_kernel with bn filters; bm = 1 -> conv_halo_kernel; bm = 2 -> conv_gather_pipe_kernel; bm = 4 ->
+ * conv1x1_stream_kernel; bm = 5 -> conv1x1_regw_kernel, classes of bn = 192 filters resident in registers): lets a profiler-side caller
+ * name the kernel a launch resolves to */
 int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t* bn);
 /* which instantiation of conv_gather_fast_kernel a fwd (0) / dgrad (1) launch resolves to: flags bit 0 = FASTK (scalar k-walk), bit 1 = 8 waves
  * (4 x 2) instead of 4 (2 x 2) -- so that a profiler-side caller can spell the exact kernel name rocprofv3 prints */

@@ -89,6 +89,15 @@ CONV_CASES = [
     ("st_48_8", 1, 48, 19, 23, 8, (1, 1), (1, 1), (0, 0), 1),
     ("st_192_64_long", 8, 192, 87, 157, 64, (1, 1), (1, 1), (0, 0), 1),      # > 256 items: every workgroup walks several
     ("st_96_176", 2, 96, 31, 45, 176, (1, 1), (1, 1), (0, 0), 1),            # the 192-filter tile on its 3-slot ring (forward), 96-filter tile (dgrad)
+    # filters resident in registers (conv1x1_regw_kernel<20 | 24, masked>, bf16; forced on these small maps with DIN_CONV_REGW=2): one to
+    # four classes of 192 filters, a last class with idle waves / partial 16-byte pieces, ragged last pixel tile, fewer tiles than teams, forward
+    # (reduction 640 / 768) and dgrad (reduction 640 / 736 / 768: plain and with the ReLU mask through the ring)
+    ("rw_768_192", 8, 768, 57, 55, 192, (1, 1), (1, 1), (0, 0), 1),          # (>= 192 tiles each: below that the planner splits the reduction)
+    ("rw_768_448", 5, 768, 43, 41, 448, (1, 1), (1, 1), (0, 0), 1),          # three classes, the third with 64 filters (two idle waves); dgrad elsewhere
+    ("rw_640_200", 12, 640, 33, 37, 200, (1, 1), (1, 1), (0, 0), 1),         # reduction 640 (20 k-steps); two classes, the second with 8 filters
+    ("rw_160_736", 19, 160, 35, 39, 736, (1, 1), (1, 1), (0, 0), 1),         # dgrad: reduction 736 (the last stage half zero padding) -> 160 channels (a wave with 16 filters)
+    ("rw_768_768", 4, 768, 43, 78, 768, (1, 1), (1, 1), (0, 0), 1),          # fwd and dgrad, four classes, every team walks several tiles
+    ("rw_96_640", 20, 96, 35, 39, 640, (1, 1), (1, 1), (0, 0), 1),           # dgrad: reduction 640 -> 96 channels (two waves idle)
 ]
 
 
@@ -102,6 +111,8 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
         monkeypatch.setenv("DIN_WGRAD_HALO", "2")       # ... and the halo weight-gradient kernel only on launches of >= 256K pixels
     if name.startswith("st_"):
         monkeypatch.setenv("DIN_CONV_STREAM", "2")      # ... and the streaming 1x1 kernel only on maps of >= 256K pixels
+    if name.startswith("rw_"):
+        monkeypatch.setenv("DIN_CONV_REGW", "2")        # ... and the register-resident-filter kernel only on maps of >= 96K pixels
     if name.startswith("gp"):
         monkeypatch.setenv("DIN_GATHER_PIPE", "2")      # ... and the 256-pixel pipelined tiles only on launches that fill the chip
         monkeypatch.setenv("DIN_CONV_HALO", "0")
@@ -145,6 +156,11 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
             bm, bn = C.c_int32(0), C.c_int32(0)
             lib.din_conv_kernel_tile(C.byref(d), which, C.byref(bm), C.byref(bn))
             assert bm.value == 4, f"{name}: {('forward', 'dgrad')[which]} not on the streaming 1x1 kernel (tile {bm.value} x {bn.value})"
+    if name.startswith("rw_") and dtype == "bf16":
+        for which, cred in ((0, cin), (1, cout)):
+            bm, bn = C.c_int32(0), C.c_int32(0)
+            lib.din_conv_kernel_tile(C.byref(d), which, C.byref(bm), C.byref(bn))
+            assert (bm.value == 5) == (cred in (640, 736, 768)), f"{name}: {('forward', 'dgrad')[which]} kernel code {bm.value}"
     xin = to_nhwc(x, tdt, ldi)
     wdev, bdev = wt.cuda(), bias.cuda()
     wpk = torch.empty(lib.din_conv_packed_elems(C.byref(d), 0), dtype=tdt, device="cuda")
@@ -191,6 +207,12 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
         torch.cuda.synchronize()
         want = xr.grad + xr.grad * (x > 0).float()
         assert rel(from_nhwc(dx, cin), want) <= 2 * tolg
+        if name.startswith("rw_"):                       # mask without accumulate: the launch the block-entry dgrads make (mask stages through the ring)
+            dx.fill_(3.0)
+            L.check(lib.din_conv_dgrad(C.byref(d), gz.data_ptr(), wpt.data_ptr(), dx.data_ptr(), xin.data_ptr(), ldi, 0, L.CONV_MASK,
+                                       ws.data_ptr(), wsb, st))
+            torch.cuda.synchronize()
+            assert rel(from_nhwc(dx, cin), xr.grad * (x > 0).float()) <= tolg
 
 
 @pytest.mark.parametrize("cout", [32, 64], ids=["dY32_conv_small_4", "dY64_conv_small_8"])
@@ -224,14 +246,16 @@ def test_stem_dgrad_early_operand_request_is_bit_identical(env, monkeypatch, cou
     assert not bool((changed & ~(xin > 0)).any())                         # nothing was added where the mask is off
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_pipe", "bf16_stream"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_pipe", "bf16_stream", "bf16_regw"])
 def test_conv_fwd_two_destinations(env, dtype, monkeypatch):
     """din_conv_fwd2: sibling 1x1 convs of one input as ONE launch -- channels [0, csplit) into the first tensor's view, the rest into a second
     tensor; equals the separate convs, and nothing outside the two channel ranges is touched.  bf16_pipe: through the 256-pixel tiles;
     bf16_stream: through the persistent streaming kernel (conv1x1_stream_kernel)."""
     lib, L, nhwc, ops = env
     monkeypatch.setenv("DIN_CONV_STREAM", "2" if dtype == "bf16_stream" else "0")
-    if dtype == "bf16_stream":
+    regw = dtype == "bf16_regw"
+    monkeypatch.setenv("DIN_CONV_REGW", "2" if regw else "0")
+    if dtype in ("bf16_stream", "bf16_regw"):
         dtype = "bf16"
     if dtype == "bf16_pipe":
         monkeypatch.setenv("DIN_GATHER_PIPE", "2")
@@ -241,6 +265,8 @@ def test_conv_fwd_two_destinations(env, dtype, monkeypatch):
     g = torch.Generator().manual_seed(21)
     nb, h, w, cin = 2, 40, 48, 192
     couts = (64, 48, 64)
+    if regw:                                                 # the Mixed_6c entry group: 768 -> 192 | 160 + 160 (conv1x1_regw_kernel, three classes)
+        nb, h, w, cin, couts = 3, 43, 78, 768, (192, 160, 160)
     ctot = sum(couts)
     x = torch.randn(nb, cin, h, w, generator=g)
     ws_ = [torch.randn(c, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5 for c in couts]
@@ -249,6 +275,8 @@ def test_conv_fwd_two_destinations(env, dtype, monkeypatch):
         x, ws_ = x.bfloat16().float(), [t.bfloat16().float() for t in ws_]
     ref = F.relu(F.conv2d(x, torch.cat(ws_), bias))
     ldi, ld1, off1, ld2, off2 = cin, 256, 8, 128, 8
+    if regw:
+        ld1, ld2 = 768, 336
     d = L.ConvDesc()
     d.nb, d.h, d.w, d.cin, d.oh, d.ow, d.cout = nb, h, w, cin, h, w, ctot
     d.kh = d.kw = d.sh = d.sw = d.dh = d.dw = 1
@@ -286,11 +314,14 @@ def test_conv_fwd_two_destinations(env, dtype, monkeypatch):
     out2 = torch.full((nb, h, w, ld2), 7.0, dtype=tdt, device="cuda")
     bdev = bias.cuda()
     craw = couts[0] + couts[1]                               # the last sibling stored raw: no bias, no ReLU (branch_pool conv)
+    if regw:
+        craw = 0                                             # (raw-stored siblings stay on the tile kernels: conv1x1_regw_eligible)
     L.check(lib.din_conv_fwd2(C.byref(d), xin.data_ptr(), bank.data_ptr(), bdev.data_ptr(), out1.data_ptr(), out2.data_ptr(), ld2, off2,
                               couts[0], craw, L.CONV_BIAS | L.CONV_RELU, None, 0, None))
     torch.cuda.synchronize()
     tol = 2e-5 if dtype == "fp32" else 1.5e-2
-    ref = torch.cat([ref[:, :craw], F.conv2d(x, ws_[2])], dim=1)
+    if craw:
+        ref = torch.cat([ref[:, :craw], F.conv2d(x, ws_[2])], dim=1)
     assert rel(from_nhwc(out1, couts[0], off1), ref[:, :couts[0]]) <= tol
     assert rel(from_nhwc(out2, ctot - couts[0], off2), ref[:, couts[0]:]) <= tol
     assert float(out1[..., :off1].float().min()) == 7.0 and float(out1[..., off1 + couts[0]:].float().min()) == 7.0
@@ -917,25 +948,32 @@ def test_head_and_adam(env):
         assert rel(d_.detach(), r_.detach()) <= 1e-5
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_stream"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_stream", "bf16_regw", "bf16_regw_768"])
 def test_conv1x1_dgrad_multi_source(env, dtype, monkeypatch):
     """fused dgrad of three 1x1 convs reading the same tensor == sum of the three separate dgrads (+ mask, + accumulate); bf16_stream: through
     the persistent streaming kernel (each source = its own 64-channel blocks, the 48- and 104-channel sources end in partial blocks)"""
     lib, L, nhwc, ops = env
     monkeypatch.setenv("DIN_CONV_STREAM", "2" if dtype == "bf16_stream" else "0")
-    if dtype == "bf16_stream":
+    regw = dtype.startswith("bf16_regw")
+    monkeypatch.setenv("DIN_CONV_REGW", "2" if regw else "0")
+    nb, h, w, cin = 2, 9, 13, 288
+    couts = [64, 48, 104]
+    if regw:
+        # bf16_regw: the Mixed_6c / 6d block entry (sources 192 + 160 + 160 + 192: the 160-channel sources end in half-padded stages)
+        # -> 768 channels in four classes, through conv1x1_regw_kernel; bf16_regw_768: Mixed_6e (24 k-steps), three tiles per team
+        nb, h, w, cin = (2, 37, 41, 768) if dtype == "bf16_regw" else (3, 87, 157, 768)
+        couts = [192, 160, 160, 192] if dtype == "bf16_regw" else [192, 192, 192, 192]
+    if dtype in ("bf16_stream", "bf16_regw", "bf16_regw_768"):
         dtype = "bf16"
     dt = L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
     tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
     g = torch.Generator().manual_seed(21)
-    nb, h, w, cin = 2, 9, 13, 288
-    couts = [64, 48, 104]
     x = torch.randn(nb, cin, h, w, generator=g)
     if dtype == "bf16":
         x = x.bfloat16().float()
     xr = x.clone().requires_grad_(True)
     total = 0
-    srcs = (L.ConvSrc * 3)()
+    srcs = (L.ConvSrc * len(couts))()
     keep = []
     for j, co in enumerate(couts):
         wt = torch.randn(co, cin, 1, 1, generator=g) * 0.1
@@ -958,14 +996,27 @@ def test_conv1x1_dgrad_multi_source(env, dtype, monkeypatch):
     total.backward()
     xin = to_nhwc(x, tdt)
     dx = torch.zeros(nb, h, w, cin, dtype=tdt, device="cuda")
-    L.check(lib.din_conv1x1_dgrad_multi(3, srcs, dt, nb, h, w, cin, cin, 0, dx.data_ptr(), None, 0, 0, 0, None))
+    L.check(lib.din_conv1x1_dgrad_multi(len(couts), srcs, dt, nb, h, w, cin, cin, 0, dx.data_ptr(), None, 0, 0, 0, None))
     torch.cuda.synchronize()
     tol = 5e-5 if dtype == "fp32" else 2e-2
     assert rel(from_nhwc(dx, cin), xr.grad) <= tol
-    L.check(lib.din_conv1x1_dgrad_multi(3, srcs, dt, nb, h, w, cin, cin, 0, dx.data_ptr(), xin.data_ptr(), cin, 0,
+    L.check(lib.din_conv1x1_dgrad_multi(len(couts), srcs, dt, nb, h, w, cin, cin, 0, dx.data_ptr(), xin.data_ptr(), cin, 0,
                                         L.CONV_MASK | L.CONV_ACCUM, None))
     torch.cuda.synchronize()
     assert rel(from_nhwc(dx, cin), xr.grad + xr.grad * (x > 0).float()) <= 2 * tol
+    if regw:
+        # the launch the block entries make: mask, no accumulate -- and the register-resident kernel against the tile kernel on the same operands
+        # (different summation order: not bit-identical; both within the bf16 output rounding of the fp32 reference)
+        outs = []
+        for mode in ("2", "0"):
+            monkeypatch.setenv("DIN_CONV_REGW", mode)
+            dx.fill_(5.0)
+            L.check(lib.din_conv1x1_dgrad_multi(len(couts), srcs, dt, nb, h, w, cin, cin, 0, dx.data_ptr(), xin.data_ptr(), cin, 0, L.CONV_MASK, None))
+            torch.cuda.synchronize()
+            assert rel(from_nhwc(dx, cin), xr.grad * (x > 0).float()) <= tol
+            outs.append(dx.clone())
+        assert bool(((outs[0] == 0) == (outs[1] == 0)).all())               # the same positions are masked
+        assert rel(outs[0].float(), outs[1].float()) <= 2.0 ** -7
 
 
 @pytest.mark.parametrize("case", [("fused_bf16", "bf16", 288, 21, 25, 1, "1"), ("fused_bf16_p1_ragged", "bf16", 96, 20, 27, 1, "1"),

@@ -75,10 +75,12 @@ def test_occupancy_critical_kernels_hold_their_register_budgets():
             budget = 128
         elif re.search(r"conv_wgrad_pipe_kernelILi\d+ELi256ELb[01]ELi8E", name):        # sixteen waves (wave grid 2 x 8) in one workgroup
             budget = 128
+        elif "conv1x1_regw_kernel" in name:         # one wave per SIMD with the filters resident: the whole file, and NOT ONE spill -- a filter
+            budget = 512                            # fragment reloaded from scratch inside the tile loop drains every transfer in flight (vmcnt)
         if budget is not None:
             checked += 1
             assert regs <= budget and spill == 0, f"{name}: {regs} registers (+{spill} spilled) > {budget}: a workgroup per CU is lost"
-    assert checked >= 14, checked
+    assert checked >= 18, checked
 
 
 def test_conv_planning_is_callable_without_gpu():

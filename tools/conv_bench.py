@@ -44,6 +44,11 @@ LAYERS = {  # name: (nb, h, w, cin, cout, k, s, p)
     "inc_6c_7x1_192": (96, 43, 78, 160, 192, (7, 1), 1, (3, 0)),
     "k_1x1_768_64": (96, 43, 78, 768, 64, 1, 1, 0),
     "k_1x1_1536_64": (96, 43, 78, 1536, 64, 1, 1, 0),
+    "inc_6e_entry_576": (96, 43, 78, 768, 576, 1, 1, 0),      # the sibling group 768 -> 192 + 192 + 192 as one bank
+    "inc_6b_entry_448": (96, 43, 78, 768, 448, 1, 1, 0),
+    "k_1x1_768_768": (96, 43, 78, 768, 768, 1, 1, 0),         # dgrad: the shape of the Mixed_6e block-entry data gradient (one source)
+    "k_1x1_768_768_b4": (12, 43, 78, 768, 768, 1, 1, 0),
+    "inc_6e_1x1_768_b4": (12, 43, 78, 768, 192, 1, 1, 0),
 }
 
 def main():
@@ -55,6 +60,7 @@ def main():
     ap.add_argument("--flags", type=int, default=8, help="dgrad epilogue flags (8 = ReLU mask, 4 = accumulate)")
     ap.add_argument("--no-dbias", action="store_true", help="wgrad without the bias gradient (what do its per-workgroup atomics cost?)")
     ap.add_argument("--const", action="store_true", help="constant operands (low toggle rate): shows how much the clock sags on random data")
+    ap.add_argument("--relu", action="store_true", help="half of the activations / gradients zero, as behind a ReLU (what the mid-network layers see)")
     a = ap.parse_args()
     lib = L.load()
     nb, h, w, cin, cout, k, s, p = LAYERS[a.layer]
@@ -72,6 +78,8 @@ def main():
     gy = torch.randn(nb, oh, ow, cout, device="cuda").to(tdt)
     wt = torch.randn(cout, cin, k[0], k[1], device="cuda") * 0.05
     bias = torch.zeros(cout, device="cuda")
+    if a.relu:
+        x = torch.relu(x); gy = gy * (torch.rand_like(gy, dtype=torch.float32) > 0.5).to(tdt)
     if a.const:
         x.fill_(1.0); gy.fill_(1.0); wt.fill_(0.03125)
     y = torch.empty(nb, oh, ow, cout, device="cuda", dtype=tdt)
