@@ -3266,18 +3266,21 @@ int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t
             (mode == 2 || (blocks <= 6 && M >= (DIN_OPT("DIN_CONV_STREAM_MINPIX") ? atoll(DIN_OPT("DIN_CONV_STREAM_MINPIX")) : 256 * 1024) && (cprod <= 96 || (cprod <= 192 && which == 0))))) { *bm = 4; *bn = din_gather::conv1x1_stream_tile(cprod); }
     }
     {   // 1x1 layers with a 640..768-channel reduction over a large map run conv1x1_regw_kernel (conv_regw.hip, filters resident in registers):
-        // bm = 5, bn = 192 (same conditions as din_gather::conv1x1_regw_eligible, evaluated on the descriptor; single destination, no accumulate)
+        // bm = 5, bn = 192 | 128 filters per class (same conditions as din_gather::conv1x1_regw_eligible, evaluated on the descriptor; single destination, no accumulate)
         const char* rv = DIN_OPT("DIN_CONV_REGW");
         const int mode = rv ? atoi(rv) : 1;
         const int cred = which == 0 ? d->cin : d->cout, cprod = which == 0 ? d->cout : d->cin;
         const int64_t M = which == 0 ? (int64_t)d->nb * d->oh * d->ow : (int64_t)d->nb * d->h * d->w;
         const int ldr = which == 0 ? d->ldi : d->ldo, offr = which == 0 ? d->cioff : d->cooff;
         const int ldp = which == 0 ? d->ldo : d->ldi, offp = which == 0 ? d->cooff : d->cioff;
-        const int nks = cred % 32 == 0 ? (cred + 63) / 64 * 2 : 0;      // (a multi-source launch pads EACH source to whole stages: din_conv1x1_dgrad_multi decides itself)
+        const int nks = cred % 8 == 0 ? (cred + 63) / 64 * 2 : 0;      // (a multi-source launch pads EACH source to whole stages: din_conv1x1_dgrad_multi decides itself)
+        const bool shortk = nks == 6 || nks == 8 || nks == 10;          // Mixed_5: classes of 128 filters, two workgroups per CU
+        const char* sk = DIN_OPT("DIN_CONV_REGW_SHORT");
         const char* mp = DIN_OPT("DIN_CONV_REGW_MINPIX");
         if (mode && d->dtype == DIN_BF16 && d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 && !d->in_u8 &&
-            g.splitk == 1 && (nks == 20 || nks == 24) && cprod <= 768 && cprod % 8 == 0 && ldp % 8 == 0 && offp % 8 == 0 &&
-            ldr % 8 == 0 && offr % 8 == 0 && M * ldr * 2 < 0x7fffffffll && (mode == 2 || M >= (mp ? atoll(mp) : 96 * 1024))) { *bm = 5; *bn = 192; }
+            g.splitk == 1 && (shortk || nks == 20 || nks == 24) && cprod <= (shortk ? 512 : 768) && cprod % 8 == 0 && ldp % 8 == 0 && offp % 8 == 0 &&
+            ldr % 8 == 0 && offr % 8 == 0 && M * ldr * 2 < 0x7fffffffll &&
+            (mode == 2 || (shortk ? (sk ? atoi(sk) != 0 : true) && M >= (mp ? atoll(mp) : 256 * 1024) && cprod > 96 : M >= (mp ? atoll(mp) : 96 * 1024)))) { *bm = 5; *bn = shortk ? 128 : 192; }
     }
     {   // stem layers run conv_small_kernel (same conditions as run_gather, for tensors with 16-byte aligned channel offsets): bm = 0
         const int cred = which == 0 ? d->cin : d->cout, cprod = which == 0 ? d->cout : d->cin;

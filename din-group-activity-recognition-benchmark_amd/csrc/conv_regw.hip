@@ -13,8 +13,8 @@
 // asm with hand-counted lgkmcnt: with the register file full the compiler collapses any prefetch it is given).
 // More than 192 filters: CLASSES of 192.  The classes of one TEAM sit on CUs of one XCD (workgroup b -> XCD b & 7) and walk the same tile sequence
 // at the same pace, so the pixel stages of all but the first to arrive come out of that XCD's L2 -- HBM sees the pixels once.
-//   768 -> 576 forward 372 -> 311 us, 768 -> 768 from four sources 551 -> ~400 us (tools/probes/regw_probe.hip; numbers of the integrated kernel in
-//   profiles/r05_conv1x1_regw.txt).
+//   Same box, 96 frames (profiles/r05_conv1x1_regw.txt): 768 -> 192 161 -> 140 us, 768 -> 576 386 -> 314 us, masked 768 -> 768 dgrad 571 -> 457 us.
+//   Tried and dropped there: the four transfers of a step spread among its MFMAs instead of in front of them (+-1 %).
 // Layout of a pixel stage: [128 pixels][128 B], 16-byte chunk c of row r at chunk position c ^ ((r >> 1) & 7): conflict-free for the 16-row
 // ds_read_b128 fragments; every transfer moves whole 128-byte lines (a first version with 64-byte half rows -- sources switching at k-step
 // granularity -- ran 30 % slower: twice the line requests).  The sources of a multi-source launch switch at STAGE granularity; a source whose
@@ -36,11 +36,9 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int RW_TPX = 128;                    // pixels per tile
 constexpr int RW_STAGE = 16384;                // bytes per ring slot
-constexpr int RW_NS = 9;                       // ring slots
-constexpr int RW_RT = 3;                       // 16-row filter tiles per wave: 4 waves x 48 = 192 filters per workgroup
 constexpr int RW_D = 4;                        // fragment reads in flight ahead of the MFMAs
 constexpr uint32_t RW_OOB = 0x80000000u;
-constexpr size_t RW_LDS = (size_t)RW_NS * RW_STAGE + 16384;
+constexpr size_t rw_lds(int ns) { return (size_t)ns * RW_STAGE + 16384; }     // ring + 4 KB of staging per wave
 
 struct RegwSrc { const void* in; const void* w; unsigned in_bytes, w_bytes; int ld, coff, wld, st0, cpt; };   // st0: first 64-channel stage of the source; cpt: its 16-byte chunks per pixel
 struct RegwK {
@@ -49,17 +47,25 @@ struct RegwK {
     void* out; void* out2; const float* bias; const void* mask;
     unsigned mask_bytes;
     int M, ldo, cooff, ldo2, cooff2, csplit, Cout, flags, ldm, moff, ntiles, ncls;
+    int craw;                        // > 0: produced channels >= craw get neither bias nor ReLU (ConvK::craw)
 };
 
 __device__ __forceinline__ void rw_dma16(uint32_t lds_addr, __amdgpu_buffer_rsrc_t rs, uint32_t voff, int soff) {   // see din_wgrad::lds_dma16
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
 }
 
-template <int NKS, bool MASKED>
-__global__ __launch_bounds__(256, 1) void conv1x1_regw_kernel(RegwK p) {
+// NKS: 32-channel k-steps (filter registers: 12 NKS per lane); NS: ring slots; OCC: workgroups per CU -- 1 with the 640..768-channel reductions (the
+// filters fill the register file), 2 with the 192..288-channel reductions of Mixed_5 (<= 120 filter registers: two workgroups of 80 KB LDS, one
+// in its epilogue while the other multiplies)
+// RT: 16-row filter tiles per wave (4 waves x 16 RT = 192 | 128 filters per workgroup class)
+template <int NKS, bool MASKED, int NS, int OCC, int RT>
+__global__ __launch_bounds__(256, OCC) void conv1x1_regw_kernel(RegwK p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(NKS % 2 == 0 && NKS <= 24, "whole 64-channel stages, <= 288 filter registers");
-    constexpr int NS = RW_NS, RT = RW_RT, D = RW_D, STAGE = RW_STAGE;
+    static_assert(NS >= 4 && (NS - 2) * 4 <= 63, "ring depth");
+    constexpr int D = RW_D, STAGE = RW_STAGE;
+    constexpr int PITCH = 32 * RT + 16, BIAS_OFF = 32 * PITCH;     // staging: 32 pixels x 32 RT bytes per wave (+ 16: ds_write_b64 without 4-way conflicts), bias behind it
+    static_assert(RT == 2 || RT == 3, "pieces per pixel");
     constexpr int NST = NKS / 2, STEPS = NST + (MASKED ? 4 : 0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -150,13 +156,16 @@ __global__ __launch_bounds__(256, 1) void conv1x1_regw_kernel(RegwK p) {
             int ln = lane;
             asm volatile("" : "+v"(ln));            // recomputed per use: hoisted out of the tile loop, these addresses cost registers the kernel does not have
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const unsigned ci = (unsigned)((3 * wid + t) * 64 + ln), px = ci / 24u, c = ci - px * 24u;
-                const int m = tile * RW_TPX + q * 32 + (int)px;
-                const uint32_t voff = (live && m < p.M) ? (uint32_t)(m * p.ldm * 2) + c * 16u : RW_OOB;
-                rw_dma16(dst + (uint32_t)((3 * wid + t) * 1024), rsM, voff, soff);
+            for (int t = 0; t < 4; ++t) {                                                 // RT real transfers ([32 pixels][8 RT chunks] = 64 RT lanes' worth), the rest empty
+                if (t < RT) {
+                    const unsigned ci = (unsigned)((RT * wid + t) * 64 + ln), px = ci / (unsigned)(8 * RT), c = ci - px * (unsigned)(8 * RT);
+                    const int m = tile * RW_TPX + q * 32 + (int)px;
+                    const uint32_t voff = (live && m < p.M) ? (uint32_t)(m * p.ldm * 2) + c * 16u : RW_OOB;
+                    rw_dma16(dst + (uint32_t)((RT * wid + t) * 1024), rsM, voff, soff);
+                } else {
+                    rw_dma16(dst + (uint32_t)(4096 * RT + ((4 - RT) * wid + t - RT) * 1024), rsM, RW_OOB, 0);   // keeps the count at four (zeros into the slot's unused tail)
+                }
             }
-            rw_dma16(dst + (uint32_t)(12288 + wid * 1024), rsM, RW_OOB, 0);                          // keeps the count at four (zeros into the slot's unused tail)
         }
         i_slot = i_slot + 1 == NS ? 0 : i_slot + 1;
         i_slot = __builtin_amdgcn_readfirstlane(i_slot);
@@ -195,13 +204,13 @@ __global__ __launch_bounds__(256, 1) void conv1x1_regw_kernel(RegwK p) {
     // vmcnt(0) -- every transfer in flight -- once per tile (measured: 768 -> 576 filters 311 -> 285 us)
     if (lane < 16 * RT) {
         const int c = wbase + lane;
-        *reinterpret_cast<float*>(stg + 3584 + lane * 4) = (!MASKED && (p.flags & DIN_CONV_BIAS) && c < p.Cout) ? p.bias[c] : 0.f;
+        *reinterpret_cast<float*>(stg + BIAS_OFF + lane * 4) = (!MASKED && (p.flags & DIN_CONV_BIAS) && c < p.Cout && (p.craw == 0 || c < p.craw)) ? p.bias[c] : 0.f;
     }
     f32x4 acc[RT][8];
     // one pass of the epilogue: pixel fragments 2 ps and 2 ps + 1 (32 pixels) of the tile; mslot: the mask stage [32][384 B] of these pixels
     auto epilogue_pass = [&](int tile, int ps, [[maybe_unused]] const unsigned char* mslot) __attribute__((always_inline)) {
-        int relu_o = relu ? 1 : 0, csplit = MASKED ? 0 : p.csplit;
-        asm volatile("" : "+s"(relu_o), "+s"(csplit));          // (opaque: no loop unswitching on launch flags)
+        int relu_o = relu ? 1 : 0, csplit = MASKED ? 0 : p.csplit, craw = MASKED ? 0 : p.craw;
+        asm volatile("" : "+s"(relu_o), "+s"(csplit), "+s"(craw));          // (opaque: no loop unswitching on launch flags)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -209,10 +218,11 @@ __global__ __launch_bounds__(256, 1) void conv1x1_regw_kernel(RegwK p) {
                 asm volatile("" : "+a"(acc[rt][ps * 2 + jj]));        // pinned in its accumulation registers until HERE: the scheduler otherwise copies the
                 f32x4 v = acc[rt][ps * 2 + jj];                        // accumulators of all four passes into VGPRs early (+80 live registers -> filter spills)
                 if (!MASKED && relu_o) {
+                    const float lo = (craw > 0 && wbase + g * 4 * RT + rt * 4 >= craw) ? -__builtin_inff() : 0.f;      // (raw-stored sibling: no clamp)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);
                 }
-                *reinterpret_cast<u32x2*>(stg + (jj * 16 + frow) * 112 + g * 24 + rt * 8) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(stg + (jj * 16 + frow) * PITCH + g * 8 * RT + rt * 8) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                 asm volatile("" ::: "memory");        // one piece at a time: scheduled freely, the epilogue's temporaries push filters out of the register file
             }
         asm volatile("" ::: "memory");
@@ -220,11 +230,11 @@ __global__ __launch_bounds__(256, 1) void conv1x1_regw_kernel(RegwK p) {
         int ln = lane;
         asm volatile("" : "+v"(ln));                // (as in issue(): keep the piece addresses out of the tile loop's live registers)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const unsigned fi = (unsigned)(ln + 64 * i), px = fi / 6u, pc = fi - px * 6u;            // 32 pixels x 6 sixteen-byte pieces
-            u32x4 v = *reinterpret_cast<const u32x4*>(stg + px * 112 + pc * 16);
+        for (int i = 0; i < RT; ++i) {
+            const unsigned fi = (unsigned)(ln + 64 * i), px = fi / (unsigned)(2 * RT), pc = fi - px * (unsigned)(2 * RT);   // 32 pixels x 2 RT sixteen-byte pieces
+            u32x4 v = *reinterpret_cast<const u32x4*>(stg + px * PITCH + pc * 16);
             if constexpr (MASKED) {                                                                  // ReLU backward: keep where the forward output was > 0
-                const u32x4 mk = *reinterpret_cast<const u32x4*>(mslot + px * 384 + (wid * 6 + (int)pc) * 16);
+                const u32x4 mk = *reinterpret_cast<const u32x4*>(mslot + px * (128 * RT) + (wid * 2 * RT + (int)pc) * 16);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)                                                          // bf16 > 0: sign clear and not zero, per half
                     v[e] &= ((int32_t)mk[e] >= 0x00010000 ? 0xffff0000u : 0u) | ((int32_t)(mk[e] << 16) >= 0x00010000 ? 0x0000ffffu : 0u);
@@ -249,7 +259,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_regw_kernel(RegwK p) {
     for (int tile = team; tile < p.ntiles; tile += gstep) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(stg + 3584 + (g * 4 * RT + rt * 4) * 4);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(stg + BIAS_OFF + (g * 4 * RT + rt * 4) * 4);
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[rt][j] = b;
         }
@@ -298,16 +308,16 @@ __global__ __launch_bounds__(256, 1) void conv1x1_regw_kernel(RegwK p) {
 
 int regw_mode() { const char* e = DIN_OPT("DIN_CONV_REGW"); return e ? atoi(e) : 1; }       // 0: never, 1: where measured to win, 2: every eligible launch
 
-template <int NKS>
-void launch_regw_nks(const RegwK& r, bool masked, int grid, hipStream_t st) {
+template <int NKS, int NS, int OCC, int RT>
+void launch_regw_nks(const RegwK& r, bool masked, int cus, hipStream_t st) {
     if (masked) {
-        auto kern = conv1x1_regw_kernel<NKS, true>;
-        din_raise_lds(reinterpret_cast<const void*>(kern), RW_LDS);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), RW_LDS, st, r);
+        auto kern = conv1x1_regw_kernel<NKS, true, NS, OCC, RT>;
+        din_raise_lds(reinterpret_cast<const void*>(kern), rw_lds(NS));
+        hipLaunchKernelGGL(kern, dim3(cus * OCC), dim3(256), rw_lds(NS), st, r);
     } else {
-        auto kern = conv1x1_regw_kernel<NKS, false>;
-        din_raise_lds(reinterpret_cast<const void*>(kern), RW_LDS);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), RW_LDS, st, r);
+        auto kern = conv1x1_regw_kernel<NKS, false, NS, OCC, RT>;
+        din_raise_lds(reinterpret_cast<const void*>(kern), rw_lds(NS));
+        hipLaunchKernelGGL(kern, dim3(cus * OCC), dim3(256), rw_lds(NS), st, r);
     }
 }
 
@@ -316,20 +326,20 @@ int regw_ksteps(const ConvK& k) {                         // 32-channel k-steps 
     const int ns = k.nsrc > 0 ? k.nsrc : 1;
     for (int s = 0; s < ns; ++s) {
         const int cpt = k.nsrc > 0 ? k.src[s].cpt : k.cpt;
-        if (cpt <= 0 || cpt % 4 != 0) return 0;
+        if (cpt <= 0) return 0;
         nks += (cpt + 7) / 8 * 2;
     }
-    return (nks == 20 || nks == 24) ? nks : 0;
+    return (nks == 6 || nks == 8 || nks == 10 || nks == 20 || nks == 24) ? nks : 0;
 }
 }  // namespace
 
 bool conv1x1_regw_eligible(const ConvK& k, int dtype) {
     const int mode = regw_mode();
     if (!mode || dtype != DIN_BF16 || k.kh != 1 || k.kw != 1 || k.ay != 1 || k.ax != 1 || k.by != 0 || k.bx != 0 || k.divy != 1 || k.divx != 1 ||
-        k.remap || k.out_sy != 0 || k.u8 || k.xsteps != 0 || k.craw != 0 || k.M <= 0 || k.M >= (1 << 24) || (k.splitk > 1) || k.nsrc > 4)
+        k.remap || k.out_sy != 0 || k.u8 || k.xsteps != 0 || k.craw % 4 != 0 || ((k.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM)) && k.craw != 0) || k.M <= 0 || k.M >= (1 << 24) || (k.splitk > 1) || k.nsrc > 4)
         return false;
     if (k.flags & DIN_CONV_ACCUM) return false;
-    if (k.Cout <= 0 || k.Cout > 4 * 64 * RW_RT || k.Cout % 8 != 0 || k.ldo % 8 != 0 || k.cooff % 8 != 0) return false;
+    if (k.Cout <= 0 || k.Cout > 4 * 64 * (regw_ksteps(k) <= 10 ? 2 : 3) || k.Cout % 8 != 0 || k.ldo % 8 != 0 || k.cooff % 8 != 0) return false;
     if ((k.flags & DIN_CONV_MASK) && (!k.mask || k.ldm % 8 != 0 || k.moff % 8 != 0 || (long long)k.M * k.ldm * 2 >= 0x7fffffffll || k.csplit > 0)) return false;
     if (k.csplit > 0 && (k.csplit % 8 != 0 || k.ldo2 % 8 != 0 || k.cooff2 % 8 != 0 || !k.out2)) return false;
     if (!regw_ksteps(k)) return false;
@@ -342,6 +352,11 @@ bool conv1x1_regw_eligible(const ConvK& k, int dtype) {
     if (mode == 2) return true;
     // measured window (profiles/r05_conv1x1_regw.txt): every launch pays ~9 us for loading its filters into the registers of all CUs
     const char* mp = DIN_OPT("DIN_CONV_REGW_MINPIX");
+    if (regw_ksteps(k) <= 10) {                                                      // Mixed_5: against the streaming kernel (conv_stream.hip) / the 128-pixel tiles
+        const char* sv = DIN_OPT("DIN_CONV_REGW_SHORT");
+        const int sm = sv ? atoi(sv) : 1;                                            // 0: never, 1: launches of more than 96 filters, 2: all
+        return sm && (long long)k.M >= (mp ? atoll(mp) : 256 * 1024) && (k.Cout > 96 || sm == 2);   // (<= 96 filters: conv1x1_stream_kernel is faster, 154 vs 169 us)
+    }
     return (long long)k.M >= (mp ? atoll(mp) : 96 * 1024);
 }
 
@@ -361,15 +376,19 @@ int launch_conv1x1_regw(const ConvK& k, hipStream_t st) {
     r.out = k.out; r.out2 = k.out2; r.bias = k.bias; r.mask = k.mask;
     r.mask_bytes = (k.flags & DIN_CONV_MASK) ? (unsigned)((long long)k.M * k.ldm * 2) : 0u;
     r.M = k.M; r.ldo = k.ldo; r.cooff = k.cooff; r.ldo2 = k.ldo2; r.cooff2 = k.cooff2; r.csplit = k.csplit; r.Cout = k.Cout;
-    r.flags = k.flags; r.ldm = k.ldm; r.moff = k.moff;
+    r.flags = k.flags; r.ldm = k.ldm; r.moff = k.moff; r.craw = k.craw;
     r.ntiles = (k.M + RW_TPX - 1) / RW_TPX;
-    r.ncls = (k.Cout + 64 * RW_RT - 1) / (64 * RW_RT);
+    const int cw = ks <= 10 ? 128 : 192;                      // filters per class (RT = 2 | 3)
+    r.ncls = (k.Cout + cw - 1) / cw;
     static int cus = 0;
     if (!cus) { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); cus = n >= 8 ? n / 8 * 8 : 8; }
     const bool masked = (k.flags & DIN_CONV_MASK) != 0;
     switch (ks) {
-        case 20: launch_regw_nks<20>(r, masked, cus, st); break;
-        case 24: launch_regw_nks<24>(r, masked, cus, st); break;
+        case 6: launch_regw_nks<6, 4, 2, 2>(r, masked, cus, st); break;
+        case 8: launch_regw_nks<8, 4, 2, 2>(r, masked, cus, st); break;
+        case 10: launch_regw_nks<10, 4, 2, 2>(r, masked, cus, st); break;
+        case 20: launch_regw_nks<20, 9, 1, 3>(r, masked, cus, st); break;
+        case 24: launch_regw_nks<24, 9, 1, 3>(r, masked, cus, st); break;
         default: return 1;
     }
     return hipGetLastError() == hipSuccess ? 0 : 1;

@@ -98,6 +98,11 @@ CONV_CASES = [
     ("rw_160_736", 19, 160, 35, 39, 736, (1, 1), (1, 1), (0, 0), 1),         # dgrad: reduction 736 (the last stage half zero padding) -> 160 channels (a wave with 16 filters)
     ("rw_768_768", 4, 768, 43, 78, 768, (1, 1), (1, 1), (0, 0), 1),          # fwd and dgrad, four classes, every team walks several tiles
     ("rw_96_640", 20, 96, 35, 39, 640, (1, 1), (1, 1), (0, 0), 1),           # dgrad: reduction 640 -> 96 channels (two waves idle)
+    # ... and its short-reduction form (<6 | 8 | 10, ..., two workgroups per CU, classes of 128 filters>: the Mixed_5 block entries)
+    ("rw_192_176", 2, 192, 21, 25, 176, (1, 1), (1, 1), (0, 0), 1),          # Mixed_5b sibling group: 3 stages, classes 128 + 48
+    ("rw_256_264", 6, 256, 45, 47, 264, (1, 1), (1, 1), (0, 0), 1),          # 4 stages, classes 128 + 128 + 8; dgrad: reduction 264 (4.1 stages) -> 256 channels
+    ("rw_288_64", 12, 288, 45, 47, 64, (1, 1), (1, 1), (0, 0), 1),           # Mixed_5d branch_pool / Mixed_6a entry: 4.5 stages (half a stage zero padding), two waves idle
+    ("rw_64_208", 3, 64, 33, 37, 208, (1, 1), (1, 1), (0, 0), 1),            # dgrad: reduction 208 -> 64 channels
 ]
 
 
@@ -157,10 +162,12 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
             lib.din_conv_kernel_tile(C.byref(d), which, C.byref(bm), C.byref(bn))
             assert bm.value == 4, f"{name}: {('forward', 'dgrad')[which]} not on the streaming 1x1 kernel (tile {bm.value} x {bn.value})"
     if name.startswith("rw_") and dtype == "bf16":
-        for which, cred in ((0, cin), (1, cout)):
+        for which, cred, cprod in ((0, cin, cout), (1, cout, cin)):
             bm, bn = C.c_int32(0), C.c_int32(0)
             lib.din_conv_kernel_tile(C.byref(d), which, C.byref(bm), C.byref(bn))
-            assert (bm.value == 5) == (cred in (640, 736, 768)), f"{name}: {('forward', 'dgrad')[which]} kernel code {bm.value}"
+            nks = (cred + 63) // 64 * 2                      # 64-channel stages x 2; short reductions: classes of 128 filters, at most four
+            want = (nks in (20, 24) and cprod <= 768) or (nks in (6, 8, 10) and cprod <= 512)
+            assert (bm.value == 5) == want, f"{name}: {('forward', 'dgrad')[which]} kernel code {bm.value}"
     xin = to_nhwc(x, tdt, ldi)
     wdev, bdev = wt.cuda(), bias.cuda()
     wpk = torch.empty(lib.din_conv_packed_elems(C.byref(d), 0), dtype=tdt, device="cuda")
@@ -246,7 +253,7 @@ def test_stem_dgrad_early_operand_request_is_bit_identical(env, monkeypatch, cou
     assert not bool((changed & ~(xin > 0)).any())                         # nothing was added where the mask is off
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_pipe", "bf16_stream", "bf16_regw"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_pipe", "bf16_stream", "bf16_regw", "bf16_regw_short"])
 def test_conv_fwd_two_destinations(env, dtype, monkeypatch):
     """din_conv_fwd2: sibling 1x1 convs of one input as ONE launch -- channels [0, csplit) into the first tensor's view, the rest into a second
     tensor; equals the separate convs, and nothing outside the two channel ranges is touched.  bf16_pipe: through the 256-pixel tiles;
@@ -254,8 +261,8 @@ def test_conv_fwd_two_destinations(env, dtype, monkeypatch):
     lib, L, nhwc, ops = env
     monkeypatch.setenv("DIN_CONV_STREAM", "2" if dtype == "bf16_stream" else "0")
     regw = dtype == "bf16_regw"
-    monkeypatch.setenv("DIN_CONV_REGW", "2" if regw else "0")
-    if dtype in ("bf16_stream", "bf16_regw"):
+    monkeypatch.setenv("DIN_CONV_REGW", "2" if dtype.startswith("bf16_regw") else "0")     # (bf16_regw_short: the Mixed_5 group 192 -> 64 | 48 + 64 below, raw-stored
+    if dtype in ("bf16_stream", "bf16_regw", "bf16_regw_short"):                           #  sibling included, on the short-reduction instantiation)
         dtype = "bf16"
     if dtype == "bf16_pipe":
         monkeypatch.setenv("DIN_GATHER_PIPE", "2")
@@ -314,8 +321,6 @@ def test_conv_fwd_two_destinations(env, dtype, monkeypatch):
     out2 = torch.full((nb, h, w, ld2), 7.0, dtype=tdt, device="cuda")
     bdev = bias.cuda()
     craw = couts[0] + couts[1]                               # the last sibling stored raw: no bias, no ReLU (branch_pool conv)
-    if regw:
-        craw = 0                                             # (raw-stored siblings stay on the tile kernels: conv1x1_regw_eligible)
     L.check(lib.din_conv_fwd2(C.byref(d), xin.data_ptr(), bank.data_ptr(), bdev.data_ptr(), out1.data_ptr(), out2.data_ptr(), ld2, off2,
                               couts[0], craw, L.CONV_BIAS | L.CONV_RELU, None, 0, None))
     torch.cuda.synchronize()
@@ -948,7 +953,7 @@ def test_head_and_adam(env):
         assert rel(d_.detach(), r_.detach()) <= 1e-5
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_stream", "bf16_regw", "bf16_regw_768"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_stream", "bf16_regw", "bf16_regw_768", "bf16_regw_short"])
 def test_conv1x1_dgrad_multi_source(env, dtype, monkeypatch):
     """fused dgrad of three 1x1 convs reading the same tensor == sum of the three separate dgrads (+ mask, + accumulate); bf16_stream: through
     the persistent streaming kernel (each source = its own 64-channel blocks, the 48- and 104-channel sources end in partial blocks)"""
@@ -961,9 +966,10 @@ def test_conv1x1_dgrad_multi_source(env, dtype, monkeypatch):
     if regw:
         # bf16_regw: the Mixed_6c / 6d block entry (sources 192 + 160 + 160 + 192: the 160-channel sources end in half-padded stages)
         # -> 768 channels in four classes, through conv1x1_regw_kernel; bf16_regw_768: Mixed_6e (24 k-steps), three tiles per team
-        nb, h, w, cin = (2, 37, 41, 768) if dtype == "bf16_regw" else (3, 87, 157, 768)
-        couts = [192, 160, 160, 192] if dtype == "bf16_regw" else [192, 192, 192, 192]
-    if dtype in ("bf16_stream", "bf16_regw", "bf16_regw_768"):
+        # bf16_regw_short: the Mixed_5c entry (64 + 64 + 48 + 64: every source its own, partly padded, stage) -> 256 channels in two classes of 128
+        nb, h, w, cin = {"bf16_regw": (2, 37, 41, 768), "bf16_regw_768": (3, 87, 157, 768), "bf16_regw_short": (3, 87, 157, 256)}[dtype]
+        couts = {"bf16_regw": [192, 160, 160, 192], "bf16_regw_768": [192, 192, 192, 192], "bf16_regw_short": [64, 64, 48, 64]}[dtype]
+    if dtype in ("bf16_stream", "bf16_regw", "bf16_regw_768", "bf16_regw_short"):
         dtype = "bf16"
     dt = L.DIN_F32 if dtype == "fp32" else L.DIN_BF16
     tdt = torch.float32 if dtype == "fp32" else torch.bfloat16

@@ -44,6 +44,11 @@ LAYERS = {  # name: (nb, h, w, cin, cout, k, s, p)
     "inc_6c_7x1_192": (96, 43, 78, 160, 192, (7, 1), 1, (3, 0)),
     "k_1x1_768_64": (96, 43, 78, 768, 64, 1, 1, 0),
     "k_1x1_1536_64": (96, 43, 78, 1536, 64, 1, 1, 0),
+    "inc_5b_entry_176": (96, 87, 157, 192, 176, 1, 1, 0),     # Mixed_5b sibling group 192 -> 64 + 48 + 64
+    "inc_5c_entry_176": (96, 87, 157, 256, 176, 1, 1, 0),
+    "inc_5d_entry_176": (96, 87, 157, 288, 176, 1, 1, 0),
+    "inc_5c_pool_64": (96, 87, 157, 256, 64, 1, 1, 0),
+    "k_1x1_256_240": (96, 87, 157, 256, 240, 1, 1, 0),        # dgrad: the shape of the Mixed_5c block-entry data gradient (one source)
     "inc_6e_entry_576": (96, 43, 78, 768, 576, 1, 1, 0),      # the sibling group 768 -> 192 + 192 + 192 as one bank
     "inc_6b_entry_448": (96, 43, 78, 768, 448, 1, 1, 0),
     "k_1x1_768_768": (96, 43, 78, 768, 768, 1, 1, 0),         # dgrad: the shape of the Mixed_6e block-entry data gradient (one source)
@@ -63,6 +68,7 @@ def main():
     ap.add_argument("--relu", action="store_true", help="half of the activations / gradients zero, as behind a ReLU (what the mid-network layers see)")
     a = ap.parse_args()
     lib = L.load()
+    torch.manual_seed(0)                                  # (same operands in every process: the checksums of an A/B pair are comparable)
     nb, h, w, cin, cout, k, s, p = LAYERS[a.layer]
     k = (k, k) if isinstance(k, int) else k
     p = (p, p) if isinstance(p, int) else p
