@@ -285,11 +285,18 @@ class MyInception_v3(_GraphBackbone):
             out_tid = gb.tensor(h6, w6, 768)
             c7 = spec[blk + "branch7x7_1"][2]
             bc(blk + "branch1x1", v, View(out_tid, 0, 192))
-            if os.environ.get("DIN_FUSE_FWD6", "1") != "0":
-                tmp_tid = gb.tensor(h6, w6, 2 * c7)
+            fuse6 = os.environ.get("DIN_FUSE_FWD6", "1") != "0"
+            # round 5: with the filters resident in registers (conv1x1_regw_kernel: classes of 192 filters on one XCD share the pixel stream)
+            # the commuted branch_pool conv rides as a FOURTH, raw-stored sibling: one pass over the block input instead of two
+            # (DIN_FUSE_POOL6=0 restores the separate launch)
+            pool6 = fuse6 and commute and os.environ.get("DIN_FUSE_POOL6", "1") != "0"
+            if fuse6:
+                tmp_tid = gb.tensor(h6, w6, 2 * c7 + (192 if pool6 else 0))
                 t7 = bc(blk + "branch7x7_1", v, View(tmp_tid, 0, c7))
                 td = bc(blk + "branch7x7dbl_1", v, View(tmp_tid, c7, c7))
-                gb.fuse_forward(3)
+                if pool6:
+                    branch_pool(blk + "branch_pool", v, View(out_tid, 576, 192), mid=View(tmp_tid, 2 * c7, 192))
+                gb.fuse_forward(4 if pool6 else 3)
             else:
                 t7 = bc(blk + "branch7x7_1", v)
                 td = bc(blk + "branch7x7dbl_1", v)
@@ -299,7 +306,8 @@ class MyInception_v3(_GraphBackbone):
             t = bc(blk + "branch7x7dbl_3", t)
             t = bc(blk + "branch7x7dbl_4", t)
             bc(blk + "branch7x7dbl_5", t, View(out_tid, 384, 192))
-            branch_pool(blk + "branch_pool", v, View(out_tid, 576, 192))
+            if not pool6:
+                branch_pool(blk + "branch_pool", v, View(out_tid, 576, 192))
             v = View(out_tid, 0, 768)
         if self.materialise_fuse:
             # multiscale fuse (infer_model.py:165-172): resize Mixed_6e to the Mixed_5d grid into channels [288, 1056)

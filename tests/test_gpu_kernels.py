@@ -348,7 +348,8 @@ def test_conv_kernel_variant_names_the_instantiation(env):
         L.check(lib.din_conv_kernel_variant(C.byref(d), which, C.byref(f)))
         return f.value
     assert flags(192, 192, (7, 1)) == 3                 # whole k-steps per tap, 8-wave 128x192 tile
-    assert flags(768, 192, (1, 1)) == 3                 # single tap
+    assert flags(512, 192, (1, 1)) == 3                 # single tap
+    assert flags(768, 192, (1, 1)) == 0                 # (the 768-channel entries left the gather tiles in round 5: conv1x1_regw_kernel, din_conv_kernel_tile code 5)
     assert flags(80, 192, (3, 3)) == 2                  # 80 channels: k-steps straddle taps -> general loop, still 8 waves
     assert flags(192, 192, (7, 1), dtype=L.DIN_F32) == 0
 
