@@ -254,9 +254,10 @@ class MyInception_v3(_GraphBackbone):
                 out_tid, base = gb.tensor(h5, w5, ctot), 0
             # the three 1x1 convs that read the block input are laid out for ONE forward launch (nhwc.Graph.fwd_groups): consecutive ops,
             # the two temporaries adjacent views of one tensor.  Separately they are three 64-wide launches bound by re-reading the input.
-            # opt-in: the branch_pool conv as a fourth, raw-stored sibling (din_conv_fwd2 craw).  Measured no gain (64.55 vs 64.49 ms/step): 208 / 240
-            # filters need two 128-wide tiles instead of one 192-wide tile for the three-way group
-            pool4 = commute and os.environ.get("DIN_FUSE_POOL", "0") != "0"
+            # The branch_pool conv as a fourth, raw-stored sibling (din_conv_fwd2 craw): no gain on the 128-wide tiles of round 2 (208 / 240 filters
+            # needed two tiles instead of one 192-wide), but the round-5 kernel runs 176 and 208 / 240 filters alike as two classes of 128:
+            # the pool conv's own launch goes away (+0.15 % end to end; DIN_FUSE_POOL=0 restores it)
+            pool4 = commute and os.environ.get("DIN_FUSE_POOL", "1") != "0"
             tmp_tid = gb.tensor(h5, w5, 48 + 64 + (pf if pool4 else 0))
             bc(blk + "branch1x1", v, View(out_tid, base, 64))
             t5 = bc(blk + "branch5x5_1", v, View(tmp_tid, 0, 48))
