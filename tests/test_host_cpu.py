@@ -582,3 +582,32 @@ def test_return_dataset_builds_both_datasets(golden_dir):
     cfg.image_size, cfg.out_size, cfg.num_frames, cfg.num_boxes, cfg.training_stage = (64, 96), (2, 3), 3, 13, 2
     tr, te = return_dataset(cfg)
     assert len(tr) == 2 and len(te) == 2 and len(tr[0]) == 5 and tr[0][1].shape == (3, 13, 4)
+
+
+def test_block_entry_shapes_plan_onto_the_register_resident_kernel():
+    """din_conv_kernel_tile (no GPU needed): the 1x1 block entries of Mixed_5 / Mixed_6 at 96 frames resolve to conv1x1_regw_kernel (code 5, classes of
+    192 | 128 filters), small maps and other reductions do not, and DIN_CONV_REGW=0 hands them back to the tile kernels."""
+    from din_amd import _lib
+    lib = _lib.load()
+
+    def plan(nb, h, w, cin, cout, which):
+        d = _lib.ConvDesc()
+        d.nb, d.h, d.w, d.cin, d.oh, d.ow, d.cout = nb, h, w, cin, h, w, cout
+        d.kh = d.kw = d.sh = d.sw = d.dh = d.dw = 1
+        d.ph = d.pw = 0
+        d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = cin, 0, cout, 0, _lib.DIN_BF16
+        bm, bn = ctypes.c_int32(0), ctypes.c_int32(0)
+        assert lib.din_conv_kernel_tile(ctypes.byref(d), which, ctypes.byref(bm), ctypes.byref(bn)) == 0
+        return bm.value, bn.value
+
+    assert plan(96, 43, 78, 768, 576, 0) == (5, 192)            # Mixed_6e sibling group, forward
+    assert plan(96, 43, 78, 768, 768, 1) == (5, 192)            # the shape of its four-source data gradient
+    assert plan(96, 87, 157, 288, 176, 0) == (5, 128)           # Mixed_5d sibling group: short reduction, two workgroups per CU
+    assert plan(96, 87, 157, 256, 64, 0)[0] != 5                # <= 96 filters: the streaming kernel keeps it
+    assert plan(12, 43, 78, 768, 576, 0)[0] != 5                # 40 K pixels: below the threshold
+    assert plan(96, 43, 78, 512, 192, 0)[0] != 5                # a reduction the kernel is not instantiated for
+    _lib.set_option("DIN_CONV_REGW", "0")
+    try:
+        assert plan(96, 43, 78, 768, 576, 0)[0] != 5
+    finally:
+        _lib.set_option("DIN_CONV_REGW", None)
