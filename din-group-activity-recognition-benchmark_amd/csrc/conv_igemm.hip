@@ -3280,7 +3280,7 @@ int din_conv_kernel_tile(const din_conv_desc* d, int which, int32_t* bm, int32_t
         if (mode && d->dtype == DIN_BF16 && d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 && !d->in_u8 &&
             g.splitk == 1 && (shortk || nks == 20 || nks == 24) && cprod <= (shortk ? 512 : 768) && cprod % 8 == 0 && ldp % 8 == 0 && offp % 8 == 0 &&
             ldr % 8 == 0 && offr % 8 == 0 && M * ldr * 2 < 0x7fffffffll &&
-            (mode == 2 || (shortk ? (sk ? atoi(sk) != 0 : true) && M >= (mp ? atoll(mp) : 256 * 1024) && cprod > 96 : M >= (mp ? atoll(mp) : 96 * 1024)))) { *bm = 5; *bn = shortk ? 128 : 192; }
+            (mode == 2 || (shortk ? (sk ? atoi(sk) != 0 : true) && M >= (mp ? atoll(mp) : 128 * 1024) && cprod > 96 : M >= (mp ? atoll(mp) : 64 * 1024)))) { *bm = 5; *bn = shortk ? 128 : 192; }
     }
     {   // stem layers run conv_small_kernel (same conditions as run_gather, for tensors with 16-byte aligned channel offsets): bm = 0
         const int cred = which == 0 ? d->cin : d->cout, cprod = which == 0 ? d->cout : d->cin;

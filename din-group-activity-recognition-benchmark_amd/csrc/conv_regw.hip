@@ -355,9 +355,9 @@ bool conv1x1_regw_eligible(const ConvK& k, int dtype) {
     if (regw_ksteps(k) <= 10) {                                                      // Mixed_5: against the streaming kernel (conv_stream.hip) / the 128-pixel tiles
         const char* sv = DIN_OPT("DIN_CONV_REGW_SHORT");
         const int sm = sv ? atoi(sv) : 1;                                            // 0: never, 1: launches of more than 96 filters, 2: all
-        return sm && (long long)k.M >= (mp ? atoll(mp) : 256 * 1024) && (k.Cout > 96 || sm == 2);   // (<= 96 filters: conv1x1_stream_kernel is faster, 154 vs 169 us)
+        return sm && (long long)k.M >= (mp ? atoll(mp) : 128 * 1024) && (k.Cout > 96 || sm == 2);      // (4 clips, 164 K pixels: 9.60 -> 9.52 ms per step)   // (<= 96 filters: conv1x1_stream_kernel is faster, 154 vs 169 us)
     }
-    return (long long)k.M >= (mp ? atoll(mp) : 96 * 1024);
+    return (long long)k.M >= (mp ? atoll(mp) : 64 * 1024);                           // (8 clips, 80 K pixels: 15.40 -> 15.29 ms; 40 K pixels: neutral)
 }
 
 int launch_conv1x1_regw(const ConvK& k, hipStream_t st) {

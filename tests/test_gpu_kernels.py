@@ -117,7 +117,7 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
     if name.startswith("st_"):
         monkeypatch.setenv("DIN_CONV_STREAM", "2")      # ... and the streaming 1x1 kernel only on maps of >= 256K pixels
     if name.startswith("rw_"):
-        monkeypatch.setenv("DIN_CONV_REGW", "2")        # ... and the register-resident-filter kernel only on maps of >= 96K pixels
+        monkeypatch.setenv("DIN_CONV_REGW", "2")        # ... and the register-resident-filter kernel only on maps of >= 64K / 128K pixels
     if name.startswith("gp"):
         monkeypatch.setenv("DIN_GATHER_PIPE", "2")      # ... and the 256-pixel pipelined tiles only on launches that fill the chip
         monkeypatch.setenv("DIN_CONV_HALO", "0")
