@@ -25,6 +25,7 @@
 // The epilogue goes through 4 KB of wave-private LDS (the MFMA result layout gives a lane 24 contiguous bytes; stored directly, the write path
 // sees 64 scattered 8-byte pieces per instruction: 24 % of the kernel) and leaves as 16-byte stores of whole 96-byte runs.
 #include "conv_gather.h"
+#include <atomic>
 
 namespace din_gather {
 namespace {
@@ -380,8 +381,16 @@ int launch_conv1x1_regw(const ConvK& k, hipStream_t st) {
     r.ntiles = (k.M + RW_TPX - 1) / RW_TPX;
     const int cw = ks <= 10 ? 128 : 192;                      // filters per class (RT = 2 | 3)
     r.ncls = (k.Cout + cw - 1) / cw;
-    static int cus = 0;
-    if (!cus) { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); cus = n >= 8 ? n / 8 * 8 : 8; }
+    static std::atomic<int> cus_of[64];                          // CUs per device (a multiple of 8: the team layout counts workgroups per XCD), cached
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int cus = dev >= 0 && dev < 64 ? cus_of[dev].load(std::memory_order_relaxed) : 0;
+    if (!cus) {
+        int n = 0;
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        cus = n >= 8 ? n / 8 * 8 : 8;
+        if (dev >= 0 && dev < 64) cus_of[dev].store(cus, std::memory_order_relaxed);
+    }
     const bool masked = (k.flags & DIN_CONV_MASK) != 0;
     switch (ks) {
         case 6: launch_regw_nks<6, 4, 2, 2>(r, masked, cus, st); break;
