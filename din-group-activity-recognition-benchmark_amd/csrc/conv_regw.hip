@@ -1,8 +1,9 @@
 // conv1x1_regw_kernel: 1x1 / stride-1 convolutions with a reduction of 640..768 channels over a large map -- the block ENTRIES of Inception's
 // Mixed_6b..6e (reference backbone/backbone.py:67-74 runs torchvision's InceptionC: branch1x1, branch7x7_1, branch7x7dbl_1 and the branch_pool
-// conv all read the 768-channel block input; their data gradients land on it again).  Forward: the sibling group 768 -> 192 + c7 + c7 as one
-// launch with two destinations, and the branch_pool conv.  Backward: din_conv1x1_dgrad_multi, 2..4 gradient sources -> 768 channels with the fused
-// ReLU-backward mask.
+// conv all read the 768-channel block input; their data gradients land on it again) and, in the short-reduction form at the end of this comment,
+// of Mixed_5b..5d (InceptionA, 192 / 256 / 288 channels).  Forward: the sibling group 768 -> 192 + c7 + c7 (+ 192: the commuted branch_pool conv
+// as a raw-stored fourth sibling) as one launch with two destinations.  Backward: din_conv1x1_dgrad_multi, 2..4 gradient sources -> 768 channels
+// with the fused ReLU-backward mask.
 //
 // Why another kernel (profiles/r05_slab_stream_probe.txt, profiles/r05_conv1x1_regw.txt): the 128 x 192 tile kernels re-read a 24 KB filter slab
 // from L2 per k-step and workgroup; that traffic, not HBM, holds these launches at 4.0 TB/s / 690-770 TF.  Here the FILTERS ARE RESIDENT IN
@@ -24,6 +25,9 @@
 // second counter, no exposed HBM latency in the epilogue.
 // The epilogue goes through 4 KB of wave-private LDS (the MFMA result layout gives a lane 24 contiguous bytes; stored directly, the write path
 // sees 64 scattered 8-byte pieces per instruction: 24 % of the kernel) and leaves as 16-byte stores of whole 96-byte runs.
+// Short reductions (<= 10 k-steps: Mixed_5): classes of 128 filters (RT = 2) need <= 80 filter + 64 accumulator registers, so TWO workgroups of
+// 80 KB LDS (4-slot ring) share a CU and one's epilogue overlaps the other's MFMAs -- which the one-wave-per-SIMD long form cannot have.
+// Counters against the tile kernel (profiles/r05_pmc_regw.txt): pixels fetched from HBM once per team, 3.0 instead of 7.5 instructions per MFMA.
 #include "conv_gather.h"
 #include <atomic>
 
