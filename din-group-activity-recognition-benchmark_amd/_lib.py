@@ -198,6 +198,16 @@ def get_option(name: str):
     return buf.value.decode() if rc == 1 else None
 
 
+def host_flag(name: str, default: bool) -> bool:
+    """A switch of the PYTHON host layer (graph fusions in nhwc.py, graph variants in backbone/backbone.py), kept in the SAME option table
+    as the library's kernel-selection switches (din_set_option / din_get_option): production sets none, tests and tuning tools set them
+    through the C ABI, nothing reads the process environment.  "0" = off, anything else = on, unset = `default`."""
+    if _lib is None and not os.path.exists(LIB_PATH):
+        return default                                     # (the library is missing: every op will say so; graph construction need not)
+    v = get_option(name)
+    return default if v is None else v != "0"
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = load().din_last_error_string().decode("utf-8", "replace")

@@ -213,7 +213,7 @@ class MyInception_v3(_GraphBackbone):
             setattr(mod, parts[-1], _BasicConv2d(cin, cout, k))
         # DIN_ROI_COMPOSE=0: materialise the multi-scale fuse [5d | resize(6e)] (infer_model.py:165-172) inside the graph, as round 1 did.
         # Default: the graph ends at Mixed_5d / Mixed_6e and RoIAlign samples Mixed_6e through its virtual resize (ops.RoIAlignMultiScale).
-        self.materialise_fuse = os.environ.get("DIN_ROI_COMPOSE", "1") == "0"
+        self.materialise_fuse = not L.host_flag("DIN_ROI_COMPOSE", True)
 
     def build_graph(self, h, w, dt) -> Graph:
         gb = GraphBuilder(h, w, _cpad_image(dt))
@@ -225,7 +225,7 @@ class MyInception_v3(_GraphBackbone):
 
         # branch_pool = BasicConv2d_1x1(avg_pool2d(x, 3, 1, 1)) (torchvision InceptionA/C.forward): run as conv1x1 -> avgpool so the
         # pool moves cout (32..192) instead of cin (192..768) channels.  DIN_POOL_COMMUTE=0 keeps the reference's op order.
-        commute = os.environ.get("DIN_POOL_COMMUTE", "1") != "0"
+        commute = L.host_flag("DIN_POOL_COMMUTE", True)
 
         def branch_pool(name, src: View, dst: View, mid=None):
             if commute:
@@ -257,7 +257,7 @@ class MyInception_v3(_GraphBackbone):
             # The branch_pool conv as a fourth, raw-stored sibling (din_conv_fwd2 craw): no gain on the 128-wide tiles of round 2 (208 / 240 filters
             # needed two tiles instead of one 192-wide), but the round-5 kernel runs 176 and 208 / 240 filters alike as two classes of 128:
             # the pool conv's own launch goes away (+0.15 % end to end; DIN_FUSE_POOL=0 restores it)
-            pool4 = commute and os.environ.get("DIN_FUSE_POOL", "1") != "0"
+            pool4 = commute and L.host_flag("DIN_FUSE_POOL", True)
             tmp_tid = gb.tensor(h5, w5, 48 + 64 + (pf if pool4 else 0))
             bc(blk + "branch1x1", v, View(out_tid, base, 64))
             t5 = bc(blk + "branch5x5_1", v, View(tmp_tid, 0, 48))
@@ -286,11 +286,11 @@ class MyInception_v3(_GraphBackbone):
             out_tid = gb.tensor(h6, w6, 768)
             c7 = spec[blk + "branch7x7_1"][2]
             bc(blk + "branch1x1", v, View(out_tid, 0, 192))
-            fuse6 = os.environ.get("DIN_FUSE_FWD6", "1") != "0"
+            fuse6 = L.host_flag("DIN_FUSE_FWD6", True)
             # round 5: with the filters resident in registers (conv1x1_regw_kernel: classes of 192 filters on one XCD share the pixel stream)
             # the commuted branch_pool conv rides as a FOURTH, raw-stored sibling: one pass over the block input instead of two
             # (DIN_FUSE_POOL6=0 restores the separate launch)
-            pool6 = fuse6 and commute and os.environ.get("DIN_FUSE_POOL6", "1") != "0"
+            pool6 = fuse6 and commute and L.host_flag("DIN_FUSE_POOL6", True)
             if fuse6:
                 tmp_tid = gb.tensor(h6, w6, 2 * c7 + (192 if pool6 else 0))
                 t7 = bc(blk + "branch7x7_1", v, View(tmp_tid, 0, c7))

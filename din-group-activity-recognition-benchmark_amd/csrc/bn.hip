@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const T* __restr
     }
 }
 
-static bool bn_apply_rows() { static const bool on = !(DIN_OPT("DIN_BN_APPLY_ROWS") && atoi(DIN_OPT("DIN_BN_APPLY_ROWS")) == 0); return on; }
+static bool bn_apply_rows() { const char* e = DIN_OPT("DIN_BN_APPLY_ROWS"); return !(e && atoi(e) == 0); }     // read per launch, like every option
 // rows per workgroup of the row-walk apply kernels: ~2048 workgroups, at least four passes of the workgroup's 256 / (C / V) rows each
 static int bn_apply_rpb(int64_t rows, int c, int v) {
     const int rpp = 256 / (c / v);

@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_regw_kernel(RegwK p) {
                 if (t < RT) {
                     const unsigned ci = (unsigned)((RT * wid + t) * 64 + ln), px = ci / (unsigned)(8 * RT), c = ci - px * (unsigned)(8 * RT);
                     const int m = tile * RW_TPX + q * 32 + (int)px;
-                    const uint32_t voff = (live && m < p.M) ? (uint32_t)(m * p.ldm * 2) + c * 16u : RW_OOB;
+                    // (the channel test: the SGPR soffset is outside the descriptor's range check, so a last class narrower than 64 RT channels would read past the mask tensor's end)
+                    const uint32_t voff = (live && m < p.M && cbase + (int)c * 8 < p.Cout) ? (uint32_t)(m * p.ldm * 2) + c * 16u : RW_OOB;
                     rw_dma16(dst + (uint32_t)((RT * wid + t) * 1024), rsM, voff, soff);
                 } else {
                     rw_dma16(dst + (uint32_t)(4096 * RT + ((4 - RT) * wid + t - RT) * 1024), rsM, RW_OOB, 0);   // keeps the count at four (zeros into the slot's unused tail)

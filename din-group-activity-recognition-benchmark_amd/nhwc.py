@@ -84,12 +84,24 @@ def _dw_buffer(w: torch.Tensor) -> torch.Tensor:
         if buf is not None:
             return buf
     return torch.empty_like(w)
-import os as _os
-FUSE_1X1_DGRAD = _os.environ.get("DIN_FUSE_1X1", "1") != "0"     # fuse the dgrads of 1x1 convs that read the same tensor
-FUSE_FWD_SIBLINGS = _os.environ.get("DIN_FUSE_FWD", "1") != "0"   # run Graph.fwd_groups (sibling 1x1 convs) as one two-destination launch
-FUSE_WGRAD_SIBLINGS = _os.environ.get("DIN_FUSE_WGRAD", "1") != "0"  # ... and the wgrads of the members that share the second tensor as one launch
-FUSE_WGRAD_1X1 = _os.environ.get("DIN_FUSE_WGRAD_1X1", "1") != "0"   # weight gradients of ALL 1x1 convs reading one view in one launch (din_conv1x1_wgrad_multi)
-FUSE_DGRAD_X = _os.environ.get("DIN_FUSE_DGRAD_X", "1") != "0"       # a lone 1x1's dgrad rides in the strided sibling's launches (din_conv_dgrad_x: Mixed_6a)
+# Host-layer fusion switches.  None = ask the option table the library's kernel switches live in (din_set_option, `_lib.host_flag`: production
+# sets none, nothing reads the environment); a test may also pin one by assigning True / False to the module attribute.
+FUSE_1X1_DGRAD = None        # DIN_FUSE_1X1 (default on): fuse the dgrads of 1x1 convs that read the same tensor
+FUSE_FWD_SIBLINGS = None     # DIN_FUSE_FWD (on): run Graph.fwd_groups (sibling 1x1 convs) as one two-destination launch
+FUSE_WGRAD_SIBLINGS = None   # DIN_FUSE_WGRAD (on): ... and the wgrads of the members that share the second tensor as one launch
+FUSE_WGRAD_1X1 = None        # DIN_FUSE_WGRAD_1X1 (on): weight gradients of ALL 1x1 convs reading one view in one launch (din_conv1x1_wgrad_multi)
+FUSE_DGRAD_X = None          # DIN_FUSE_DGRAD_X (on): a lone 1x1's dgrad rides in the strided sibling's launches (din_conv_dgrad_x: Mixed_6a)
+_SWITCHES = {"FUSE_1X1_DGRAD": ("DIN_FUSE_1X1", True), "FUSE_FWD_SIBLINGS": ("DIN_FUSE_FWD", True), "FUSE_WGRAD_SIBLINGS": ("DIN_FUSE_WGRAD", True),
+             "FUSE_WGRAD_1X1": ("DIN_FUSE_WGRAD_1X1", True), "FUSE_DGRAD_X": ("DIN_FUSE_DGRAD_X", True), "WGRAD_SIDE_STREAM": ("DIN_WGRAD_STREAM", False)}
+
+
+def switch(attr: str) -> bool:
+    v = globals()[attr]
+    if v is not None:
+        return bool(v)
+    name, default = _SWITCHES[attr]
+    return L.host_flag(name, default)
+
 
 
 # ------------------------------------------------------------------------------------------------
@@ -99,7 +111,7 @@ _WS: Dict[Tuple[int, str], torch.Tensor] = {}
 
 
 _SIDE: Dict[int, "torch.cuda.Stream"] = {}
-WGRAD_SIDE_STREAM = _os.environ.get("DIN_WGRAD_STREAM", "0") != "0"     # opt-in: measured 472 -> 351 clips/s (the LDS-heavy kernels of the two streams evict each other)
+WGRAD_SIDE_STREAM = None     # DIN_WGRAD_STREAM (off), opt-in: measured 472 -> 351 clips/s (the LDS-heavy kernels of the two streams evict each other)
 
 
 def side_stream(device) -> "torch.cuda.Stream":
@@ -465,7 +477,7 @@ def graph_forward(g: Graph, image_buf: torch.Tensor, params: Sequence[torch.Tens
     # ... and every filter bank (forward and, when training, dgrad orientation) repacked with the folded scale in ONE launch
     L.check(lib.din_conv_pack_multi(_ptr(pc.table), _ptr(pc.layer_of), _ptr(pc.chunk_index), pc.nblocks, PACK_CHUNK, st), "conv_pack_multi")
     bn_i = 0
-    group_of = {grp[0]: grp for grp in g.fwd_groups} if (FUSE_FWD_SIBLINGS and not bn_train) else {}
+    group_of = {grp[0]: grp for grp in g.fwd_groups} if (switch("FUSE_FWD_SIBLINGS") and not bn_train) else {}
     fused_done = set()                                     # members whose output the group launch already produced
     for oi, op in enumerate(g.ops):
         td = g.tensors[op.dst.tid]
@@ -586,7 +598,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
     tdt = torch_dtype(dt)
     st = _stream()
     main = torch.cuda.current_stream()
-    side = side_stream(dev) if (WGRAD_SIDE_STREAM and not TIMING_ACTIVE()) else None
+    side = side_stream(dev) if (switch("WGRAD_SIDE_STREAM") and not TIMING_ACTIVE()) else None
     wtag = ""
     gbufs: Dict[int, torch.Tensor] = dict(out_grads)
 
@@ -667,7 +679,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
     # 1x1 / stride-1 convs that read the same view (branch-entry convs of the Inception blocks): their dgrads are fused into ONE
     # multi-source launch, issued when the last member (first in program order) has been visited
     groups: Dict[Tuple[int, int, int], List[int]] = {}
-    if FUSE_1X1_DGRAD:
+    if switch("FUSE_1X1_DGRAD"):
         for oi, op in enumerate(g.ops):
             if op.kind == "conv" and op.k == (1, 1) and op.s == (1, 1) and op.p == (0, 0) and op.src.tid != g.input_tid:
                 groups.setdefault((op.src.tid, op.src.coff, op.src.c), []).append(oi)
@@ -679,7 +691,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
     # branch3x3): the reverse pass meets the 1x1 first, parks its dgrad operands, and the strided conv's dgrad carries them (din_conv_dgrad_x)
     x_host: Dict[int, int] = {}                               # 1x1 op index -> strided op index that will carry its dgrad
     x_parked: Dict[int, tuple] = {}                           # strided op index -> (1x1 op index, its gout, pixel stride, channel offset)
-    if FUSE_DGRAD_X and dt == L.DIN_BF16:
+    if switch("FUSE_DGRAD_X") and dt == L.DIN_BF16:
         for oi, op in enumerate(g.ops):
             if (op.kind == "conv" and op.k == (1, 1) and op.s == (1, 1) and op.p == (0, 0) and op.src.tid != g.input_tid and oi not in member_of
                     and op.pooled is None):
@@ -769,6 +781,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
         flags = (L.CONV_ACCUM if acc else 0) | (L.CONV_MASK if ts0.relu_masked else 0)
         d0 = _conv_desc(g, op0, nb, dt)
         d0.cout = sum(g.ops[it[0]].dst.c for it in items)          # FLOP accounting of the fused launch
+        d0.src_couts = tuple(g.ops[it[0]].dst.c for it in items)   # (measurement side: profiling.LaunchTimer names the instantiation from it)
         with _timed("dgrad", d0, "+".join(g.ops[it[0]].name for it in items)):
             L.check(lib.din_conv1x1_dgrad_multi(len(items), srcs, dt, nb, ts0.h, ts0.w, op0.src.c, ts0.c, op0.src.coff, _ptr(gsrc),
                                                 _ptr(bufs[op0.src.tid]) if ts0.relu_masked else None, ts0.c, op0.src.coff, flags, st),
@@ -779,7 +792,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
     # reverse pass reaches it first; by then the consumers of every member have written their slice of the shared gradient buffer)
     wgrad_group = {}
     bn_train = bool(bn_train) and bn is not None
-    if FUSE_WGRAD_SIBLINGS and not bn_train:
+    if switch("FUSE_WGRAD_SIBLINGS") and not bn_train:
         for grp in g.fwd_groups:
             mem = tuple(i for i in grp[1:] if g.ops[i].pooled is None)      # (a commuted-pool member keeps its own wgrad: its gradient
             if len(mem) >= 2:                                               #  operand is the un-pooled map, a separate buffer)
@@ -788,7 +801,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
     # 1x1 groups whose weight gradients run as ONE launch (din_conv1x1_wgrad_multi): sources = the members, sibling pairs that share a
     # tensor (wgrad_group) counted as one source; the library says whether the group fits its kernel (0 bytes of workspace: it does not)
     multi_w: Dict[Tuple[int, int, int], tuple] = {}
-    if FUSE_WGRAD_1X1 and bn is not None and not bn_train and side is None and dt == L.DIN_BF16:
+    if switch("FUSE_WGRAD_1X1") and bn is not None and not bn_train and side is None and dt == L.DIN_BF16:
         pair_of = {i: mem for mem in wgrad_group.values() for i in mem}
         for key, members in groups.items():
             if not all(g.ops[i].bn for i in members):

@@ -144,7 +144,7 @@ class LaunchTimer:
             if bm.value == 0:
                 return f"conv_wgrad_small_kernel<..., {bn.value}, ...>"
             if bn.value >= 2000:
-                waves = int(os.environ.get("DIN_WGRAD_PIPE_WAVES", "16"))      # wave grid 2 x WN (conv_wgrad_pipe.hip launch_wgrad_pipe)
+                waves = int(L.get_option("DIN_WGRAD_PIPE_WAVES") or "16")      # wave grid 2 x WN (conv_wgrad_pipe.hip launch_wgrad_pipe)
                 wn = 8 if waves == 16 else (2 if waves == 4 and bm.value <= 192 else 4)
                 return f"conv_wgrad_pipe_kernel<{bm.value}, {bn.value - 2000}, {'true' if d.ow >= 32 else 'false'}, {wn}>"
             if bn.value >= 1000:
@@ -152,8 +152,14 @@ class LaunchTimer:
             return f"conv_wgrad_bf16_kernel<{bm.value}>" if d.dtype == L.DIN_BF16 else "conv_wgrad_f32_kernel"
         if bm.value == 4 and not (self.kind == "dgrad" and "+" in self.name):
             return f"conv1x1_stream_kernel<{bn.value}>"
-        if bm.value == 5:                                             # (multi-source dgrads included: the descriptor carries the summed reduction)
-            return f"conv1x1_regw_kernel<{24 if (d.cin if self.kind == 'fwd' else d.cout) > 640 else 20}, ...>"
+        if bm.value == 5:
+            # NKS as launch_conv1x1_regw counts it: every source padded to whole 64-channel stages (a multi-source dgrad carries its sources'
+            # channel counts as d.src_couts: 192 + 160 + 160 + 192 is 24 k-steps, not the 22 of the summed reduction)
+            srcs = getattr(d, "src_couts", None) or ((d.cin if self.kind == "fwd" else d.cout),)
+            nks = sum((c + 63) // 64 * 2 for c in srcs)
+            if nks in (6, 8, 10, 20, 24):
+                return f"conv1x1_regw_kernel<{nks}, ...>"
+            bm.value, bn.value = 128, 192                             # (the multi-source launch does not fit the register-resident form: tile kernel)
         if bm.value == 0:
             return f"conv_small_kernel<..., {bn.value}, ...>"
         if bm.value == 1:

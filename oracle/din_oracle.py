@@ -881,6 +881,29 @@ def synth_params(shapes: Dict[str, Tuple[int, ...]], seed: int = 3, din_std: flo
     return out
 
 
+def synth_smooth_images(b: int, t: int, h: int, w: int, seed: int = 0):
+    """uint8 frames with the statistics of a photograph rather than of white noise: per clip and colour plane a sum of three smooth
+    sinusoidal fields (spatial periods of 30 .. 400 pixels) that drifts by a few pixels from frame to frame (the frames of a Volleyball clip
+    are consecutive video frames, reference volleyball.py:239-243), plus sensor noise N(0, 6).  Used by the full-size fixture that holds the
+    bf16 mode's gradient direction on a realistic input (tools/gen_golden.py --only full_smooth); regenerated from the seed on both sides."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    out = np.empty((b, t, 3, h, w), dtype=np.uint8)
+    for bi in range(b):
+        comps = [[(rng.uniform(5, 64), rng.uniform(5, 64), rng.uniform(0, 6.28), rng.uniform(0, 6.28), rng.uniform(20, 60)) for _ in range(3)]
+                 for _c in range(3)]
+        drift = rng.uniform(-3, 3, size=(t, 2)).cumsum(0)
+        for ti in range(t):
+            for c in range(3):
+                f = np.full((h, w), 118.0 + 12.0 * c)
+                for (py, px, ay, ax, amp) in comps[c]:
+                    f += amp * np.sin((yy + drift[ti, 0]) / py + ay) * np.cos((xx + drift[ti, 1]) / px + ax)
+                f += rng.normal(0.0, 6.0, (h, w))
+                out[bi, ti, c] = np.clip(np.rint(f), 0, 255).astype(np.uint8)
+    return torch.from_numpy(out)
+
+
 def synth_inputs(b: int, t: int, n: int, h: int, w: int, oh: int, ow: int, num_classes: int = 8,
                  seed: int = 0):
     """uint8-valued images, player-shaped boxes in feature px, labels."""

@@ -835,12 +835,16 @@ def _probe_idx(numel, count=8192):
     return torch.arange(count, dtype=torch.int64) * (numel // count)
 
 
-def _run_full_case(gpu, path, backbone_dtype):
-    """one fwd + bwd of the full-size fixture through the HIP path; returns (fixture, logits, loss, named grads, captured stage tensors)"""
+def _run_full_case(gpu, path, backbone_dtype, tile=1, case=None):
+    """one fwd + bwd of the full-size fixture through the HIP path; returns (fixture, logits, loss, named grads, captured stage tensors).
+    tile > 1 repeats the fixture's clips `tile` times along the batch (clips are independent under running-statistics BatchNorm, reference
+    train_net_dynamic.py:17-20), which moves the run onto the launch geometry of the benchmarked batch sizes."""
     from din_amd import ops
     from din_amd.config import Config
     from din_amd.infer_model import Dynamic_volleyball
-    z, ocfg, p, images, boxes, labels = load_model_case(path)
+    z, ocfg, p, images, boxes, labels = case if case is not None else load_model_case(path)
+    if tile > 1:
+        images, boxes, labels = images.repeat(tile, 1, 1, 1, 1), boxes.repeat(tile, 1, 1, 1), labels.repeat(tile)
     cfg = Config("volleyball")
     cfg.backbone, cfg.image_size, cfg.out_size, cfg.emb_features = ocfg.backbone, ocfg.image_size, ocfg.out_size, ocfg.emb_features
     cfg.num_boxes, cfg.num_frames = ocfg.num_boxes, ocfg.num_frames
@@ -1005,9 +1009,119 @@ def test_full_size_bf16_model_tracks_reference_golden(gpu, path):
     # feature maps after 11 / 47 bf16 layers (eps 3.9e-3 per rounding): measured 1.1e-2 .. 1.6e-2 of the map's maximum (deterministic forward)
     assert errs["fm0"] <= 4e-2 and errs["fm1"] <= 4e-2 and errs["crops"] <= 4e-2, errs
     assert errs["x_emb"] <= 5e-2 and errs["graph"] <= 5e-2, errs
-    assert min(head.values()) >= 0.95, head                      # measured 0.9866 .. 0.9999 (the actor max re-routes whole windows on 1e-2 differences)
     assert cosv["fc_emb_1.weight"] >= 0.99, cosv["fc_emb_1.weight"]
+    if "smooth" in z.files and int(z["smooth"]):
+        # photograph-like frames: the floors the benchmarked mode's gradient DIRECTION is held to on a realistic input
+        assert min(head.values()) >= 0.98, head
+        assert min(body.values()) >= 0.97, sorted(body.items(), key=lambda kv: kv[1])[:5]
+        return
+    # white-noise frames: the worst case for the image layer (an incoherent sum over uncorrelated pixels inherits the gradient map's own
+    # noise, profiles/r05_bf16_grad_cosine.txt) -- kept with its explanation, the realistic-input floors are above
+    assert min(head.values()) >= 0.95, head                      # measured 0.9866 .. 0.9999 (the actor max re-routes whole windows on 1e-2 differences)
     assert min(body.values()) >= 0.80, sorted(body.items(), key=lambda kv: kv[1])[:5]   # measured 0.923 at Conv2d_1a (47 bf16 layers below the loss)
+
+
+# ---- the BENCHMARKED launch geometry tied to the reference's golden ------------------------------------------------
+# The full-size fixtures are 1 / 2 clips: 3 - 6 frames sit far below the planner's pixel-count thresholds, so the kernels the 32-clip
+# headline number is quoted on (conv1x1_regw, conv_wgrad_halo, conv1x1_wgrad_multi, conv1x1_stream, the persistent stem kernels, the
+# pipelined wgrad with many slices) were only ever compared with something in isolation, forced on by a DIN_* option.  Here the fixture's
+# clip is tiled to the benchmarked batch sizes and the WHOLE model runs with the production planner -- no option set -- against (i) the
+# reference's numbers for that clip and (ii) the same model's 1-clip run (same operands, different kernels / summation order).
+_DISPATCH_FAMILIES = {            # family -> what the per-launch survey (din_amd.profiling.LaunchTimer: the name rocprofv3 prints) must contain
+    "bf16": ("conv1x1_regw_kernel", "conv_wgrad_halo_kernel", "conv_wgrad_1x1_multi_kernel", "conv1x1_stream_kernel", "conv_small_kernel",
+             "conv_wgrad_small_kernel", "conv_wgrad_pipe_kernel", "conv_halo_kernel", "conv_gather_fast_kernel"),
+    "fp32": ("conv_gather_fast_kernel",),
+}
+
+
+def _surveyed_run(gpu, path, dtype, tile, case):
+    """_run_full_case with every conv launch named by the measurement-side launch timer (what bench.py's survey uses)"""
+    from din_amd import nhwc, profiling
+    prev = (nhwc.LAUNCH_TIMER, nhwc.TIMING_ACTIVE, profiling.PROFILE, profiling.PROFILE_ONLY)
+    profiling.install()
+    profiling.PROFILE, profiling.PROFILE_ONLY = [], None
+    try:
+        out = _run_full_case(gpu, path, dtype, tile=tile, case=case)
+        names = {}
+        for kind, variant, _fl, _dt, _e0, _e1, name in profiling.PROFILE:
+            names.setdefault(variant.split("<")[0], set()).add(f"{kind}:{name}")
+    finally:
+        nhwc.LAUNCH_TIMER, nhwc.TIMING_ACTIVE, profiling.PROFILE, profiling.PROFILE_ONLY = prev
+    return out, names
+
+
+@pytest.mark.parametrize("dtype,tile,fixture", [("bf16", 8, "full_inv3_720x1280_b1"), ("bf16", 32, "full_inv3_720x1280_b1"),
+                                                ("bf16", 32, "full_inv3_720x1280_b1_smooth"), ("fp32", 8, "full_inv3_720x1280_b1")],
+                         ids=["bf16_b8", "bf16_b32", "bf16_b32_smooth", "fp32_b8"])
+def test_benchmarked_dispatch_matches_golden_and_single_clip_run(gpu, dtype, tile, fixture):
+    """reference infer_model.py:141-234 at the batch sizes bench.py runs (8 clips = 24 frames, 32 clips = 96 frames), production planner,
+    no DIN_* option: (a) EVERY clip's logits equal the 1-clip run's and the reference's, (b) the stage probes of clip 0 hold the full-size
+    bars, (c) every parameter gradient equals the 1-clip run's (mean loss over identical clips), (d) the launch survey shows the run really
+    went through the large-batch kernel families."""
+    import din_amd._lib as L
+    path = os.path.join(os.path.dirname(__file__), "golden", fixture + ".npz")
+    for name in ("DIN_CONV_REGW", "DIN_WGRAD_HALO", "DIN_WGRAD_1X1_MULTI", "DIN_CONV_STREAM", "DIN_CONV_HALO", "DIN_GATHER_PIPE"):
+        assert not L.get_option(name) and not os.environ.get(name), f"{name} is set: this test is about the production planner"
+    case = load_model_case(path)
+    z, logits1, loss1, named1, cap1 = _run_full_case(gpu, path, dtype, tile=1, case=case)
+    grads1 = {k: v.grad.detach().clone() for k, v in named1.items() if v.grad is not None}
+    del named1
+    (z, logits, loss, named, cap), fams = _surveyed_run(gpu, path, dtype, tile, case)
+    assert logits.shape[0] == tile
+    top = logits1.abs().max()
+    # (a) logits: per clip against the 1-clip run and against the reference
+    d_self = Measured(((logits - logits1).abs().max() / top).item())
+    d_ref = rel(logits, torch.as_tensor(z["logits"]).repeat(tile, 1))
+    spread = Measured(((logits - logits[:1]).abs().max() / top).item())
+    print(f"{dtype} x{tile}: logits vs 1-clip run {d_self:.2e}, vs reference {d_ref:.2e}, between the tiled clips {spread:.2e}; "
+          f"loss {loss:.6f} vs 1-clip {loss1:.6f} vs reference {float(z['loss']):.6f}")
+    print("   kernel families launched:", {k: len(v) for k, v in sorted(fams.items())})
+    if dtype == "fp32":
+        assert d_ref <= 1e-4 and d_self <= 1e-4 and spread <= 1e-4
+        assert Measured(abs(loss - float(z["loss"]))) <= 1e-4 * max(1.0, abs(float(z["loss"])))
+    else:
+        assert d_ref <= 2e-2 and d_self <= 8e-3 and spread <= 8e-3
+        assert Measured(abs(loss - float(z["loss"]))) <= 2e-2 * max(1.0, abs(float(z["loss"])))
+    # (b) stage probes of clip 0 (first T frames / T*N boxes / first clip)
+    T, N = int(z["feat.fm0.shape"][0]), int(z["feat.crops.shape"][0]) // int(z["feat.fm0.shape"][0])
+    first = {"fm0": cap["fm0"][:T], "fm1": cap["fm1"][:T], "crops": cap["crops"][:T * N], "x_emb": cap["x_emb"][:1], "graph": cap["graph"][:1]}
+    bars = dict.fromkeys(first, 1e-4) if dtype == "fp32" else {"fm0": 4e-2, "fm1": 4e-2, "crops": 4e-2, "x_emb": 5e-2, "graph": 5e-2}
+    errs = {k: _probe_err(z, k, v) for k, v in first.items()}
+    print("   clip-0 stage probes vs reference:", {k: f"{v:.1e}" for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v <= bars[k], (k, v)
+    # ... and the LAST clip's maps equal the first clip's (same frames; another position in every tile / slice walk)
+    for k in ("fm0", "fm1"):
+        a_, b_ = cap[k][:T].float(), cap[k][-T:].float()
+        assert Measured(((a_ - b_).abs().max() / a_.abs().max()).item()) <= (1e-5 if dtype == "fp32" else 1.6e-2), k
+    # (c) parameter gradients: mean loss over `tile` identical clips == the 1-clip gradient (other kernels, other summation order)
+    rows = []
+    for k, q in named.items():
+        if q.grad is None:
+            assert k not in grads1, k
+            continue
+        g, g1 = q.grad.detach().double().flatten(), grads1[k].double().flatten()
+        rows.append((float(g @ g1 / (g.norm() * g1.norm() + 1e-300)), float((g - g1).norm() / (g1.norm() + 1e-300)), k))
+    rows.sort()
+    print("   gradients vs 1-clip run, lowest cosines (cosine, rel-L2, tensor):", [(round(c, 5), f"{r:.1e}", k) for c, r, k in rows[:8]])
+    stem = ("backbone.Conv2d_1a", "backbone.Conv2d_2a", "backbone.Conv2d_2b", "backbone.Conv2d_3b", "backbone.Conv2d_4a")
+    body = [r for r in rows if not r[2].startswith(stem)]
+    low = [r for r in rows if r[2].startswith(stem)]
+    print("   above the stem: lowest cosine %.6f, largest rel-L2 %.2e; stem: lowest cosine %.6f, largest rel-L2 %.2e" %
+          (body[0][0], max(r[1] for r in body), low[0][0], max(r[1] for r in low)))
+    if dtype == "fp32":
+        assert Measured(rows[0][0], "cos") >= 0.9999 and Measured(max(r[1] for r in rows)) <= 1e-2, rows[:4]
+    else:
+        # bf16: the two runs round different fp32 sums to bf16 (other kernels), a handful of one-ulp differences per map re-route ReLU gates
+        # and actor-max windows, and the gradient MAP that enters the backbone differs accordingly; a weight gradient is a sum over pixels
+        # of map x input, so it inherits the map's difference the less the more coherent its input is -- the 3-channel image layer on
+        # white-noise frames is the worst case (same mechanism as bf16 vs fp32, profiles/r05_bf16_grad_cosine.txt)
+        smooth = "smooth" in fixture
+        assert Measured(body[0][0], "cos") >= (0.995 if smooth else 0.99), body[:4]
+        assert Measured(low[0][0], "cos") >= (0.99 if smooth else 0.94), low[:4]
+    # (d) the launch geometry: the families the benchmarked step is made of
+    missing = [f for f in _DISPATCH_FAMILIES[dtype] if f not in fams]
+    assert not missing, (missing, sorted(fams))
 
 
 def test_captured_step_matches_eager(gpu):

@@ -420,7 +420,7 @@ def _probe_idx(numel, count=8192):
     return (torch.arange(count, dtype=torch.int64) * (numel // count))
 
 
-def full_case(name, refim, refcfg, out_dir, *, backbone, OH, OW, D, B, seed, H=720, W=1280, T=3, N=12, NFB=1024, search=True):
+def full_case(name, refim, refcfg, out_dir, *, backbone, OH, OW, D, B, seed, H=720, W=1280, T=3, N=12, NFB=1024, search=True, smooth=False):
     """ONE full-size 720x1280 run of the reference's Dynamic_volleyball (infer_model.py:141-234), fwd + backward of the
     CE loss, eval mode.  Inputs and the 29 M weights are NOT stored: both sides regenerate them from the seed recipe of
     oracle.din_oracle.synth_inputs / synth_params.  Stored: logits, loss, per-stage feature probes taken with forward hooks on the
@@ -453,6 +453,8 @@ def full_case(name, refim, refcfg, out_dir, *, backbone, OH, OW, D, B, seed, H=7
     for _try in range(64):
         p = O.synth_params(O.model_param_shapes(ocfg), seed=seed + 3, din_std=0.02)
         images, boxes, labels = O.synth_inputs(B, T, N, H, W, OH, OW, 8, seed=seed)
+        if smooth:                             # photograph-like frames instead of white noise; boxes / labels as before
+            images = O.synth_smooth_images(B, T, H, W, seed=seed + 7)
         with torch.no_grad():
             _o, inter0 = O.dynamic_volleyball_forward(ocfg, p, images.float(), boxes, return_intermediates=True)
             lw, lb = p["dpi_nl.weight"], p["dpi_nl.bias"]
@@ -538,7 +540,7 @@ def full_case(name, refim, refcfg, out_dir, *, backbone, OH, OW, D, B, seed, H=7
                dtype=np.array("float32"), logits=ref_logits.numpy(), loss=np.float64(loss.item()), labels=labels.numpy(),
                ref_seconds_fwd_bwd=np.float64(t_ref), ref_threads=np.int64(torch.get_num_threads()),
                yard_logits=np.float64(yard_logits), min_actor_gap=np.float64(min_gap), near_ties=np.int64(near_ties), searched=np.int64(1 if search else 0),
-               oracle_vs_ref_worst_grad=np.float64(eg))
+               oracle_vs_ref_worst_grad=np.float64(eg), smooth=np.int64(1 if smooth else 0))
     for k, v in yard.items():
         rec["yard." + k] = np.float64(v)
     rec.update(g64)
@@ -848,7 +850,7 @@ def main():
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--skip-big", action="store_true")
-    ap.add_argument("--only", default="", help="'inv3': only the two reduced-size Inception fixtures; 'tce': only (re)generate the Dynamic_TCE_volleyball fixtures; 'full': only the two full-size 720x1280 fixtures; 'full_unsearched': the un-searched full-size Inception draw; 'dataset': only the dataset -> tensor contract fixtures (SURVEY 8f-1)")
+    ap.add_argument("--only", default="", help="'inv3': only the two reduced-size Inception fixtures; 'tce': only (re)generate the Dynamic_TCE_volleyball fixtures; 'full': only the two full-size 720x1280 fixtures; 'full_unsearched': the un-searched full-size Inception draw; 'full_smooth': the full-size Inception fixture on photograph-like frames; 'dataset': only the dataset -> tensor contract fixtures (SURVEY 8f-1)")
     a = ap.parse_args()
     sys.dont_write_bytecode = True
     install_stubs()
@@ -890,6 +892,11 @@ def main():
     if a.only == "full_unsearched":
         # the first draw of another seed, NOT searched for a tie-free actor max (the searched fixtures above skip such draws)
         full_case("full_inv3_720x1280_b1_seed401_unsearched", refim, refcfg, a.out, backbone="inv3", OH=87, OW=157, D=1056, B=1, seed=401, search=False)
+        return
+    if a.only == "full_smooth":
+        # the same model on photograph-like frames (smooth fields + sensor noise, consecutive frames drifting): the input distribution the bf16
+        # mode's gradient-direction floors are held on (white-noise frames are the worst case for the image layer's weight gradient)
+        full_case("full_inv3_720x1280_b1_smooth", refim, refcfg, a.out, backbone="inv3", OH=87, OW=157, D=1056, B=1, seed=402, smooth=True)
         return
     if a.only == "dataset":
         dataset_cases(a.out)
