@@ -18,7 +18,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "din_hip.h")
 
 DIN_F32, DIN_BF16 = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 CONV_BIAS, CONV_RELU, CONV_ACCUM, CONV_MASK = 1, 2, 4, 8
 
 
@@ -51,6 +51,11 @@ class ConvWSrc(C.Structure):
                 ("cout", C.c_int32), ("ldo", C.c_int32), ("cooff", C.c_int32)]
 
 
+class ConvWgradItem(C.Structure):                  # din_conv_wgrad_item: the arguments of one din_conv_wgrad call
+    _fields_ = [("desc", ConvDesc), ("in_", C.c_void_p), ("dout", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p), ("scale", C.c_void_p),
+                ("w", C.c_void_p), ("wdot", C.c_void_p), ("accumulate", C.c_int32), ("reserved", C.c_int32)]
+
+
 _P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 _CD, _PD = C.POINTER(ConvDesc), C.POINTER(PoolDesc)
 
@@ -79,6 +84,9 @@ SIGNATURES: Dict[str, tuple] = {
     "din_conv_dgrad_x": (_I, [_CD, _P, _P, _P, _P, _I, _I, _I, C.POINTER(ConvSrc), _P, _L, _P]),
     "din_conv1x1_wgrad_multi_workspace": (_L, [_I, C.POINTER(ConvWSrc), _I, _L, _I]),
     "din_conv1x1_wgrad_multi": (_I, [_I, C.POINTER(ConvWSrc), _I, _L, _I, _I, _I, _P, _I, _P, _L, _P]),
+    "din_conv_wgrad_group_key": (_I, [_CD]),
+    "din_conv_wgrad_group_workspace": (_L, [_I, C.POINTER(ConvWgradItem)]),
+    "din_conv_wgrad_group": (_I, [_I, C.POINTER(ConvWgradItem), _P, _L, _P]),
     "din_conv_wgrad": (_I, [_CD, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P]),
     "din_colsum": (_I, [_P, _I, _L, _I, _I, _I, _P, _P]),
     "din_bn_fold": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),

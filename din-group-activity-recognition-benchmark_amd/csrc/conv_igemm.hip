@@ -268,7 +268,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_generic_kernel(ConvK 
 // FASTK (bf16 8-wave tiles; host: whole k-steps per tap, no tap remap, k-order = taps inside channel chunks): every piece of per-step
 // loader state is scalar except one validity select per tile row, the offsets of the NEXT transfer are prepared while the current
 // stage is multiplied (so only the transfers themselves sit between the barrier and the MFMAs), and no other mode is compiled in.
-template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS, bool MULTI = false, bool FASTK = false, bool XSRC = false>
+// LANEK (with FASTK; bf16 8-wave tiles whose reduction channels are NOT whole k-steps per tap -- Conv2d_4a's 80, the 160-channel 7-tap layers of
+// Mixed_6c / 6d): the same double-buffered, in-wave interleaved step, with the k-walk PER LANE: a lane's 16-byte chunk of a k-step is chunk
+// q = 8 ks + cq of the flattened (tap, channel) axis, so every lane carries its own (tap, channel chunk) and forms its own tap delta / validity
+// bit (~10 VALU per step); the filter side stays a scalar offset (the packed bank IS the flattened axis).  These launches used to run the
+// general loop below -- compiler-scheduled, no interleaving: Conv2d_4a forward 718 TF where the same tile reaches 1004 TF on FASTK.
+template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS, bool MULTI = false, bool FASTK = false, bool XSRC = false, bool LANEK = false>
 // (second argument = waves per SIMD the register allocation must leave room for: the 8-wave 128-pixel bf16 tiles run TWO workgroups per CU
 //  = four waves per SIMD = at most 128 VGPRs.  Left at 2, a harmless-looking edit -- round 4: the knock-out switches turned compile-time
 //  constants -- moved the FASTK 128 x 192 instantiation from 125 to 131 registers: one workgroup per CU, 186 -> 259 us per launch, -1.6 ms per
@@ -545,6 +550,7 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && BMT == 128 && WM *
     static_assert((NS - 2) * NDMA <= 63, "vmcnt field");
     if constexpr (FASTK) {
         static_assert(!MULTI && NS == 2 && PA == 2, "FASTK: 128-pixel tiles whose loader covers 64 rows per pass, double-buffered");
+        static_assert(!LANEK || KCS == 8, "LANEK: 8-chunk k-steps");
         // scalar walk over k-steps: ks -> (channel chunk ks / ntaps, tap ks % ntaps); td = byte delta of the tap, fa / fb = scalar byte
         // offsets of the step inside a pixel's channels / inside a packed filter row
         int tap = ks_begin % ntaps, tr = (tap * inv_kw) >> 16, tc = tap - tr * p.kw;
@@ -561,7 +567,24 @@ __global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 2 && BMT == 128 && WM *
 #pragma unroll
             for (int i = 0; i < PB; ++i) voffB[i] = (int)OOB;
         }
+        // LANEK: this lane's chunk of the flattened (tap, channel-chunk) axis at the walk's current step
+        [[maybe_unused]] int tap_v = (ks_begin * KC + cq) / p.cpt, cc_v = (ks_begin * KC + cq) - tap_v * p.cpt;
+        if constexpr (LANEK) fb = ks_begin * KC * 16;
         auto prepare = [&]() {                                     // offsets of the transfer for the walk's current step, then advance it
+            if constexpr (LANEK) {
+                const int r = (tap_v * inv_kw) >> 16;
+                const int tdv = r * dA + (tap_v - r * p.kw) * dB + cc_v * 16;
+                const unsigned bit = tap_v < ntaps ? (1u << tap_v) : 0u;         // (past the last tap: zeros; the bank's rows are padded to whole k-steps)
+#pragma unroll
+                for (int i = 0; i < PA; ++i) va[i] = ((vmask[i] & bit) && !knockA) ? (unsigned)(pixoff[i] + tdv) : OOB;
+                soffA = 0; soffB = fb;
+                fb += KC * 16;
+                cc_v += KC;
+                const bool wrap = cc_v >= p.cpt;                                 // cpt >= 8 (host): at most one tap boundary per k-step
+                cc_v -= wrap ? p.cpt : 0;
+                tap_v += wrap ? 1 : 0;
+                return;
+            }
             const unsigned bit = 1u << tap;
 #pragma unroll
             for (int i = 0; i < PA; ++i) va[i] = ((vmask[i] & bit) && !knockA) ? pixq[i] + (unsigned)td : OOB;
@@ -2815,7 +2838,7 @@ static bool plan_halo(int dtype, int kh, int kw, int cred, int cprod, int oh, in
     return hp.lds <= 160 * 1024;
 }
 
-template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS, bool FASTK = false, bool XSRC = false>
+template <typename T, int BMT, int BN, int WM, int WN, int KCS, int NS, bool FASTK = false, bool XSRC = false, bool LANEK = false>
 void launch_fast(const ConvK& k, dim3 grid, hipStream_t st) {
     constexpr int LR_ = 64 * WM * WN / KCS, BNP_ = (BN + LR_ - 1) / LR_ * LR_;       // filter rows padded to whole loader passes
     size_t stage = (size_t)NS * (BMT + BNP_) * KCS * 16 + (k.remap ? 128 : 0);   // stage ring (+ remap table)
@@ -2825,9 +2848,18 @@ void launch_fast(const ConvK& k, dim3 grid, hipStream_t st) {
     if (one_stage_ok && !k.remap && k.xsteps == 0 && k.ks_per_split * (8 / KCS) <= 1) stage = (size_t)(BMT + BNP_) * KCS * 16;
     size_t epi = (size_t)BMT * (BN * sizeof(T) + 16);
     size_t lds = stage > epi ? stage : epi;
-    auto kern = conv_gather_fast_kernel<T, BMT, BN, WM, WN, KCS, NS, false, FASTK, XSRC>;
+    auto kern = conv_gather_fast_kernel<T, BMT, BN, WM, WN, KCS, NS, false, FASTK, XSRC, LANEK>;
     if (lds > 65536) raise_lds_limit(kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, st, k);
+}
+
+// the per-lane k-walk (LANEK) serves: bf16 8-wave 128-pixel tiles, single source, no tap remap, tap-major k-order, reduction channels that
+// are NOT whole k-steps per tap but at least one k-step wide (so a k-step crosses at most one tap boundary)
+static bool gather_lanek(const ConvK& k) {
+    const char* lv = DIN_OPT("DIN_CONV_LANEK");
+    const char* fv = DIN_OPT("DIN_CONV_FASTK");
+    return (lv ? atoi(lv) != 0 : true) && (fv ? atoi(fv) != 0 : true) && !k.remap && k.nsrc == 0 && !k.korder && k.xsteps == 0 &&
+           (k.cpt % 8) != 0 && k.cpt >= 8 && k.kh * k.kw > 1 && k.kh * k.kw <= 31;
 }
 
 // 8-wave 128 x BN tile: the scalar-walk specialisation (FASTK) whenever the launch qualifies (bf16, whole k-steps per tap, no tap remap,
@@ -2856,6 +2888,10 @@ void launch_wave8(const ConvK& k, dim3 grid, hipStream_t st) {
 #endif
         if (fastk) {
             launch_fast<T, 128, BN, 4, 2, 8, 2, true>(k, grid, st);
+            return;
+        }
+        if (gather_lanek(k)) {
+            launch_fast<T, 128, BN, 4, 2, 8, 2, true, false, true>(k, grid, st);
             return;
         }
     }
@@ -3316,6 +3352,9 @@ int din_conv_kernel_variant(const din_conv_desc* d, int which, int32_t* flags) {
     const bool fast = ntaps <= 32 && (which == 0 || (d->sh == 1 && d->sw == 1));      // stride-1 gather: divy == divx == 1, no tap remap
     const bool korder = (ko ? atoi(ko) != 0 : true) && fast && g.splitk == 1 && cpt % KC == 0 && ntaps > 1;
     if (wave8 && fast && cpt % KC == 0 && (korder || ntaps == 1) && (fv ? atoi(fv) != 0 : true)) *flags |= 1;
+    const char* lv = DIN_OPT("DIN_CONV_LANEK");                  // bit 2: the per-lane k-walk instantiation (gather_lanek; bit 0 is set with it: FASTK = true)
+    if (wave8 && bn != 96 && fast && !strided && cpt % KC != 0 && cpt >= 8 && ntaps > 1 && ntaps <= 31 && (fv ? atoi(fv) != 0 : true) &&
+        (lv ? atoi(lv) != 0 : true)) *flags |= 1 | 4;
     return DIN_OK;
 }
 
@@ -3714,6 +3753,145 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
     if (dbias && !bias_fused) {
         if (int e = launch_colsum(d->dtype, dout, dbias, k.M, d->cout, d->ldo, d->cooff, st)) return e;
     }
+    return DIN_OK;
+}
+
+// ---- din_conv_wgrad_group: the weight gradients of several LAYERS in one launch of the pipelined kernel (conv_wgrad.h: WgradGroupK) -------
+// Plan: every item keeps the tile geometry plan_wgrad gives it alone; what changes is the pixel slicing.  One common slice length mps
+// (whole 32-pixel stages) is chosen so that the items' tiles x slices fill the chip's CUs ONCE: sum_g tiles_g * ceil(M_g / mps) <= CUs.
+struct WgradGroupPlan { WgradPlan wp[din_wgrad::WGRAD_GROUP_MAX]; int slices[din_wgrad::WGRAD_GROUP_MAX]; int64_t part_off[din_wgrad::WGRAD_GROUP_MAX]; int mps, bco, wide; int64_t ws_bytes; };
+
+static int wgrad_group_key(const din_conv_desc* d, WgradPlan* out) {
+    const char* gv = DIN_OPT("DIN_WGRAD_GROUP");
+    if (gv && atoi(gv) == 0) return 0;
+    if (!d || d->dtype != DIN_BF16 || d->in_u8 || d->nb <= 0 || d->oh <= 0 || d->ow <= 0) return 0;
+    const char* wv = DIN_OPT("DIN_WGRAD_PIPE_WAVES");
+    if (wv && atoi(wv) != 16) return 0;                           // (the group kernel is instantiated for the shipped sixteen-wave grid)
+    if (d->ldo % 8 != 0 || d->cooff % 8 != 0) return 0;
+    const WgradPlan wp = plan_wgrad(d);
+    if (!wp.pipe || wp.atomic || wp.slices < 2) return 0;         // one slice: nothing to reduce, the single launch writes dW directly
+    if (out) *out = wp;
+    return wp.bco * 2 + (d->ow >= 32 ? 1 : 0);
+}
+
+static int wgrad_group_cus() {
+    static std::atomic<int> cached{0};
+    int c = cached.load(std::memory_order_relaxed);
+    if (!c) {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        c = n > 0 ? n : 256;
+        cached.store(c, std::memory_order_relaxed);
+    }
+    return c;
+}
+
+static bool plan_wgrad_group(int n, const din_conv_wgrad_item* items, WgradGroupPlan& gp) {
+    if (!items || n < 2 || n > din_wgrad::WGRAD_GROUP_MAX) return false;
+    int key0 = 0;
+    int64_t cost = 0;
+    for (int g = 0; g < n; ++g) {
+        const int key = wgrad_group_key(&items[g].desc, &gp.wp[g]);
+        if (!key || (g && key != key0)) return false;
+        key0 = key;
+        cost += (int64_t)gp.wp[g].n_co_tiles * gp.wp[g].n_k_tiles * ((int64_t)items[g].desc.nb * items[g].desc.oh * items[g].desc.ow);
+    }
+    gp.bco = key0 / 2; gp.wide = key0 & 1;
+    const int budget = wgrad_group_cus();
+    int64_t mps = (cost + budget - 1) / budget;
+    mps = (mps + 31) / 32 * 32;
+    if (mps < 32) mps = 32;
+    for (int iter = 0; iter < 4096; ++iter) {
+        int64_t wgs = 0, next = INT64_MAX;
+        for (int g = 0; g < n; ++g) {
+            const int64_t M = (int64_t)items[g].desc.nb * items[g].desc.oh * items[g].desc.ow, sl = (M + mps - 1) / mps;
+            wgs += sl * gp.wp[g].n_co_tiles * gp.wp[g].n_k_tiles;
+            if (sl > 1) {                                           // the smallest slice length that takes one slice off this item
+                int64_t m2 = ((M + sl - 2) / (sl - 1) + 31) / 32 * 32;
+                if (m2 <= mps) m2 = mps + 32;
+                if (m2 < next) next = m2;
+            }
+        }
+        if (wgs <= budget || next == INT64_MAX) break;
+        mps = next;
+    }
+    if (mps >= (1ll << 30)) return false;
+    gp.mps = (int)mps;
+    int64_t off = 0;
+    for (int g = 0; g < n; ++g) {
+        const int64_t M = (int64_t)items[g].desc.nb * items[g].desc.oh * items[g].desc.ow;
+        gp.slices[g] = (int)((M + mps - 1) / mps);
+        gp.part_off[g] = off;
+        off += ((int64_t)gp.slices[g] * gp.wp[g].cout_pad * gp.wp[g].kcols_pad * 4 + 255) / 256 * 256;
+    }
+    gp.ws_bytes = off;
+    return true;
+}
+
+int din_conv_wgrad_group_key(const din_conv_desc* d) { return wgrad_group_key(d, nullptr); }
+
+int64_t din_conv_wgrad_group_workspace(int n, const din_conv_wgrad_item* items) {
+    WgradGroupPlan gp;
+    return plan_wgrad_group(n, items, gp) ? gp.ws_bytes : 0;
+}
+
+int din_conv_wgrad_group(int n, const din_conv_wgrad_item* items, void* workspace, int64_t workspace_bytes, void* stream) {
+    DIN_REQUIRE(items && n >= 1, "conv_wgrad_group: no items");
+    WgradGroupPlan gp;
+    if (!plan_wgrad_group(n, items, gp)) {                          // not a group this launch serves: layer by layer
+        for (int g = 0; g < n; ++g) {
+            const din_conv_wgrad_item& it = items[g];
+            const int64_t need = din_conv_workspace_bytes(&it.desc, 2);
+            if (need > workspace_bytes) DIN_FAIL(DIN_E_WORKSPACE, "conv_wgrad_group: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+            if (int e = din_conv_wgrad(&it.desc, it.in, it.dout, it.dw, it.dbias, it.scale, it.w, it.wdot, it.accumulate, workspace, workspace_bytes, stream)) return e;
+        }
+        return DIN_OK;
+    }
+    if (!workspace || workspace_bytes < gp.ws_bytes)
+        DIN_FAIL(DIN_E_WORKSPACE, "conv_wgrad_group: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)gp.ws_bytes);
+    hipStream_t st = as_stream(stream);
+    din_wgrad::WgradGroupK G{};
+    G.n = n;
+    int first = 0;
+    for (int g = 0; g < n; ++g) {
+        const din_conv_wgrad_item& it = items[g];
+        const din_conv_desc* d = &it.desc;
+        if (int e = check_desc(d)) return e;
+        DIN_REQUIRE(it.in && it.dout && it.dw, "conv_wgrad_group: null pointer in item %d", g);
+        DIN_REQUIRE(!it.wdot || it.w, "conv_wgrad_group: wdot needs w");
+        const WgradPlan& wp = gp.wp[g];
+        const bool prezeroed = (it.accumulate & 2) != 0;
+        din_wgrad::WgradK& k = G.k[g];
+        k.in = it.in; k.g = it.dout; k.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + gp.part_off[g]); k.dbias = nullptr;
+        k.NB = d->nb; k.H = d->h; k.W = d->w; k.Cin = d->cin; k.ldi = d->ldi; k.cioff = d->cioff;
+        k.OH = d->oh; k.OW = d->ow; k.Cout = d->cout; k.ldo = d->ldo; k.cooff = d->cooff;
+        k.kh = d->kh; k.kw = d->kw; k.sh = d->sh; k.sw = d->sw; k.ph = d->ph; k.pw = d->pw; k.dh = d->dh; k.dw = d->dw;
+        k.cin_pad = wp.cin_pad; k.kcols = wp.kcols; k.kcols_pad = wp.kcols_pad; k.cout_pad = wp.cout_pad;
+        k.M = d->nb * d->oh * d->ow; k.n_co_tiles = wp.n_co_tiles; k.n_k_tiles = wp.n_k_tiles;
+        k.slices = gp.slices[g]; k.m_per_slice = gp.mps;
+        if (it.dbias) {
+            if (!prezeroed && hipMemsetAsync(it.dbias, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad_group: memset");
+            k.dbias = it.dbias;
+        }
+        if (it.wdot && !prezeroed && hipMemsetAsync(it.wdot, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad_group: memset");
+        G.first[g] = first;
+        first += wp.n_co_tiles * wp.n_k_tiles * gp.slices[g];
+    }
+    for (int g = n; g <= din_wgrad::WGRAD_GROUP_MAX; ++g) G.first[g] = first;
+    if (int e = din_wgrad::launch_wgrad_pipe_group(G, gp.bco, gp.wide != 0, st)) return e;
+    DIN_CHECK_LAUNCH("conv_wgrad_group");
+    for (int g = 0; g < n; ++g) {
+        const din_conv_wgrad_item& it = items[g];
+        const din_conv_desc* d = &it.desc;
+        const WgradPlan& wp = gp.wp[g];
+        const int kc_total = d->kh * d->kw * wp.cin_pad;
+        dim3 rgrid(d->cout, (kc_total + 255) / 256);
+        const int nsg = gp.slices[g] >= 64 ? 16 : gp.slices[g] >= 8 ? 4 : 1;
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, rgrid, dim3(64, nsg), 0, st, G.k[g].partial, it.dw, it.scale, it.w, it.wdot,
+                           d->cout, d->cin, d->kh, d->kw, wp.cin_pad, wp.cout_pad, wp.kcols_pad, gp.slices[g], it.accumulate & 1);
+    }
+    DIN_CHECK_LAUNCH("conv_wgrad_group reduce");
     return DIN_OK;
 }
 

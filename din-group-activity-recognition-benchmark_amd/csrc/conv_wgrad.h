@@ -25,6 +25,14 @@ struct WgradK {
                     // XCD's L2 holds and dY comes from HBM once.  Speed only: no sibling is ever waited for indefinitely.
 };
 
+// conv_wgrad_pipe.hip, grouped launch: the weight gradients of up to WGRAD_GROUP_MAX LAYERS in one launch (din_conv_wgrad_group).  Every launch of
+// the pipe kernel fills the chip with one workgroup per CU, and every workgroup writes a full fp32 partial tile: slices x |dW| = ~50 MB per
+// layer whatever the batch, read back by the reduce launch.  Layers that share a launch share the 256 workgroups: a layer of a group of six
+// is cut into 7 instead of 42 pixel slices and leaves 8 MB of partials.  Logical block l (after the XCD remap) belongs to item g with
+// first[g] <= l < first[g + 1]; inside the item it is (tile, slice) exactly as in the single-layer launch.
+constexpr int WGRAD_GROUP_MAX = 8;
+struct WgradGroupK { WgradK k[WGRAD_GROUP_MAX]; int first[WGRAD_GROUP_MAX + 1]; int n; };
+
 // conv_wgrad_1x1.hip: weight gradients of up to four 1x1 convs that read one tensor, in one launch (dW stationary in registers)
 struct Wg1x1K {
     const void* x; float* partial;
@@ -47,6 +55,7 @@ __device__ __forceinline__ void lds_dma16(uint32_t lds_addr, __amdgpu_buffer_rsr
 
 // host entry of conv_wgrad_pipe.hip: launches the software-pipelined 32x32x16 ring kernel for a plan with pipe != 0
 int launch_wgrad_pipe(const WgradK& k, int bco, int bk, dim3 grid, hipStream_t st);
+int launch_wgrad_pipe_group(const WgradGroupK& g, int bco, bool wide, hipStream_t st);     // 16-wave instantiations only; grid = g.first[g.n] blocks
 size_t wgrad_pipe_lds_bytes(int bco, int bk);
 // host entries of conv_wgrad_halo.hip: the halo-tiled weight gradient of the narrow mid-network layers (dW block stationary in registers)
 bool wgrad_halo_shape(int cin, int cout, int kh, int kw, int* bnt);

@@ -45,9 +45,9 @@ template <int V> struct IC { static constexpr int value = V; };
 // WN: waves along the k columns (WM = 2 along the filter rows): 8 -> 16 waves with (BCO/2) x 32 wave tiles (shipped: four waves per SIMD);
 // 4 -> 8 waves with (BCO/2) x 64 wave tiles; 2 -> 4 waves with (BCO/2) x 128 wave tiles (one wave per SIMD, 7 instead of 10 fragment reads
 // per 12 MFMAs).  Measured (profiles/r02_wgrad_pipe_knockout.txt): more waves win although they read more fragments.
-template <int BCO, int BK, bool WIDE, int WN = 4>
-__global__ __launch_bounds__(128 * WN, 1) void conv_wgrad_pipe_kernel(WgradK p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+template <int BCO, int BK, bool WIDE, int WN>
+__device__ __forceinline__ void wgrad_pipe_body(const WgradK& p, const int bx_, const int by_) {
     constexpr int PK = 32, NS = 4, NWV = 2 * WN;
     constexpr int TR = 16 / NWV;                                   // wave-level transfers per operand and stage (2 tile rows each)
     constexpr int ROWB = 512;                                      // LDS row pitch of both operand tiles (bytes)
@@ -62,8 +62,6 @@ __global__ __launch_bounds__(128 * WN, 1) void conv_wgrad_pipe_kernel(WgradK p) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: lives in an SGPR, branches on it are scalar
     const int wm = wid / WN, wn = wid % WN;
-    int bx_, by_;
-    xcd_block(bx_, by_);
     const int k_tile = bx_ % p.n_k_tiles, co_tile = bx_ / p.n_k_tiles;
     const int slice = by_;
     const int m_begin = slice * p.m_per_slice;                     // multiple of PK
@@ -384,6 +382,33 @@ __global__ __launch_bounds__(128 * WN, 1) void conv_wgrad_pipe_kernel(WgradK p) 
             if (lane < 32 && co < p.Cout) atomicAdd(p.dbias + co, tsum);
         }
     }
+}
+#endif
+
+template <int BCO, int BK, bool WIDE, int WN = 4>
+__global__ __launch_bounds__(128 * WN, 1) void conv_wgrad_pipe_kernel(WgradK p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int bx_, by_;
+    xcd_block(bx_, by_);
+    wgrad_pipe_body<BCO, BK, WIDE, WN>(p, bx_, by_);
+#endif
+}
+
+// several layers in one launch (conv_wgrad.h: WgradGroupK).  The item is found with a scalar scan of first[]; its argument block is read
+// from the kernel-argument segment through a wave-uniform index (scalar loads), the body is the single-layer kernel's.
+template <int BCO, int BK, bool WIDE, int WN>
+__global__ __launch_bounds__(128 * WN, 1) void conv_wgrad_pipe_group_kernel(WgradGroupK grp) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int l = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < WGRAD_GROUP_MAX; ++i) gi += (i < grp.n && l >= grp.first[i]) ? 1 : 0;
+    gi = __builtin_amdgcn_readfirstlane(gi);
+    const WgradK p = grp.k[gi];                                    // a COPY: through a reference the stage loop re-reads fields with s_load (5 per stage)
+    const int local = l - grp.first[gi], nx = p.n_co_tiles * p.n_k_tiles;
+    const int by_ = local / nx, bx_ = local - by_ * nx;
+    if (by_ >= p.slices) return;                                   // (an item's range is padded to whole rows of tiles only: never taken)
+    wgrad_pipe_body<BCO, BK, WIDE, WN>(p, bx_, by_);
 #endif
 }
 
@@ -422,6 +447,20 @@ int launch_wgrad_pipe(const WgradK& k, int bco, int bk, dim3 grid, hipStream_t s
     if (bco == 128) { if (wide) launch(conv_wgrad_pipe_kernel<128, 256, true>, 512); else launch(conv_wgrad_pipe_kernel<128, 256, false>, 512); }
     else if (bco == 192) { if (wide) launch(conv_wgrad_pipe_kernel<192, 256, true>, 512); else launch(conv_wgrad_pipe_kernel<192, 256, false>, 512); }
     else { if (wide) launch(conv_wgrad_pipe_kernel<256, 256, true>, 512); else launch(conv_wgrad_pipe_kernel<256, 256, false>, 512); }
+    return DIN_OK;
+}
+
+int launch_wgrad_pipe_group(const WgradGroupK& g, int bco, bool wide, hipStream_t st) {
+    DIN_REQUIRE(g.n >= 1 && g.n <= WGRAD_GROUP_MAX && (bco == 128 || bco == 192 || bco == 256), "wgrad pipe group: %d items, tile %d", g.n, bco);
+    const size_t lds = wgrad_pipe_lds_bytes(bco, 256);
+    const dim3 grid(g.first[g.n]);
+    auto launch = [&](auto kern) {
+        raise_lds(kern, lds);
+        hipLaunchKernelGGL(kern, grid, dim3(1024), lds, st, g);
+    };
+    if (bco == 128) { if (wide) launch(conv_wgrad_pipe_group_kernel<128, 256, true, 8>); else launch(conv_wgrad_pipe_group_kernel<128, 256, false, 8>); }
+    else if (bco == 192) { if (wide) launch(conv_wgrad_pipe_group_kernel<192, 256, true, 8>); else launch(conv_wgrad_pipe_group_kernel<192, 256, false, 8>); }
+    else { if (wide) launch(conv_wgrad_pipe_group_kernel<256, 256, true, 8>); else launch(conv_wgrad_pipe_group_kernel<256, 256, false, 8>); }
     return DIN_OK;
 }
 

@@ -91,8 +91,10 @@ FUSE_FWD_SIBLINGS = None     # DIN_FUSE_FWD (on): run Graph.fwd_groups (sibling 
 FUSE_WGRAD_SIBLINGS = None   # DIN_FUSE_WGRAD (on): ... and the wgrads of the members that share the second tensor as one launch
 FUSE_WGRAD_1X1 = None        # DIN_FUSE_WGRAD_1X1 (on): weight gradients of ALL 1x1 convs reading one view in one launch (din_conv1x1_wgrad_multi)
 FUSE_DGRAD_X = None          # DIN_FUSE_DGRAD_X (on): a lone 1x1's dgrad rides in the strided sibling's launches (din_conv_dgrad_x: Mixed_6a)
+GROUP_WGRAD = None           # DIN_GROUP_WGRAD (on): weight gradients of up to GROUP_WGRAD_MAX layers share one launch (din_conv_wgrad_group)
+GROUP_WGRAD_MAX = 8          # layers per grouped launch (<= the library's WGRAD_GROUP_MAX)
 _SWITCHES = {"FUSE_1X1_DGRAD": ("DIN_FUSE_1X1", True), "FUSE_FWD_SIBLINGS": ("DIN_FUSE_FWD", True), "FUSE_WGRAD_SIBLINGS": ("DIN_FUSE_WGRAD", True),
-             "FUSE_WGRAD_1X1": ("DIN_FUSE_WGRAD_1X1", True), "FUSE_DGRAD_X": ("DIN_FUSE_DGRAD_X", True), "WGRAD_SIDE_STREAM": ("DIN_WGRAD_STREAM", False)}
+             "FUSE_WGRAD_1X1": ("DIN_FUSE_WGRAD_1X1", True), "FUSE_DGRAD_X": ("DIN_FUSE_DGRAD_X", True), "GROUP_WGRAD": ("DIN_GROUP_WGRAD", True), "WGRAD_SIDE_STREAM": ("DIN_WGRAD_STREAM", False)}
 
 
 def switch(attr: str) -> bool:
@@ -287,6 +289,10 @@ def _conv_desc(g: Graph, op: Op, nb: int, dt: int, cin: Optional[int] = None) ->
     d.ldi, d.cioff, d.ldo, d.cooff = ts.c, op.src.coff, td.c, op.dst.coff
     d.dtype = dt
     return d
+
+
+def _copy_desc(d: L.ConvDesc) -> L.ConvDesc:
+    return L.ConvDesc.from_buffer_copy(d)
 
 
 def _pool_desc(g: Graph, op: Op, nb: int, dt: int) -> L.PoolDesc:
@@ -760,6 +766,61 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 if GRAD_HOOK is not None:
                     GRAD_HOOK(params[offsets[i]], grads[offsets[i]])
 
+    # ---- layer-grouped weight gradients (din_conv_wgrad_group).  A weight gradient has no consumer inside the reverse pass, so layers whose
+    # kernel allows it (the pipelined wide-bank kernel, equal tile instantiation) are QUEUED with their operands and launched up to
+    # GROUP_WGRAD_MAX at a time: the launch's 256 workgroups are shared, every layer is cut into a fraction of the pixel slices it would get
+    # alone, and its fp32 slice partials (slices x |dW|, ~50 MB per layer and launch whatever the batch) shrink by the same factor.
+    wq: Dict[int, list] = {}
+    group_on = switch("GROUP_WGRAD") and dt == L.DIN_BF16 and side is None
+
+    def wgrad_now(d, x, go, dw_, dshift_, scale_, w_, wdot_, acc, name, after):
+        ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 2), dev, wtag)
+        with _timed("wgrad", d, name):
+            L.check(lib.din_conv_wgrad(C.byref(d), _ptr(x), _ptr(go), _ptr(dw_), _ptr(dshift_), _ptr(scale_), _ptr(w_), _ptr(wdot_), acc,
+                                       _ptr(ws), wsb, st), "conv_wgrad " + name)
+        if after is not None:
+            after()
+
+    def flush_wq(key):
+        q = wq.pop(key, None)
+        if not q:
+            return
+        need = 0
+        if len(q) > 1:
+            items = (L.ConvWgradItem * len(q))()
+            for it, (d, x, go, dw_, dshift_, scale_, w_, wdot_, acc, _name, _after) in zip(items, q):
+                it.desc = d
+                it.in_, it.dout, it.dw = x.data_ptr(), go.data_ptr(), dw_.data_ptr()
+                it.dbias = dshift_.data_ptr() if dshift_ is not None else None
+                it.scale = scale_.data_ptr() if scale_ is not None else None
+                it.w = w_.data_ptr() if w_ is not None else None
+                it.wdot = wdot_.data_ptr() if wdot_ is not None else None
+                it.accumulate = acc
+            need = lib.din_conv_wgrad_group_workspace(len(q), items)
+        if need <= 0:                                           # a single layer (or a list the library does not take as one launch)
+            for args in q:
+                wgrad_now(*args)
+            return
+        ws, wsb = workspace(need, dev, "wgroup")
+        dG = _copy_desc(q[0][0])
+        dG.flops_override = float(sum(2.0 * a[0].nb * a[0].oh * a[0].ow * a[0].cout * a[0].cin * a[0].kh * a[0].kw for a in q))
+        with _timed("wgrad", dG, "group:" + "+".join(a[9] for a in q)):
+            L.check(lib.din_conv_wgrad_group(len(q), items, _ptr(ws), wsb, st), "conv_wgrad_group " + q[0][9] + "+")
+        for a in q:
+            if a[10] is not None:
+                a[10]()
+
+    def wgrad_launch(d, x, go, dw_, dshift_, scale_, w_, wdot_, acc, name, after=None):
+        """one layer's weight gradient: queued for a grouped launch when its kernel allows it, launched at once otherwise"""
+        key = lib.din_conv_wgrad_group_key(C.byref(d)) if group_on else 0
+        if not key:
+            wgrad_now(d, x, go, dw_, dshift_, scale_, w_, wdot_, acc, name, after)
+            return
+        q = wq.setdefault(key, [])
+        q.append((_copy_desc(d), x, go, dw_, dshift_, scale_, w_, wdot_, acc, name, after))
+        if len(q) >= GROUP_WGRAD_MAX:
+            flush_wq(key)
+
     def flush_group(key):
         items = pending[key]
         if not items:
@@ -901,6 +962,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 gout, g_ld, g_coff = gtmp, pd.c, 0
             # ---- wgrad (+ bias / BN parameter gradients): on the side stream when enabled
             defer_w = oi in member_of and member_of[oi] in multi_w and src_needs_grad      # produced when its 1x1 group is flushed (flush_wgrad_multi)
+            hooked = False
             if defer_w or oi in wgrad_done:
                 pass                                              # produced by the group launch of a sibling (below)
             elif oi in wgrad_group and op.bn and side is None:
@@ -917,17 +979,17 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 wcat = torch.cat([params[offsets[i]] for i in mem])
                 dwf = torch.empty_like(wcat)
                 bn_touched = True
-                ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(dF), 2), dev, wtag)
-                with _timed("wgrad", dF, "+".join(o.name for o in mops)):
-                    L.check(lib.din_conv_wgrad(C.byref(dF), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dwf), _ptr(bn_dshift[o0:o1]),
-                                               _ptr(pcache.bn_scale[o0:o1]), _ptr(wcat), _ptr(bn_wdot[o0:o1]), 2, _ptr(ws), wsb, st),
-                            "conv_wgrad " + mops[0].name + "+")
                 r0 = 0
                 for i, o in zip(mem, mops):
                     grads[offsets[i]] = dwf[r0:r0 + o.dst.c]
                     r0 += o.dst.c
+
+                def _hooks(mem=mem):
                     if GRAD_HOOK is not None:
-                        GRAD_HOOK(params[offsets[i]], grads[offsets[i]])
+                        for i in mem:
+                            GRAD_HOOK(params[offsets[i]], grads[offsets[i]])
+                wgrad_launch(dF, bufs[op.src.tid], gout, dwf, bn_dshift[o0:o1], pcache.bn_scale[o0:o1], wcat, bn_wdot[o0:o1], 2,
+                             "+".join(o.name for o in mops), _hooks)
                 wgrad_done.update(mem)
             if defer_w:
                 dw = None
@@ -950,13 +1012,14 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                     stw = on_side([bufs[op.src.tid], gout, dw, bn_acc, scale])
                     with torch.cuda.stream(side):
                         ws, wsb = workspace(wsbytes, dev, "side")
+                    with _timed("wgrad", d, op.name):
+                        L.check(lib.din_conv_wgrad(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dw),
+                                                   None if dshift_pre is not None else _ptr(dshift), _ptr(scale),
+                                                   _ptr(w), _ptr(wdot), 2, _ptr(ws), wsb, stw), "conv_wgrad " + op.name)
                 else:
-                    stw = st
-                    ws, wsb = workspace(wsbytes, dev, wtag)
-                with _timed("wgrad", d, op.name):
-                    L.check(lib.din_conv_wgrad(C.byref(d), _ptr(bufs[op.src.tid]), _ptr(gout), _ptr(dw),
-                                               None if dshift_pre is not None else _ptr(dshift), _ptr(scale),
-                                               _ptr(w), _ptr(wdot), 2, _ptr(ws), wsb, stw), "conv_wgrad " + op.name)
+                    hooked = True                                  # (the hook fires when the launch that produces dw has been enqueued)
+                    wgrad_launch(d, bufs[op.src.tid], gout, dw, None if dshift_pre is not None else dshift, scale, w, wdot, 2, op.name,
+                                 (lambda w=w, dw=dw: GRAD_HOOK(w, dw)) if GRAD_HOOK is not None else None)
                 grads[po] = dw
             else:
                 dw = _dw_buffer(w)
@@ -976,7 +1039,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
                 grads[po] = dw
                 if op.bias:
                     grads[po + 1] = db
-            if GRAD_HOOK is not None and side is None and oi not in wgrad_done and not defer_w:
+            if GRAD_HOOK is not None and side is None and oi not in wgrad_done and not defer_w and not hooked:
                 GRAD_HOOK(w, dw)
             # ---- dgrad
             if src_needs_grad and oi in member_of:
@@ -1024,6 +1087,8 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
             gbufs.pop(op.dst.tid, None)
     #  a 1x1's parked data gradient is only consumed when its strided host op reaches its own dgrad branch: a graph whose host
     # takes another path must not drop it silently
+    for key in list(wq):
+        flush_wq(key)                                  # weight gradients still queued for a grouped launch
     if x_parked:
         raise L.DinError(f"graph_backward: parked 1x1 data gradients were never carried by their strided sibling (ops {sorted(x_parked)}): "
                          "the fused strided + 1x1 dgrad (din_conv_dgrad_x) does not serve this graph shape")

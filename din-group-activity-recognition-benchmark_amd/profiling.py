@@ -20,7 +20,8 @@ HBM = None               # list while the HBM-bound launch groups are surveyed: 
 
 
 def _conv_flops(d) -> float:
-    return 2.0 * d.nb * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
+    over = getattr(d, "flops_override", None)              # a grouped launch (nhwc.flush_wq) carries the sum over its layers
+    return float(over) if over else 2.0 * d.nb * d.oh * d.ow * d.cout * d.cin * d.kh * d.kw
 
 
 def _esz(dt: int) -> int:
@@ -139,6 +140,8 @@ class LaunchTimer:
         if self.kind == "wgrad":
             if self.name.startswith("1x1multi:"):
                 return f"conv_wgrad_1x1_multi_kernel<{d.cin // 8}>"
+            if self.name.startswith("group:"):                         # din_conv_wgrad_group: the sixteen-wave pipe instantiation of the items' tile
+                return f"conv_wgrad_pipe_group_kernel<{bm.value}, {bn.value - 2000}, {'true' if d.ow >= 32 else 'false'}, 8>"
             if bm.value == 3:
                 return f"conv_wgrad_halo_kernel<..., {bn.value}, ...>"
             if bm.value == 0:
@@ -178,8 +181,9 @@ class LaunchTimer:
             geo = "4, 2, 8, 2" if (BN % 64 == 0 and d.dtype == L.DIN_BF16) else "2, 2, 8, 2"
         else:
             geo = "4, 2, 8, 2" if fl.value & 2 else "2, 2, 8, 2"     # (bit 1: the 8-wave instantiation, incl. 128 x 96 for strided dgrads)
+        # <T, BM, BN, WM, WN, KCS, NS, MULTI, FASTK, XSRC, LANEK> as rocprofv3 prints it
         return (f"conv_gather_fast_kernel<{tn}, {BM}, {BN}, {geo}, {'true' if multi else 'false'}, "
-                f"{'true' if fl.value & 1 else 'false'}>")
+                f"{'true' if fl.value & 1 else 'false'}, false, {'true' if fl.value & 4 else 'false'}>")
 
     def __enter__(self):
         if PROFILE is not None:

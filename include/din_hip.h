@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DIN_ABI_VERSION 8   /* 8: din_set_option / din_get_option replace every getenv() of the library (tests select kernels through the ABI; a stray environment variable can no longer change a launch).   7: din_conv_dgrad_x (a strided dgrad that carries the 1x1 / stride-1 dgrad of a sibling conv reading the same view).   6: batch-statistics BatchNorm is deterministic: din_bn_stats / din_bn_bwd_stats write per-workgroup fp64 slabs into a workspace (din_bn_workspace), din_bn_finalize / din_bn_reduce add them in slab order -- no atomics, nothing for the caller to zero.   5: dropout seeds take an optional device-side offset (din_layernorm_*, din_act_dropout_*), din_counter_add, din_conv1x1_wgrad_multi.   2: din_walk_* take plain / clamp / n_per_clip; + bn, mask_actors.  3: din_roi_align_* take the box grid and a crop channel range.  4: din_conv_desc.in_u8, context-encoding entry points */
+#define DIN_ABI_VERSION 9   /* 9: din_conv_wgrad_group (the weight gradients of several layers in one launch).   8: din_set_option / din_get_option replace every getenv() of the library (tests select kernels through the ABI; a stray environment variable can no longer change a launch).   7: din_conv_dgrad_x (a strided dgrad that carries the 1x1 / stride-1 dgrad of a sibling conv reading the same view).   6: batch-statistics BatchNorm is deterministic: din_bn_stats / din_bn_bwd_stats write per-workgroup fp64 slabs into a workspace (din_bn_workspace), din_bn_finalize / din_bn_reduce add them in slab order -- no atomics, nothing for the caller to zero.   5: dropout seeds take an optional device-side offset (din_layernorm_*, din_act_dropout_*), din_counter_add, din_conv1x1_wgrad_multi.   2: din_walk_* take plain / clamp / n_per_clip; + bn, mask_actors.  3: din_roi_align_* take the box grid and a crop channel range.  4: din_conv_desc.in_u8, context-encoding entry points */
 
 enum { DIN_F32 = 0, DIN_BF16 = 1 };
 
@@ -191,6 +191,30 @@ typedef struct din_conv_wsrc {
 int64_t din_conv1x1_wgrad_multi_workspace(int nsrc, const din_conv_wsrc* srcs, int dtype, int64_t pixels, int cin);
 int din_conv1x1_wgrad_multi(int nsrc, const din_conv_wsrc* srcs, int dtype, int64_t pixels, int cin, int ldi, int cioff, const void* in,
                             int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* The weight gradients of up to 8 LAYERS in one launch (autograd of the torch.nn.Conv2d layers of reference backbone/backbone.py:44-99 --
+ * torchvision's InceptionC blocks hold ten 7-tap / 1x1 layers of equal map size each).  A weight-gradient launch of the pipelined kernel puts
+ * one workgroup on every CU and each writes a full fp32 partial tile: slices x |dW| = ~50 MB per layer whatever the batch, read back by the
+ * reduce launch.  Layers whose gradients are due at about the same time share one launch and its 256 workgroups instead: a layer of a group
+ * of six is cut into 7 instead of 42 pixel slices (8 MB of partials), and the launch has one tail instead of six.
+ * An item = the arguments of one din_conv_wgrad call.  din_conv_wgrad_group_key: 0 = this layer's gradient does not run on the pipelined
+ * kernel (it cannot join a group); items with EQUAL non-zero keys may share a launch.  din_conv_wgrad_group_workspace: bytes for this group,
+ * 0 = not a valid group (the caller runs din_conv_wgrad per item; din_conv_wgrad_group itself does the same when handed such a list, with
+ * a workspace that must then hold the largest single-item need).  Results equal din_conv_wgrad's up to the order of the slice sums. */
+typedef struct din_conv_wgrad_item {
+    din_conv_desc desc;
+    const void* in;
+    const void* dout;
+    float* dw;
+    float* dbias;
+    const float* scale;
+    const float* w;
+    float* wdot;
+    int32_t accumulate, reserved;
+} din_conv_wgrad_item;
+int din_conv_wgrad_group_key(const din_conv_desc* d);
+int64_t din_conv_wgrad_group_workspace(int n, const din_conv_wgrad_item* items);
+int din_conv_wgrad_group(int n, const din_conv_wgrad_item* items, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* out[c] = sum over rows of g[row*ld + coff + c] (fp32 result; BatchNorm shift gradient of a conv whose epilogue ran in the pool) */
 int din_colsum(const void* g, int dtype, int64_t rows, int c, int ld, int coff, float* out, void* stream);

@@ -881,26 +881,44 @@ def synth_params(shapes: Dict[str, Tuple[int, ...]], seed: int = 3, din_std: flo
     return out
 
 
-def synth_smooth_images(b: int, t: int, h: int, w: int, seed: int = 0):
-    """uint8 frames with the statistics of a photograph rather than of white noise: per clip and colour plane a sum of three smooth
-    sinusoidal fields (spatial periods of 30 .. 400 pixels) that drifts by a few pixels from frame to frame (the frames of a Volleyball clip
-    are consecutive video frames, reference volleyball.py:239-243), plus sensor noise N(0, 6).  Used by the full-size fixture that holds the
-    bf16 mode's gradient direction on a realistic input (tools/gen_golden.py --only full_smooth); regenerated from the seed on both sides."""
+def synth_scene_images(boxes, h: int, w: int, oh: int, ow: int, seed: int = 0):
+    """uint8 frames with the statistics of a photographed scene rather than of white noise: per clip and colour plane a smooth background
+    (three sinusoidal fields, spatial periods 30 .. 400 pixels) that drifts by a few pixels from frame to frame (the frames of a Volleyball
+    clip are consecutive video frames, reference volleyball.py:239-243), DISTINCT actors -- inside every box (given in feature-map pixels
+    like the model's `boxes_in`, [B, T, N, 4]) an oriented texture with the actor's own period, orientation, colour and brightness, the same
+    in all frames of the clip -- and sensor noise N(0, 5).  Used by the full-size fixture that holds the bf16 mode's gradient direction on a
+    realistic input (tools/gen_golden.py --only full_scene); regenerated from the seed and the boxes on both sides."""
     import numpy as np
     rng = np.random.default_rng(seed)
+    bx = boxes.numpy() if hasattr(boxes, "numpy") else np.asarray(boxes)
+    b, t, n = bx.shape[:3]
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
     out = np.empty((b, t, 3, h, w), dtype=np.uint8)
+    sy, sx = h / float(oh), w / float(ow)
     for bi in range(b):
-        comps = [[(rng.uniform(5, 64), rng.uniform(5, 64), rng.uniform(0, 6.28), rng.uniform(0, 6.28), rng.uniform(20, 60)) for _ in range(3)]
+        comps = [[(rng.uniform(5, 64), rng.uniform(5, 64), rng.uniform(0, 6.28), rng.uniform(0, 6.28), rng.uniform(10, 35)) for _ in range(3)]
                  for _c in range(3)]
         drift = rng.uniform(-3, 3, size=(t, 2)).cumsum(0)
+        actors = [(rng.uniform(3.0, 14.0), rng.uniform(0, 3.1416), rng.uniform(40, 215, 3), rng.uniform(25, 70, 3), rng.uniform(0, 6.28)) for _ in range(n)]
         for ti in range(t):
+            planes = []
             for c in range(3):
-                f = np.full((h, w), 118.0 + 12.0 * c)
+                f = np.full((h, w), 112.0 + 10.0 * c)
                 for (py, px, ay, ax, amp) in comps[c]:
                     f += amp * np.sin((yy + drift[ti, 0]) / py + ay) * np.cos((xx + drift[ti, 1]) / px + ax)
-                f += rng.normal(0.0, 6.0, (h, w))
-                out[bi, ti, c] = np.clip(np.rint(f), 0, 255).astype(np.uint8)
+                planes.append(f)
+            for ai in range(n):
+                x1, y1, x2, y2 = bx[bi, ti, ai]
+                r0, r1 = int(max(0, np.floor(y1 * sy))), int(min(h, np.ceil(y2 * sy)))
+                c0, c1 = int(max(0, np.floor(x1 * sx))), int(min(w, np.ceil(x2 * sx)))
+                if r1 <= r0 or c1 <= c0:
+                    continue
+                period, ang, mean, amp, ph = actors[ai]
+                u = ((yy[r0:r1, c0:c1] - r0) * np.cos(ang) + (xx[r0:r1, c0:c1] - c0) * np.sin(ang)) * (6.2832 / period) + ph
+                for c in range(3):
+                    planes[c][r0:r1, c0:c1] = mean[c] + amp[c] * np.sin(u + 0.7 * c)
+            for c in range(3):
+                out[bi, ti, c] = np.clip(np.rint(planes[c] + rng.normal(0.0, 5.0, (h, w))), 0, 255).astype(np.uint8)
     return torch.from_numpy(out)
 
 

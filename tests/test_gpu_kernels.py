@@ -103,6 +103,13 @@ CONV_CASES = [
     ("rw_256_264", 6, 256, 45, 47, 264, (1, 1), (1, 1), (0, 0), 1),          # 4 stages, classes 128 + 128 + 8; dgrad: reduction 264 (4.1 stages) -> 256 channels
     ("rw_288_64", 12, 288, 45, 47, 64, (1, 1), (1, 1), (0, 0), 1),           # Mixed_5d branch_pool / Mixed_6a entry: 4.5 stages (half a stage zero padding), two waves idle
     ("rw_64_208", 3, 64, 33, 37, 208, (1, 1), (1, 1), (0, 0), 1),            # dgrad: reduction 208 -> 64 channels
+    # per-lane k-walk (conv_gather_fast_kernel<..., FASTK, LANEK>, bf16): reduction channels that are not whole 64-channel k-steps per tap -- a
+    # k-step straddles two taps -- on every 8-wave tile width; ragged pixel tiles, padding taps, a last k-step that runs past the last tap
+    ("lanek_3x3_80_192_p0", 1, 80, 45, 70, 192, (3, 3), (1, 1), (0, 0), 1),     # Conv2d_4a (backbone.py:52): 11.25 k-steps; dgrad: whole k-steps (FASTK)
+    ("lanek_1x7_160_160", 2, 160, 19, 37, 160, (1, 7), (1, 1), (0, 3), 1),       # Mixed_6c / 6d 7-tap layers: forward AND dgrad straddle (17.5 k-steps)
+    ("lanek_7x1_160_192", 2, 160, 37, 19, 192, (7, 1), (1, 1), (3, 0), 1),
+    ("lanek_3x3_96_128", 2, 96, 21, 23, 128, (3, 3), (1, 1), (1, 1), 1),         # 12 chunks per tap, 128-filter tile
+    ("lanek_3x3_72_64", 1, 72, 33, 31, 64, (3, 3), (1, 1), (1, 1), 1),           # 9 chunks per tap, 64-filter tile
 ]
 
 
@@ -161,6 +168,10 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
             bm, bn = C.c_int32(0), C.c_int32(0)
             lib.din_conv_kernel_tile(C.byref(d), which, C.byref(bm), C.byref(bn))
             assert bm.value == 4, f"{name}: {('forward', 'dgrad')[which]} not on the streaming 1x1 kernel (tile {bm.value} x {bn.value})"
+    if name.startswith("lanek_") and dtype == "bf16":
+        fl = C.c_int32(0)
+        lib.din_conv_kernel_variant(C.byref(d), 0, C.byref(fl))
+        assert fl.value & 4, f"{name}: forward not on the per-lane k-walk instantiation (flags {fl.value})"
     if name.startswith("rw_") and dtype == "bf16":
         for which, cred, cprod in ((0, cin, cout), (1, cout, cin)):
             bm, bn = C.c_int32(0), C.c_int32(0)
@@ -220,6 +231,53 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
                                        ws.data_ptr(), wsb, st))
             torch.cuda.synchronize()
             assert rel(from_nhwc(dx, cin), xr.grad * (x > 0).float()) <= tolg
+
+
+@pytest.mark.parametrize("shape", [(80, 192, (3, 3), (0, 0), 2, 61, 77), (160, 160, (1, 7), (0, 3), 3, 43, 78), (160, 192, (7, 1), (3, 0), 3, 43, 78)],
+                         ids=["conv2d_4a", "mixed_6c_1x7", "mixed_6c_7x1"])
+def test_lane_k_walk_is_bit_identical_to_the_general_loop(env, monkeypatch, shape):
+    """conv_gather_fast_kernel<..., LANEK> against the general loop (DIN_CONV_LANEK=0) on the shapes it was built for (reference
+    backbone/backbone.py:52 Conv2d_4a_3x3, :67-74 the 160-channel 7-tap layers of InceptionC): same 16-byte chunks per k-step, same
+    accumulation order -> the same bits, forward (bias + ReLU) and data gradient (mask + accumulate)."""
+    lib, L, nhwc, ops = env
+    cin, cout, k, p, nb, h, w = shape
+    g = torch.Generator().manual_seed(cin + cout)
+    bf = torch.bfloat16
+    oh, ow = h + 2 * p[0] - k[0] + 1, w + 2 * p[1] - k[1] + 1
+    d = L.ConvDesc()
+    d.nb, d.h, d.w, d.cin, d.oh, d.ow, d.cout = nb, h, w, cin, oh, ow, cout
+    d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.dh, d.dw = k[0], k[1], 1, 1, p[0], p[1], 1, 1
+    d.ldi, d.cioff, d.ldo, d.cooff, d.dtype = cin + 16, 8, cout + 8, 0, L.DIN_BF16
+    xin = torch.randn(nb, h, w, cin + 16, generator=g).to(bf).cuda()
+    gy = torch.randn(nb, oh, ow, cout + 8, generator=g).to(bf).cuda()
+    wt = (torch.randn(cout, cin, *k, generator=g) * (2.0 / (cin * k[0] * k[1])) ** 0.5).cuda()
+    bias = (torch.randn(cout, generator=g) * 0.1).cuda()
+    wpk = torch.empty(lib.din_conv_packed_elems(C.byref(d), 0), dtype=bf, device="cuda")
+    wpt = torch.empty(lib.din_conv_packed_elems(C.byref(d), 1), dtype=bf, device="cuda")
+    L.check(lib.din_conv_pack_weights(C.byref(d), wt.data_ptr(), None, wpk.data_ptr(), 0, None))
+    L.check(lib.din_conv_pack_weights(C.byref(d), wt.data_ptr(), None, wpt.data_ptr(), 1, None))
+    base = torch.randn(nb, h, w, cin + 16, generator=g).to(bf).cuda()
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DIN_CONV_LANEK", mode)
+        fl = C.c_int32(0)
+        lib.din_conv_kernel_variant(C.byref(d), 0, C.byref(fl))
+        assert bool(fl.value & 4) == (mode == "1"), (mode, fl.value)
+        y = torch.full((nb, oh, ow, cout + 8), 5.0, dtype=bf, device="cuda")
+        wsb = lib.din_conv_workspace_bytes(C.byref(d), 0)
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device="cuda")
+        L.check(lib.din_conv_fwd(C.byref(d), xin.data_ptr(), wpk.data_ptr(), bias.data_ptr(), y.data_ptr(), L.CONV_BIAS | L.CONV_RELU,
+                                 ws.data_ptr(), wsb, None))
+        dx = base.clone()
+        wsb = lib.din_conv_workspace_bytes(C.byref(d), 1)
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device="cuda")
+        L.check(lib.din_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), dx.data_ptr(), xin.data_ptr(), cin + 16, 8,
+                                   L.CONV_MASK | L.CONV_ACCUM, ws.data_ptr(), wsb, None))
+        torch.cuda.synchronize()
+        outs.append((y, dx))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0][..., :cout].float().abs().max()) > 0.1 and not bool((outs[0][1] == base).all())
 
 
 @pytest.mark.parametrize("cout", [32, 64], ids=["dY32_conv_small_4", "dY64_conv_small_8"])
@@ -1410,6 +1468,88 @@ def test_conv1x1_wgrad_multi_source(env, monkeypatch, cin, couts):
             assert rel(dev["db"], db_ref) <= 2e-5, j
         else:
             assert float(dev["db"].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", ["inception_c_block", "mixed_maps", "two_tiles"])
+def test_conv_wgrad_group_matches_per_layer_launches(env, case):
+    """din_conv_wgrad_group (several layers' weight gradients in ONE launch of the pipelined kernel, conv_wgrad.h: WgradGroupK) against
+    din_conv_wgrad layer by layer and against fp32 F.conv2d autograd on the bf16-rounded operands: dW with the BatchNorm scale folded, the
+    <W, dW> dot, the bias gradient; 7-tap and 1x1 layers of one map size (an InceptionC block's shapes, reference backbone/backbone.py:67-74
+    through torchvision), layers of DIFFERENT map sizes in one group, a bank of two filter tiles, gradient / input views at channel offsets."""
+    lib, L, nhwc, ops = env
+    g = torch.Generator().manual_seed(len(case))
+    if case == "inception_c_block":      # (cin, cout, kh, kw, ph, pw, nb, h, w)
+        layers = [(160, 160, 1, 7, 0, 3, 2, 19, 37), (160, 192, 7, 1, 3, 0, 2, 19, 37), (160, 160, 7, 1, 3, 0, 2, 19, 37),
+                  (768, 192, 1, 1, 0, 0, 2, 19, 37), (160, 192, 1, 7, 0, 3, 2, 19, 37), (192, 192, 7, 1, 3, 0, 2, 19, 37)]
+    elif case == "mixed_maps":
+        layers = [(192, 192, 1, 7, 0, 3, 1, 21, 40), (80, 192, 3, 3, 0, 0, 1, 45, 70), (192, 192, 7, 1, 3, 0, 3, 17, 33)]
+    else:
+        layers = [(288, 384, 3, 3, 1, 1, 1, 23, 35), (256, 384, 1, 1, 0, 0, 2, 23, 35)]
+    items = (L.ConvWgradItem * len(layers))()
+    keep, refs = [], []
+    for j, (cin, cout, kh, kw, ph, pw, nb, h, w) in enumerate(layers):
+        oh, ow = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+        ldi, cioff, ldo, cooff = cin + 16, 8 * (j % 2), cout + 24, 16 if j % 2 else 0
+        xb = torch.randn(nb, h, w, ldi, generator=g).bfloat16()
+        gb = torch.randn(nb, oh, ow, ldo, generator=g).bfloat16()
+        wj = torch.randn(cout, cin, kh, kw, generator=g) * 0.05
+        scale = torch.rand(cout, generator=g) + 0.5
+        xr = xb[..., cioff:cioff + cin].float().permute(0, 3, 1, 2)
+        gr = gb[..., cooff:cooff + cout].float().permute(0, 3, 1, 2)
+        dw_raw = torch.nn.grad.conv2d_weight(xr, wj.shape, gr, padding=(ph, pw))
+        refs.append((dw_raw * scale[:, None, None, None], (dw_raw * wj).sum((1, 2, 3)), gr.sum((0, 2, 3))))
+        dev = dict(x=xb.cuda(), g=gb.cuda(), w=wj.cuda(), scale=scale.cuda())
+        for tag in ("grp", "one"):
+            dev["dw_" + tag] = torch.full(wj.shape, 7.0, device="cuda")
+            dev["db_" + tag], dev["wdot_" + tag] = torch.zeros(cout, device="cuda"), torch.zeros(cout, device="cuda")
+        keep.append(dev)
+        d = items[j].desc
+        d.nb, d.h, d.w, d.cin, d.oh, d.ow, d.cout = nb, h, w, cin, oh, ow, cout
+        d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, d.dh, d.dw = kh, kw, 1, 1, ph, pw, 1, 1
+        d.ldi, d.cioff, d.ldo, d.cooff, d.dtype, d.in_u8 = ldi, cioff, ldo, cooff, L.DIN_BF16, 0
+        it = items[j]
+        it.in_, it.dout, it.dw = dev["x"].data_ptr(), dev["g"].data_ptr(), dev["dw_grp"].data_ptr()
+        it.dbias = dev["db_grp"].data_ptr() if j != 1 else None
+        it.scale, it.w, it.wdot, it.accumulate = dev["scale"].data_ptr(), dev["w"].data_ptr(), dev["wdot_grp"].data_ptr(), 2
+    keys = [lib.din_conv_wgrad_group_key(C.byref(items[j].desc)) for j in range(len(layers))]
+    assert all(k > 0 for k in keys) and len(set(keys)) == 1, keys
+    f32 = L.ConvDesc.from_buffer_copy(items[0].desc)
+    f32.dtype = L.DIN_F32
+    assert lib.din_conv_wgrad_group_key(C.byref(f32)) == 0                      # bf16 pipelined kernel only
+    wsb = lib.din_conv_wgrad_group_workspace(len(layers), items)
+    assert wsb > 0
+    single = sum(lib.din_conv_workspace_bytes(C.byref(items[j].desc), 2) for j in range(len(layers)))
+    print(f"{case}: group workspace {wsb / 1e6:.1f} MB for {len(layers)} layers, the per-layer launches' partials {single / 1e6:.1f} MB")
+    assert wsb < single                                                          # the point of the exercise: fewer slice partials
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    L.check(lib.din_conv_wgrad_group(len(layers), items, ws.data_ptr(), wsb, None))
+    for j, dev in enumerate(keep):
+        d = items[j].desc
+        nb1 = lib.din_conv_workspace_bytes(C.byref(d), 2)
+        w1 = torch.empty(nb1, dtype=torch.uint8, device="cuda")
+        L.check(lib.din_conv_wgrad(C.byref(d), dev["x"].data_ptr(), dev["g"].data_ptr(), dev["dw_one"].data_ptr(),
+                                   dev["db_one"].data_ptr() if j != 1 else None, dev["scale"].data_ptr(), dev["w"].data_ptr(),
+                                   dev["wdot_one"].data_ptr(), 2, w1.data_ptr(), nb1, None))
+    torch.cuda.synchronize()
+    for j, (dev, (dw_ref, wdot_ref, db_ref)) in enumerate(zip(keep, refs)):
+        assert rel(dev["dw_grp"], dev["dw_one"]) <= 2e-6, j                      # same products, another slicing of the pixel sum
+        assert rel(dev["wdot_grp"], dev["wdot_one"]) <= 2e-5, j
+        assert rel(dev["dw_grp"], dw_ref) <= 2e-5 and rel(dev["wdot_grp"], wdot_ref) <= 2e-5, j
+        if j != 1:
+            assert rel(dev["db_grp"], db_ref) <= 2e-5 and rel(dev["db_grp"], dev["db_one"]) <= 2e-6, j
+        else:
+            assert float(dev["db_grp"].abs().max()) == 0.0
+    # a list the library does not take as one launch (a lone item) still produces the gradient: the per-layer path
+    keep[0]["dw_grp"].fill_(3.0)
+    keep[0]["wdot_grp"].zero_()
+    if items[0].dbias:
+        keep[0]["db_grp"].zero_()
+    assert lib.din_conv_wgrad_group_workspace(1, items) == 0
+    nb1 = lib.din_conv_workspace_bytes(C.byref(items[0].desc), 2)
+    w1 = torch.empty(nb1, dtype=torch.uint8, device="cuda")
+    L.check(lib.din_conv_wgrad_group(1, items, w1.data_ptr(), nb1, None))
+    torch.cuda.synchronize()
+    assert rel(keep[0]["dw_grp"], keep[0]["dw_one"]) == 0.0
 
 
 @pytest.mark.parametrize("shape", [(144, 26400, 1024), (37, 776, 200)], ids=["fc_emb_1_cfg1_4clips", "ragged"])

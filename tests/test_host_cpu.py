@@ -23,7 +23,7 @@ def test_library_exports_every_header_symbol():
         assert hasattr(lib, n), f"{n} declared in include/din_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes table out of sync with include/din_hip.h"
     loaded = _lib.load()
-    assert loaded.din_abi_version() == _lib.ABI_VERSION == 8 and loaded.din_build_arch() == b"gfx950"
+    assert loaded.din_abi_version() == _lib.ABI_VERSION == 9 and loaded.din_build_arch() == b"gfx950"
 
 
 def test_options_go_through_the_abi_not_the_environment(monkeypatch):
@@ -73,14 +73,14 @@ def test_occupancy_critical_kernels_hold_their_register_budgets():
             budget = 128
         elif re.search(r"conv_halo_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi16E", name):     # sixteen waves in one workgroup
             budget = 128
-        elif re.search(r"conv_wgrad_pipe_kernelILi\d+ELi256ELb[01]ELi8E", name):        # sixteen waves (wave grid 2 x 8) in one workgroup
+        elif re.search(r"conv_wgrad_pipe(_group)?_kernelILi\d+ELi256ELb[01]ELi8E", name):   # sixteen waves (wave grid 2 x 8) in one workgroup; the grouped launch too
             budget = 128
         elif "conv1x1_regw_kernel" in name:         # one wave per SIMD with the filters resident: the whole file, and NOT ONE spill -- a filter
             budget = 512                            # fragment reloaded from scratch inside the tile loop drains every transfer in flight (vmcnt)
         if budget is not None:
             checked += 1
             assert regs <= budget and spill == 0, f"{name}: {regs} registers (+{spill} spilled) > {budget}: a workgroup per CU is lost"
-    assert checked >= 18, checked
+    assert checked >= 28, checked
 
 
 def test_conv_planning_is_callable_without_gpu():

@@ -106,8 +106,8 @@ def load_model_case(path):
         p["DPI.hier_LN.weight"] = 0.75 + 0.5 * torch.rand(p["DPI.hier_LN.weight"].shape, generator=g_)
         p["DPI.hier_LN.bias"] = 0.1 * torch.randn(p["DPI.hier_LN.bias"].shape, generator=g_)
     images, boxes, labels = O.synth_inputs(B, T, N, H, W, OH, OW, 8, seed=seed)
-    if "smooth" in z.files and int(z["smooth"]):     # photograph-like frames (tools/gen_golden.py --only full_smooth)
-        images = O.synth_smooth_images(B, T, H, W, seed=seed + 7)
+    if "smooth" in z.files and int(z["smooth"]):     # scene-like frames (tools/gen_golden.py --only full_scene)
+        images = O.synth_scene_images(boxes, H, W, OH, OW, seed=seed + 7)
     return z, cfg, p, images, boxes, labels
 
 
@@ -134,13 +134,14 @@ def test_full_size_fixtures_are_present_and_seed_reproducible():
     re-running it here would take minutes): both backbones present, the seed recipe still regenerates the stored labels, every stage
     probe and gradient record is there"""
     assert {os.path.basename(p) for p in FULL_CASES} == {"full_inv3_720x1280_b1.npz", "full_vgg16_720x1280_cfg1_b2.npz",
-                                                         "full_inv3_720x1280_b1_seed401_unsearched.npz", "full_inv3_720x1280_b1_smooth.npz"}
-    sm = np.load([p for p in FULL_CASES if "smooth" in p][0])
+                                                         "full_inv3_720x1280_b1_seed401_unsearched.npz", "full_inv3_720x1280_b1_scene.npz"}
+    sm = np.load([p for p in FULL_CASES if "scene" in p][0])
     assert int(sm["smooth"]) == 1 and int(sm["searched"]) == 1
-    fr = O.synth_smooth_images(1, 2, 48, 64, seed=int(sm["seed"]) + 7)          # photograph-like: neighbouring pixels and consecutive frames correlate
+    bx = torch.tensor([[[[1.0, 1.0, 3.0, 4.0]], [[1.5, 1.0, 3.5, 4.0]]]])             # one actor, two frames, 6 x 8 feature grid
+    fr = O.synth_scene_images(bx, 48, 64, 6, 8, seed=int(sm["seed"]) + 7)          # scene-like: neighbouring pixels and consecutive frames correlate
     a = fr[0, 0, 0].double()
     assert float(torch.corrcoef(torch.stack([a[:, :-1].flatten(), a[:, 1:].flatten()]))[0, 1]) > 0.9
-    assert float(torch.corrcoef(torch.stack([fr[0, 0].double().flatten(), fr[0, 1].double().flatten()]))[0, 1]) > 0.8
+    assert float(torch.corrcoef(torch.stack([fr[0, 0].double().flatten(), fr[0, 1].double().flatten()]))[0, 1]) > 0.5      # (the actor moved by half a feature cell; white noise: 0)
     un = np.load([p for p in FULL_CASES if "unsearched" in p][0])
     assert int(un["searched"]) == 0 and int(un["seed"]) == 401 and int(un["near_ties"]) >= 0 and float(un["min_actor_gap"]) >= 0.0
     for path in FULL_CASES:
@@ -304,8 +305,8 @@ def load_tce_case(path):
         p["DPI.hier_LN.weight"] = 0.75 + 0.5 * torch.rand(p["DPI.hier_LN.weight"].shape, generator=g_)
         p["DPI.hier_LN.bias"] = 0.1 * torch.randn(p["DPI.hier_LN.bias"].shape, generator=g_)
     images, boxes, labels = O.synth_inputs(B, T, N, H, W, OH, OW, 8, seed=seed)
-    if "smooth" in z.files and int(z["smooth"]):     # photograph-like frames (tools/gen_golden.py --only full_smooth)
-        images = O.synth_smooth_images(B, T, H, W, seed=seed + 7)
+    if "smooth" in z.files and int(z["smooth"]):     # scene-like frames (tools/gen_golden.py --only full_scene)
+        images = O.synth_scene_images(boxes, H, W, OH, OW, seed=seed + 7)
     return z, cfg, p, images, boxes, labels
 
 

@@ -453,8 +453,8 @@ def full_case(name, refim, refcfg, out_dir, *, backbone, OH, OW, D, B, seed, H=7
     for _try in range(64):
         p = O.synth_params(O.model_param_shapes(ocfg), seed=seed + 3, din_std=0.02)
         images, boxes, labels = O.synth_inputs(B, T, N, H, W, OH, OW, 8, seed=seed)
-        if smooth:                             # photograph-like frames instead of white noise; boxes / labels as before
-            images = O.synth_smooth_images(B, T, H, W, seed=seed + 7)
+        if smooth:                             # scene-like frames instead of white noise; boxes / labels as before
+            images = O.synth_scene_images(boxes, H, W, OH, OW, seed=seed + 7)
         with torch.no_grad():
             _o, inter0 = O.dynamic_volleyball_forward(ocfg, p, images.float(), boxes, return_intermediates=True)
             lw, lb = p["dpi_nl.weight"], p["dpi_nl.bias"]
@@ -850,7 +850,7 @@ def main():
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--skip-big", action="store_true")
-    ap.add_argument("--only", default="", help="'inv3': only the two reduced-size Inception fixtures; 'tce': only (re)generate the Dynamic_TCE_volleyball fixtures; 'full': only the two full-size 720x1280 fixtures; 'full_unsearched': the un-searched full-size Inception draw; 'full_smooth': the full-size Inception fixture on photograph-like frames; 'dataset': only the dataset -> tensor contract fixtures (SURVEY 8f-1)")
+    ap.add_argument("--only", default="", help="'inv3': only the two reduced-size Inception fixtures; 'tce': only (re)generate the Dynamic_TCE_volleyball fixtures; 'full': only the two full-size 720x1280 fixtures; 'full_unsearched': the un-searched full-size Inception draw; 'full_scene': the full-size Inception fixture on scene-like frames; 'dataset': only the dataset -> tensor contract fixtures (SURVEY 8f-1)")
     a = ap.parse_args()
     sys.dont_write_bytecode = True
     install_stubs()
@@ -893,10 +893,11 @@ def main():
         # the first draw of another seed, NOT searched for a tie-free actor max (the searched fixtures above skip such draws)
         full_case("full_inv3_720x1280_b1_seed401_unsearched", refim, refcfg, a.out, backbone="inv3", OH=87, OW=157, D=1056, B=1, seed=401, search=False)
         return
-    if a.only == "full_smooth":
-        # the same model on photograph-like frames (smooth fields + sensor noise, consecutive frames drifting): the input distribution the bf16
-        # mode's gradient-direction floors are held on (white-noise frames are the worst case for the image layer's weight gradient)
-        full_case("full_inv3_720x1280_b1_smooth", refim, refcfg, a.out, backbone="inv3", OH=87, OW=157, D=1056, B=1, seed=402, smooth=True)
+    if a.only == "full_scene":
+        # the same model on scene-like frames (smooth drifting background, a distinct textured actor in every box, sensor noise): the input
+        # distribution the bf16 mode's gradient-direction floors are held on (white-noise frames are the worst case for the image layer's
+        # weight gradient; a smooth field WITHOUT actors is the worst case for the head: every crop looks alike and the actor max ties)
+        full_case("full_inv3_720x1280_b1_scene", refim, refcfg, a.out, backbone="inv3", OH=87, OW=157, D=1056, B=1, seed=402, smooth=True)
         return
     if a.only == "dataset":
         dataset_cases(a.out)
