@@ -2386,18 +2386,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_bf16_tail_kernel(Wgrad
 }
 
 // reduce the slices, un-permute to the reference layout [cout][cin][kh][kw], apply scale, optional <w, dw_raw>
-__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                         const float* __restrict__ scale, const float* __restrict__ w,
-                                         float* __restrict__ wdot, int cout, int cin, int kh, int kw, int cin_pad,
-                                         int cout_pad, int kcols_pad, int slices, int accumulate) {
-    // grid (co, 256-column chunk), block (64 lanes x 4 columns, SG slice groups): every wave reads 1 KiB contiguous of one slice per
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partial, float* __restrict__ dw,
+                                                  const float* __restrict__ scale, const float* __restrict__ w,
+                                                  float* __restrict__ wdot, int cout, int cin, int kh, int kw, int cin_pad,
+                                                  int cout_pad, int kcols_pad, int slices, int accumulate, const int co, const int kchunk) {
+    // (co, 256-column chunk) per workgroup, block (64 lanes x 4 columns, SG slice groups): every wave reads 1 KiB contiguous of one slice per
     // step as float4 (partials keep their own column order; cin_pad % 4 == 0, so a float4 never straddles a tap), the SG partial sums
     // meet in LDS in a fixed order (deterministic result).  50 MB of partials per layer: 16-byte lanes run this 14 -> ~8 us.
     __shared__ f32x4 red[16][64];
-    const int co = blockIdx.x;
     const int taps = kh * kw;
     const int per = cin * taps;
-    const int kc = (blockIdx.y * 64 + threadIdx.x) * 4;
+    const int kc = (kchunk * 64 + threadIdx.x) * 4;
     const int sg = threadIdx.y, nsg = blockDim.y;
     const bool col_ok = kc < taps * cin_pad;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -2438,6 +2437,29 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ partial, floa
         dot = wave_sum(dot);
         if (threadIdx.x == 0) atomicAdd(wdot + co, dot);
     }
+}
+
+__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                         const float* __restrict__ scale, const float* __restrict__ w,
+                                         float* __restrict__ wdot, int cout, int cin, int kh, int kw, int cin_pad,
+                                         int cout_pad, int kcols_pad, int slices, int accumulate) {
+    wgrad_reduce_body(partial, dw, scale, w, wdot, cout, cin, kh, kw, cin_pad, cout_pad, kcols_pad, slices, accumulate, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// the slice reduces of all layers of a grouped weight-gradient launch (din_conv_wgrad_group) as ONE launch: block l of item g
+// (first[g] <= l < first[g + 1]) is (filter l' / kchunks, 256-column chunk l' % kchunks) of that layer
+struct WgradReduceItem { const float* partial; float* dw; const float* scale; const float* w; float* wdot;
+                         int cout, cin, kh, kw, cin_pad, cout_pad, kcols_pad, slices, accumulate, kchunks; };
+struct WgradReduceGroupK { WgradReduceItem it[din_wgrad::WGRAD_GROUP_MAX]; int first[din_wgrad::WGRAD_GROUP_MAX + 1]; int n; };
+__global__ void conv_wgrad_reduce_group_kernel(WgradReduceGroupK grp) {
+    const int l = (int)blockIdx.x;
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < din_wgrad::WGRAD_GROUP_MAX; ++i) gi += (i < grp.n && l >= grp.first[i]) ? 1 : 0;
+    const WgradReduceItem it = grp.it[gi];
+    const int local = l - grp.first[gi], co = local / it.kchunks;
+    wgrad_reduce_body(it.partial, it.dw, it.scale, it.w, it.wdot, it.cout, it.cin, it.kh, it.kw, it.cin_pad, it.cout_pad, it.kcols_pad, it.slices,
+                      it.accumulate, co, local - co * it.kchunks);
 }
 
 // column sums of G [M][cout] (pixel stride ld, offset coff) -> dbias[cout] (atomic accumulate; caller zeroes)
@@ -2858,7 +2880,12 @@ void launch_fast(const ConvK& k, dim3 grid, hipStream_t st) {
 static bool gather_lanek(const ConvK& k) {
     const char* lv = DIN_OPT("DIN_CONV_LANEK");
     const char* fv = DIN_OPT("DIN_CONV_FASTK");
-    return (lv ? atoi(lv) != 0 : true) && (fv ? atoi(fv) != 0 : true) && !k.remap && k.nsrc == 0 && !k.korder && k.xsteps == 0 &&
+    // measured (tools/ab_lanek.sh, profiles/r06_lanek.txt): forward launches +4..7 % (Conv2d_4a 1929 -> 1858 us, the 160-channel 7-tap layers
+    // 165 -> 155 us); data gradients (ReLU mask / accumulate operands in the epilogue, the register file full) 1-2 % SLOWER: forward only
+    // unless DIN_CONV_LANEK=2
+    const int mode = lv ? atoi(lv) : 1;
+    if (mode == 1 && (k.flags & (DIN_CONV_MASK | DIN_CONV_ACCUM))) return false;
+    return mode != 0 && (fv ? atoi(fv) != 0 : true) && !k.remap && k.nsrc == 0 && !k.korder && k.xsteps == 0 &&
            (k.cpt % 8) != 0 && k.cpt >= 8 && k.kh * k.kw > 1 && k.kh * k.kw <= 31;
 }
 
@@ -3353,8 +3380,9 @@ int din_conv_kernel_variant(const din_conv_desc* d, int which, int32_t* flags) {
     const bool korder = (ko ? atoi(ko) != 0 : true) && fast && g.splitk == 1 && cpt % KC == 0 && ntaps > 1;
     if (wave8 && fast && cpt % KC == 0 && (korder || ntaps == 1) && (fv ? atoi(fv) != 0 : true)) *flags |= 1;
     const char* lv = DIN_OPT("DIN_CONV_LANEK");                  // bit 2: the per-lane k-walk instantiation (gather_lanek; bit 0 is set with it: FASTK = true)
+    const int lmode = lv ? atoi(lv) : 1;                          // (1: forward launches only -- a data gradient carries the mask / accumulate flags)
     if (wave8 && bn != 96 && fast && !strided && cpt % KC != 0 && cpt >= 8 && ntaps > 1 && ntaps <= 31 && (fv ? atoi(fv) != 0 : true) &&
-        (lv ? atoi(lv) != 0 : true)) *flags |= 1 | 4;
+        (lmode == 2 || (lmode == 1 && which == 0))) *flags |= 1 | 4;
     return DIN_OK;
 }
 
@@ -3881,16 +3909,24 @@ int din_conv_wgrad_group(int n, const din_conv_wgrad_item* items, void* workspac
     for (int g = n; g <= din_wgrad::WGRAD_GROUP_MAX; ++g) G.first[g] = first;
     if (int e = din_wgrad::launch_wgrad_pipe_group(G, gp.bco, gp.wide != 0, st)) return e;
     DIN_CHECK_LAUNCH("conv_wgrad_group");
+    WgradReduceGroupK R{};
+    R.n = n;
+    int rfirst = 0, max_slices = 1;
     for (int g = 0; g < n; ++g) {
         const din_conv_wgrad_item& it = items[g];
         const din_conv_desc* d = &it.desc;
         const WgradPlan& wp = gp.wp[g];
-        const int kc_total = d->kh * d->kw * wp.cin_pad;
-        dim3 rgrid(d->cout, (kc_total + 255) / 256);
-        const int nsg = gp.slices[g] >= 64 ? 16 : gp.slices[g] >= 8 ? 4 : 1;
-        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, rgrid, dim3(64, nsg), 0, st, G.k[g].partial, it.dw, it.scale, it.w, it.wdot,
-                           d->cout, d->cin, d->kh, d->kw, wp.cin_pad, wp.cout_pad, wp.kcols_pad, gp.slices[g], it.accumulate & 1);
+        WgradReduceItem& r = R.it[g];
+        r.partial = G.k[g].partial; r.dw = it.dw; r.scale = it.scale; r.w = it.w; r.wdot = it.wdot;
+        r.cout = d->cout; r.cin = d->cin; r.kh = d->kh; r.kw = d->kw; r.cin_pad = wp.cin_pad; r.cout_pad = wp.cout_pad; r.kcols_pad = wp.kcols_pad;
+        r.slices = gp.slices[g]; r.accumulate = it.accumulate & 1; r.kchunks = (d->kh * d->kw * wp.cin_pad + 255) / 256;
+        R.first[g] = rfirst;
+        rfirst += d->cout * r.kchunks;
+        if (gp.slices[g] > max_slices) max_slices = gp.slices[g];
     }
+    for (int g = n; g <= din_wgrad::WGRAD_GROUP_MAX; ++g) R.first[g] = rfirst;
+    const int nsg = max_slices >= 64 ? 16 : max_slices >= 8 ? 4 : 1;
+    hipLaunchKernelGGL(conv_wgrad_reduce_group_kernel, dim3(rfirst), dim3(64, nsg), 0, st, R);
     DIN_CHECK_LAUNCH("conv_wgrad_group reduce");
     return DIN_OK;
 }

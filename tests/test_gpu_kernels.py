@@ -169,6 +169,7 @@ def test_conv_fwd_dgrad_wgrad(env, case, dtype, monkeypatch):
             lib.din_conv_kernel_tile(C.byref(d), which, C.byref(bm), C.byref(bn))
             assert bm.value == 4, f"{name}: {('forward', 'dgrad')[which]} not on the streaming 1x1 kernel (tile {bm.value} x {bn.value})"
     if name.startswith("lanek_") and dtype == "bf16":
+        monkeypatch.setenv("DIN_CONV_LANEK", "2")       # forward and data gradient (the planner keeps data gradients on the general loop: slower there)
         fl = C.c_int32(0)
         lib.din_conv_kernel_variant(C.byref(d), 0, C.byref(fl))
         assert fl.value & 4, f"{name}: forward not on the per-lane k-walk instantiation (flags {fl.value})"
@@ -258,11 +259,11 @@ def test_lane_k_walk_is_bit_identical_to_the_general_loop(env, monkeypatch, shap
     L.check(lib.din_conv_pack_weights(C.byref(d), wt.data_ptr(), None, wpt.data_ptr(), 1, None))
     base = torch.randn(nb, h, w, cin + 16, generator=g).to(bf).cuda()
     outs = []
-    for mode in ("1", "0"):
+    for mode in ("2", "0"):                                        # (2: data gradients too; the shipped 1 keeps them on the general loop)
         monkeypatch.setenv("DIN_CONV_LANEK", mode)
         fl = C.c_int32(0)
         lib.din_conv_kernel_variant(C.byref(d), 0, C.byref(fl))
-        assert bool(fl.value & 4) == (mode == "1"), (mode, fl.value)
+        assert bool(fl.value & 4) == (mode == "2"), (mode, fl.value)
         y = torch.full((nb, oh, ow, cout + 8), 5.0, dtype=bf, device="cuda")
         wsb = lib.din_conv_workspace_bytes(C.byref(d), 0)
         ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device="cuda")
@@ -392,7 +393,7 @@ def test_conv_fwd_two_destinations(env, dtype, monkeypatch):
 
 
 def test_conv_kernel_variant_names_the_instantiation(env):
-    """din_conv_kernel_variant: bit 0 = FASTK, bit 1 = 8 waves -- the flags bench.py spells the rocprofv3 kernel name from."""
+    """din_conv_kernel_variant: bit 0 = FASTK, bit 1 = 8 waves, bit 2 = LANEK -- the flags bench.py spells the rocprofv3 kernel name from."""
     lib, L, nhwc, ops = env
     def flags(cin, cout, k, which=0, dtype=None, s=1):
         d = L.ConvDesc()
@@ -408,7 +409,13 @@ def test_conv_kernel_variant_names_the_instantiation(env):
     assert flags(192, 192, (7, 1)) == 3                 # whole k-steps per tap, 8-wave 128x192 tile
     assert flags(512, 192, (1, 1)) == 3                 # single tap
     assert flags(768, 192, (1, 1)) == 0                 # (the 768-channel entries left the gather tiles in round 5: conv1x1_regw_kernel, din_conv_kernel_tile code 5)
-    assert flags(80, 192, (3, 3)) == 2                  # 80 channels: k-steps straddle taps -> general loop, still 8 waves
+    assert flags(80, 192, (3, 3)) == 7                  # 80 channels: k-steps straddle taps -> the per-lane k-walk (bit 2, with FASTK), 8 waves
+    assert flags(160, 160, (1, 7), which=1) == 2        # ... forward launches only: the data gradient keeps the general loop
+    L.set_option("DIN_CONV_LANEK", "0")
+    try:
+        assert flags(80, 192, (3, 3)) == 2
+    finally:
+        L.set_option("DIN_CONV_LANEK", None)
     assert flags(192, 192, (7, 1), dtype=L.DIN_F32) == 0
 
 
