@@ -37,18 +37,6 @@ def _cpad_image(dt: int) -> int:
     return 4 if dt == L.DIN_F32 else 8
 
 
-# bumped whenever ANY module (re)binds a Parameter / buffer object: cached parameter lists are then rebuilt (one integer compare per step)
-_PARAM_EPOCH = [0]
-
-
-def _bump_param_epoch(*_args, **_kwargs):
-    _PARAM_EPOCH[0] += 1
-
-
-torch.nn.modules.module.register_module_parameter_registration_hook(_bump_param_epoch)
-torch.nn.modules.module.register_module_buffer_registration_hook(_bump_param_epoch)
-
-
 class _GraphBackbone(nn.Module):
     """Common machinery: lazily builds (and caches) the NHWC graph for an input size and runs it."""
 
@@ -70,18 +58,23 @@ class _GraphBackbone(nn.Module):
 
     def _ordered_params(self, graph: Graph) -> List[torch.Tensor]:
         # cached per graph: walking named_parameters() / named_buffers() of ~300 modules is milliseconds of host time per step -- as much as the
-        # whole forward dispatch on the 4-clip step.  `_apply` (.to / .cuda / .float: buffers are REPLACED there) drops the cache.
-        # A parameter / buffer object replaced WITHOUT _apply (load_state_dict(assign=True), module.weight = nn.Parameter(...), pruning
-        # re-registration) is caught by `_param_epoch`, which every such path bumps (register_parameter / register_buffer /
-        # __setattr__ of a tensor / _load_from_state_dict on any submodule -- hooked once, below).
+        # whole forward dispatch on the 4-clip step.  `_apply` (.to / .cuda / .float: buffers are REPLACED there) drops the cache; any other
+        # rebinding (load_state_dict(assign=True), module.weight = nn.Parameter(...), pruning re-registration, a direct write to
+        # module._parameters[...]) is caught by the identity check below: every cached tensor must still be the object its
+        # owning module holds under that name (~300 dict lookups, ~25 us).  Nothing is hooked process-wide any more.
         cache = self.__dict__.setdefault("_ordered_cache", {})
-        epoch = _PARAM_EPOCH[0]
         hit = cache.get(id(graph))
-        if hit is None or hit[0] != epoch:
-            table = dict(self.named_parameters())
-            table.update(dict(self.named_buffers()))
-            hit = cache[id(graph)] = (epoch, [table[n] for n in graph.param_names()])
-        return hit[1]
+        if hit is not None and all(owner.get(key) is t for (owner, key), t in zip(hit[0], hit[1])):
+            return hit[1]
+        slots, tensors = [], []
+        for name in graph.param_names():
+            mod_path, _, attr = name.rpartition(".")
+            mod = self.get_submodule(mod_path) if mod_path else self
+            owner = mod._parameters if attr in mod._parameters else mod._buffers
+            slots.append((owner, attr))
+            tensors.append(owner[attr])
+        cache[id(graph)] = (slots, tensors)
+        return tensors
 
     def _apply(self, fn, *args, **kwargs):
         self.__dict__.pop("_ordered_cache", None)

@@ -83,6 +83,40 @@ def test_occupancy_critical_kernels_hold_their_register_budgets():
     assert checked >= 28, checked
 
 
+def test_register_resident_kernel_keeps_its_hand_counted_lds_reads_hazard_free(tmp_path):
+    """conv_regw.hip issues its fragment reads as inline-asm ds_read_b128 and waits for them with hand-counted s_waitcnt
+    lgkmcnt(n); with the register file full, a compiler that copied or reused a destination register between the read and its wait would
+    corrupt data silently.  tools/lds_hazard_check.py walks the ISA of every instantiation (FIFO of outstanding LGKM operations, retired
+    at each wait) and reports any instruction that touches the destination of a read still in flight."""
+    import shutil
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lds_hazard_check as H
+    # the checker itself: a read in flight, then a use before / after the wait
+    bad = ["ds_read_b128 v[4:7], v9 offset:16", "v_add_u32 v1, v5, v2", "s_waitcnt lgkmcnt(0)", "v_add_u32 v1, v5, v2"]
+    hz = H.check_kernel(bad)
+    assert len(hz) == 1 and hz[0][0] == 1
+    ok = ["ds_read_b128 v[4:7], v9", "ds_read_b128 v[10:13], v9", "s_waitcnt lgkmcnt(1)", "v_mfma_f32_16x16x32_bf16 a[0:3], v[20:23], v[4:7], a[0:3]",
+          "s_waitcnt lgkmcnt(0)", "v_mov_b32 v30, v10"]
+    assert not H.check_kernel(ok)
+    assert len(H.check_kernel(ok[:2] + ["s_waitcnt lgkmcnt(1)", "v_mov_b32 v30, v10"])) == 1      # the second read is still outstanding
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc: the ISA of conv_regw.hip cannot be produced here")
+    csrc = os.path.join(ROOT, "din-group-activity-recognition-benchmark_amd", "csrc")
+    out = str(tmp_path / "regw.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics", "-S",
+                           "--cuda-device-only", "-o", out, os.path.join(csrc, "conv_regw.hip")], stderr=subprocess.DEVNULL)
+    checked = 0
+    for name, body in H.kernels(out):
+        if "conv1x1_regw_kernel" in name:
+            checked += 1
+            assert sum(1 for l in body if "ds_read_b128" in l) >= 60, name
+            hz = H.check_kernel(body)
+            assert not hz, (name, hz[:3])
+    assert checked == 10
+
+
 def test_conv_planning_is_callable_without_gpu():
     from din_amd import _lib
     lib = _lib.load()
@@ -145,6 +179,37 @@ def test_inception_graph_shapes_and_keys():
     t = gv.tensors[gv.output_tids[0]]
     assert (t.h, t.w, t.c) == (22, 40, 512)
     assert sum(1 for o in gv.ops if o.kind == "conv") == 13
+
+
+def test_backbone_parameter_cache_follows_every_kind_of_rebinding():
+    """_GraphBackbone._ordered_params caches the parameter / buffer list per graph (host time on the 4-clip step) and must notice EVERY way a
+    module can come to hold another tensor object -- attribute assignment, load_state_dict(assign=True), a direct write into
+    module._parameters / _buffers (the process-wide registration hooks of round 5 missed that one and fired for every module of the
+    process; the cache now checks object identity per call and hooks nothing)."""
+    import torch.nn as nn
+    import torch.nn.modules.module as tm
+    from din_amd.backbone.backbone import MyInception_v3
+    assert not tm._global_parameter_registration_hooks and not tm._global_buffer_registration_hooks       # nothing installed process-wide
+    net = MyInception_v3(compute_dtype="bf16")
+    g, _ = net.graph_for(139, 203)
+    names = g.param_names()
+    first = net._ordered_params(g)
+    assert net._ordered_params(g) is first                                        # cache hit: the same list object
+    iw = names.index("Conv2d_1a_3x3.conv.weight")
+    net.Conv2d_1a_3x3.conv.weight = nn.Parameter(torch.zeros_like(net.Conv2d_1a_3x3.conv.weight))            # attribute assignment
+    second = net._ordered_params(g)
+    assert second is not first and second[iw] is net.Conv2d_1a_3x3.conv.weight and first[iw] is not second[iw]
+    im = names.index("Mixed_6e.branch7x7_3.bn.running_mean")
+    net.Mixed_6e.branch7x7_3.bn._buffers["running_mean"] = torch.ones_like(net.Mixed_6e.branch7x7_3.bn.running_mean)   # direct write
+    third = net._ordered_params(g)
+    assert third[im] is net.Mixed_6e.branch7x7_3.bn.running_mean and float(third[im].sum()) == third[im].numel()
+    sd = {k: v.clone() + 1 for k, v in net.state_dict().items()}
+    net.load_state_dict(sd, assign=True)                                           # every tensor replaced
+    fourth = net._ordered_params(g)
+    table = dict(net.named_parameters())
+    table.update(dict(net.named_buffers()))
+    assert all(t is table[n] for t, n in zip(fourth, names))
+    assert net._ordered_params(g) is fourth
 
 
 def test_product_path_fails_loudly_on_cpu_tensors():
