@@ -25,12 +25,12 @@ struct WgradK {
                     // XCD's L2 holds and dY comes from HBM once.  Speed only: no sibling is ever waited for indefinitely.
 };
 
-// conv_wgrad_pipe.hip, grouped launch: the weight gradients of up to WGRAD_GROUP_MAX LAYERS in one launch (din_conv_wgrad_group).  Every launch of
+// conv_wgrad_pipe.hip, grouped launch: the weight gradients of up to WGRAD_GROUP_MAX LAYERS (16 x 184 B of arguments: inside the 4 KB kernel-argument segment) in one launch (din_conv_wgrad_group).  Every launch of
 // the pipe kernel fills the chip with one workgroup per CU, and every workgroup writes a full fp32 partial tile: slices x |dW| = ~50 MB per
 // layer whatever the batch, read back by the reduce launch.  Layers that share a launch share the 256 workgroups: a layer of a group of six
 // is cut into 7 instead of 42 pixel slices and leaves 8 MB of partials.  Logical block l (after the XCD remap) belongs to item g with
 // first[g] <= l < first[g + 1]; inside the item it is (tile, slice) exactly as in the single-layer launch.
-constexpr int WGRAD_GROUP_MAX = 8;
+constexpr int WGRAD_GROUP_MAX = 16;
 struct WgradGroupK { WgradK k[WGRAD_GROUP_MAX]; int first[WGRAD_GROUP_MAX + 1]; int n; };
 
 // conv_wgrad_1x1.hip: weight gradients of up to four 1x1 convs that read one tensor, in one launch (dW stationary in registers)

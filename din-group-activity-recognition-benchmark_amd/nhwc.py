@@ -92,7 +92,12 @@ FUSE_WGRAD_SIBLINGS = None   # DIN_FUSE_WGRAD (on): ... and the wgrads of the me
 FUSE_WGRAD_1X1 = None        # DIN_FUSE_WGRAD_1X1 (on): weight gradients of ALL 1x1 convs reading one view in one launch (din_conv1x1_wgrad_multi)
 FUSE_DGRAD_X = None          # DIN_FUSE_DGRAD_X (on): a lone 1x1's dgrad rides in the strided sibling's launches (din_conv_dgrad_x: Mixed_6a)
 GROUP_WGRAD = None           # DIN_GROUP_WGRAD (on): weight gradients of up to GROUP_WGRAD_MAX layers share one launch (din_conv_wgrad_group)
-GROUP_WGRAD_MAX = 8          # layers per grouped launch (<= the library's WGRAD_GROUP_MAX)
+# A queue is flushed at GROUP_WGRAD_MAX layers or when the operands it holds back (input + output gradient of every queued layer) reach
+# GROUP_WGRAD_MB: measured on one box (profiles/r06_wgrad_group.txt) -- 4 clips (31 MB per Mixed_6 layer): 12 layers 8.80 ms, 8 layers 8.84,
+# no grouping 9.74; 32 clips (248 MB per layer): 4 layers 663.6 clips/s = no grouping 663.0, 8 layers 659.7, 16 layers 650 (a deferred launch
+# reads operands that have left the 256 MB last-level cache; the slice partials it saves are ~5 % of a launch at that size).
+GROUP_WGRAD_MAX = 12         # (<= the library's WGRAD_GROUP_MAX = 16; option DIN_GROUP_WGRAD_MAX overrides)
+GROUP_WGRAD_MB = 768         # (option DIN_GROUP_WGRAD_MB overrides)
 _SWITCHES = {"FUSE_1X1_DGRAD": ("DIN_FUSE_1X1", True), "FUSE_FWD_SIBLINGS": ("DIN_FUSE_FWD", True), "FUSE_WGRAD_SIBLINGS": ("DIN_FUSE_WGRAD", True),
              "FUSE_WGRAD_1X1": ("DIN_FUSE_WGRAD_1X1", True), "FUSE_DGRAD_X": ("DIN_FUSE_DGRAD_X", True), "GROUP_WGRAD": ("DIN_GROUP_WGRAD", True), "WGRAD_SIDE_STREAM": ("DIN_WGRAD_STREAM", False)}
 
@@ -772,6 +777,9 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
     # alone, and its fp32 slice partials (slices x |dW|, ~50 MB per layer and launch whatever the batch) shrink by the same factor.
     wq: Dict[int, list] = {}
     group_on = switch("GROUP_WGRAD") and dt == L.DIN_BF16 and side is None
+    group_max = max(2, min(16, int(L.get_option("DIN_GROUP_WGRAD_MAX") or GROUP_WGRAD_MAX))) if group_on else 0
+    group_bytes = int(L.get_option("DIN_GROUP_WGRAD_MB") or GROUP_WGRAD_MB) << 20 if group_on else 0
+    wq_bytes: Dict[int, int] = {}
 
     def wgrad_now(d, x, go, dw_, dshift_, scale_, w_, wdot_, acc, name, after):
         ws, wsb = workspace(lib.din_conv_workspace_bytes(C.byref(d), 2), dev, wtag)
@@ -783,6 +791,7 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
 
     def flush_wq(key):
         q = wq.pop(key, None)
+        wq_bytes.pop(key, None)
         if not q:
             return
         need = 0
@@ -818,7 +827,8 @@ def graph_backward(g: Graph, bufs, aux, params: Sequence[torch.Tensor], dt: int,
             return
         q = wq.setdefault(key, [])
         q.append((_copy_desc(d), x, go, dw_, dshift_, scale_, w_, wdot_, acc, name, after))
-        if len(q) >= GROUP_WGRAD_MAX:
+        wq_bytes[key] = wq_bytes.get(key, 0) + 2 * (d.nb * d.h * d.w * d.cin + d.nb * d.oh * d.ow * d.cout)      # bf16 operands held back
+        if len(q) >= group_max or wq_bytes[key] >= group_bytes:
             flush_wq(key)
 
     def flush_group(key):

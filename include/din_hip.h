@@ -192,7 +192,7 @@ int64_t din_conv1x1_wgrad_multi_workspace(int nsrc, const din_conv_wsrc* srcs, i
 int din_conv1x1_wgrad_multi(int nsrc, const din_conv_wsrc* srcs, int dtype, int64_t pixels, int cin, int ldi, int cioff, const void* in,
                             int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
-/* The weight gradients of up to 8 LAYERS in one launch (autograd of the torch.nn.Conv2d layers of reference backbone/backbone.py:44-99 --
+/* The weight gradients of up to 16 LAYERS in one launch (autograd of the torch.nn.Conv2d layers of reference backbone/backbone.py:44-99 --
  * torchvision's InceptionC blocks hold ten 7-tap / 1x1 layers of equal map size each).  A weight-gradient launch of the pipelined kernel puts
  * one workgroup on every CU and each writes a full fp32 partial tile: slices x |dW| = ~50 MB per layer whatever the batch, read back by the
  * reduce launch.  Layers whose gradients are due at about the same time share one launch and its 256 workgroups instead: a layer of a group

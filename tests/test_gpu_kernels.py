@@ -1477,7 +1477,7 @@ def test_conv1x1_wgrad_multi_source(env, monkeypatch, cin, couts):
             assert float(dev["db"].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("case", ["inception_c_block", "mixed_maps", "two_tiles"])
+@pytest.mark.parametrize("case", ["inception_c_block", "mixed_maps", "two_tiles", "twelve_layers"])
 def test_conv_wgrad_group_matches_per_layer_launches(env, case):
     """din_conv_wgrad_group (several layers' weight gradients in ONE launch of the pipelined kernel, conv_wgrad.h: WgradGroupK) against
     din_conv_wgrad layer by layer and against fp32 F.conv2d autograd on the bf16-rounded operands: dW with the BatchNorm scale folded, the
@@ -1488,6 +1488,8 @@ def test_conv_wgrad_group_matches_per_layer_launches(env, case):
     if case == "inception_c_block":      # (cin, cout, kh, kw, ph, pw, nb, h, w)
         layers = [(160, 160, 1, 7, 0, 3, 2, 19, 37), (160, 192, 7, 1, 3, 0, 2, 19, 37), (160, 160, 7, 1, 3, 0, 2, 19, 37),
                   (768, 192, 1, 1, 0, 0, 2, 19, 37), (160, 192, 1, 7, 0, 3, 2, 19, 37), (192, 192, 7, 1, 3, 0, 2, 19, 37)]
+    elif case == "twelve_layers":         # more items than one hand of the first[] scan: two blocks' worth in one launch
+        layers = [(160, 160, 1, 7, 0, 3, 1, 19, 37), (160, 192, 7, 1, 3, 0, 1, 19, 37), (768, 192, 1, 1, 0, 0, 1, 19, 37)] * 4
     elif case == "mixed_maps":
         layers = [(192, 192, 1, 7, 0, 3, 1, 21, 40), (80, 192, 3, 3, 0, 0, 1, 45, 70), (192, 192, 7, 1, 3, 0, 3, 17, 33)]
     else:
