@@ -736,9 +736,16 @@ def main():
         if True:
             was_training = model.training
             model.eval()
+            # (the hierarchical module's dropout is ALWAYS on, also under eval() -- the reference's `F.dropout(x)` with functional defaults,
+            #  infer_module/dynamic_infer_module.py:495 -- and its mask depends on the position in the batch: switched off for this comparison)
+            always_on = [(m, m.hier_dropout_p) for m in model.modules() if hasattr(m, "hier_dropout_p")]
+            for m, _p in always_on:
+                m.hier_dropout_p = 0.0
             with torch.no_grad():
                 full = model(batch(images))["activities"].float()
                 one = model(tuple(None if t is None else t[:1] for t in batch(images)))["activities"].float()
+            for m, p_ in always_on:
+                m.hier_dropout_p = p_
             if was_training:
                 model.train()
                 if cfg.set_bn_eval:

@@ -3787,7 +3787,7 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
 // ---- din_conv_wgrad_group: the weight gradients of several LAYERS in one launch of the pipelined kernel (conv_wgrad.h: WgradGroupK) -------
 // Plan: every item keeps the tile geometry plan_wgrad gives it alone; what changes is the pixel slicing.  One common slice length mps
 // (whole 32-pixel stages) is chosen so that the items' tiles x slices fill the chip's CUs ONCE: sum_g tiles_g * ceil(M_g / mps) <= CUs.
-struct WgradGroupPlan { WgradPlan wp[din_wgrad::WGRAD_GROUP_MAX]; int slices[din_wgrad::WGRAD_GROUP_MAX]; int64_t part_off[din_wgrad::WGRAD_GROUP_MAX]; int mps, bco, wide; int64_t ws_bytes; };
+struct WgradGroupPlan { WgradPlan wp[din_wgrad::WGRAD_GROUP_MAX]; int slices[din_wgrad::WGRAD_GROUP_MAX]; int64_t part_off[din_wgrad::WGRAD_GROUP_MAX], pace_off[din_wgrad::WGRAD_GROUP_MAX]; int mps, bco, wide; int64_t ws_bytes; };
 
 static int wgrad_group_key(const din_conv_desc* d, WgradPlan* out) {
     const char* gv = DIN_OPT("DIN_WGRAD_GROUP");
@@ -3853,6 +3853,10 @@ static bool plan_wgrad_group(int n, const din_conv_wgrad_item* items, WgradGroup
         gp.part_off[g] = off;
         off += ((int64_t)gp.slices[g] * gp.wp[g].cout_pad * gp.wp[g].kcols_pad * 4 + 255) / 256 * 256;
     }
+    for (int g = 0; g < n; ++g) {                                   // sibling-pacing words (WgradK::pace) behind the partial tiles
+        gp.pace_off[g] = off;
+        off += ((int64_t)gp.slices[g] * gp.wp[g].n_co_tiles * 8 * 4 + 255) / 256 * 256;
+    }
     gp.ws_bytes = off;
     return true;
 }
@@ -3903,6 +3907,15 @@ int din_conv_wgrad_group(int n, const din_conv_wgrad_item* items, void* workspac
             k.dbias = it.dbias;
         }
         if (it.wdot && !prezeroed && hipMemsetAsync(it.wdot, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad_group: memset");
+        {   // the k-tile siblings of one (filter tile, pixel slice) stream the same dY rows: paced as in the single-layer launch (2..3 siblings by default)
+            const char* pe = DIN_OPT("DIN_WGRAD_PACE");
+            const int want = pe ? atoi(pe) : 1;
+            if (want && wp.n_k_tiles >= 2 && wp.n_k_tiles <= (want >= 2 ? 8 : 3) && gp.mps / 32 < (1 << 20) - 1) {
+                static std::atomic<unsigned> group_pace_epoch{0};
+                k.pace = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + gp.pace_off[g]);
+                k.pace_base = (int)(((group_pace_epoch.fetch_add(1) % 1023u) + 1u) << 20);
+            }
+        }
         G.first[g] = first;
         first += wp.n_co_tiles * wp.n_k_tiles * gp.slices[g];
     }
