@@ -3907,9 +3907,11 @@ int din_conv_wgrad_group(int n, const din_conv_wgrad_item* items, void* workspac
             k.dbias = it.dbias;
         }
         if (it.wdot && !prezeroed && hipMemsetAsync(it.wdot, 0, sizeof(float) * d->cout, st) != hipSuccess) DIN_FAIL(DIN_E_LAUNCH, "conv_wgrad_group: memset");
-        {   // the k-tile siblings of one (filter tile, pixel slice) stream the same dY rows: paced as in the single-layer launch (2..3 siblings by default)
-            const char* pe = DIN_OPT("DIN_WGRAD_PACE");
-            const int want = pe ? atoi(pe) : 1;
+        {   // the k-tile siblings of one (filter tile, pixel slice) stream the same dY rows.  Pacing them as the single-layer launch does was
+            // measured inside groups (tools/ab_group_pace.sh, profiles/r06_group_pace.txt): HBM fetch 1617 -> 1549 MB per launch, but the naps cost
+            // time -- 32 clips 656.3 -> 654.7 clips/s, 4 clips 9.04 -> 9.15 ms: OFF unless DIN_WGRAD_GROUP_PACE=1 (2: up to 8 siblings)
+            const char* pe = DIN_OPT("DIN_WGRAD_GROUP_PACE");
+            const int want = pe ? atoi(pe) : 0;
             if (want && wp.n_k_tiles >= 2 && wp.n_k_tiles <= (want >= 2 ? 8 : 3) && gp.mps / 32 < (1 << 20) - 1) {
                 static std::atomic<unsigned> group_pace_epoch{0};
                 k.pace = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + gp.pace_off[g]);
