@@ -2053,11 +2053,16 @@ __global__ __launch_bounds__(512, (4 * (((32 * (BCO / 8) + 511) / 512) * 8192 + 
 // ------------------------------------------------------------------------------------------------
 // NW: waves per workgroup.  The 32 -> 64 layer (Conv2d_2b) needs 108 KiB of LDS, i.e. one workgroup per CU: with four waves that is ONE wave
 // per SIMD (3.1 TB/s); eight waves split the 18 column tiles 3 / 2 per wave instead of 5 / 4 and give every SIMD two waves.
-template <int CPP, int BN, int ST, bool U8 = false, int NW = 4>
+// TH_ / RING (round 6): the 32 -> 64 layer runs ONE workgroup per CU, and with two 54 KB stages only one tile's operands are in flight per CU
+// while the current tile is multiplied -- the tile time was the memory latency + transfer of one stage (3.05 us, 4.1 TB/s), not max(compute,
+// transfer).  <..., TH_ = 6, RING = 3>: 6 x 32 tiles (42 KB per stage: 24.6 KB of G + 17.4 KB of halo) in a THREE-slot ring with TWO stages in
+// flight (126 KB), the oldest waited for with a counted vmcnt.  The halo overhead grows from 10/8 to 8/6 of the input (+2 % bytes).
+template <int CPP, int BN, int ST, bool U8 = false, int NW = 4, int TH_ = 8, int RING = 2>
 __global__ __launch_bounds__(64 * NW, (CPP == 4 && BN == 64) ? 1 : 2) void conv_wgrad_small_kernel(WgradK p) {
     static_assert(!U8 || CPP == 1, "uint8 frames feed the image layer only");
+    static_assert(RING == 2 || (RING == 3 && !U8), "three-slot ring: LDS-DMA operands only");
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int TH = 8, TW = 32, NPX = TH * TW, KH = 3, KW = 3;
+    constexpr int TH = TH_, TW = 32, NPX = TH * TW, KH = 3, KW = 3;
     constexpr int HWW = (TW - 1) * ST + KW, HWH = (TH - 1) * ST + KH, HPX = HWW * HWH, HC = HPX * CPP;
     constexpr int HBYTES = (HC * 16 + 1023) / 1024 * 1024, NSLOT_H = HBYTES / 1024, NTR_H = (NSLOT_H + NW - 1) / NW;
     constexpr int CG = BN / 8, GBYTES = NPX * CG * 16, NTR_G = GBYTES / (1024 * NW);
@@ -2161,22 +2166,9 @@ __global__ __launch_bounds__(64 * NW, (CPP == 4 && BN == 64) ? 1 : 2) void conv_
         const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
         u8h.template load<NSLOT_H>(p.u8, n, p.H, p.W, ty * TH * ST - p.ph, tx * TW * ST - p.pw, wid, hyv, hxv, relH);
     };
-    int cur = 0;
-    int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    if (tile < ntiles) {
-        issue(0, tile);
-        if (U8) { u8_load(tile); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); u8h.landed(); u8h.template store<NSLOT_H>(smem_raw, u8lut, wid, lane); }
-    }
-    for (; tile < ntiles; tile += gridDim.x) {
-        if (U8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                   // stage(cur) landed; everyone finished reading stage(cur^1)
-        asm volatile("" ::: "memory");
-        const bool have_next = tile + (int)gridDim.x < ntiles;
-        if (have_next) issue(cur ^ 1, tile + gridDim.x);
-        if (U8 && have_next) u8_load(tile + gridDim.x);
-        const uint32_t Hb = lds_base + (uint32_t)(cur * STAGE), Gb = Hb + (uint32_t)HBYTES;
-        // software pipeline: the transpose reads of k-step ks+1 are in flight while the MFMAs of k-step ks run
+    // one tile's MFMAs from ring slot `slot` (shared by both ring forms)
+    auto multiply = [&](int slot) {
+        const uint32_t Hb = lds_base + (uint32_t)(slot * STAGE), Gb = Hb + (uint32_t)HBYTES;
         u32x4 gf[2][TI], xf[2][TJ];
         auto load_frags = [&](int ks, u32x4 (&gfr)[TI], u32x4 (&xfr)[TJ]) {
 #pragma unroll
@@ -2224,11 +2216,52 @@ __global__ __launch_bounds__(64 * NW, (CPP == 4 && BN == 64) ? 1 : 2) void conv_
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    int cur = 0;
+    int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    if constexpr (RING == 3) {
+        // transfers per wave and stage: NTR_G for the G tile + the halo slots this wave owns (wave w: slots w, w + NW, ... < NSLOT_H)
+        constexpr int HREM = NSLOT_H % NW, NH_LO = NSLOT_H / NW;            // waves < HREM issue NH_LO + 1 halo transfers, the others NH_LO
+        const bool more_h = HREM != 0 && wid < HREM;                        // wave-uniform
+        const int stride = (int)gridDim.x;
+        if (tile < ntiles) issue(0, tile);
+        if (tile + stride < ntiles) issue(1, tile + stride);
+        int fill = 2;                                                       // slot the next issue goes to
+        for (; tile < ntiles; tile += stride) {
+            // stage `cur` (this tile) must have landed; the stage of tile + stride, if it exists, stays in flight
+            if (tile + stride < ntiles) {
+                if (more_h) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NTR_G + NH_LO + 1) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NTR_G + NH_LO) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();                                   // stage(cur) complete; everyone finished reading the slot consumed last (= fill)
+            asm volatile("" ::: "memory");
+            if (tile + 2 * stride < ntiles) issue(fill, tile + 2 * stride);
+            multiply(cur);
+            cur = cur + 1 == 3 ? 0 : cur + 1;
+            fill = fill + 1 == 3 ? 0 : fill + 1;
+        }
+    } else {
+    if (tile < ntiles) {
+        issue(0, tile);
+        if (U8) { u8_load(tile); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); u8h.landed(); u8h.template store<NSLOT_H>(smem_raw, u8lut, wid, lane); }
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        if (U8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                   // stage(cur) landed; everyone finished reading stage(cur^1)
+        asm volatile("" ::: "memory");
+        const bool have_next = tile + (int)gridDim.x < ntiles;
+        if (have_next) issue(cur ^ 1, tile + gridDim.x);
+        if (U8 && have_next) u8_load(tile + gridDim.x);
+        multiply(cur);                                                  // (the transpose reads of k-step ks+1 are in flight while the MFMAs of k-step ks run)
         if (U8 && have_next) {                                          // requested at the top of this tile (after the next G tile's transfers)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); u8h.landed();
             u8h.template store<NSLOT_H>(smem_raw + (cur ^ 1) * STAGE, u8lut, wid, lane);
         }
         cur ^= 1;
+    }
     }
     // ---- this workgroup's partial slab: [BN][NCT * 16] fp32 ------------------------------------------------------------------
     float* dst = p.partial + (int64_t)blockIdx.x * p.cout_pad * p.kcols_pad;
@@ -3140,7 +3173,11 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
             const int st_ = image ? 2 : 1;
             const int hpx = (7 * st_ + 3) * (31 * st_ + 3);
             const int hbytes = (hpx * g.cpt * 16 + 1023) / 1024 * 1024;
-            const int nbuf = g.cpt == 8 ? 1 : 2;
+            // 128-byte pixels (the 64-channel dgrad of Conv2d_2b): one halo buffer (80 KiB) or -- DIN_CONV_SMALL_NBUF8=2 -- two (124 KiB, the next
+            // halo in flight under this tile's MFMAs like the 64-byte-pixel variants); one workgroup per CU either way
+            const char* nb8 = DIN_OPT("DIN_CONV_SMALL_NBUF8");
+            const bool two8 = g.cpt == 8 && (nb8 ? atoi(nb8) == 2 : false);
+            const int nbuf = (g.cpt == 8 && !two8) ? 1 : 2;
             const size_t lds = (size_t)(image ? 3 * bnS * 64 : 9 * bnS * g.cpt * 16) + (size_t)nbuf * hbytes + (k.u8 ? 512 : 0);   // (+ the uint8 -> bf16 table)
             dim3 grid(512);
             // dgrad launches with a mask / accumulate operand: the variant that requests them a tile phase early (DIN_CONV_SMALL_EPI=0: in the store loop)
@@ -3165,6 +3202,7 @@ int run_gather(ConvK& k, GatherPlan g, int dtype, void* workspace, int64_t ws_by
                     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, k);
                 };
                 if (g.cpt == 4) { if (w8) launch8(conv_small_kernel<4, 64, 2, 3, 3, 1, false, 8>); else launch(conv_small_kernel<4, 64, 2, 3, 3, 1>); }
+                else if (two8 && w8) { if (epi) launch8(conv_small_kernel<8, 32, 2, 3, 3, 1, false, 8, true>); else launch8(conv_small_kernel<8, 32, 2, 3, 3, 1, false, 8>); }
                 else if (epi && w8) launch8(conv_small_kernel<8, 32, 1, 3, 3, 1, false, 8, true>);
                 else { if (w8) launch8(conv_small_kernel<8, 32, 1, 3, 3, 1, false, 8>); else launch(conv_small_kernel<8, 32, 1, 3, 3, 1>); }
             }
@@ -3693,8 +3731,15 @@ int din_conv_wgrad(const din_conv_desc* d, const void* in, const void* dout, flo
             };
             if (wp.small == 1) launch(conv_wgrad_small_kernel<4, 32, 1>);
             else if (wp.small == 2 && !(DIN_OPT("DIN_WGRAD_SMALL_WAVES") && atoi(DIN_OPT("DIN_WGRAD_SMALL_WAVES")) == 4)) {
-                if (lds > 65536) raise_lds_limit(conv_wgrad_small_kernel<4, 64, 1, false, 8>, lds);
-                hipLaunchKernelGGL((conv_wgrad_small_kernel<4, 64, 1, false, 8>), dim3(WGRAD_SMALL_GRID), dim3(512), lds, st, k);
+                const char* rg = DIN_OPT("DIN_WGRAD_SMALL_RING");
+                if ((rg ? atoi(rg) : 3) == 3) {                       // 6 x 32 tiles, three-slot ring, two stages in flight (126 KB)
+                    const size_t hb6 = ((size_t)(5 + 3) * (31 + 3) * 4 * 16 + 1023) / 1024 * 1024, lds3 = 3 * (hb6 + 192 * (size_t)wp.bco * 2);
+                    raise_lds_limit(conv_wgrad_small_kernel<4, 64, 1, false, 8, 6, 3>, lds3);
+                    hipLaunchKernelGGL((conv_wgrad_small_kernel<4, 64, 1, false, 8, 6, 3>), dim3(WGRAD_SMALL_GRID), dim3(512), lds3, st, k);
+                } else {
+                    if (lds > 65536) raise_lds_limit(conv_wgrad_small_kernel<4, 64, 1, false, 8>, lds);
+                    hipLaunchKernelGGL((conv_wgrad_small_kernel<4, 64, 1, false, 8>), dim3(WGRAD_SMALL_GRID), dim3(512), lds, st, k);
+                }
             }
             else if (wp.small == 2) launch(conv_wgrad_small_kernel<4, 64, 1>);
             else if (d->in_u8) { k.u8 = reinterpret_cast<const unsigned char*>(in); launch(conv_wgrad_small_kernel<1, 32, 2, true>); }
