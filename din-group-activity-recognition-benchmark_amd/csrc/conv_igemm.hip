@@ -2811,7 +2811,7 @@ WgradPlan plan_wgrad(const din_conv_desc* d) {
     int tiles = w.n_co_tiles * w.n_k_tiles;
     // v2/v3 kernels: ~4 workgroups per CU; short reductions (small per-GPU batch) take 2 -- every workgroup writes a full partial tile, so
     // halving them halves the partial traffic (4-clip step 12.47 -> 12.14 ms).  The ring kernel sets its own count below.
-    static const int want_env = DIN_OPT("DIN_WGRAD_BLOCKS") ? atoi(DIN_OPT("DIN_WGRAD_BLOCKS")) : 0;
+    const int want_env = DIN_OPT("DIN_WGRAD_BLOCKS") ? atoi(DIN_OPT("DIN_WGRAD_BLOCKS")) : 0;
     const int want_total = want_env > 0 ? want_env : (M < 128 * 1024 ? 512 : 1024);
     int want = (want_total + tiles - 1) / tiles;
     if (w.ring) {                                      // one resident workgroup per CU: a single full round (or two for long slices)
@@ -2899,7 +2899,7 @@ void launch_fast(const ConvK& k, dim3 grid, hipStream_t st) {
     size_t stage = (size_t)NS * (BMT + BNP_) * KCS * 16 + (k.remap ? 128 : 0);   // stage ring (+ remap table)
     // a single k-step (1x1 layers with <= 64 input channels: Conv2d_3b, the 64-channel dgrads) only ever touches ring stage 0: ask for one
     // stage, so that more of these memory-bound workgroups are resident per CU and their loads / stores overlap (DIN_CONV_ONESTAGE=0: off)
-    static const bool one_stage_ok = !(DIN_OPT("DIN_CONV_ONESTAGE") && atoi(DIN_OPT("DIN_CONV_ONESTAGE")) == 0);
+    const bool one_stage_ok = !(DIN_OPT("DIN_CONV_ONESTAGE") && atoi(DIN_OPT("DIN_CONV_ONESTAGE")) == 0);
     if (one_stage_ok && !k.remap && k.xsteps == 0 && k.ks_per_split * (8 / KCS) <= 1) stage = (size_t)(BMT + BNP_) * KCS * 16;
     size_t epi = (size_t)BMT * (BN * sizeof(T) + 16);
     size_t lds = stage > epi ? stage : epi;
@@ -2933,7 +2933,7 @@ void launch_wave8(const ConvK& k, dim3 grid, hipStream_t st) {
         if constexpr (BN == 192) {
             // wave grid 2 x 4 (64 pixels x 48 filters per wave: 4 + 3 fragments per 12 MFMAs) instead of 4 x 2 (32 x 96: 2 + 6): an eighth
             // fewer LDS fragment reads for the same tile (experiment switch DIN_CONV_WAVEGRID=24)
-            static const bool grid24 = DIN_OPT("DIN_CONV_WAVEGRID") && atoi(DIN_OPT("DIN_CONV_WAVEGRID")) == 24;
+            const bool grid24 = DIN_OPT("DIN_CONV_WAVEGRID") && atoi(DIN_OPT("DIN_CONV_WAVEGRID")) == 24;
             if (grid24) {
                 if (fastk) launch_fast<T, 128, BN, 2, 4, 8, 2, true>(k, grid, st);
                 else launch_fast<T, 128, BN, 2, 4, 8, 2>(k, grid, st);
@@ -2942,7 +2942,7 @@ void launch_wave8(const ConvK& k, dim3 grid, hipStream_t st) {
         }
 #ifdef DIN_EXPERIMENTS
         if constexpr (BN >= 128) {
-            static const bool wg3 = DIN_OPT("DIN_CONV_WG3") && atoi(DIN_OPT("DIN_CONV_WG3")) == 1;
+            const bool wg3 = DIN_OPT("DIN_CONV_WG3") && atoi(DIN_OPT("DIN_CONV_WG3")) == 1;
             if (fastk && wg3) { launch_fast<T, 128, BN, 2, 2, 4, 2, true>(k, grid, st); return; }
         }
 #endif
@@ -2959,7 +2959,7 @@ void launch_wave8(const ConvK& k, dim3 grid, hipStream_t st) {
         // experiment switch DIN_CONV_RING=3: three 32-deep stages (two in flight, one counted vmcnt per barrier) instead of two 64-deep ones
         // (one in flight, vmcnt(0)) for the general loop's 8-wave tiles -- same LDS budget (72 vs 80 KiB per workgroup), half the MFMAs per barrier
         #ifdef DIN_EXPERIMENTS
-        static const bool ring3 = DIN_OPT("DIN_CONV_RING") && atoi(DIN_OPT("DIN_CONV_RING")) == 3;
+        const bool ring3 = DIN_OPT("DIN_CONV_RING") && atoi(DIN_OPT("DIN_CONV_RING")) == 3;
 #else
         constexpr bool ring3 = false;
 #endif
@@ -3033,7 +3033,7 @@ void launch_gather(const ConvK& k, int n_px_tiles, int bm, int bn, hipStream_t s
                 // experiment (DIN_CONV_W16=1 with DIN_CONV_TILE=256): sixteen waves as 8 x 2 on the 256 x 192 tile -- the 128 x 192 kernel's wave
                 // tile and four waves per SIMD, but ONE filter stage per 256 pixels: 64 instead of 80 LDS-DMA transfers per 256-pixel k-step
                 #ifdef DIN_EXPERIMENTS
-                static const bool w16 = DIN_OPT("DIN_CONV_W16") && atoi(DIN_OPT("DIN_CONV_W16")) == 1;
+                const bool w16 = DIN_OPT("DIN_CONV_W16") && atoi(DIN_OPT("DIN_CONV_W16")) == 1;
 #else
                 constexpr bool w16 = false;
 #endif
@@ -3241,8 +3241,8 @@ static int launch_colsum(int dtype, const void* g, float* out, int64_t M, int c,
         // Every workgroup ends with `c` float atomics on the SAME few cache lines, which L2 serialises at ~44 ns per workgroup: the kernel's time
         // grew with its workgroup count (1024: 45 us, 2048: 64 us, 4096: 110 us on the 192-channel maps; 256: 30 us -- tools/colsum_probe.py;
         // the seven launches of the default step 335 -> 248 us).  DIN_COLSUM_WGS / DIN_COLSUM_UNROLL: tuning aids
-        static const int wgs = DIN_OPT("DIN_COLSUM_WGS") ? atoi(DIN_OPT("DIN_COLSUM_WGS")) : 256;
-        static const int unr = DIN_OPT("DIN_COLSUM_UNROLL") ? atoi(DIN_OPT("DIN_COLSUM_UNROLL")) : 8;
+        const int wgs = DIN_OPT("DIN_COLSUM_WGS") ? atoi(DIN_OPT("DIN_COLSUM_WGS")) : 256;
+        const int unr = DIN_OPT("DIN_COLSUM_UNROLL") ? atoi(DIN_OPT("DIN_COLSUM_UNROLL")) : 8;
         int64_t rpb = ceil_div64(M, wgs > 0 ? wgs : 1024);
         if (rpb < 64) rpb = 64;
         int blocks = (int)ceil_div64(M, rpb);
